@@ -1,0 +1,287 @@
+"""oracle/pyref.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+CPU (torch fp32, single precision end to end) restatement of everything on the hot path
+that is *not* the native query op: grid hyper-parameters, ray sample generation, the
+world->perspective projection, the per-neighbor gather, the aggregator (distance weights +
+``viewmlp`` MLP), ray-dist, ``ray_march``, ``fill_invalid`` and the training loss.  Gradients
+of the oracle come from torch.autograd over these functions.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+Reference followed (under /root/reference), function by function:
+  grid_hyperparameters     models/neural_points/point_query.py:27-71
+  ray_samples              models/rendering/diff_ray_marching.py:349-392 (jitter=0)
+  w2pers                   models/neural_points/neural_points.py:604-610, point_query.py:101-108
+  gather_neighbors         models/neural_points/neural_points.py:699-730
+  positional_encoding      models/helpers/networks.py:175-190
+  aggregate                models/aggregators/point_aggregators.py:727-814 (+ linear :421-429,
+                           viewmlp :488-644, raw2out_* :262-273, gradiant_clamp :722-724)
+  ray_dist                 models/neural_points_volumetric_model.py:271-279
+  ray_march                models/rendering/diff_ray_marching.py:508-554,
+                           models/rendering/diff_render_func.py:36-62 (radiance / alpha / off)
+  fill_invalid             models/neural_points_volumetric_model.py:87-123
+  training_loss            models/base_rendering_model.py:543-551,630-641
+
+Parity pin: the reference's own PointAggregator / ray_march / near_far_linear_ray_generation
+import and run on CPU in the authoring container; tests/golden/make_golden.py stores their
+outputs on seeded inputs and tests/test_oracle_golden.py checks this file against them.
+Only the lego-script configuration of the aggregator (agg_dist_pers=20,
+linear kernel, agg_intrp_order=2, LeakyReLU, apply_pnt_mask=1, *_xyz_mode None) is restated.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import query as oq
+
+
+# ----------------------------------------------------------------------------- grid / rays
+def grid_hyperparameters(opt, xyz):
+    """point_query.py:27-71.  xyz [N,3] f32 tensor -> dict of fp32/int32 numpy values."""
+    vsize = np.asarray(opt.vsize, dtype=np.float64)                 # python floats -> f64 (point_query.py:69)
+    vscale = np.asarray(opt.vscale, dtype=np.int32)
+    scaled_vsize = (np.asarray(opt.vsize) * vscale).astype(np.float32)          # :37
+    radius = np.asarray(opt.radius_limit_scale * max(opt.vsize[0], opt.vsize[1])).astype(np.float32)   # :35
+    mn, mx = xyz.min(dim=0)[0], xyz.max(dim=0)[0]
+    rmin = torch.as_tensor(opt.ranges[:3], dtype=torch.float32)
+    rmax = torch.as_tensor(opt.ranges[3:], dtype=torch.float32)
+    mn, mx = torch.maximum(mn, rmin), torch.minimum(mx, rmax)       # :62
+    pad = torch.as_tensor(scaled_vsize * np.asarray(opt.kernel_size) / 2, dtype=torch.float32)   # :65 (f64 -> f32)
+    mn, mx = mn - pad, mx + pad
+    vdim = (mx - mn).numpy() / vsize                                # :69  f32 / f64 -> f64
+    scaled_vdim = np.ceil(vdim / vscale).astype(np.int32)           # :70
+    return dict(ranges=torch.cat([mn, mx]).numpy().astype(np.float32), scaled_vsize=scaled_vsize,
+                scaled_vdim=scaled_vdim, radius=float(radius), vsize=np.asarray(opt.vsize))
+
+
+def ray_samples(campos, raydir, D, near, far):
+    """diff_ray_marching.py:369-392 with jitter=0.  campos [1,3], raydir [1,R,3] -> raypos [1,R,D,3], mid [D]."""
+    t = torch.linspace(0, 1, D + 1).view(1, -1)
+    t = near * (1 - t) + far * t
+    seg = (t[..., 1:] - t[..., :-1]) * (1 + 0.0 * (torch.zeros(1, 1, D) - 0.5))
+    end = torch.cumsum(seg, dim=2)
+    end = near + torch.cat([torch.zeros(1, 1, 1), end], dim=2)
+    mid = (end[:, :, :-1] + end[:, :, 1:]) / 2
+    raypos = campos[:, None, None, :] + raydir[:, :, None, :] * mid[:, :, :, None]
+    return raypos, mid.reshape(-1)
+
+
+def w2pers(p, camrot, campos):
+    """p [...,3] world -> (x/z, y/z, z) in the camera frame.  camrot [3,3] is c2w, campos [3]."""
+    c = (p - campos) @ camrot          # (R^T (p - o))_j = sum_i (p-o)_i R_ij
+    return torch.stack([c[..., 0] / c[..., 2], c[..., 1] / c[..., 2], c[..., 2]], dim=-1)
+
+
+def query(opt, xyz, inp, impl="oracle", nthreads=1):
+    """lighting_fast_querier.query_points (point_query.py:74-98) on CPU.
+    Returns dict(sample_pidx [1,R2,SR,K] i32, sample_loc_w, sample_loc (pers), sample_ray_dirs, ray_mask [1,R] i8, hp)."""
+    hp = grid_hyperparameters(opt, xyz)
+    campos, raydir = inp["campos"], inp["raydir"]
+    near, far = float(inp["near"].min()), float(inp["far"].max())
+    raypos, _ = ray_samples(campos, raydir, opt.z_depth_dim, near, far)
+    R = raydir.shape[1]
+    fn = oq.oracle_query if impl == "oracle" else oq.ref_query
+    pidx, loc_w, ray_mask, info = fn(raypos[0].numpy(), xyz.numpy(), opt.kernel_size, opt.query_size,
+                                     opt.SR, opt.K, hp["scaled_vdim"], opt.max_o, opt.P, hp["radius"],
+                                     hp["ranges"], hp["scaled_vsize"], nthreads=nthreads)
+    pidx, loc_w, ray_mask = torch.from_numpy(pidx)[None], torch.from_numpy(loc_w)[None], torch.from_numpy(ray_mask)[None]
+    dirs = raydir[0][ray_mask[0] > 0][None, :, None, :].expand(-1, -1, opt.SR, -1).contiguous()
+    loc_p = w2pers(loc_w, inp["camrotc2w"][0], campos[0])
+    return dict(sample_pidx=pidx, sample_loc_w=loc_w, sample_loc=loc_p, sample_ray_dirs=dirs,
+                ray_mask=ray_mask, hp=hp, info=info, R=R)
+
+
+# ----------------------------------------------------------------------------- aggregator
+def positional_encoding(x, freqs, ori=False):
+    """networks.py:175-190: per input dim d, per freq f: (sin, cos) interleaved; ori=True is
+    [x | all sins | all coss]."""
+    bands = 2.0 ** torch.arange(freqs, dtype=torch.float32)
+    p = (x[..., None] * bands).reshape(x.shape[:-1] + (freqs * x.shape[-1],))
+    if ori:
+        return torch.cat([x, torch.sin(p), torch.cos(p)], dim=-1)
+    return torch.stack([torch.sin(p), torch.cos(p)], dim=-1).reshape(p.shape[:-1] + (p.shape[-1] * 2,))
+
+
+def mlp_param_shapes(opt):
+    """state_dict key -> shape of the reference PointAggregator built from the lego flags
+    (viewmlp_init, point_aggregators.py:276-348)."""
+    Fd, H = opt.point_features_dim, opt.shading_feature_num
+    dist_dim = 6 if opt.agg_dist_pers == 20 else 3
+    in1 = Fd + 2 * opt.num_feat_freqs * Fd + 2 * abs(opt.dist_xyz_freq) * dist_dim      # 284
+    in3 = H + 3 + 4                                                                       # 263
+    inc = H + 2 * opt.num_viewdir_freqs * 3 + opt.view_ori * 3                            # 280
+    Hc = H // 2
+    s = {"block1.0": (H, in1), "block1.2": (H, H), "block3.0": (H, in3), "block3.2": (H, H),
+         "alpha_branch.0": (1, H), "color_branch.0": (Hc, inc), "color_branch.2": (Hc, Hc),
+         "color_branch.4": (Hc, Hc), "color_branch.6": (3, Hc)}
+    out = {}
+    for k, v in s.items():
+        out[k + ".weight"] = v
+        out[k + ".bias"] = (v[0],)
+    return out
+
+
+def init_mlp_params(opt, seed=0, bias_scale=0.0):
+    """Xavier-uniform weights with the reference's gains (networks.py:163-172: leaky_relu gain for
+    layers followed by LeakyReLU, gain 1 for the last layer of each Sequential), zero biases unless
+    bias_scale>0 (tests use non-zero biases so that bias handling is exercised)."""
+    g = torch.Generator().manual_seed(seed)
+    gain_l = math.sqrt(2.0 / (1 + 0.01 ** 2))
+    # in the reference every Linear that is followed by a LeakyReLU *inside its Sequential* gets the
+    # leaky gain; the final Linear of each Sequential gets gain 1.  block1/block3 end with an activation
+    # module, so their second Linear is also followed by LeakyReLU -> leaky gain; init_seq's trailing
+    # init_weights(s[-1]) then hits the activation module (no-op).
+    last = {"alpha_branch.0", "color_branch.6"}
+    params = {}
+    for k, shp in mlp_param_shapes(opt).items():
+        if k.endswith(".weight"):
+            gain = 1.0 if k[:-7] in last else gain_l
+            bound = gain * math.sqrt(6.0 / (shp[0] + shp[1]))
+            params[k] = (torch.rand(shp, generator=g) * 2 - 1) * bound
+        else:
+            params[k] = (torch.rand(shp, generator=g) * 2 - 1) * bias_scale
+    return params
+
+
+def gather_neighbors(points, pidx, camrot, campos):
+    """neural_points.py:699-717: -1 slots read point 0, validity lives in the mask only."""
+    mask = pidx >= 0
+    idx = pidx.clamp(min=0).long().view(-1)
+    xyz = points["xyz"]
+    xyz_pers = w2pers(xyz, camrot, campos)
+    shp = pidx.shape
+    g = lambda t: t.reshape(-1, t.shape[-1])[idx].view(shp + (t.shape[-1],))
+    return dict(mask=mask, xyz=g(xyz), xyz_pers=g(xyz_pers), emb=g(points["points_embeding"][0]),
+                color=g(points["points_color"][0]), dir=g(points["points_dir"][0]),
+                conf=g(points["points_conf"][0]))
+
+
+def aggregate(opt, mlp, nb, loc_p, loc_w, ray_dirs, Rw2c=None):
+    """PointAggregator.forward + viewmlp for the lego configuration.
+    nb: dict from gather_neighbors with tensors [1,R,SR,K,*]; loc_* / ray_dirs [1,R,SR,3].
+    Returns output [1,R,SR,4], ray_valid [1,R,SR] bool, weight [1,R,SR,K], conf_coefficient [1,R,SR,K]."""
+    mask = nb["mask"]
+    B, R, SR, K = mask.shape
+    Rw2c = torch.eye(3) if Rw2c is None else Rw2c
+    Rt = Rw2c.transpose(-1, -2)
+    ray_valid = mask.any(dim=-1)
+    out = torch.zeros(B, R, SR, 4)
+    xp, lp = nb["xyz_pers"], loc_p[..., None, :]
+    dists = torch.cat([nb["xyz"] - loc_w[..., None, :],
+                       torch.stack([xp[..., 0] * xp[..., 2] - lp[..., 0] * lp[..., 2],
+                                    xp[..., 1] * xp[..., 2] - lp[..., 1] * lp[..., 2],
+                                    xp[..., 2] - lp[..., 2]], dim=-1)], dim=-1)          # :773-781
+    w = mask.float() / torch.clamp(torch.linalg.norm(dists[..., :3], dim=-1), min=1e-6)     # linear :425-428
+    w = w / torch.clamp(w.sum(dim=-1, keepdim=True), min=1e-8)                               # :801-802
+    conf = nb["conf"][..., 0]
+    conf_c = conf - (conf - conf.clamp(1e-4, 1.0)).detach()                                  # gradiant_clamp
+    if ray_valid.sum() == 0:
+        return out, ray_valid, w, conf_c
+    wc = w * conf_c                                                                          # :811
+    mf = mask.view(-1)
+    vf = ray_valid.view(-1)
+    # per-neighbor rows (compacted by the point mask, :523-538)
+    d = dists.view(-1, 6)[mf]
+    d = torch.cat([d[:, :3] @ Rt, d[:, 3:]], dim=-1)                                         # :526
+    d = positional_encoding(d, opt.dist_xyz_freq)
+    feat = nb["emb"].reshape(-1, nb["emb"].shape[-1])[mf]
+    feat = torch.cat([feat, positional_encoding(feat, opt.num_feat_freqs), d], dim=-1)       # 284
+    act = lambda x: F.leaky_relu(x, 0.01)
+    lin = lambda x, k: F.linear(x, mlp[k + ".weight"], mlp[k + ".bias"])
+    feat = act(lin(act(lin(feat, "block1.0")), "block1.2"))
+    view = ray_dirs.reshape(-1, 3) @ Rt                                                      # :506
+    view_pe = positional_encoding(view, opt.num_viewdir_freqs, ori=True)[:, 3:]              # 24
+    view_k = view[:, None, :].expand(-1, K, -1).reshape(-1, 3)[mf]
+    pdir = nb["dir"].reshape(-1, 3)[mf] @ Rt                                                 # :564-566
+    feat = torch.cat([feat, nb["color"].reshape(-1, 3)[mf], pdir - view_k,
+                      (pdir * view_k).sum(-1, keepdim=True)], dim=-1)                        # 263
+    feat = act(lin(act(lin(feat, "block3.0")), "block3.2"))
+    alpha = F.softplus(lin(feat, "alpha_branch.0") - 1)                                      # :262-265
+    n_all = B * R * SR * K
+    a_full = torch.zeros(n_all, 1).index_put((mf.nonzero()[:, 0],), alpha)
+    f_full = torch.zeros(n_all, feat.shape[-1]).index_put((mf.nonzero()[:, 0],), feat)
+    wk = wc.reshape(-1, K, 1)
+    sigma = (a_full.view(-1, K, 1) * wk).sum(dim=1)[vf]                                      # :608-614
+    fs = (f_full.view(-1, K, feat.shape[-1]) * wk).sum(dim=1)[vf]                            # :622-628
+    c = torch.cat([fs, view_pe[vf]], dim=-1)                                                 # 280
+    c = act(lin(c, "color_branch.0")); c = act(lin(c, "color_branch.2")); c = act(lin(c, "color_branch.4"))
+    rgb = torch.sigmoid(lin(c, "color_branch.6")) * (1 + 2 * 0.001) - 0.001                  # :269-273
+    res = torch.cat([sigma, rgb], dim=-1)
+    out = out.view(-1, 4).index_put((vf.nonzero()[:, 0],), res).view(B, R, SR, 4)
+    return out, ray_valid, w, conf_c
+
+
+# ----------------------------------------------------------------------------- renderer
+def ray_dist(opt, loc_p, ray_valid):
+    """neural_points_volumetric_model.py:271-279."""
+    vs2 = float(opt.vsize[2])
+    z = torch.cummax(loc_p[..., 2], dim=-1)[0]
+    d = torch.cat([z[..., 1:] - z[..., :-1], torch.full(z.shape[:2] + (1,), vs2)], dim=-1)
+    m = d < 1e-8
+    if opt.raydist_mode_unit > 0:
+        m = m | (d > 2 * vs2)
+    m = m.float()
+    d = d * (1.0 - m) + m * vs2
+    return d * ray_valid.float()
+
+
+def ray_march(rdist, ray_valid, feats, bg_color=None):
+    """diff_ray_marching.py:508-554 with radiance_render / alpha_blend."""
+    rgb = feats[..., 1:4]
+    sigma = feats[..., 0] * ray_valid.float()
+    opacity = 1 - torch.exp(-sigma * rdist)
+    acc = torch.cumprod(1.0 - opacity + 1e-10, dim=-1)
+    bg_t = acc[:, :, [-1]]
+    acc = torch.cat([torch.ones_like(acc[:, :, :1]), acc[:, :, :-1]], dim=-1)
+    bw = (opacity * acc)[..., None]
+    color = (rgb * bw).sum(dim=-2)
+    if bg_color is not None:
+        color = color + bg_color.float().view(bg_t.shape[0], 1, 3) * bg_t
+    return color, rgb, opacity, acc, bw, bg_t
+
+
+def render(opt, points, mlp, inp, impl="oracle", q=None, nthreads=1):
+    """NeuralPointsRayMarching.forward (neural_points_volumetric_model.py:252-329) on CPU.
+    points: dict xyz [N,3], points_embeding [1,N,F], points_conf [1,N,1], points_dir/color [1,N,3]."""
+    if q is None:
+        with torch.no_grad():
+            q = query(opt, points["xyz"].detach(), inp, impl=impl, nthreads=nthreads)
+    camrot, campos = inp["camrotc2w"][0], inp["campos"][0]
+    nb = gather_neighbors(points, q["sample_pidx"], camrot, campos)
+    feats, ray_valid, w, conf_c = aggregate(opt, mlp, nb, q["sample_loc"], q["sample_loc_w"], q["sample_ray_dirs"])
+    rd = ray_dist(opt, q["sample_loc"], ray_valid)
+    color, _, opacity, acc, bw, bg_t = ray_march(rd, ray_valid, feats, inp["bg_color"])
+    return dict(coarse_raycolor=color, coarse_point_opacity=opacity, coarse_is_background=bg_t,
+                ray_mask=q["ray_mask"], weight=w, blend_weight=bw, conf_coefficient=conf_c,
+                decoded_features=feats, ray_valid=ray_valid, ray_dist=rd, query=q,
+                queried_shading=torch.logical_not(ray_valid.any(dim=-1, keepdim=True)).repeat(1, 1, 3).float())
+
+
+def fill_invalid(out, inp):
+    """neural_points_volumetric_model.py:87-123: scatter the R'' hit rays back to all R rays."""
+    mask = out["ray_mask"][0] > 0
+    R = mask.numel()
+    bgt = torch.ones(1, R, 1); bgt[0, mask] = out["coarse_is_background"][0]
+    col = (torch.ones(1, R, 3) * inp["bg_color"][None]).clone(); col[0, mask] = out["coarse_raycolor"][0]
+    op = torch.zeros(1, R, out["coarse_point_opacity"].shape[2]); op[0, mask] = out["coarse_point_opacity"][0]
+    return dict(coarse_raycolor=col, coarse_is_background=bgt, coarse_mask=1 - bgt, coarse_point_opacity=op)
+
+
+def training_loss(opt, out, inp, zero_epsilon=1e-3):
+    """base_rendering_model.py:543-551 (ray_masked_coarse_raycolor, weight 1.0 + 1e-6) and :630-641
+    (zero_one on conf_coefficient, weight opt.zero_one_loss_weights[0])."""
+    mask = out["ray_mask"][0] > 0
+    gt = inp["gt_image"][0][mask]
+    pred = out["coarse_raycolor"][0]
+    loss = F.mse_loss(pred, gt) if pred.shape[0] > 0 else torch.tensor(0.0)
+    total = loss * 1.0 + 1e-6
+    if "conf_coefficient" in opt.zero_one_loss_items and out["conf_coefficient"] is not None:
+        v = out["conf_coefficient"].clamp(zero_epsilon, 1 - zero_epsilon)
+        total = total + torch.mean(torch.log(v) + torch.log(1 - v)) * opt.zero_one_loss_weights[0]
+    return total
+
+
+def to_torch_inputs(d):
+    return {k: (torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v) for k, v in d.items()}

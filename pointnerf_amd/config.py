@@ -1,0 +1,79 @@
+"""Option namespaces for the hot path.
+
+The reference has no config files: every run is a shell script with ~130 flags
+(``dev_scripts/w_n360/lego_cuda.sh:1-291``).  The hot path reads only a few dozen of
+them from the mutable ``opt`` namespace at call time.  ``lego_opt`` reproduces exactly the
+values of ``lego_cuda.sh`` for those flags (line numbers beside each), so that modules
+built from it have the same shapes/state_dict keys as a reference checkpoint of that run.
+"""
+from argparse import Namespace
+
+
+def lego_opt(**overrides):
+    opt = Namespace(
+        # --- query (neural_points.py flags; lego_cuda.sh:48-63) ---
+        vsize=[0.004, 0.004, 0.004],          # :55
+        vscale=[2, 2, 2],                      # :52
+        kernel_size=[3, 3, 3],                 # :53
+        query_size=[3, 3, 3],                  # :54
+        ranges=[-0.638, -1.141, -0.346, 0.634, 1.149, 1.141],   # :59
+        z_depth_dim=400,                       # :57
+        max_o=830000,                          # :58
+        SR=80, K=8, P=9, NN=2,                 # :60-63
+        radius_limit_scale=4,                  # :48
+        depth_limit_scale=0,
+        inverse=0,
+        wcoord_query=-1,                       # :56
+        gpu_maxthr=1024,
+        is_train=0,
+        load_points=1,
+        xyz_grad=0, feat_grad=1, conf_grad=1, dir_grad=1, color_grad=1,   # :12-15
+        point_features_dim=32,                 # :72
+        point_conf_mode="1", point_dir_mode="1", point_color_mode="1",   # :37-39
+        # --- aggregator (point_aggregators.py flags; lego_cuda.sh:41-85) ---
+        which_agg_model="viewmlp",
+        agg_distance_kernel="linear",          # :68
+        agg_axis_weight=None,                  # " 1. 1. 1." takes the same branch (point_aggregators.py:424)
+        agg_dist_pers=20,                      # :47
+        agg_intrp_order=2,                     # :67
+        agg_weight_norm=1,
+        apply_pnt_mask=1,
+        act_type="LeakyReLU",                  # :65
+        act_super=1,
+        shading_feature_mlp_layer0=1, shading_feature_mlp_layer1=2,
+        shading_feature_mlp_layer2=0, shading_feature_mlp_layer3=2,      # :77-80
+        shading_alpha_mlp_layer=1, shading_color_mlp_layer=4,            # :81-82
+        shading_feature_num=256,               # :83
+        shading_color_channel_num=3,
+        point_hyper_dim=256,
+        dist_xyz_freq=5, num_feat_freqs=3, dist_xyz_deno=0,              # :84-86
+        num_pos_freqs=10, num_viewdir_freqs=4, view_ori=0,               # :104-105
+        agg_feat_xyz_mode="None", agg_alpha_xyz_mode="None", agg_color_xyz_mode="None",   # :41-43
+        weight_xyz_freq=2, weight_feat_dim=8, sh_degree=4,
+        # --- renderer / model shell ---
+        raydist_mode_unit=1,                   # :89
+        which_render_func="radiance", which_blend_func="alpha", which_tonemap_func="off",   # :99-101
+        near_plane=2.0, far_plane=6.0,         # :93-94
+        sparse_loss_weight=0,                  # :146
+        zero_one_loss_items="conf_coefficient",   # :144
+        zero_one_loss_weights=[0.0001],
+        prob=0,
+        lr=0.0005, plr=0.002,                  # :112-113
+    )
+    for k, v in overrides.items():
+        setattr(opt, k, v)
+    return opt
+
+
+def chair_opt(**overrides):
+    """BASELINE.json configs[0]: chair_cuda.sh values (ranges :57, P :60, max_o :56), K=4, SR=32."""
+    kw = dict(ranges=[-0.721, -0.695, -0.995, 0.658, 0.706, 1.050], P=12, max_o=410000, K=4, SR=32)
+    kw.update(overrides)
+    return lego_opt(**kw)
+
+
+def bench_lego_opt(**overrides):
+    """BASELINE.json configs[1]: lego script values with the benchmark's SR=128, K=8."""
+    kw = dict(SR=128, K=8)
+    kw.update(overrides)
+    return lego_opt(**kw)

@@ -1,0 +1,91 @@
+"""Generate tests/golden/*.npz from the REFERENCE's own Python modules (run in the authoring
+container only, where /root/reference exists; the GPU box just reads the committed .npz).
+
+    python tests/golden/make_golden.py
+
+What is pinned (the reference has no tests or golden vectors of its own):
+  * models/aggregators/point_aggregators.py  PointAggregator(lego flags).forward   -> agg_*.npz
+  * models/rendering/diff_ray_marching.py    ray_march, near_far_linear_ray_generation
+  * models/helpers/networks.py               positional_encoding
+  * gradients of a fixed scalar of the rendered colour w.r.t. the MLP weights and the point
+    tensors, through the reference modules (torch.autograd)
+Inputs are NOT stored: they are regenerated from seeds by pointnerf_amd/scenes.py,
+oracle/pyref.init_mlp_params and the C oracle query, all deterministic.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(1, os.path.join(ROOT, "tests"))
+sys.path.insert(2, "/root/reference")
+
+from pointnerf_amd import config, scenes          # noqa: E402
+from oracle import pyref                           # noqa: E402
+from cases import CASES, build_case, probe_scalar   # noqa: E402
+
+from models.aggregators.point_aggregators import PointAggregator          # noqa: E402  (reference)
+from models.rendering.diff_ray_marching import ray_march, near_far_linear_ray_generation   # noqa: E402
+from models.rendering.diff_render_func import find_render_function, find_blend_function   # noqa: E402
+from models.helpers.networks import positional_encoding                   # noqa: E402
+
+
+def ref_opt(opt):
+    """The reference's own argparse defaults, overridden by our namespace's values."""
+    p = argparse.ArgumentParser()
+    PointAggregator.modify_commandline_options(p, True)
+    ro = p.parse_args([])
+    for k, v in vars(opt).items():
+        setattr(ro, k, v)
+    ro.agg_axis_weight = None      # a non-None value is put on "cuda" (point_aggregators.py:247); same branch
+    return ro
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+    for name in CASES:
+        opt, xyz, attrs, inp, mlp = build_case(name)
+        q = pyref.query(opt, xyz, inp)
+        points = dict(xyz=xyz, **{k: v.clone().requires_grad_(True) for k, v in attrs.items()})
+        agg = PointAggregator(ref_opt(opt))
+        agg.load_state_dict(mlp, strict=True)
+        nb = pyref.gather_neighbors(points, q["sample_pidx"], inp["camrotc2w"][0], inp["campos"][0])
+        out, ray_valid, weight, conf_c = agg(nb["color"], torch.eye(3), nb["dir"], nb["conf"], nb["emb"],
+                                             nb["xyz_pers"], nb["xyz"], nb["mask"], q["sample_loc"],
+                                             q["sample_loc_w"], q["sample_ray_dirs"], q["hp"]["vsize"], 0)
+        rd = pyref.ray_dist(opt, q["sample_loc"], ray_valid)
+        color, _, opacity, acc, bw, bg_t, _ = ray_march(rd, ray_valid, out, find_render_function("radiance"),
+                                                        find_blend_function("alpha"), inp["bg_color"])
+        scalar = probe_scalar(color, conf_c)
+        scalar.backward()
+        sd = dict(agg.named_parameters())
+        fix = dict(output=out.detach().numpy(), ray_valid=ray_valid.numpy(), weight=weight.detach().numpy(),
+                   conf_coefficient=conf_c.detach().numpy(), ray_color=color.detach().numpy(),
+                   opacity=opacity.detach().numpy(), bg_transmission=bg_t.detach().numpy(),
+                   blend_weight=bw.detach().numpy(), scalar=np.float64(scalar.item()))
+        for k, p in sd.items():
+            fix["grad_mlp." + k] = p.grad.flatten()[::7].numpy().copy()
+            fix["gradnorm_mlp." + k] = np.float64(p.grad.double().norm().item())
+        for k in ("points_embeding", "points_conf", "points_color", "points_dir"):
+            fix["grad_pts." + k] = points[k].grad.numpy()
+        np.savez_compressed(os.path.join(HERE, "agg_%s.npz" % name), **fix)
+        print(name, "rays", out.shape[1], "valid samples", int(ray_valid.sum()), "rows", int(nb["mask"].sum()),
+              "scalar", scalar.item())
+
+    # ray generation + positional encoding known answers
+    inp = pyref.to_torch_inputs(scenes.block_rays(size=4))
+    raypos, seg, _, mid = near_far_linear_ray_generation(inp["campos"], inp["raydir"], 400, near=2.0, far=6.0, jitter=0.0)
+    x = torch.linspace(-2.0, 2.0, 15).view(5, 3)
+    np.savez_compressed(os.path.join(HERE, "raygen_pe.npz"), raypos=raypos.numpy(), mid=mid[0, 0].numpy(),
+                        pe5=positional_encoding(x, 5).numpy(), pe4_ori=positional_encoding(x, 4, ori=True).numpy())
+    print("raygen_pe ok")
+
+
+if __name__ == "__main__":
+    main()
