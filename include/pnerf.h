@@ -1,0 +1,174 @@
+/*
+ * pnerf.h -- C ABI of libpnerf_hip.so, the MI355X (gfx950) implementation of the Point-NeRF
+ * render/optimise hot path.
+ *
+ * Conventions
+ *   - every pointer named d_* is DEVICE memory owned by the caller (contiguous, 16-byte aligned);
+ *     the library never allocates or frees device memory: sizes of scratch areas are returned by
+ *     the *_bytes() queries and the caller (torch's caching allocator in the Python host) provides
+ *     them;
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it (no host
+ *     synchronisation) unless its comment says "synchronous";
+ *   - return value: 0 = ok, <0 = PNERF_E_* (nothing was enqueued);
+ *   - not thread-safe per stream, re-entrant across streams.
+ *
+ * Each entry point cites the reference interface it replaces (paths under /root/reference).
+ */
+#ifndef PNERF_H
+#define PNERF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNERF_E_INVAL   (-1)   /* bad argument (null pointer, K/SR/P out of range, ...) */
+#define PNERF_E_WS      (-2)   /* workspace too small */
+#define PNERF_E_LAUNCH  (-3)   /* hipGetLastError() != hipSuccess after a launch */
+#define PNERF_E_UNSUP   (-4)   /* configuration not supported by this build */
+
+#define PNERF_MAX_K 16
+
+/* Grid description: what lighting_fast_querier.get_hyperparameters computes per call
+ * (models/neural_points/point_query.py:47-71) plus the querier constants of :35-42. */
+typedef struct pnerf_grid_params {
+    float ranges[6];       /* padded min xyz [0..2] / max xyz [3..5]  (ranges_tensor) */
+    float vsize[3];        /* scaled voxel size = vsize * vscale       (scaled_vsize)  */
+    int32_t vdim[3];       /* grid dimensions                          (scaled_vdim)   */
+    int32_t kernel_size[3];/* neighbor search window (layers = (ks[0]+1)/2) */
+    int32_t query_size[3]; /* occupancy dilation window */
+    int32_t P;             /* max points per voxel */
+    int32_t max_o;         /* max occupied voxels (overflow is reported, see pnerf_grid_info) */
+    float radius;          /* radius_limit (0 disables the radius test) */
+} pnerf_grid_params;
+
+/* info words written by pnerf_grid_build at the start of the grid workspace */
+enum { PNERF_GI_N_IN_GRID = 0, PNERF_GI_N_OCC = 1, PNERF_GI_MAX_CNT = 2, PNERF_GI_CELL0 = 3,
+       PNERF_GI_FIRST_IDX = 4, PNERF_GI_LEN = 8 };
+
+/* ---- library ---------------------------------------------------------------------------- */
+int pnerf_version(void);                 /* 1000*major + minor */
+const char *pnerf_arch(void);            /* "gfx950" */
+
+/* ---- voxel grid (replaces claim_occ / map_coor2occ / fill_occ2pnts and their ~140 MB of
+ * per-call tables: models/neural_points/cuda/query_worldcoords.cu:18-162, host :308-365).
+ * Deterministic by construction: points of a cell are stored in ascending point index (the
+ * reference's canonical serial order), the dilated occupancy is a bit field.  The grid is a
+ * function of (xyz, params) only and is meant to be cached across calls by the host. */
+size_t pnerf_grid_workspace_bytes(const pnerf_grid_params *gp, int n_points);
+int pnerf_grid_build(const pnerf_grid_params *gp, const float *d_xyz, int n_points,
+                     void *d_grid_ws, size_t ws_bytes, void *stream);
+/* synchronous: copies the PNERF_GI_* words to host_info[PNERF_GI_LEN] (stream is synchronised) */
+int pnerf_grid_info(const void *d_grid_ws, int32_t *host_info, void *stream);
+
+/* ---- query (replaces mask_raypos / get_shadingloc / query_neigh_along_ray_layered and the ATen
+ * glue between them: query_worldcoords.cu:165-302, host :367-431; entry point
+ * woord_query_grid_point_index, query_worldcoords.cpp:34-82).
+ *
+ * Ray samples come either from d_raypos [R,D,3] (the native op's own input) or -- fused, never
+ * materialised -- from campos + raydir * mid[d] with the D mid-point depths d_mid computed by the
+ * host exactly as near_far_linear_ray_generation does (models/rendering/diff_ray_marching.py:369-392).
+ * If jitter > 0 (training: point_query.py:81 uses 0.3) segment lengths are perturbed in-kernel by a
+ * counter-based RNG keyed on (seed, ray, d); near/far are then required.
+ *
+ * Outputs are DENSE OVER ALL R RAYS (no host sync, no compaction):
+ *   d_sample_loc  [R,SR,3] f32   world position of the first <=SR occupied samples, 0 elsewhere
+ *   d_sample_pidx [R,SR,K] i32   neighbor point indices in the reference's slot order, -1 padded
+ *   d_sample_nn   [R,SR]   i32   number of valid neighbors of each sample (0 for empty slots)
+ *   d_ray_hit     [R]      i32   1 if the ray has at least one sample with a neighbor
+ *   d_valid_list  [R*SR]   i32   ascending list of r*SR+s with nn>0 (the aggregator's work list)
+ *   d_counters    [8]      i32   [0]=#valid samples (len of d_valid_list) [1]=#rays hit
+ *                                [2]=#selected samples [3]=#valid neighbor slots
+ * The reference's [R'',...] outputs are row gathers of these by d_ray_hit (done by the host). */
+size_t pnerf_query_workspace_bytes(int R, int SR);
+int pnerf_query(const pnerf_grid_params *gp, const void *d_grid_ws,
+                const float *d_raypos,                       /* [R,D,3] or NULL */
+                const float *campos3_host, const float *d_raydir, const float *d_mid,   /* used if d_raypos==NULL */
+                float near_depth, float far_depth, float jitter, uint64_t seed,
+                int R, int D, int SR, int K,
+                float *d_sample_loc, int32_t *d_sample_pidx, int32_t *d_sample_nn,
+                int32_t *d_ray_hit, int32_t *d_valid_list, int32_t *d_counters,
+                void *d_query_ws, size_t ws_bytes, void *stream);
+
+/* ---- per-neighbor gather (NeuralPoints.forward's index_select block,
+ * models/neural_points/neural_points.py:706-717) and its backward scatter-add.  Row i of each
+ * output holds point max(idx[i],0): -1 slots read point 0 exactly as the reference does. */
+int pnerf_gather_rows(const float *d_src, int n_src, int width, const int32_t *d_idx, int64_t n_idx,
+                      float *d_dst, void *stream);
+int pnerf_scatter_add_rows(const float *d_grad_rows, const int32_t *d_idx, int64_t n_idx, int width,
+                           float *d_grad_src, int n_src, void *stream);
+
+/* ---- aggregator MLP + renderer (PointAggregator.forward/viewmlp,
+ * models/aggregators/point_aggregators.py:488-644,727-814; ray-dist,
+ * models/neural_points_volumetric_model.py:271-279; ray_march,
+ * models/rendering/diff_ray_marching.py:508-554).  Lego-script architecture only:
+ * 284->256->256, (+7)->256->256, alpha 256->1, colour 280->128->128->128->3, LeakyReLU(0.01),
+ * linear distance kernel, agg_dist_pers=20, agg_intrp_order=2.                                   */
+
+/* Offsets (in floats) of each tensor inside the flat MLP parameter / gradient vector, in the
+ * reference's state_dict order: block1.0.{weight,bias}, block1.2.*, block3.0.*, block3.2.*,
+ * alpha_branch.0.*, color_branch.{0,2,4,6}.* ; every weight is [out,in] row-major (torch layout). */
+#define PNERF_MLP_NTENSORS 18
+int pnerf_mlp_layout(int feat_dim, int64_t *offsets /*[PNERF_MLP_NTENSORS+1]*/);
+size_t pnerf_mlp_packed_bytes(void);
+/* repack the flat parameter vector into MFMA fragment order (forward and dgrad images) */
+int pnerf_mlp_pack(const float *d_params, void *d_packed, void *stream);
+
+typedef struct pnerf_camera {
+    float campos[3];
+    float camrot[9];       /* c2w rotation, row-major */
+    float rw2c[9];         /* NeuralPoints.Rw2c, row-major (identity unless normview) */
+    float vsize_z;         /* unscaled opt.vsize[2] (ray-dist clamp) */
+    int32_t raydist_mode_unit;
+    float bg[3];           /* background colour */
+    int32_t has_bg;
+} pnerf_camera;
+
+typedef struct pnerf_points {        /* the neural point cloud, all [N,*] row-major f32 */
+    const float *xyz;                /* [N,3]  */
+    const float *embedding;          /* [N,F]  */
+    const float *conf;               /* [N,1]  */
+    const float *dir;                /* [N,3]  */
+    const float *color;              /* [N,3]  */
+    int32_t n, feat_dim;
+} pnerf_points;
+
+typedef struct pnerf_point_grads {   /* gradient accumulators (added to, never zeroed) */
+    float *embedding, *conf, *dir, *color;
+} pnerf_point_grads;
+
+/* bytes of saved activations per valid neighbor row / per valid sample (training forward) */
+size_t pnerf_agg_saved_bytes(int64_t n_valid_samples, int K);
+size_t pnerf_agg_workspace_bytes(int R, int SR, int K);
+
+/* Forward: for every valid sample in d_valid_list computes (sigma, r, g, b) into
+ * d_decoded [R,SR,4] (zero elsewhere), d_weight [R,SR,K] (normalised distance weights, before
+ * confidence), then ray-dist + alpha compositing into d_ray_color [R,3], d_opacity [R,SR],
+ * d_bg_trans [R], d_blend_w [R,SR].  d_saved != NULL keeps the activations needed by
+ * pnerf_render_backward (n_valid_max = capacity of d_saved in samples). */
+int pnerf_render_forward(const pnerf_camera *cam, const pnerf_points *pts, const void *d_packed_mlp,
+                         const float *d_raydir, const float *d_sample_loc, const int32_t *d_sample_pidx,
+                         const int32_t *d_sample_nn, const int32_t *d_valid_list, const int32_t *d_counters,
+                         int R, int SR, int K,
+                         float *d_decoded, float *d_weight, float *d_ray_color, float *d_opacity,
+                         float *d_bg_trans, float *d_blend_w,
+                         void *d_saved, int64_t n_valid_max, void *d_ws, size_t ws_bytes, void *stream);
+
+/* Backward of pnerf_render_forward for dL/d(ray_color) = d_grad_ray_color [R,3]:
+ * accumulates dL/d(MLP params) into d_grad_params (flat, pnerf_mlp_layout order) and
+ * dL/d(point tensors) into pg.  n_valid = host copy of d_counters[0]. */
+int pnerf_render_backward(const pnerf_camera *cam, const pnerf_points *pts, const void *d_packed_mlp,
+                          const float *d_params,
+                          const float *d_raydir, const float *d_sample_loc, const int32_t *d_sample_pidx,
+                          const int32_t *d_sample_nn, const int32_t *d_valid_list, const int32_t *d_counters,
+                          int R, int SR, int K, int64_t n_valid,
+                          const float *d_decoded, const float *d_weight, const float *d_opacity,
+                          const float *d_grad_ray_color,
+                          void *d_saved, float *d_grad_params, const pnerf_point_grads *pg,
+                          void *d_ws, size_t ws_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNERF_H */

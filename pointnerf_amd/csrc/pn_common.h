@@ -1,0 +1,62 @@
+// pn_common.h -- shared host/device helpers of libpnerf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "pnerf.h"
+
+#define PN_WAVE 64
+
+#define PN_CHECK_LAUNCH()                                         \
+    do {                                                          \
+        if (hipGetLastError() != hipSuccess) return PNERF_E_LAUNCH; \
+    } while (0)
+
+static inline size_t pn_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline int pn_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// simple bump carver over a caller-provided workspace
+struct PnCarver {
+    char *base; size_t off, cap;
+    PnCarver(void *p, size_t c) : base((char *)p), off(0), cap(c) {}
+    template <class T> T *take(size_t n) {
+        T *r = (T *)(base + off);
+        off += pn_align(n * sizeof(T));
+        return r;
+    }
+    bool ok() const { return off <= cap; }
+};
+
+// ---- scan / compaction primitives (scan.hip) ----------------------------------------------
+// scratch needed (ints) for n elements
+size_t pn_scan_scratch_ints(long long n);
+// out[i] = sum_{j<i} in[j]; out[n] = total (out has n+1 entries; may not alias in)
+int pn_exclusive_scan_i32(const int *in, int *out, long long n, int *scratch, hipStream_t s);
+// list = ascending indices i with in[i] > 0 ; *count_out = their number
+int pn_compact_gt0_i32(const int *in, long long n, int *list, int *count_out, int *scratch, hipStream_t s);
+
+// ---- device view of the voxel grid (grid.hip builds it, query.hip walks it) ----------------
+struct PnGridDev {
+    float ox, oy, oz;        // grid origin (ranges[0..2])
+    float vx, vy, vz;        // scaled voxel size
+    int gx, gy, gz;          // dims
+    int P;
+    const int *info;         // PNERF_GI_* words
+    const int *cell_start;   // [G+1] CSR offsets into pts
+    const uint32_t *occ;     // [(G+31)/32] dilated occupancy bits
+    const float4 *pts;       // [n_in_grid] (x,y,z,bitcast idx) sorted by (cell, idx)
+};
+
+struct PnGridLayout {       // byte offsets inside the grid workspace
+    size_t info, cell_start, occ, pts, keys, cursor, tmp_idx, scan, total;
+    long long G;
+};
+PnGridLayout pn_grid_layout(const pnerf_grid_params *gp, int n);
+PnGridDev pn_grid_dev(const pnerf_grid_params *gp, const void *ws, int n_unused);
+
+// cell coordinate exactly as the reference computes it (query_worldcoords.cu:38-40):
+// fp32 subtract, IEEE fp32 divide (hipcc's default correctly-rounded division), floor.
+// Files using this are compiled with -ffp-contract=off.
+__device__ __forceinline__ int pn_cell(float p, float o, float v) {
+    return (int)floorf((p - o) / v);
+}

@@ -1,0 +1,222 @@
+// query.hip -- ray probe + shading-sample selection + radius-limited layered K-neighbor query.
+//
+// Replaces mask_raypos, the two ATen compactions, get_shadingloc and
+// query_neigh_along_ray_layered (models/neural_points/cuda/query_worldcoords.cu:165-302, host
+// :367-431).  Differences in HOW (results are bit-identical to the reference's canonical serial
+// execution):
+//   * k_probe: one 64-lane wavefront per ray walks the D depth samples in 64-wide strides; the
+//     occupancy test is one bit in a ~1 MB L2-resident field; __ballot + popcount gives each hit its
+//     slot, so the [R,D,3] sample array, the [R,D] mask, its cumsum and both masked_select copies of
+//     the reference never exist, and the walk stops as soon as SR samples are found.
+//   * k_neighbors: one thread per selected sample, the reference's exact sequential top-K insertion
+//     (needed for bit-exact slot order), but candidates come from contiguous float4 records of the
+//     CSR grid (one 16 B load per candidate instead of cell->occ->count->pidx->xyz chains), the
+//     K-buffer lives in registers, and all 64 lanes of a wave belong to the same ray.
+//   * no device->host sync anywhere: ray compaction is replaced by dense [R,...] outputs plus a
+//     device-built work list of the valid samples.
+// Compiled with -ffp-contract=off (cell arithmetic and squared distances must round like the
+// reference: left-to-right fp32, no FMA).
+#include "pn_common.h"
+
+namespace {
+constexpr int TPB = 256;
+
+struct RayGen {            // how sample positions are produced
+    const float *raypos;   // [R,D,3] or null
+    const float *raydir;   // [R,3]
+    const float *mid;      // [D] mid depths (jitter==0) or base segment lengths (jitter>0)
+    float cx, cy, cz;      // campos
+    float near_d, jitter;
+    unsigned long long seed;
+};
+
+__device__ __forceinline__ float pn_uniform(unsigned long long seed, unsigned long long ctr) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ bool pn_occupied(const PnGridDev &g, float x, float y, float z) {
+    int cx = pn_cell(x, g.ox, g.vx), cy = pn_cell(y, g.oy, g.vy), cz = pn_cell(z, g.oz, g.vz);
+    if (cx < 0 || cx >= g.gx || cy < 0 || cy >= g.gy || cz < 0 || cz >= g.gz) return false;
+    int lin = cx * (g.gy * g.gz) + cy * g.gz + cz;
+    return (g.occ[lin >> 5] >> (lin & 31)) & 1u;
+}
+
+// one wavefront per ray
+template <bool FROM_RAYPOS, bool JITTER>
+__global__ __launch_bounds__(TPB) void k_probe(PnGridDev g, RayGen rg, int R, int D, int SR,
+                                               float *__restrict__ sample_loc, int *__restrict__ sel_cnt) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (!FROM_RAYPOS) { dx = rg.raydir[3 * r]; dy = rg.raydir[3 * r + 1]; dz = rg.raydir[3 * r + 2]; }
+    float *out = sample_loc + (size_t)r * SR * 3;
+    int count = 0;
+    float carry = 0.f;   // JITTER: running sum of segment lengths
+    for (int base = 0; base < D && count < SR; base += 64) {
+        const int d = base + lane;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        bool hit = false;
+        if (JITTER) {
+            float seg = 0.f;
+            if (d < D) seg = rg.mid[d] * (1.0f + rg.jitter * (pn_uniform(rg.seed, (unsigned long long)r * D + d) - 0.5f));
+            float inc = seg;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                float y = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += y;
+            }
+            float e1 = rg.near_d + (carry + inc), e0 = rg.near_d + (carry + (inc - seg));
+            carry += __shfl(inc, 63, 64);
+            if (d < D) {
+                float t = (e0 + e1) * 0.5f;
+                px = rg.cx + dx * t; py = rg.cy + dy * t; pz = rg.cz + dz * t;
+                hit = pn_occupied(g, px, py, pz);
+            }
+        } else if (d < D) {
+            if (FROM_RAYPOS) {
+                const float *p = rg.raypos + ((size_t)r * D + d) * 3;
+                px = p[0]; py = p[1]; pz = p[2];
+            } else {
+                // raypos = campos + raydir * mid: separate multiply and add (diff_ray_marching.py:385)
+                float t = rg.mid[d];
+                px = rg.cx + dx * t; py = rg.cy + dy * t; pz = rg.cz + dz * t;
+            }
+            hit = pn_occupied(g, px, py, pz);
+        }
+        unsigned long long b = __ballot(hit);
+        int slot = count + __popcll(b & ((1ull << lane) - 1ull));
+        if (hit && slot < SR) { out[3 * slot] = px; out[3 * slot + 1] = py; out[3 * slot + 2] = pz; }
+        count += __popcll(b);
+    }
+    if (count > SR) count = SR;
+    for (int s = count + lane; s < SR; s += 64) { out[3 * s] = 0.f; out[3 * s + 1] = 0.f; out[3 * s + 2] = 0.f; }
+    if (lane == 0) sel_cnt[r] = count;
+}
+
+// one thread per (ray, slot)
+template <int KMAX>
+__global__ __launch_bounds__(TPB) void k_neighbors(PnGridDev g, int ks0, float radius2, long long total, int SR, int K,
+                                                   const float *__restrict__ sample_loc, const int *__restrict__ sel_cnt,
+                                                   int *__restrict__ sample_pidx, int *__restrict__ sample_nn) {
+    const long long index = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (index >= total) return;
+    const int r = (int)(index / SR), s = (int)(index - (long long)r * SR);
+    int out[KMAX];
+    float buf[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) { out[j] = -1; buf[j] = 0.f; }
+    int kid = 0;
+    if (s < sel_cnt[r]) {
+        const float cx = sample_loc[index * 3], cy = sample_loc[index * 3 + 1], cz = sample_loc[index * 3 + 2];
+        const int fx = pn_cell(cx, g.ox, g.vx), fy = pn_cell(cy, g.oy, g.vy), fz = pn_cell(cz, g.oz, g.vz);
+        const int cell0 = g.info[PNERF_GI_CELL0];
+        const int gyz = g.gy * g.gz;
+        int far_ind = 0;
+        float far2 = 0.f;
+        const int nlayer = (ks0 + 1) / 2;
+        for (int layer = 0; layer < nlayer; ++layer) {
+            for (int x = max(-fx, -layer); x < min(g.gx - fx, layer + 1); ++x) {
+                for (int y = max(-fy, -layer); y < min(g.gy - fy, layer + 1); ++y) {
+                    for (int z = max(-fz, -layer); z < min(g.gz - fz, layer + 1); ++z) {
+                        if (max(abs(z), max(abs(x), abs(y))) != layer) continue;
+                        const int lin = (fx + x) * gyz + (fy + y) * g.gz + (fz + z);
+                        if (lin == cell0) continue;            // reference: voxel id 0 holds no points (.cu:147)
+                        const int st = g.cell_start[lin];
+                        const int n = min(g.P, g.cell_start[lin + 1] - st);
+                        for (int gi = 0; gi < n; ++gi) {
+                            const float4 p = g.pts[st + gi];
+                            const float xv = p.x - cx, yv = p.y - cy, zv = p.z - cz;
+                            const float d2 = xv * xv + yv * yv + zv * zv;    // contract=off: ((xx+yy)+zz)
+                            if (radius2 == 0.f || d2 <= radius2) {
+                                const int pid = __float_as_int(p.w);
+                                if (kid < K) {
+#pragma unroll
+                                    for (int j = 0; j < KMAX; ++j) if (j == kid) { out[j] = pid; buf[j] = d2; }
+                                    if (d2 > far2) { far2 = d2; far_ind = kid; }
+                                } else if (d2 < far2) {
+#pragma unroll
+                                    for (int j = 0; j < KMAX; ++j) if (j == far_ind) { out[j] = pid; buf[j] = d2; }
+                                    far2 = d2;
+#pragma unroll
+                                    for (int j = 0; j < KMAX; ++j) if (j < K && buf[j] > far2) { far2 = buf[j]; far_ind = j; }
+                                }
+                                ++kid;
+                            }
+                        }
+                    }
+                }
+            }
+            if (kid >= K) break;
+        }
+    }
+    int *o = sample_pidx + index * K;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) if (j < K) o[j] = out[j];
+    sample_nn[index] = min(kid, K);
+}
+
+// one wavefront per ray: does the ray have any sample with a neighbor?  + global tallies
+__global__ __launch_bounds__(TPB) void k_ray_hit(int R, int SR, const int *__restrict__ sel_cnt, const int *__restrict__ sample_nn,
+                                                 int *__restrict__ ray_hit, int *__restrict__ counters) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    int nb = 0;
+    for (int s = lane; s < SR; s += 64) nb += sample_nn[(size_t)r * SR + s];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nb += __shfl_xor(nb, off, 64);
+    if (lane == 0) {
+        ray_hit[r] = nb > 0;
+        if (nb > 0) atomicAdd(&counters[1], 1);
+        atomicAdd(&counters[2], sel_cnt[r]);
+        atomicAdd(&counters[3], nb);
+    }
+}
+}  // namespace
+
+extern "C" size_t pnerf_query_workspace_bytes(int R, int SR) {
+    return pn_align((size_t)(R > 0 ? R : 1) * sizeof(int)) + pn_align(pn_scan_scratch_ints((long long)R * SR) * sizeof(int));
+}
+
+extern "C" int pnerf_query(const pnerf_grid_params *gp, const void *d_grid_ws, const float *d_raypos,
+                           const float *campos3_host, const float *d_raydir, const float *d_mid,
+                           float near_depth, float far_depth, float jitter, uint64_t seed,
+                           int R, int D, int SR, int K,
+                           float *d_sample_loc, int32_t *d_sample_pidx, int32_t *d_sample_nn,
+                           int32_t *d_ray_hit, int32_t *d_valid_list, int32_t *d_counters,
+                           void *d_query_ws, size_t ws_bytes, void *stream) {
+    (void)far_depth;
+    if (!gp || !d_grid_ws || R < 0 || D <= 0 || SR <= 0 || K <= 0 || K > PNERF_MAX_K) return PNERF_E_INVAL;
+    if (!d_sample_loc || !d_sample_pidx || !d_sample_nn || !d_ray_hit || !d_valid_list || !d_counters || !d_query_ws) return PNERF_E_INVAL;
+    if (!d_raypos && (!campos3_host || !d_raydir || !d_mid)) return PNERF_E_INVAL;
+    if (ws_bytes < pnerf_query_workspace_bytes(R, SR)) return PNERF_E_WS;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(d_counters, 0, 8 * sizeof(int), s) != hipSuccess) return PNERF_E_LAUNCH;
+    if (R == 0) return 0;
+    PnCarver cv(d_query_ws, ws_bytes);
+    int *sel_cnt = cv.take<int>(R);
+    int *scan = cv.take<int>(pn_scan_scratch_ints((long long)R * SR));
+    PnGridDev g = pn_grid_dev(gp, d_grid_ws, 0);
+    RayGen rg;
+    rg.raypos = d_raypos; rg.raydir = d_raydir; rg.mid = d_mid;
+    rg.cx = campos3_host ? campos3_host[0] : 0.f; rg.cy = campos3_host ? campos3_host[1] : 0.f; rg.cz = campos3_host ? campos3_host[2] : 0.f;
+    rg.near_d = near_depth; rg.jitter = jitter; rg.seed = seed;
+    const int wb = pn_cdiv(R, TPB / 64);
+    if (d_raypos) hipLaunchKernelGGL((k_probe<true, false>), dim3(wb), dim3(TPB), 0, s, g, rg, R, D, SR, d_sample_loc, sel_cnt);
+    else if (jitter > 0.f) hipLaunchKernelGGL((k_probe<false, true>), dim3(wb), dim3(TPB), 0, s, g, rg, R, D, SR, d_sample_loc, sel_cnt);
+    else hipLaunchKernelGGL((k_probe<false, false>), dim3(wb), dim3(TPB), 0, s, g, rg, R, D, SR, d_sample_loc, sel_cnt);
+    const long long total = (long long)R * SR;
+    const float radius2 = gp->radius * gp->radius;     // fp32 product, as .cu:410
+    const int nbk = pn_cdiv(total, TPB);
+    if (K <= 4) hipLaunchKernelGGL(k_neighbors<4>, dim3(nbk), dim3(TPB), 0, s, g, gp->kernel_size[0], radius2, total, SR, K, d_sample_loc, sel_cnt, d_sample_pidx, d_sample_nn);
+    else if (K <= 8) hipLaunchKernelGGL(k_neighbors<8>, dim3(nbk), dim3(TPB), 0, s, g, gp->kernel_size[0], radius2, total, SR, K, d_sample_loc, sel_cnt, d_sample_pidx, d_sample_nn);
+    else hipLaunchKernelGGL(k_neighbors<16>, dim3(nbk), dim3(TPB), 0, s, g, gp->kernel_size[0], radius2, total, SR, K, d_sample_loc, sel_cnt, d_sample_pidx, d_sample_nn);
+    hipLaunchKernelGGL(k_ray_hit, dim3(wb), dim3(TPB), 0, s, R, SR, sel_cnt, d_sample_nn, d_ray_hit, d_counters);
+    PN_CHECK_LAUNCH();
+    return pn_compact_gt0_i32(d_sample_nn, total, d_valid_list, d_counters, scan, s);
+}
