@@ -140,15 +140,18 @@ typedef struct pnerf_point_grads {   /* gradient accumulators (added to, never z
 
 /* bytes of saved activations per valid neighbor row / per valid sample (training forward) */
 size_t pnerf_agg_saved_bytes(int64_t n_valid_samples, int K);
-size_t pnerf_agg_workspace_bytes(int R, int SR, int K);
+size_t pnerf_agg_workspace_bytes(int64_t n_valid_max, int K);   /* inference scratch for n_valid_max valid samples */
+size_t pnerf_render_backward_workspace_bytes(int R, int SR);
 
 /* Forward: for every valid sample in d_valid_list computes (sigma, r, g, b) into
  * d_decoded [R,SR,4] (zero elsewhere), d_weight [R,SR,K] (normalised distance weights, before
  * confidence), then ray-dist + alpha compositing into d_ray_color [R,3], d_opacity [R,SR],
- * d_bg_trans [R], d_blend_w [R,SR].  d_saved != NULL keeps the activations needed by
- * pnerf_render_backward (n_valid_max = capacity of d_saved in samples). */
+ * d_bg_trans [R], d_blend_w [R,SR].  n_valid_max = capacity in valid samples (>= d_counters[0], which
+ * the host reads once per call to size its buffers).  Inference: d_saved == NULL and d_ws holds
+ * pnerf_agg_workspace_bytes(n_valid_max, K).  Training: d_saved holds pnerf_agg_saved_bytes(n_valid_max, K)
+ * and keeps the activations needed by pnerf_render_backward (which must get the same n_valid_max). */
 int pnerf_render_forward(const pnerf_camera *cam, const pnerf_points *pts, const void *d_packed_mlp,
-                         const float *d_raydir, const float *d_sample_loc, const int32_t *d_sample_pidx,
+                         const float *d_params, const float *d_raydir, const float *d_sample_loc, const int32_t *d_sample_pidx,
                          const int32_t *d_sample_nn, const int32_t *d_valid_list, const int32_t *d_counters,
                          int R, int SR, int K,
                          float *d_decoded, float *d_weight, float *d_ray_color, float *d_opacity,
@@ -157,7 +160,8 @@ int pnerf_render_forward(const pnerf_camera *cam, const pnerf_points *pts, const
 
 /* Backward of pnerf_render_forward for dL/d(ray_color) = d_grad_ray_color [R,3]:
  * accumulates dL/d(MLP params) into d_grad_params (flat, pnerf_mlp_layout order) and
- * dL/d(point tensors) into pg.  n_valid = host copy of d_counters[0]. */
+ * dL/d(point tensors) into pg.  n_valid = the n_valid_max given to the forward call;
+ * d_ws holds pnerf_render_backward_workspace_bytes(R, SR). */
 int pnerf_render_backward(const pnerf_camera *cam, const pnerf_points *pts, const void *d_packed_mlp,
                           const float *d_params,
                           const float *d_raydir, const float *d_sample_loc, const int32_t *d_sample_pidx,

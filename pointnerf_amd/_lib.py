@@ -54,16 +54,15 @@ PROTOTYPES = {
     "pnerf_query": (c_int, [ctypes.POINTER(GridParams), c_void_p, c_void_p, ctypes.POINTER(c_f32), c_void_p, c_void_p,
                             c_f32, c_f32, c_f32, ctypes.c_uint64, c_int, c_int, c_int, c_int,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-}
-PROTOTYPES_PENDING = {
     "pnerf_gather_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_i64, c_void_p, c_void_p]),
     "pnerf_scatter_add_rows": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_int, c_void_p]),
     "pnerf_mlp_layout": (c_int, [c_int, ctypes.POINTER(c_i64)]),
     "pnerf_mlp_packed_bytes": (c_size_t, []),
     "pnerf_mlp_pack": (c_int, [c_void_p, c_void_p, c_void_p]),
     "pnerf_agg_saved_bytes": (c_size_t, [c_i64, c_int]),
-    "pnerf_agg_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "pnerf_render_forward": (c_int, [ctypes.POINTER(Camera), ctypes.POINTER(Points), c_void_p,
+    "pnerf_agg_workspace_bytes": (c_size_t, [c_i64, c_int]),
+    "pnerf_render_backward_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "pnerf_render_forward": (c_int, [ctypes.POINTER(Camera), ctypes.POINTER(Points), c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

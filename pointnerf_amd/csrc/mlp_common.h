@@ -1,0 +1,150 @@
+// mlp_common.h -- layout of the aggregator MLP, its MFMA-fragment weight images, and the 64-row tile
+// GEMM built on v_mfma_f32_32x32x2_f32 (exact fp32: the 1e-4 parity bar on sigma/RGB against an fp32
+// reference rules out plain bf16 inputs; see DESIGN.md "precision").
+#pragma once
+#include "pn_common.h"
+
+// ---- architecture (reference viewmlp_init, models/aggregators/point_aggregators.py:276-348, lego flags)
+#define PN_F      32                 // point_features_dim
+#define PN_IN1    284                // 32 + 2*3*32 + 2*5*6
+#define PN_IN1P   288                // padded to a multiple of 8 (zero columns)
+#define PN_H      256                // shading_feature_num
+#define PN_IN3    263                // 256 + colour 3 + (dir - view) 3 + dir.view 1
+#define PN_INC    280                // 256 + view PE 24
+#define PN_HC     128
+#define PN_TILE   64                 // rows per GEMM tile (2 MFMA row tiles)
+
+// flat parameter vector (state_dict order, torch [out,in] row-major)
+enum : int {
+    PO_W1 = 0, PO_B1 = PO_W1 + PN_H * PN_IN1, PO_W2 = PO_B1 + PN_H, PO_B2 = PO_W2 + PN_H * PN_H,
+    PO_W3 = PO_B2 + PN_H, PO_B3 = PO_W3 + PN_H * PN_IN3, PO_W4 = PO_B3 + PN_H, PO_B4 = PO_W4 + PN_H * PN_H,
+    PO_W5 = PO_B4 + PN_H, PO_B5 = PO_W5 + PN_H, PO_WC1 = PO_B5 + 1, PO_BC1 = PO_WC1 + PN_HC * PN_INC,
+    PO_WC2 = PO_BC1 + PN_HC, PO_BC2 = PO_WC2 + PN_HC * PN_HC, PO_WC3 = PO_BC2 + PN_HC, PO_BC3 = PO_WC3 + PN_HC * PN_HC,
+    PO_WC4 = PO_BC3 + PN_HC, PO_BC4 = PO_WC4 + 3 * PN_HC, PO_TOTAL = PO_BC4 + 3
+};
+static_assert(PO_TOTAL == 341764, "parameter count of the lego-script aggregator");
+
+// packed images (float offsets).  An image of a B operand [Kpad x N] is stored as
+//   float4 img[c][w][ct][lane] ,  element i = B[8c + 4*(lane>>5) + i][w*NT*32 + ct*32 + (lane&31)]
+// i.e. exactly what lane `lane` of wave `w` feeds to 4 consecutive 32x32x2 MFMAs of column tile ct.
+enum : int {
+    PK_F1 = 0, PK_F2 = PK_F1 + PN_IN1P * PN_H, PK_F3 = PK_F2 + PN_H * PN_H, PK_F4 = PK_F3 + (PN_H + 8) * PN_H,
+    PK_C1 = PK_F4 + PN_H * PN_H, PK_C2 = PK_C1 + PN_INC * PN_HC, PK_C3 = PK_C2 + PN_HC * PN_HC,
+    PK_D4 = PK_C3 + PN_HC * PN_HC, PK_D3 = PK_D4 + PN_H * PN_H, PK_D2 = PK_D3 + PN_H * PN_H, PK_D1 = PK_D2 + PN_H * PN_H,
+    PK_DC3 = PK_D1 + PN_H * PN_H, PK_DC2 = PK_DC3 + PN_HC * PN_HC, PK_DC1 = PK_DC2 + PN_HC * PN_HC,
+    PK_TOTAL = PK_DC1 + PN_HC * PN_H
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float pn_lrelu(float v) { return v > 0.f ? v : 0.01f * v; }
+__device__ __forceinline__ float pn_lrelu_grad(float post) { return post > 0.f ? 1.f : 0.01f; }
+
+// C[64 x (4 waves * NT * 32)] += A[64 x 8*nchunks] * B   (A in LDS, row stride lda floats, lda % 4 == 0;
+// B = packed image).  Each wave owns NT column tiles x both row tiles.  K order inside a chunk is
+// {0,4},{1,5},{2,6},{3,7} (lanes 0-31 / 32-63), identical for A and B, so the sum is a permutation of the
+// textbook order.  One chunk is prefetched ahead (one wave per SIMD: the MFMA pipe is the only latency cover).
+template <int NT>
+__device__ __forceinline__ void pn_tile_gemm(const float *__restrict__ A, int lda, int nchunks,
+                                             const float4 *__restrict__ Wp, int wave, int lane, f32x16 (&acc)[2][NT]) {
+    const float *a0p = A + (lane & 31) * lda + 4 * (lane >> 5);
+    const float *a1p = a0p + 32 * lda;
+    const float4 *wp = Wp + (wave * NT) * 64 + lane;
+    float4 a0 = *reinterpret_cast<const float4 *>(a0p);
+    float4 a1 = *reinterpret_cast<const float4 *>(a1p);
+    float4 b[NT];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) b[ct] = wp[ct * 64];
+#pragma unroll 1
+    for (int c = 0; c < nchunks; ++c) {
+        float4 na0 = a0, na1 = a1, nb[NT];
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) nb[ct] = b[ct];
+        if (c + 1 < nchunks) {
+            na0 = *reinterpret_cast<const float4 *>(a0p + 8 * (c + 1));
+            na1 = *reinterpret_cast<const float4 *>(a1p + 8 * (c + 1));
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) nb[ct] = wp[((c + 1) * 4 * NT + ct) * 64];
+        }
+        const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                const float bv = i == 0 ? b[ct].x : (i == 1 ? b[ct].y : (i == 2 ? b[ct].z : b[ct].w));
+                acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[i], bv, acc[0][ct], 0, 0, 0);
+                acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[i], bv, acc[1][ct], 0, 0, 0);
+            }
+        }
+        a0 = na0; a1 = na1;
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) b[ct] = nb[ct];
+    }
+}
+
+// accumulator element (rt, ct, reg) of wave `wave` sits at row / col:
+__device__ __forceinline__ int pn_acc_row(int rt, int reg, int lane) { return rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+template <int NT> __device__ __forceinline__ int pn_acc_col(int wave, int ct, int lane) { return wave * NT * 32 + ct * 32 + (lane & 31); }
+
+template <int NT>
+__device__ __forceinline__ void pn_acc_init_bias(f32x16 (&acc)[2][NT], const float *__restrict__ bias, int wave, int lane) {
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+        const float bv = bias ? bias[pn_acc_col<NT>(wave, ct, lane)] : 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) { acc[0][ct][reg] = bv; acc[1][ct][reg] = bv; }
+    }
+}
+
+// Forward epilogue: LeakyReLU, write the tile to LDS (row stride ldh) and optionally to a saved
+// activation matrix in HBM (row stride ldg, rows g_row0 .. g_row0+63).
+template <int NT, bool SAVE>
+__device__ __forceinline__ void pn_store_act(f32x16 (&acc)[2][NT], float *__restrict__ H, int ldh,
+                                             float *__restrict__ G, int ldg, long long g_row0, int wave, int lane) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            const int col = pn_acc_col<NT>(wave, ct, lane);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = pn_acc_row(rt, reg, lane);
+                const float v = pn_lrelu(acc[rt][ct][reg]);
+                H[row * ldh + col] = v;
+                if (SAVE) G[(g_row0 + row) * ldg + col] = v;
+            }
+        }
+}
+
+// Backward epilogue: dY = dH (acc) * LeakyReLU'(saved post-activation), to LDS and to HBM.
+template <int NT>
+__device__ __forceinline__ void pn_store_dact(f32x16 (&acc)[2][NT], const float *__restrict__ Hsaved, int ldhs,
+                                              float *__restrict__ Dlds, int ldd, float *__restrict__ Dg, int ldg,
+                                              long long g_row0, int wave, int lane) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            const int col = pn_acc_col<NT>(wave, ct, lane);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = pn_acc_row(rt, reg, lane);
+                const float v = acc[rt][ct][reg] * pn_lrelu_grad(Hsaved[(g_row0 + row) * ldhs + col]);
+                Dlds[row * ldd + col] = v;
+                Dg[(g_row0 + row) * ldg + col] = v;
+            }
+        }
+}
+
+// ---- saved-activation area (training) -------------------------------------------------------
+struct PnSaved {
+    // per neighbor row (rows = row tiles * 64)
+    float *x0, *h1, *h2, *h3, *h4, *ex, *wrow, *dy1, *dy2, *dy3, *dy4;
+    // per valid sample (padded to colour tiles * 64)
+    float *fs, *pe, *c1, *c2, *c3, *dfs, *dc1, *dc2, *dc3;
+    long long rows, samples;
+};
+size_t pn_saved_bytes(long long n_valid, int K, long long *rows_out, long long *samples_out);
+PnSaved pn_saved_carve(void *base, long long n_valid, int K);
+
+__host__ __device__ inline int pn_tile_samples(int K) { return PN_TILE / K; }

@@ -1,0 +1,312 @@
+// render.hip -- ray-dist + alpha-composite volume renderer (forward and backward) and the C-ABI entry
+// points of the fused render path.
+//
+// Replaces the ray_dist block of NeuralPointsRayMarching.forward
+// (models/neural_points_volumetric_model.py:271-279) and ray_march
+// (models/rendering/diff_ray_marching.py:508-554; radiance_render / alpha_blend / no_tone_map,
+// models/rendering/diff_render_func.py:36-62).  One 64-lane wavefront per ray: the cummax over the
+// perspective depth and the exclusive transmittance product are wave scans (shuffle), no intermediate
+// [R,SR] tensors of the reference (sigma, opacity, cumprod, blend weight, ...) are materialised except
+// the ones the caller asks for.
+#include "mlp_common.h"
+
+int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, const float *d_params, const void *d_packed,
+                          const float *d_raydir, const float *d_sample_loc, const int32_t *d_sample_pidx,
+                          const int32_t *d_valid_list, const int32_t *d_counters, int R, int SR, int K,
+                          float *d_decoded, float *d_weight, const PnSaved &sv, long long cap_samples, bool train,
+                          hipStream_t s);
+int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, const float *d_params, const void *d_packed,
+                           const float *d_raydir, const float *d_sample_loc, const int32_t *d_sample_pidx,
+                           const int32_t *d_valid_list, const int32_t *d_counters, int R, int SR, int K,
+                           const float *d_decoded, const float *d_weight, const float *d_grad_decoded,
+                           const PnSaved &sv, long long n_valid, float *d_grad_params, const pnerf_point_grads *pg,
+                           float *d_partials, hipStream_t s);
+size_t pn_wgrad_partials_bytes();
+
+namespace {
+constexpr int TPB = 256;
+
+struct RmArgs {
+    pnerf_camera cam;
+    const float *sample_loc, *decoded;
+    const int *nn;
+    int R, SR;
+};
+
+__device__ __forceinline__ float wave_incl_max(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { float y = __shfl_up(v, off, 64); if (lane >= off) v = fmaxf(v, y); }
+    return v;
+}
+__device__ __forceinline__ float wave_incl_prod(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { float y = __shfl_up(v, off, 64); if (lane >= off) v *= y; }
+    return v;
+}
+__device__ __forceinline__ float wave_incl_sum(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { float y = __shfl_up(v, off, 64); if (lane >= off) v += y; }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// perspective depth of a world position: ((p - campos) @ camrot)[2]   (point_query.py:101-108)
+__device__ __forceinline__ float pers_z(const pnerf_camera &c, const float *p) {
+    return (p[0] - c.campos[0]) * c.camrot[2] + (p[1] - c.campos[1]) * c.camrot[5] + (p[2] - c.campos[2]) * c.camrot[8];
+}
+
+// Per-sample quantities of one 64-sample chunk of a ray.  `cm_prev` is the running cummax before the
+// chunk.  Returns delta (ray_dist), valid flag, and updates cm_prev.
+__device__ __forceinline__ void chunk_raydist(const RmArgs &a, int r, int s, int lane, float &cm_prev, float &delta, bool &valid) {
+    const int SR = a.SR;
+    float z = -INFINITY, znext = -INFINITY;
+    if (s < SR) z = pers_z(a.cam, a.sample_loc + ((long long)r * SR + s) * 3);
+    if (s + 1 < SR) znext = pers_z(a.cam, a.sample_loc + ((long long)r * SR + s + 1) * 3);
+    float cm = fmaxf(wave_incl_max(z, lane), cm_prev);             // torch.cummax(sample_loc[...,2])  :271
+    const float vs = a.cam.vsize_z;
+    float d = (s + 1 < SR) ? fmaxf(cm, znext) - cm : vs;            // cm[s+1] - cm[s]; last = vsize[2]   :272
+    bool m = d < 1e-8f;
+    if (a.cam.raydist_mode_unit > 0) m = m || (d > 2.f * vs);       // :274-276
+    if (m) d = vs;                                                  // :278
+    valid = s < SR && a.nn[(long long)r * SR + s] > 0;              // ray_valid = any_K(mask)  point_aggregators.py:741
+    delta = valid ? d : 0.f;                                        // :279
+    cm_prev = __shfl(cm, 63, 64);
+}
+
+__global__ __launch_bounds__(TPB) void k_raymarch_forward(RmArgs a, float *__restrict__ ray_color, float *__restrict__ opacity_out,
+                                                          float *__restrict__ bg_trans, float *__restrict__ blend_w) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (r >= a.R) return;
+    const int SR = a.SR;
+    float cm_prev = -INFINITY, T_carry = 1.f;
+    float cr = 0.f, cg = 0.f, cb = 0.f;
+    for (int base = 0; base < SR; base += 64) {
+        const int s = base + lane;
+        float delta; bool valid;
+        chunk_raydist(a, r, s, lane, cm_prev, delta, valid);
+        float sigma = 0.f, rr = 0.f, gg = 0.f, bb = 0.f;
+        if (s < SR) {
+            const float4 f = *reinterpret_cast<const float4 *>(a.decoded + ((long long)r * SR + s) * 4);
+            sigma = valid ? f.x : 0.f; rr = f.y; gg = f.z; bb = f.w;
+        }
+        const float op = 1.f - expf(-sigma * delta);                    // diff_ray_marching.py:530
+        const float u = s < SR ? (1.f - op + 1e-10f) : 1.f;             // :533
+        const float incl = wave_incl_prod(u, lane);
+        float Tx = __shfl_up(incl, 1, 64);                              // exclusive product by lane shift   :533-539
+        if (lane == 0) Tx = 1.f;
+        Tx *= T_carry;
+        const float bw = op * Tx;                                       // alpha_blend
+        if (s < SR) {
+            opacity_out[(long long)r * SR + s] = op;
+            blend_w[(long long)r * SR + s] = bw;
+        }
+        cr += bw * rr; cg += bw * gg; cb += bw * bb;
+        T_carry *= __shfl(incl, 63, 64);
+    }
+    cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb);
+    if (lane == 0) {
+        if (a.cam.has_bg) { cr += a.cam.bg[0] * T_carry; cg += a.cam.bg[1] * T_carry; cb += a.cam.bg[2] * T_carry; }   // :543-545
+        ray_color[3 * r] = cr; ray_color[3 * r + 1] = cg; ray_color[3 * r + 2] = cb;
+        bg_trans[r] = T_carry;
+    }
+}
+
+// Backward: dL/d(ray_color) -> dL/d(decoded) = (d sigma, d r, d g, d b) per sample.
+//   color = sum_s bw_s rgb_s + bg T_end ;  bw_s = op_s T_s ; T_s = prod_{j<s} u_j ; u = 1 - op + eps ; op = 1 - exp(-sigma delta)
+//   d color / d op_s = T_s rgb_s - (sum_{j>s} bw_j rgb_j + T_end bg) / u_s
+__global__ __launch_bounds__(TPB) void k_raymarch_backward(RmArgs a, const float *__restrict__ grad_color, float *__restrict__ grad_decoded) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (r >= a.R) return;
+    const int SR = a.SR;
+    const float g0 = grad_color[3 * r], g1 = grad_color[3 * r + 1], g2 = grad_color[3 * r + 2];
+    // pass 1: T_end and total = sum_j bw_j (g . rgb_j)
+    float cm_prev = -INFINITY, T_carry = 1.f, tot = 0.f;
+    for (int base = 0; base < SR; base += 64) {
+        const int s = base + lane;
+        float delta; bool valid;
+        chunk_raydist(a, r, s, lane, cm_prev, delta, valid);
+        float sigma = 0.f, c = 0.f;
+        if (s < SR) {
+            const float4 f = *reinterpret_cast<const float4 *>(a.decoded + ((long long)r * SR + s) * 4);
+            sigma = valid ? f.x : 0.f; c = g0 * f.y + g1 * f.z + g2 * f.w;
+        }
+        const float op = 1.f - expf(-sigma * delta);
+        const float u = s < SR ? (1.f - op + 1e-10f) : 1.f;
+        const float incl = wave_incl_prod(u, lane);
+        float Tx = __shfl_up(incl, 1, 64);
+        if (lane == 0) Tx = 1.f;
+        Tx *= T_carry;
+        tot += op * Tx * c;
+        T_carry *= __shfl(incl, 63, 64);
+    }
+    tot = wave_sum(tot);
+    const float T_end = T_carry;
+    const float gbg = a.cam.has_bg ? (g0 * a.cam.bg[0] + g1 * a.cam.bg[1] + g2 * a.cam.bg[2]) * T_end : 0.f;
+    // pass 2: per-sample gradients with the running prefix of bw_j c_j
+    cm_prev = -INFINITY; T_carry = 1.f;
+    float pre_carry = 0.f;
+    for (int base = 0; base < SR; base += 64) {
+        const int s = base + lane;
+        float delta; bool valid;
+        chunk_raydist(a, r, s, lane, cm_prev, delta, valid);
+        float sigma = 0.f, c = 0.f;
+        if (s < SR) {
+            const float4 f = *reinterpret_cast<const float4 *>(a.decoded + ((long long)r * SR + s) * 4);
+            sigma = valid ? f.x : 0.f; c = g0 * f.y + g1 * f.z + g2 * f.w;
+        }
+        const float e = expf(-sigma * delta);
+        const float op = 1.f - e;
+        const float u = s < SR ? (1.f - op + 1e-10f) : 1.f;
+        const float incl = wave_incl_prod(u, lane);
+        float Tx = __shfl_up(incl, 1, 64);
+        if (lane == 0) Tx = 1.f;
+        Tx *= T_carry;
+        const float bwc = op * Tx * c;
+        const float incl_sum = wave_incl_sum(bwc, lane) + pre_carry;      // sum_{j<=s}
+        const float suffix = tot - incl_sum + gbg;                        // sum_{j>s} bw_j c_j + T_end (g.bg)
+        const float dop = Tx * c - suffix / u;
+        if (s < SR) {
+            const float bw = op * Tx;
+            float4 o;
+            o.x = valid ? dop * delta * e : 0.f;                          // d op / d sigma = delta exp(-sigma delta)
+            o.y = bw * g0; o.z = bw * g1; o.w = bw * g2;
+            *reinterpret_cast<float4 *>(grad_decoded + ((long long)r * SR + s) * 4) = o;
+        }
+        pre_carry = __shfl(incl_sum, 63, 64);
+        T_carry *= __shfl(incl, 63, 64);
+    }
+}
+
+// ---- row gather / scatter-add (NeuralPoints.forward's index_select and its backward) -----------
+__global__ __launch_bounds__(TPB) void k_gather_rows(const float *__restrict__ src, int n_src, int width, const int *__restrict__ idx,
+                                                     long long n_idx, float *__restrict__ dst) {
+    const long long total = n_idx * width;
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
+        const long long i = e / width;
+        const int c = (int)(e - i * width);
+        int p = idx[i];
+        p = p < 0 ? 0 : (p >= n_src ? n_src - 1 : p);         // torch.clamp(sample_pidx, min=0)  neural_points.py:708
+        dst[e] = src[(long long)p * width + c];
+    }
+}
+__global__ __launch_bounds__(TPB) void k_scatter_add_rows(const float *__restrict__ grad_rows, const int *__restrict__ idx, long long n_idx,
+                                                          int width, float *__restrict__ grad_src, int n_src) {
+    const long long total = n_idx * width;
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
+        const long long i = e / width;
+        const int c = (int)(e - i * width);
+        int p = idx[i];
+        p = p < 0 ? 0 : (p >= n_src ? n_src - 1 : p);
+        atomicAdd(&grad_src[(long long)p * width + c], grad_rows[e]);
+    }
+}
+}  // namespace
+
+extern "C" int pnerf_gather_rows(const float *d_src, int n_src, int width, const int32_t *d_idx, int64_t n_idx, float *d_dst, void *stream) {
+    if (!d_src || !d_idx || !d_dst || n_src <= 0 || width <= 0 || n_idx < 0) return PNERF_E_INVAL;
+    if (n_idx == 0) return 0;
+    long long total = n_idx * width;
+    int grid = (int)((total + TPB - 1) / TPB < 16384 ? (total + TPB - 1) / TPB : 16384);
+    hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, d_src, n_src, width, d_idx, (long long)n_idx, d_dst);
+    PN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pnerf_scatter_add_rows(const float *d_grad_rows, const int32_t *d_idx, int64_t n_idx, int width, float *d_grad_src, int n_src, void *stream) {
+    if (!d_grad_rows || !d_idx || !d_grad_src || n_src <= 0 || width <= 0 || n_idx < 0) return PNERF_E_INVAL;
+    if (n_idx == 0) return 0;
+    long long total = n_idx * width;
+    int grid = (int)((total + TPB - 1) / TPB < 16384 ? (total + TPB - 1) / TPB : 16384);
+    hipLaunchKernelGGL(k_scatter_add_rows, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, d_grad_rows, d_idx, (long long)n_idx, width, d_grad_src, n_src);
+    PN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" size_t pnerf_agg_workspace_bytes(int64_t n_valid_max, int K) {
+    if (K <= 0 || K > PNERF_MAX_K || n_valid_max < 0) return 0;
+    // inference: only fs lives here; training: the caller passes a pnerf_agg_saved_bytes() area instead.
+    long long rows, samples;
+    pn_saved_bytes(n_valid_max, K, &rows, &samples);
+    return pn_align((size_t)samples * PN_H * sizeof(float)) + pn_wgrad_partials_bytes();
+}
+
+static int check_common(const pnerf_camera *cam, const pnerf_points *pts, int R, int SR, int K) {
+    if (!cam || !pts || R < 0 || SR <= 0 || K <= 0 || K > PNERF_MAX_K) return PNERF_E_INVAL;
+    if (pts->feat_dim != PN_F) return PNERF_E_UNSUP;
+    if (!pts->xyz || !pts->embedding || !pts->conf || !pts->dir || !pts->color) return PNERF_E_UNSUP;
+    return 0;
+}
+
+extern "C" int pnerf_render_forward(const pnerf_camera *cam, const pnerf_points *pts, const void *d_packed_mlp, const float *d_params,
+                                    const float *d_raydir, const float *d_sample_loc, const int32_t *d_sample_pidx,
+                                    const int32_t *d_sample_nn, const int32_t *d_valid_list, const int32_t *d_counters,
+                                    int R, int SR, int K,
+                                    float *d_decoded, float *d_weight, float *d_ray_color, float *d_opacity,
+                                    float *d_bg_trans, float *d_blend_w,
+                                    void *d_saved, int64_t n_valid_max, void *d_ws, size_t ws_bytes, void *stream) {
+    int rc = check_common(cam, pts, R, SR, K);
+    if (rc) return rc;
+    if (!d_packed_mlp || !d_params || !d_raydir || !d_sample_loc || !d_sample_pidx || !d_sample_nn || !d_valid_list || !d_counters) return PNERF_E_INVAL;
+    if (!d_decoded || !d_weight || !d_ray_color || !d_opacity || !d_bg_trans || !d_blend_w) return PNERF_E_INVAL;
+    if (R == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    PnSaved sv;
+    const bool train = d_saved != nullptr;
+    if (train) sv = pn_saved_carve(d_saved, n_valid_max, K);
+    else {
+        if (!d_ws || ws_bytes < pnerf_agg_workspace_bytes(n_valid_max, K)) return PNERF_E_WS;
+        sv = PnSaved();
+        pn_saved_bytes(n_valid_max, K, &sv.rows, &sv.samples);
+        sv.fs = (float *)d_ws;
+    }
+    if (hipMemsetAsync(d_decoded, 0, (size_t)R * SR * 4 * sizeof(float), s) != hipSuccess) return PNERF_E_LAUNCH;
+    if (hipMemsetAsync(d_weight, 0, (size_t)R * SR * K * sizeof(float), s) != hipSuccess) return PNERF_E_LAUNCH;
+    if (n_valid_max > 0) {
+        rc = pn_agg_forward_launch(cam, pts, d_params, d_packed_mlp, d_raydir, d_sample_loc, d_sample_pidx, d_valid_list, d_counters,
+                                   R, SR, K, d_decoded, d_weight, sv, n_valid_max, train, s);
+        if (rc) return rc;
+    }
+    RmArgs ra;
+    ra.cam = *cam; ra.sample_loc = d_sample_loc; ra.decoded = d_decoded; ra.nn = d_sample_nn; ra.R = R; ra.SR = SR;
+    hipLaunchKernelGGL(k_raymarch_forward, dim3(pn_cdiv(R, TPB / 64)), dim3(TPB), 0, s, ra, d_ray_color, d_opacity, d_bg_trans, d_blend_w);
+    PN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pnerf_render_backward(const pnerf_camera *cam, const pnerf_points *pts, const void *d_packed_mlp, const float *d_params,
+                                     const float *d_raydir, const float *d_sample_loc, const int32_t *d_sample_pidx,
+                                     const int32_t *d_sample_nn, const int32_t *d_valid_list, const int32_t *d_counters,
+                                     int R, int SR, int K, int64_t n_valid,
+                                     const float *d_decoded, const float *d_weight, const float *d_opacity,
+                                     const float *d_grad_ray_color,
+                                     void *d_saved, float *d_grad_params, const pnerf_point_grads *pg,
+                                     void *d_ws, size_t ws_bytes, void *stream) {
+    (void)d_opacity;
+    int rc = check_common(cam, pts, R, SR, K);
+    if (rc) return rc;
+    if (!d_packed_mlp || !d_params || !d_raydir || !d_sample_loc || !d_sample_pidx || !d_sample_nn || !d_valid_list || !d_counters) return PNERF_E_INVAL;
+    if (!d_decoded || !d_weight || !d_grad_ray_color || !d_saved || !d_grad_params || !pg || !d_ws) return PNERF_E_INVAL;
+    const size_t gd_bytes = pn_align((size_t)R * SR * 4 * sizeof(float));
+    if (ws_bytes < gd_bytes + pn_wgrad_partials_bytes()) return PNERF_E_WS;
+    if (R == 0 || n_valid == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    float *grad_decoded = (float *)d_ws;
+    float *partials = (float *)((char *)d_ws + gd_bytes);
+    RmArgs ra;
+    ra.cam = *cam; ra.sample_loc = d_sample_loc; ra.decoded = d_decoded; ra.nn = d_sample_nn; ra.R = R; ra.SR = SR;
+    hipLaunchKernelGGL(k_raymarch_backward, dim3(pn_cdiv(R, TPB / 64)), dim3(TPB), 0, s, ra, d_grad_ray_color, grad_decoded);
+    PN_CHECK_LAUNCH();
+    PnSaved sv = pn_saved_carve(d_saved, n_valid, K);
+    return pn_agg_backward_launch(cam, pts, d_params, d_packed_mlp, d_raydir, d_sample_loc, d_sample_pidx, d_valid_list, d_counters,
+                                  R, SR, K, d_decoded, d_weight, grad_decoded, sv, n_valid, d_grad_params, pg, partials, s);
+}
+
+extern "C" size_t pnerf_render_backward_workspace_bytes(int R, int SR) {
+    return pn_align((size_t)R * SR * 4 * sizeof(float)) + pn_wgrad_partials_bytes();
+}

@@ -125,3 +125,106 @@ def query_dense(grid, R, D, SR, K, raypos=None, campos=None, raydir=None, mid=No
                             _ptr(loc), _ptr(pidx), _ptr(nn), _ptr(hit), _ptr(vlist), _ptr(counters),
                             _ptr(ws), nws, _stream()), "pnerf_query")
     return dict(sample_loc=loc, sample_pidx=pidx, sample_nn=nn, ray_hit=hit, valid_list=vlist, counters=counters)
+
+
+# ------------------------------------------------------------------------------------------ MLP + renderer
+def mlp_layout():
+    """name -> (offset, shape) of the flat parameter vector, reference state_dict order."""
+    offs = (ctypes.c_int64 * (L.MLP_NTENSORS + 1))()
+    L.check(L.lib().pnerf_mlp_layout(32, offs), "pnerf_mlp_layout")
+    names = ["block1.0", "block1.2", "block3.0", "block3.2", "alpha_branch.0",
+             "color_branch.0", "color_branch.2", "color_branch.4", "color_branch.6"]
+    shapes = [(256, 284), (256, 256), (256, 263), (256, 256), (1, 256), (128, 280), (128, 128), (128, 128), (3, 128)]
+    out, i = {}, 0
+    for n, shp in zip(names, shapes):
+        out[n + ".weight"] = (offs[i], shp); out[n + ".bias"] = (offs[i + 1], (shp[0],)); i += 2
+    return out, offs[L.MLP_NTENSORS]
+
+
+def flatten_mlp(state, device):
+    """dict of reference-named tensors -> flat fp32 device vector."""
+    lay, total = mlp_layout()
+    flat = torch.empty(total, dtype=torch.float32, device=device)
+    for k, (o, shp) in lay.items():
+        flat[o:o + int(np.prod(shp))] = state[k].detach().reshape(-1).to(device=device, dtype=torch.float32)
+    return flat
+
+
+def pack_mlp(flat, out=None):
+    """Re-pack the flat parameters into MFMA fragment order (must be called after every weight update)."""
+    _need_cuda(flat, "mlp parameters")
+    lib = L.lib()
+    if out is None:
+        out = torch.empty(lib.pnerf_mlp_packed_bytes(), dtype=torch.uint8, device=flat.device)
+    L.check(lib.pnerf_mlp_pack(_ptr(flat), _ptr(out), _stream()), "pnerf_mlp_pack")
+    return out
+
+
+def make_camera(campos, camrot, vsize_z, raydist_mode_unit=1, bg=None, rw2c=None):
+    c = L.Camera()
+    c.campos[:] = [float(x) for x in np.asarray(campos, dtype=np.float64).reshape(-1)[:3]]
+    c.camrot[:] = [float(x) for x in np.asarray(camrot, dtype=np.float64).reshape(-1)[:9]]
+    r = np.eye(3) if rw2c is None else np.asarray(rw2c, dtype=np.float64)
+    c.rw2c[:] = [float(x) for x in r.reshape(-1)[:9]]
+    c.vsize_z = float(vsize_z)
+    c.raydist_mode_unit = int(raydist_mode_unit)
+    if bg is None:
+        c.has_bg = 0
+        c.bg[:] = [0.0, 0.0, 0.0]
+    else:
+        c.has_bg = 1
+        c.bg[:] = [float(x) for x in np.asarray(bg, dtype=np.float64).reshape(-1)[:3]]
+    return c
+
+
+def make_points(xyz, emb, conf, pdir, color):
+    for n, t in (("xyz", xyz), ("points_embeding", emb), ("points_conf", conf), ("points_dir", pdir), ("points_color", color)):
+        _need_cuda(t, n)
+        assert t.is_contiguous() and t.dtype == torch.float32, n
+    p = L.Points()
+    p.xyz, p.embedding, p.conf, p.dir, p.color = xyz.data_ptr(), emb.data_ptr(), conf.data_ptr(), pdir.data_ptr(), color.data_ptr()
+    p.n, p.feat_dim = int(xyz.reshape(-1, 3).shape[0]), int(emb.shape[-1])
+    return p
+
+
+def render_forward(cam, pts, packed, flat, raydir, dense, R, SR, K, n_valid, train):
+    """pnerf_render_forward.  n_valid = host copy of dense['counters'][0] (capacity of the scratch).
+    Returns dict(decoded, weight, ray_color, opacity, bg_trans, blend_w, saved)."""
+    dev = raydir.device
+    lib = L.lib()
+    f32 = dict(dtype=torch.float32, device=dev)
+    decoded = torch.empty(R, SR, 4, **f32); weight = torch.empty(R, SR, K, **f32)
+    ray_color = torch.empty(R, 3, **f32); opacity = torch.empty(R, SR, **f32)
+    bg_trans = torch.empty(R, **f32); blend_w = torch.empty(R, SR, **f32)
+    saved = ws = None
+    if train:
+        saved = torch.empty(lib.pnerf_agg_saved_bytes(n_valid, K), dtype=torch.uint8, device=dev)
+        nws = 0
+    else:
+        nws = lib.pnerf_agg_workspace_bytes(n_valid, K)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    L.check(lib.pnerf_render_forward(ctypes.byref(cam), ctypes.byref(pts), _ptr(packed), _ptr(flat), _ptr(raydir),
+                                     _ptr(dense["sample_loc"]), _ptr(dense["sample_pidx"]), _ptr(dense["sample_nn"]),
+                                     _ptr(dense["valid_list"]), _ptr(dense["counters"]), R, SR, K,
+                                     _ptr(decoded), _ptr(weight), _ptr(ray_color), _ptr(opacity), _ptr(bg_trans), _ptr(blend_w),
+                                     _ptr(saved), n_valid, _ptr(ws), nws, _stream()), "pnerf_render_forward")
+    return dict(decoded=decoded, weight=weight, ray_color=ray_color, opacity=opacity, bg_trans=bg_trans,
+                blend_w=blend_w, saved=saved)
+
+
+def render_backward(cam, pts, packed, flat, raydir, dense, R, SR, K, n_valid, fwd, grad_ray_color, grad_flat, grads):
+    """pnerf_render_backward: accumulates into grad_flat (MLP) and grads = dict(points_embeding=..., points_conf=...,
+    points_dir=..., points_color=...) (device tensors, same shapes as the parameters)."""
+    lib = L.lib()
+    pg = L.PointGrads()
+    pg.embedding, pg.conf = grads["points_embeding"].data_ptr(), grads["points_conf"].data_ptr()
+    pg.dir, pg.color = grads["points_dir"].data_ptr(), grads["points_color"].data_ptr()
+    nws = lib.pnerf_render_backward_workspace_bytes(R, SR)
+    ws = torch.empty(nws, dtype=torch.uint8, device=raydir.device)
+    g = grad_ray_color.contiguous().float()
+    L.check(lib.pnerf_render_backward(ctypes.byref(cam), ctypes.byref(pts), _ptr(packed), _ptr(flat), _ptr(raydir),
+                                      _ptr(dense["sample_loc"]), _ptr(dense["sample_pidx"]), _ptr(dense["sample_nn"]),
+                                      _ptr(dense["valid_list"]), _ptr(dense["counters"]), R, SR, K, n_valid,
+                                      _ptr(fwd["decoded"]), _ptr(fwd["weight"]), _ptr(fwd["opacity"]), _ptr(g),
+                                      _ptr(fwd["saved"]), _ptr(grad_flat), ctypes.byref(pg), _ptr(ws), nws, _stream()),
+            "pnerf_render_backward")
