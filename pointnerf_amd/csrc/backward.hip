@@ -1,7 +1,470 @@
-// backward.hip -- (stub while the forward path is brought up; replaced by the real kernels)
+// backward.hip -- backward of the aggregator: colour MLP dgrad, per-neighbor MLP dgrad + gather
+// scatter-add, and the weight-gradient GEMMs.
+//
+// The reference gets all of this from torch.autograd over ~60 ATen ops (loss.backward() in
+// models/mvs_points_volumetric_model.py:98-118): cuBLAS dgrad/wgrad per nn.Linear, dense
+// index_select backward into [1,N,F] buffers, boolean-mask scatter backward.  Here:
+//   k_color_backward : 64 valid samples per tile; d rgb -> colour chain dgrad on MFMA -> d f[256]
+//   k_agg_backward   : TS samples x K rows per tile; (d sigma, d f) -> alpha head, K-weighted sums,
+//                      block3/block1 dgrad on MFMA, PE chain rule, atomic scatter-add into the
+//                      embedding / colour / dir / conf gradients of the touched points only
+//   k_wgrad          : dW = dY^T X as split-K MFMA GEMMs over the saved activations, full dW tile
+//                      resident in accumulators, deterministic partial-sum reduction
+// LeakyReLU masks come from the saved post-activations (sign(post) == sign(pre)).
 #include "mlp_common.h"
-size_t pn_wgrad_partials_bytes() { return 256; }
-int pn_agg_backward_launch(const pnerf_camera *, const pnerf_points *, const float *, const void *,
-                           const float *, const float *, const int32_t *, const int32_t *, const int32_t *, int, int, int,
-                           const float *, const float *, const float *, const PnSaved &, long long, float *, const pnerf_point_grads *,
-                           float *, hipStream_t) { return PNERF_E_UNSUP; }
+
+namespace {
+constexpr int LDH = 260;
+constexpr int LDC = 132;
+constexpr int WG_CHUNKS = 256;                 // split-K factor of the wgrad GEMMs
+constexpr size_t PARTIAL_FLOATS = (size_t)WG_CHUNKS * PN_H * PN_H;
+
+struct BwdArgs {
+    pnerf_camera cam;
+    const float *dir;                          // point dirs (for nothing but symmetry with forward; grads only need idx)
+    const float *params;
+    const float4 *packed;
+    const float *raydir;
+    const int *pidx, *valid_list, *counters;
+    int SR, K, TS;
+    long long cap_samples;
+    const float *decoded, *weight, *grad_decoded;
+    PnSaved sv;
+    float *gparams;
+    float *g_emb, *g_conf, *g_dir, *g_color;
+};
+
+__device__ __forceinline__ void rot3b(const float *M, float x, float y, float z, bool transpose, float &ox, float &oy, float &oz) {
+    if (!transpose) { ox = x * M[0] + y * M[3] + z * M[6]; oy = x * M[1] + y * M[4] + z * M[7]; oz = x * M[2] + y * M[5] + z * M[8]; }
+    else { ox = x * M[0] + y * M[1] + z * M[2]; oy = x * M[3] + y * M[4] + z * M[5]; oz = x * M[6] + y * M[7] + z * M[8]; }
+}
+
+// ------------------------------------------------------------------------------ colour backward
+constexpr int COLB_LDS_FLOATS = 2 * PN_TILE * LDC + PN_TILE * 4;
+
+__global__ __launch_bounds__(256, 1) void k_color_backward(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *D1 = smem;                          // [64][LDC]
+    float *D2 = D1 + PN_TILE * LDC;            // [64][LDC]
+    float *draw = D2 + PN_TILE * LDC;          // [64][4] d(pre-sigmoid colour)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Ns = a.counters[0] < a.cap_samples ? a.counters[0] : (int)a.cap_samples;
+    const float *P = a.params;
+    const int cc = tid & 127, half = tid >> 7;
+    float gw4[3] = {0.f, 0.f, 0.f}, gb3 = 0.f, gb2 = 0.f, gb1 = 0.f, gb4 = 0.f;
+
+    for (long long tile = blockIdx.x; tile * PN_TILE < Ns; tile += gridDim.x) {
+        const long long grow0 = tile * PN_TILE;
+        __syncthreads();
+        if (tid < PN_TILE) {
+            const long long vs = grow0 + tid;
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+            if (vs < Ns) {
+                const long long si = a.valid_list[vs];
+                const float *o = a.decoded + si * 4, *g = a.grad_decoded + si * 4;
+                // rgb = sigmoid(raw) * 1.002 - 0.001  ->  d raw = d rgb * 1.002 * s (1 - s)
+                const float s0 = (o[1] + 0.001f) / 1.002f, s1 = (o[2] + 0.001f) / 1.002f, s2 = (o[3] + 0.001f) / 1.002f;
+                d0 = g[1] * 1.002f * s0 * (1.f - s0); d1 = g[2] * 1.002f * s1 * (1.f - s1); d2 = g[3] * 1.002f * s2 * (1.f - s2);
+            }
+            draw[tid * 4] = d0; draw[tid * 4 + 1] = d1; draw[tid * 4 + 2] = d2; draw[tid * 4 + 3] = 0.f;
+        }
+        __syncthreads();
+        // d c3 = (d raw @ Wc4) * lrelu'(c3) ; accumulate d Wc4, d bc4
+        {
+            const float w0 = P[PO_WC4 + cc], w1 = P[PO_WC4 + PN_HC + cc], w2 = P[PO_WC4 + 2 * PN_HC + cc];
+            _Pragma("unroll 4") for (int row = half; row < PN_TILE; row += 2) {
+                const float d0 = draw[row * 4], d1 = draw[row * 4 + 1], d2 = draw[row * 4 + 2];
+                const float c3 = a.sv.c3[(grow0 + row) * PN_HC + cc];
+                const float v = (d0 * w0 + d1 * w1 + d2 * w2) * pn_lrelu_grad(c3);
+                D1[row * LDC + cc] = v;
+                a.sv.dc3[(grow0 + row) * PN_HC + cc] = v;
+                gw4[0] += d0 * c3; gw4[1] += d1 * c3; gw4[2] += d2 * c3;
+                gb3 += v;
+            }
+            if (tid < 3) _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) gb4 += draw[row * 4 + tid];
+        }
+        __syncthreads();
+        f32x16 acc[2][1];
+        pn_acc_init_bias<1>(acc, nullptr, wave, lane);
+        pn_tile_gemm<1>(D1, LDC, PN_HC / 8, a.packed + PK_DC3 / 4, wave, lane, acc);
+        pn_store_dact<1>(acc, a.sv.c2, PN_HC, D2, LDC, a.sv.dc2, PN_HC, grow0, wave, lane);
+        __syncthreads();
+        _Pragma("unroll 4") for (int row = half; row < PN_TILE; row += 2) gb2 += D2[row * LDC + cc];
+        pn_acc_init_bias<1>(acc, nullptr, wave, lane);
+        pn_tile_gemm<1>(D2, LDC, PN_HC / 8, a.packed + PK_DC2 / 4, wave, lane, acc);
+        pn_store_dact<1>(acc, a.sv.c1, PN_HC, D1, LDC, a.sv.dc1, PN_HC, grow0, wave, lane);
+        __syncthreads();
+        _Pragma("unroll 4") for (int row = half; row < PN_TILE; row += 2) gb1 += D1[row * LDC + cc];
+        f32x16 acc2[2][2];
+        pn_acc_init_bias<2>(acc2, nullptr, wave, lane);
+        pn_tile_gemm<2>(D1, LDC, PN_HC / 8, a.packed + PK_DC1 / 4, wave, lane, acc2);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int col = pn_acc_col<2>(wave, ct, lane);
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    a.sv.dfs[(grow0 + pn_acc_row(rt, reg, lane)) * PN_H + col] = acc2[rt][ct][reg];
+            }
+    }
+    atomicAdd(&a.gparams[PO_WC4 + cc], gw4[0]);
+    atomicAdd(&a.gparams[PO_WC4 + PN_HC + cc], gw4[1]);
+    atomicAdd(&a.gparams[PO_WC4 + 2 * PN_HC + cc], gw4[2]);
+    atomicAdd(&a.gparams[PO_BC3 + cc], gb3);
+    atomicAdd(&a.gparams[PO_BC2 + cc], gb2);
+    atomicAdd(&a.gparams[PO_BC1 + cc], gb1);
+    if (tid < 3) atomicAdd(&a.gparams[PO_BC4 + tid], gb4);
+}
+
+// ------------------------------------------------------------------------------ aggregator backward
+constexpr int AGGB_LDS_FLOATS = 2 * PN_TILE * LDH + PN_TILE * 8 + 7 * PN_H + PN_H + 5 * PN_TILE;
+
+__global__ __launch_bounds__(256, 1) void k_agg_backward(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *bufA = smem;                        // [64][LDH]
+    float *bufB = bufA + PN_TILE * LDH;        // [64][LDH]
+    float *exs = bufB + PN_TILE * LDH;         // [64][8]
+    float *w3ex = exs + PN_TILE * 8;           // [7][256]  W3[o][256+j]
+    float *w5s = w3ex + 7 * PN_H;              // [256]
+    float *wrow = w5s + PN_H;                  // [64]
+    float *wnrm = wrow + PN_TILE;              // [64]
+    float *draw = wnrm + PN_TILE;              // [64] d(alpha pre-activation)
+    float *dsg = draw + PN_TILE;               // [64] d sigma of the row's sample
+    int *sidx = reinterpret_cast<int *>(dsg + PN_TILE);   // [64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K, TS = a.TS;
+    const int Ns = a.counters[0] < a.cap_samples ? a.counters[0] : (int)a.cap_samples;
+    const float *P = a.params;
+    w5s[tid] = P[PO_W5 + tid];
+    for (int j = 0; j < 7; ++j) w3ex[j * PN_H + tid] = P[PO_W3 + tid * PN_IN3 + PN_H + j];
+    const float b5 = P[PO_B5];
+    float gb1 = 0.f, gb2 = 0.f, gb3 = 0.f, gb4 = 0.f, gw5 = 0.f, gb5 = 0.f;
+    float gw3e[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    for (long long tile = blockIdx.x; tile * TS < Ns; tile += gridDim.x) {
+        const long long grow0 = tile * PN_TILE;
+        __syncthreads();
+        if (tid < PN_TILE) {
+            const int ls = tid / K, k = tid - ls * K;
+            const long long vs = tile * TS + ls;
+            const int si = (ls < TS && vs < Ns) ? a.valid_list[vs] : -1;
+            sidx[tid] = si;                                        // per ROW here (row -> its sample id)
+            wrow[tid] = si >= 0 ? a.sv.wrow[grow0 + tid] : 0.f;
+            wnrm[tid] = si >= 0 ? a.weight[(long long)si * K + k] : 0.f;
+            dsg[tid] = si >= 0 ? a.grad_decoded[(long long)si * 4] : 0.f;
+        }
+        for (int e = tid; e < PN_TILE * 64; e += 256) {
+            const int row = e >> 6, c4 = e & 63;
+            *reinterpret_cast<float4 *>(bufA + row * LDH + c4 * 4) = *reinterpret_cast<const float4 *>(a.sv.h4 + (grow0 + row) * PN_H + c4 * 4);
+        }
+        for (int e = tid; e < PN_TILE * 2; e += 256) {
+            const int row = e >> 1, h = e & 1;
+            *reinterpret_cast<float4 *>(exs + row * 8 + h * 4) = *reinterpret_cast<const float4 *>(a.sv.ex + (grow0 + row) * 8 + h * 4);
+        }
+        __syncthreads();
+        // ---- alpha head + weight gradient ------------------------------------------------------
+        {
+            const int row = tid >> 2, q = tid & 3;
+            const int si = sidx[row];
+            const int ls = row / K;
+            const long long vs = tile * TS + ls;
+            const float *h = bufA + row * LDH + q * 64;
+            float s = 0.f, dotf = 0.f;
+            if (si >= 0) {
+                const float *df = a.sv.dfs + vs * PN_H + q * 64;
+#pragma unroll
+                for (int c = 0; c < 64; c += 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(h + c);
+                    const float4 g = *reinterpret_cast<const float4 *>(df + c);
+                    s += v.x * w5s[q * 64 + c] + v.y * w5s[q * 64 + c + 1] + v.z * w5s[q * 64 + c + 2] + v.w * w5s[q * 64 + c + 3];
+                    dotf += v.x * g.x + v.y * g.y + v.z * g.z + v.w * g.w;
+                }
+            }
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+            dotf += __shfl_xor(dotf, 1, 64); dotf += __shfl_xor(dotf, 2, 64);
+            if (q == 0) {
+                float dr = 0.f;
+                if (si >= 0) {
+                    const float x = s + b5 - 1.0f;
+                    const float alpha = x > 20.f ? x : log1pf(expf(x));
+                    const float sg = x > 20.f ? 1.f : 1.0f / (1.0f + expf(-x));
+                    const int k = row - ls * K;
+                    const int p = a.pidx[(long long)si * K + k];
+                    if (p >= 0) {
+                        // w = wn * clamp(conf) with a straight-through clamp (gradiant_clamp, point_aggregators.py:722-724)
+                        const float dw = dsg[row] * alpha + dotf;
+                        atomicAdd(&a.g_conf[p], dw * wnrm[row]);
+                    }
+                    dr = dsg[row] * wrow[row] * sg;
+                }
+                draw[row] = dr;
+            }
+        }
+        __syncthreads();
+        // ---- d W5 / d b5 (column tid), then dY4 = (w * d f + d raw * w5) * lrelu'(h4) ----------
+        {
+            float accw = 0.f;
+            _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) accw += draw[row] * bufA[row * LDH + tid];
+            gw5 += accw;
+            if (tid == 0) _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) gb5 += draw[row];
+        }
+        for (int e = tid; e < PN_TILE * 64; e += 256) {
+            const int row = e >> 6, c4 = e & 63;
+            const int si = sidx[row];
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (si >= 0) {
+                const long long vs = tile * TS + row / K;
+                const float4 hv = *reinterpret_cast<const float4 *>(bufA + row * LDH + c4 * 4);
+                const float4 g = *reinterpret_cast<const float4 *>(a.sv.dfs + vs * PN_H + c4 * 4);
+                const float w = wrow[row], dr = draw[row];
+                o.x = (w * g.x + dr * w5s[c4 * 4]) * pn_lrelu_grad(hv.x);
+                o.y = (w * g.y + dr * w5s[c4 * 4 + 1]) * pn_lrelu_grad(hv.y);
+                o.z = (w * g.z + dr * w5s[c4 * 4 + 2]) * pn_lrelu_grad(hv.z);
+                o.w = (w * g.w + dr * w5s[c4 * 4 + 3]) * pn_lrelu_grad(hv.w);
+            }
+            *reinterpret_cast<float4 *>(bufB + row * LDH + c4 * 4) = o;
+            *reinterpret_cast<float4 *>(a.sv.dy4 + (grow0 + row) * PN_H + c4 * 4) = o;
+        }
+        __syncthreads();
+        // ---- block3 second layer: dY3 = (dY4 @ W4) * lrelu'(h3) ----------------------------------
+        _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) gb4 += bufB[row * LDH + tid];
+        f32x16 acc[2][2];
+        pn_acc_init_bias<2>(acc, nullptr, wave, lane);
+        pn_tile_gemm<2>(bufB, LDH, PN_H / 8, a.packed + PK_D4 / 4, wave, lane, acc);
+        pn_store_dact<2>(acc, a.sv.h3, PN_H, bufA, LDH, a.sv.dy3, PN_H, grow0, wave, lane);
+        __syncthreads();
+        // ---- block3 first layer: extras (colour, dir) + dY2 = (dY3 @ W3[:, :256]) * lrelu'(h2) ----
+        _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) {
+            const float v = bufA[row * LDH + tid];
+            gb3 += v;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) gw3e[j] += v * exs[row * 8 + j];
+        }
+        {
+            const int row = tid >> 2, q = tid & 3;
+            const int si = sidx[row];
+            float dex[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (si >= 0) {
+                const float *dy = bufA + row * LDH + q * 64;
+                _Pragma("unroll 2") for (int c = 0; c < 64; c += 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(dy + c);
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) {
+                        const float *w = w3ex + j * PN_H + q * 64 + c;
+                        dex[j] += v.x * w[0] + v.y * w[1] + v.z * w[2] + v.w * w[3];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 7; ++j) { dex[j] += __shfl_xor(dex[j], 1, 64); dex[j] += __shfl_xor(dex[j], 2, 64); }
+            if (q == 0 && si >= 0) {
+                const int ls = row / K, k = row - ls * K;
+                const int p = a.pidx[(long long)si * K + k];
+                if (p >= 0) {
+                    atomicAdd(&a.g_color[3 * p], dex[0]); atomicAdd(&a.g_color[3 * p + 1], dex[1]); atomicAdd(&a.g_color[3 * p + 2], dex[2]);
+                    const int r = si / a.SR;
+                    float vx, vy, vz, gx, gy, gz;
+                    rot3b(a.cam.rw2c, a.raydir[3 * r], a.raydir[3 * r + 1], a.raydir[3 * r + 2], true, vx, vy, vz);
+                    // features (q - v, q . v) with q = dir @ Rw2c^T  ->  d q = dex[3:6] + dex[6] * v ; d dir = d q @ Rw2c
+                    rot3b(a.cam.rw2c, dex[3] + dex[6] * vx, dex[4] + dex[6] * vy, dex[5] + dex[6] * vz, false, gx, gy, gz);
+                    atomicAdd(&a.g_dir[3 * p], gx); atomicAdd(&a.g_dir[3 * p + 1], gy); atomicAdd(&a.g_dir[3 * p + 2], gz);
+                }
+            }
+        }
+        pn_acc_init_bias<2>(acc, nullptr, wave, lane);
+        pn_tile_gemm<2>(bufA, LDH, PN_H / 8, a.packed + PK_D3 / 4, wave, lane, acc);
+        pn_store_dact<2>(acc, a.sv.h2, PN_H, bufB, LDH, a.sv.dy2, PN_H, grow0, wave, lane);
+        __syncthreads();
+        // ---- block1 second layer: dY1 = (dY2 @ W2) * lrelu'(h1) ----------------------------------
+        _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) gb2 += bufB[row * LDH + tid];
+        pn_acc_init_bias<2>(acc, nullptr, wave, lane);
+        pn_tile_gemm<2>(bufB, LDH, PN_H / 8, a.packed + PK_D2 / 4, wave, lane, acc);
+        pn_store_dact<2>(acc, a.sv.h1, PN_H, bufA, LDH, a.sv.dy1, PN_H, grow0, wave, lane);
+        __syncthreads();
+        // ---- block1 first layer: d X0[:, :256] = dY1 @ W1[:, :256] --------------------------------
+        _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) gb1 += bufA[row * LDH + tid];
+        pn_acc_init_bias<2>(acc, nullptr, wave, lane);
+        pn_tile_gemm<2>(bufA, LDH, PN_H / 8, a.packed + PK_D1 / 4, wave, lane, acc);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int col = pn_acc_col<2>(wave, ct, lane);
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) bufB[pn_acc_row(rt, reg, lane) * LDH + col] = acc[rt][ct][reg];
+            }
+        __syncthreads();
+        // ---- embedding gradient through [e | PE3(e)]: d e = dX[e] + sum_f 2^f (dX[sin] cos - dX[cos] sin)
+        {
+            const int row = tid >> 2, q = tid & 3;
+            const int si = sidx[row];
+            if (si >= 0) {
+                const int ls = row / K, k = row - ls * K;
+                const int p = a.pidx[(long long)si * K + k];
+                if (p >= 0) {
+                    const float *dx = bufB + row * LDH;
+                    const float *x0 = a.sv.x0 + (grow0 + row) * PN_IN1P;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int dd = 8 * q + i;
+                        float g = dx[dd], fr = 1.f;
+#pragma unroll
+                        for (int f = 0; f < 3; ++f) {
+                            const int o = PN_F + (dd * 3 + f) * 2;
+                            g += fr * (dx[o] * x0[o + 1] - dx[o + 1] * x0[o]);
+                            fr *= 2.f;
+                        }
+                        atomicAdd(&a.g_emb[(long long)p * PN_F + dd], g);
+                    }
+                }
+            }
+        }
+    }
+    atomicAdd(&a.gparams[PO_B1 + tid], gb1);
+    atomicAdd(&a.gparams[PO_B2 + tid], gb2);
+    atomicAdd(&a.gparams[PO_B3 + tid], gb3);
+    atomicAdd(&a.gparams[PO_B4 + tid], gb4);
+    atomicAdd(&a.gparams[PO_W5 + tid], gw5);
+    if (tid == 0) atomicAdd(&a.gparams[PO_B5], gb5);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) atomicAdd(&a.gparams[PO_W3 + tid * PN_IN3 + PN_H + j], gw3e[j]);
+}
+
+// ------------------------------------------------------------------------------ weight gradients
+// partial[chunk][m][n] = sum_{r in chunk} A[r][m] B[r][n]   (A = dY [rows,lda], B = X [rows,ldb])
+// Block tile (WM*MT*32) x (WN*NT*32); the whole tile lives in MFMA accumulators, operands stream
+// straight from HBM/L2 in the MFMA fragment layout (lane l: row r + (l>>5), column base + (l&31):
+// two 128-byte segments per load).
+template <int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(WM *WN * 64) void k_wgrad(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+                                                       long long rows, int rows_per_chunk, float *__restrict__ partial, int Mtot, int Ntot) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = wm * MT * 32, n0 = blockIdx.x * (WN * NT * 32) + wn * NT * 32;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+    long long r1 = r0 + rows_per_chunk;
+    if (r1 > rows) r1 = rows;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) acc[mt][nt][reg] = 0.f;
+    const float *ap = A + m0 + (lane & 31) + (long long)(lane >> 5) * lda;
+    const float *bp = B + n0 + (lane & 31) + (long long)(lane >> 5) * ldb;
+    constexpr int U = 4;                       // k-steps (2 rows each) per unrolled body
+    long long r = r0;
+    for (; r + 2 * U <= r1; r += 2 * U) {
+        float av[U][MT], bv[U][NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[u][mt] = ap[(r + 2 * u) * lda + mt * 32];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[u][nt] = bp[(r + 2 * u) * ldb + nt * 32];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][mt], bv[u][nt], acc[mt][nt], 0, 0, 0);
+    }
+    for (; r + 2 <= r1; r += 2) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[r * lda + mt * 32], bp[r * ldb + nt * 32], acc[mt][nt], 0, 0, 0);
+    }
+    float *out = partial + (size_t)blockIdx.y * Mtot * Ntot;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = m0 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                const int n = n0 + nt * 32 + (lane & 31);
+                out[(size_t)m * Ntot + n] = acc[mt][nt][reg];
+            }
+}
+
+// grad[dst + m*ldc + n] += sum_chunk partial[chunk][m][n]   for n < Nreal
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial, int chunks, int Mtot, int Ntot, int Nreal,
+                                                      float *__restrict__ grad, int dst, int ldc) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Mtot * Ntot) return;
+    const int m = e / Ntot, n = e - m * Ntot;
+    if (n >= Nreal) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += partial[(size_t)c * Mtot * Ntot + e];
+    grad[dst + m * ldc + n] += s;
+}
+
+template <int MT, int NT, int WM, int WN>
+int launch_wgrad(const float *A, int lda, const float *B, int ldb, long long rows, float *partial, int Ntot, int Nreal,
+                 float *grad, int dst, int ldc, hipStream_t s) {
+    constexpr int Mtot = WM * MT * 32;
+    const int ntiles = Ntot / (WN * NT * 32);
+    int chunks = WG_CHUNKS / ntiles;
+    long long rpc = (rows + chunks - 1) / chunks;
+    rpc = (rpc + 63) / 64 * 64;                       // whole row tiles per chunk
+    if (rpc < 64) rpc = 64;
+    chunks = (int)((rows + rpc - 1) / rpc);
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL((k_wgrad<MT, NT, WM, WN>), dim3(ntiles, chunks), dim3(WM * WN * 64), 0, s, A, lda, B, ldb, rows, (int)rpc, partial, Mtot, Ntot);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(pn_cdiv((long long)Mtot * Ntot, 256)), dim3(256), 0, s, partial, chunks, Mtot, Ntot, Nreal, grad, dst, ldc);
+    PN_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
+size_t pn_wgrad_partials_bytes() { return pn_align(PARTIAL_FLOATS * sizeof(float)); }
+
+int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, const float *d_params, const void *d_packed,
+                           const float *d_raydir, const float *d_sample_loc, const int32_t *d_sample_pidx,
+                           const int32_t *d_valid_list, const int32_t *d_counters, int R, int SR, int K,
+                           const float *d_decoded, const float *d_weight, const float *d_grad_decoded,
+                           const PnSaved &sv, long long n_valid, float *d_grad_params, const pnerf_point_grads *pg,
+                           float *d_partials, hipStream_t s) {
+    (void)d_sample_loc; (void)R;
+    BwdArgs a;
+    a.cam = *cam; a.dir = pts->dir; a.params = d_params; a.packed = (const float4 *)d_packed; a.raydir = d_raydir;
+    a.pidx = d_sample_pidx; a.valid_list = d_valid_list; a.counters = d_counters;
+    a.SR = SR; a.K = K; a.TS = pn_tile_samples(K); a.cap_samples = n_valid;
+    a.decoded = d_decoded; a.weight = d_weight; a.grad_decoded = d_grad_decoded; a.sv = sv;
+    a.gparams = d_grad_params; a.g_emb = pg->embedding; a.g_conf = pg->conf; a.g_dir = pg->dir; a.g_color = pg->color;
+    if (!a.g_emb || !a.g_conf || !a.g_dir || !a.g_color) return PNERF_E_INVAL;
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) != hipSuccess) return PNERF_E_LAUNCH;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
+    const long long tiles = (n_valid + a.TS - 1) / a.TS;
+    const long long ctiles = (n_valid + PN_TILE - 1) / PN_TILE;
+    const int grid_a = (int)(tiles < ncu ? (tiles > 0 ? tiles : 1) : ncu);
+    const int grid_c = (int)(ctiles < ncu ? (ctiles > 0 ? ctiles : 1) : ncu);
+    const size_t lds_c = COLB_LDS_FLOATS * sizeof(float), lds_a = AGGB_LDS_FLOATS * sizeof(float);
+    if (hipFuncSetAttribute((const void *)k_color_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
+    if (hipFuncSetAttribute((const void *)k_agg_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
+    hipLaunchKernelGGL(k_color_backward, dim3(grid_c), dim3(256), lds_c, s, a);
+    hipLaunchKernelGGL(k_agg_backward, dim3(grid_a), dim3(256), lds_a, s, a);
+    PN_CHECK_LAUNCH();
+    // weight gradients over the rows / samples of the tiles that actually ran
+    const long long rows = tiles * PN_TILE, smp = ctiles * PN_TILE;
+    int rc;
+    float *g = d_grad_params;
+    if ((rc = launch_wgrad<4, 2, 2, 4>(sv.dy1, PN_H, sv.x0, PN_IN1P, rows, d_partials, 256, 256, g, PO_W1, PN_IN1, s))) return rc;
+    if ((rc = launch_wgrad<1, 1, 8, 1>(sv.dy1, PN_H, sv.x0 + 256, PN_IN1P, rows, d_partials, 32, PN_IN1 - 256, g, PO_W1 + 256, PN_IN1, s))) return rc;
+    if ((rc = launch_wgrad<4, 2, 2, 4>(sv.dy2, PN_H, sv.h1, PN_H, rows, d_partials, 256, 256, g, PO_W2, PN_H, s))) return rc;
+    if ((rc = launch_wgrad<4, 2, 2, 4>(sv.dy3, PN_H, sv.h2, PN_H, rows, d_partials, 256, 256, g, PO_W3, PN_IN3, s))) return rc;
+    if ((rc = launch_wgrad<4, 2, 2, 4>(sv.dy4, PN_H, sv.h3, PN_H, rows, d_partials, 256, 256, g, PO_W4, PN_H, s))) return rc;
+    if ((rc = launch_wgrad<2, 2, 2, 4>(sv.dc1, PN_HC, sv.fs, PN_H, smp, d_partials, 256, 256, g, PO_WC1, PN_INC, s))) return rc;
+    if ((rc = launch_wgrad<1, 1, 4, 1>(sv.dc1, PN_HC, sv.pe, 32, smp, d_partials, 32, PN_INC - 256, g, PO_WC1 + 256, PN_INC, s))) return rc;
+    if ((rc = launch_wgrad<2, 1, 2, 4>(sv.dc2, PN_HC, sv.c1, PN_HC, smp, d_partials, 128, 128, g, PO_WC2, PN_HC, s))) return rc;
+    if ((rc = launch_wgrad<2, 1, 2, 4>(sv.dc3, PN_HC, sv.c2, PN_HC, smp, d_partials, 128, 128, g, PO_WC3, PN_HC, s))) return rc;
+    return 0;
+}

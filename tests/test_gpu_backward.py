@@ -1,0 +1,91 @@
+"""GPU parity of the HIP backward (ray-march, colour MLP, aggregator MLP dgrad, gather scatter-add, weight-grad
+GEMMs) against torch.autograd over the CPU oracle.  Tolerance: 1e-3 of each tensor's max |grad| (fp32
+accumulation-order noise); the oracle's own gradients are pinned to the reference modules' gradients by
+tests/test_oracle_golden.py."""
+import numpy as np
+import pytest
+import torch
+
+from cases import CASES, build_case
+from gpu_util import hip_render, DEV
+from pointnerf_amd import config, scenes, ops
+from oracle import pyref
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-3
+
+
+def _hip_grads(opt, xyz, attrs, inp, mlp, probe_hit):
+    dense, fwd, ctx = hip_render(opt, xyz, attrs, inp, mlp, train=True)
+    dev = torch.device(DEV)
+    hit = dense["ray_hit"] > 0
+    g = torch.zeros(ctx["R"], 3, device=dev)
+    g[hit] = probe_hit.to(dev)
+    gflat = torch.zeros_like(ctx["flat"])
+    grads = {k: torch.zeros_like(v) for k, v in ctx["pts_t"].items()}
+    ops.render_backward(ctx["cam"], ctx["pts"], ctx["packed"], ctx["flat"], ctx["raydir"], dense, ctx["R"], opt.SR, opt.K,
+                        ctx["n_valid"], fwd, g, gflat, grads)
+    torch.cuda.synchronize()
+    lay, _ = ops.mlp_layout()
+    gm = {k: gflat[o:o + int(np.prod(shp))].view(shp).cpu() for k, (o, shp) in lay.items()}
+    return gm, {k: v.cpu() for k, v in grads.items()}, fwd, hit.cpu()
+
+
+def _oracle_grads(opt, xyz, attrs, inp, mlp, probe=None):
+    torch.set_num_threads(8)
+    mlp = {k: v.clone().requires_grad_(True) for k, v in mlp.items()}
+    points = dict(xyz=xyz, **{k: v.clone().requires_grad_(True) for k, v in attrs.items()})
+    out = pyref.render(opt, points, mlp, inp, nthreads=8)
+    col = out["coarse_raycolor"]
+    if probe is None:
+        probe = torch.rand(col.shape, generator=torch.Generator().manual_seed(123))
+    (col * probe).sum().backward()
+    return {k: v.grad for k, v in mlp.items()}, {k: points[k].grad[0] for k in attrs}, probe[0]
+
+
+def _check(name, a, b):
+    """>= 99.9 % of the elements within RTOL of the tensor's max |grad|, and no element beyond 10x that.
+    The slack exists because LeakyReLU's derivative is discontinuous: among ~1e8 hidden activations a handful
+    have |pre-activation| < 1e-7, where an ulp of summation-order noise flips 1 <-> 0.01 for that unit of that
+    row on one side only (measured on MI355X: 3 of 8192 points, err 2e-3 of max; everything else <= 1e-5)."""
+    scale = max(float(b.abs().max()), 1e-8)
+    e = (a - b).abs()
+    err = float(e.max())
+    frac_bad = float((e > RTOL * scale).float().mean())
+    print("%-28s max|grad| %.3e  err %.3e  rel %.2e  frac>tol %.1e" % (name, scale, err, err / scale, frac_bad))
+    assert frac_bad <= 1e-3, (name, frac_bad)
+    assert err <= 10 * RTOL * scale, (name, err, scale)
+
+
+def _run(opt, xyz, attrs, inp, mlp):
+    gm_o, gp_o, probe = _oracle_grads(opt, xyz, attrs, inp, mlp)
+    gm, gp, fwd, hit = _hip_grads(opt, xyz, attrs, inp, mlp, probe)
+    for k in gm_o:
+        _check(k, gm[k], gm_o[k])
+    for k in gp_o:
+        _check(k, gp[k], gp_o[k])
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_backward_matches_oracle(name):
+    opt, xyz, attrs, inp, mlp = build_case(name)
+    _run(opt, xyz, attrs, inp, mlp)
+
+
+@pytest.mark.parametrize("K,SR", [(12, 20), (3, 70), (16, 12)])
+def test_backward_other_K(K, SR):
+    opt = config.lego_opt(K=K, SR=SR, P=24, max_o=50000, ranges=[-0.3, -0.3, -0.3, 0.3, 0.3, 0.3])
+    xyz = torch.from_numpy(scenes.chair_points(2500, seed=5, radius=0.06))
+    attrs = {k: torch.from_numpy(v) for k, v in scenes.point_attributes(2500, 32, 5).items()}
+    inp = pyref.to_torch_inputs(scenes.block_rays(theta_deg=55.0, x0=394, y0=394, size=12))
+    mlp = pyref.init_mlp_params(opt, seed=3, bias_scale=0.1)
+    _run(opt, xyz, attrs, inp, mlp)
+
+
+def test_backward_config1_chair():
+    opt = config.chair_opt()
+    xyz = torch.from_numpy(scenes.chair_points())
+    attrs = {k: torch.from_numpy(v) for k, v in scenes.point_attributes(8192, 32, 0).items()}
+    inp = pyref.to_torch_inputs(scenes.block_rays())
+    mlp = pyref.init_mlp_params(opt, seed=0, bias_scale=0.05)
+    _run(opt, xyz, attrs, inp, mlp)
