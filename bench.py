@@ -1,0 +1,223 @@
+"""bench.py -- rays/sec (render + backward) of the Point-NeRF hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: synthetic NeRF-synthetic 'lego' (2M neural points, 800x800 poses, K=8,
+128 samples/ray, lego_cuda.sh values for everything else).  One "step" is one optimisation step of
+the hot path over one batch of `--rays` rays per GPU, inputs already resident in HBM:
+    query (grid cached: xyz is fixed) -> aggregator MLP -> ray-march -> masked MSE + conf regulariser
+    -> backward -> [N>1: RCCL all-reduce of the gradients] -> 2x Adam (MLP lr, points plr) .
+N>1 shards the rays of the global batch across ranks with the point cloud and MLP replicated (weak scaling:
+per-GPU ray count fixed); the only collectives are the gradient all-reduce and a 2-float loss normaliser.
+Rank 0 prints ONE JSON line; `value` is whole-job rays/sec.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_ROW_FWD = 542720            # per valid neighbor row, forward (2*(284*256+256*256+263*256+256*256+256))
+FLOP_SAMPLE_FWD = 137984         # per valid sample, colour MLP forward
+FLOP_ROW_DGRAD = 2 * (256 * 256 + 256 * 263 + 256 * 256 + 256 * 256) + 2 * 256   # dY @ W for the four layers + alpha head
+FLOP_ROW_WGRAD = 2 * (284 * 256 + 256 * 256 + 256 * 256 + 256 * 256)             # dY^T X GEMMs (block3 extras are VALU)
+FLOP_SAMPLE_WGRAD = 2 * (280 * 128 + 2 * 128 * 128)
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rays", type=int, default=65536, help="rays per GPU per step")
+    ap.add_argument("--points", type=int, default=2_000_000)
+    ap.add_argument("--cpu-rays", type=int, default=1024, help="rays of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events")
+    return ap.parse_args()
+
+
+def build_model(opt, n_points, dev):
+    from pointnerf_amd import scenes
+    from pointnerf_amd.neural_points import NeuralPoints
+    from pointnerf_amd.point_aggregators import PointAggregator
+    from pointnerf_amd.neural_points_volumetric_model import NeuralPointsRayMarching
+    xyz = torch.from_numpy(scenes.lego_points(n_points)).to(dev)
+    attrs = {k: torch.from_numpy(v).to(dev) for k, v in scenes.point_attributes(xyz.shape[0], opt.point_features_dim, 1).items()}
+    torch.manual_seed(0)                                   # identical random-init weights on every rank (replicated)
+    agg = PointAggregator(opt).to(dev)
+    agg.flatten_()
+    npnt = NeuralPoints(opt.point_features_dim, xyz.shape[0], opt, dev)
+    npnt.set_points(xyz, attrs["points_embeding"], points_color=attrs["points_color"], points_dir=attrs["points_dir"],
+                    points_conf=attrs["points_conf"], parameter=True)
+    model = NeuralPointsRayMarching(aggregator=agg, neural_points=npnt, opt=opt).to(dev)
+    agg.flatten_()
+    return model
+
+
+def step_inputs(step, rank, world, rays, dev):
+    """Rank `rank`'s contiguous slice of the global batch of world*rays random pixels of train-like pose `step`."""
+    from pointnerf_amd import scenes
+    d = scenes.random_rays(step % 100, rays * world)
+    sl = slice(rank * rays, (rank + 1) * rays)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return dict(campos=t(d["campos"]), camrotc2w=t(d["camrotc2w"]), raydir=t(d["raydir"][:, sl]), gt_image=t(d["gt_image"][:, sl]),
+                near=t(d["near"]), far=t(d["far"]), bg_color=t(d["bg_color"]), pixel_idx=t(d["pixel_idx"][:, sl]))
+
+
+def loss_fn(opt, out, inp, world):
+    """compute_losses of the reference for the lego script (models/base_rendering_model.py:543-551,630-641):
+    MSE over the hit rays (+1e-6) + 1e-4 * zero_one(conf_coefficient).  Multi-GPU: the means are taken over the
+    GLOBAL batch (one 4-float all-reduce), so that summed gradients equal the single-GPU gradients."""
+    mask = out["ray_mask"][0] > 0
+    pred, gt = out["coarse_raycolor"][0], inp["gt_image"][0][mask]
+    cc = out["conf_coefficient"]
+    n_col = torch.tensor([float(pred.numel()), float(cc.numel())], device=pred.device)
+    if world > 1:
+        torch.distributed.all_reduce(n_col)
+    sq = ((pred - gt) ** 2).sum() / n_col[0].clamp(min=1.0)
+    v = cc.clamp(1e-3, 1 - 1e-3)
+    zo = (torch.log(v) + torch.log(1 - v)).sum() / n_col[1].clamp(min=1.0)
+    return sq + 1e-6 + zo * opt.zero_one_loss_weights[0]
+
+
+def cpu_baseline(opt, n_points, rays, threads):
+    """The oracle (C restatement of the query + torch-CPU restatement of aggregator/ray-march, `kind: port`) on a
+    bounded sample of the SAME workload: the first `rays` rays of step 0, forward + loss + backward."""
+    from pointnerf_amd import scenes
+    from oracle import pyref
+    torch.set_num_threads(threads)
+    xyz = torch.from_numpy(scenes.lego_points(n_points))
+    attrs = {k: torch.from_numpy(v).requires_grad_(True) for k, v in scenes.point_attributes(xyz.shape[0], 32, 1).items()}
+    mlp = {k: v.requires_grad_(True) for k, v in pyref.init_mlp_params(opt, seed=0).items()}
+    d = scenes.random_rays(0, 65536)
+    d["raydir"], d["gt_image"] = d["raydir"][:, :rays], d["gt_image"][:, :rays]
+    inp = pyref.to_torch_inputs(d)
+    t0 = time.time()
+    out = pyref.render(opt, dict(xyz=xyz, **attrs), mlp, inp, nthreads=threads)
+    loss = pyref.training_loss(opt, out, inp)
+    loss.backward()
+    dt = time.time() - t0
+    return dict(value=rays / dt, unit="rays/s", cores=threads, kind="port",
+                sample="first %d rays of step 0 of the same workload (query incl. serial grid build over %d points, "
+                       "aggregator+ray-march fwd, loss, backward), %.1f s" % (rays, xyz.shape[0], dt))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.distributed.init_process_group(backend="nccl")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation (oracle/ is the checker only)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    from pointnerf_amd import config, ops
+
+    opt = config.bench_lego_opt(is_train=0)    # jitter off: every step is reproducible against the oracle
+    model = build_model(opt, args.points, dev)
+    agg, npnt = model.aggregator, model.neural_points
+    mlp_params = [p for p in agg.parameters() if p.requires_grad]
+    pt_params = [p for p in (npnt.points_embeding, npnt.points_conf, npnt.points_dir, npnt.points_color) if p.requires_grad]
+    opt_mlp = torch.optim.Adam(mlp_params, lr=opt.lr, betas=(0.9, 0.999))       # neural_points_volumetric_model.py:196-201
+    opt_pts = torch.optim.Adam(pt_params, lr=opt.plr, betas=(0.9, 0.999))
+
+    total = args.warmup + args.steps
+    inputs = [step_inputs(i, rank, world, args.rays, dev) for i in range(total)]   # resident in HBM before timing
+
+    def one_step(inp):
+        opt_mlp.zero_grad(set_to_none=True); opt_pts.zero_grad(set_to_none=True)
+        out = model(**inp)
+        loss = loss_fn(opt, out, inp, world)
+        loss.backward()
+        if world > 1:
+            grads = [p.grad for p in mlp_params + pt_params]
+            flat = torch.cat([g.reshape(-1) for g in grads[:len(mlp_params)]])
+            torch.distributed.all_reduce(flat)                                   # 1.37 MB: one latency-bound collective
+            o = 0
+            for g in grads[:len(mlp_params)]:
+                g.copy_(flat[o:o + g.numel()].view_as(g)); o += g.numel()
+            for g in grads[len(mlp_params):]:
+                torch.distributed.all_reduce(g)                                  # dense N x (32+1+3+3) point gradients
+        opt_mlp.step(); opt_pts.step()
+        return loss, model.last_stats
+
+    stats = []
+    for i in range(args.warmup):
+        one_step(inputs[i])
+    torch.cuda.synchronize()
+    if not args.no_prof:
+        ops.prof_enable(True)
+        ops.prof_collect()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        loss, st = one_step(inputs[i])
+        stats.append(st)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = None
+    if not args.no_prof:
+        prof = ops.prof_collect()
+        ops.prof_enable(False)
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        rays_total = args.rays * world * args.steps
+        rows = float(np.mean([s["n_neighbor_rows"] for s in stats])); smp = float(np.mean([s["n_valid_samples"] for s in stats]))
+        out = {"metric": "rays/sec (render+bwd) NeRF-synth lego 800^2, K=8, 128 samp/ray", "value": rays_total / dt, "unit": "rays/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BASELINE.json configs[1]: synthetic lego, %d neural points, 800x800 poses, K=%d, SR=%d, D=%d, "
+                                      "%d rays/GPU/step, fwd+loss+bwd+Adam, grid cached" % (args.points, opt.K, opt.SR, opt.z_depth_dim, args.rays),
+                          "parallelism": "ray-shard dp%d, point cloud + MLP replicated" % world,
+                          "valid_samples_per_step": smp, "neighbor_rows_per_step": rows,
+                          "rays_hit_per_step": float(np.mean([s["rays_hit"] for s in stats])), "final_loss": float(loss.item())}}
+        if prof is not None:
+            per = {k: {"ms_per_launch": ms / max(n, 1), "launches": n, "ms_per_step": ms / args.steps} for k, (ms, n) in prof.items() if n > 0}
+            alg = {"agg_forward": rows * FLOP_ROW_FWD, "agg_backward": rows * FLOP_ROW_DGRAD,
+                   "wgrad": rows * FLOP_ROW_WGRAD + smp * FLOP_SAMPLE_WGRAD, "color_forward": smp * FLOP_SAMPLE_FWD}
+            dom = max((k for k in alg if k in per), key=lambda k: per[k]["ms_per_step"])
+            achieved = alg[dom] / (per[dom]["ms_per_step"] * 1e-3) / 1e12
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived HBM bytes per launch (separate rocprofv3 --pmc pass)
+            if os.path.exists(tf):
+                traffic = json.load(open(tf)).get(dom)
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                               "algorithmic_flop_per_step": alg[dom], "ms_per_step": per[dom]["ms_per_step"]}
+            out["kernels"] = per
+            for k in alg:
+                if k in per:
+                    out["kernels"][k]["tflops"] = alg[k] / (per[k]["ms_per_step"] * 1e-3) / 1e12
+        if world == 1 and args.cpu_rays > 0:
+            try:
+                out["cpu_baseline"] = cpu_baseline(opt, args.points, args.cpu_rays, min(os.cpu_count() or 1, 32))
+            except Exception as e:       # the checker failing must not hide the GPU number
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -172,6 +172,13 @@ int pnerf_render_backward(const pnerf_camera *cam, const pnerf_points *pts, cons
                           void *d_saved, float *d_grad_params, const pnerf_point_grads *pg,
                           void *d_ws, size_t ws_bytes, void *stream);
 
+/* ---- per-kernel timing (HIP events recorded on the launch stream; off by default) --------------- */
+int pnerf_prof_enable(int on);
+int pnerf_prof_kernel_count(void);
+const char *pnerf_prof_kernel_name(int id);
+/* synchronous: device is synchronised; totals of every launch recorded since the last collect */
+int pnerf_prof_collect(double *total_ms, int64_t *launches);
+
 #ifdef __cplusplus
 }
 #endif

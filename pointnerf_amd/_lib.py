@@ -67,6 +67,10 @@ PROTOTYPES = {
                                      c_int, c_int, c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_i64, c_void_p, c_size_t, c_void_p]),
+    "pnerf_prof_enable": (c_int, [c_int]),
+    "pnerf_prof_kernel_count": (c_int, []),
+    "pnerf_prof_kernel_name": (ctypes.c_char_p, [c_int]),
+    "pnerf_prof_collect": (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
     "pnerf_render_backward": (c_int, [ctypes.POINTER(Camera), ctypes.POINTER(Points), c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_int, c_int, c_int, c_i64,

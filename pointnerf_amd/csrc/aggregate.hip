@@ -65,6 +65,7 @@ extern "C" int pnerf_mlp_pack(const float *d_params, void *d_packed, void *strea
         {PO_WC2, PN_HC, 0, PN_HC, PN_HC, PN_HC, PN_HC, 1, PK_DC2},
         {PO_WC1, PN_INC, 0, PN_HC, PN_H, PN_HC, PN_H, 2, PK_DC1},
     }};
+    PnProfScope prof(PNK_PACK, (hipStream_t)stream);
     hipLaunchKernelGGL(k_pack, dim3(64, 14), dim3(256), 0, (hipStream_t)stream, t, d_params, (float *)d_packed);
     PN_CHECK_LAUNCH();
     return 0;
@@ -439,13 +440,13 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     if (train) {
         hipFuncSetAttribute((const void *)k_agg_forward<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
         hipFuncSetAttribute((const void *)k_color_forward<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
-        hipLaunchKernelGGL(k_agg_forward<true>, dim3(grid_a), dim3(256), lds_a, s, a);
-        hipLaunchKernelGGL(k_color_forward<true>, dim3(grid_c), dim3(256), lds_c, s, a);
+        { PnProfScope prof(PNK_AGG_FWD, s); hipLaunchKernelGGL(k_agg_forward<true>, dim3(grid_a), dim3(256), lds_a, s, a); }
+        { PnProfScope prof(PNK_COLOR_FWD, s); hipLaunchKernelGGL(k_color_forward<true>, dim3(grid_c), dim3(256), lds_c, s, a); }
     } else {
         hipFuncSetAttribute((const void *)k_agg_forward<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
         hipFuncSetAttribute((const void *)k_color_forward<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
-        hipLaunchKernelGGL(k_agg_forward<false>, dim3(grid_a), dim3(256), lds_a, s, a);
-        hipLaunchKernelGGL(k_color_forward<false>, dim3(grid_c), dim3(256), lds_c, s, a);
+        { PnProfScope prof(PNK_AGG_FWD, s); hipLaunchKernelGGL(k_agg_forward<false>, dim3(grid_a), dim3(256), lds_a, s, a); }
+        { PnProfScope prof(PNK_COLOR_FWD, s); hipLaunchKernelGGL(k_color_forward<false>, dim3(grid_c), dim3(256), lds_c, s, a); }
     }
     PN_CHECK_LAUNCH();
     return 0;

@@ -11,6 +11,7 @@
 //   k_wgrad          : dW = dY^T X as split-K MFMA GEMMs over the saved activations, full dW tile
 //                      resident in accumulators, deterministic partial-sum reduction
 // LeakyReLU masks come from the saved post-activations (sign(post) == sign(pre)).
+#include <stdlib.h>
 #include "mlp_common.h"
 
 namespace {
@@ -32,6 +33,7 @@ struct BwdArgs {
     PnSaved sv;
     float *gparams;
     float *g_emb, *g_conf, *g_dir, *g_color;
+    int debug_skip;                            // dev knob (PNERF_DEBUG_SKIP): timing ablations only, results are wrong when set
 };
 
 __device__ __forceinline__ void rot3b(const float *M, float x, float y, float z, bool transpose, float &ox, float &oy, float &oz) {
@@ -229,14 +231,14 @@ __global__ __launch_bounds__(256, 1) void k_agg_backward(BwdArgs a) {
         }
         __syncthreads();
         // ---- block3 second layer: dY3 = (dY4 @ W4) * lrelu'(h3) ----------------------------------
-        _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) gb4 += bufB[row * LDH + tid];
+        if (!(a.debug_skip & 2)) _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) gb4 += bufB[row * LDH + tid];
         f32x16 acc[2][2];
         pn_acc_init_bias<2>(acc, nullptr, wave, lane);
-        pn_tile_gemm<2>(bufB, LDH, PN_H / 8, a.packed + PK_D4 / 4, wave, lane, acc);
+        if (!(a.debug_skip & 4)) pn_tile_gemm<2>(bufB, LDH, PN_H / 8, a.packed + PK_D4 / 4, wave, lane, acc);
         pn_store_dact<2>(acc, a.sv.h3, PN_H, bufA, LDH, a.sv.dy3, PN_H, grow0, wave, lane);
         __syncthreads();
         // ---- block3 first layer: extras (colour, dir) + dY2 = (dY3 @ W3[:, :256]) * lrelu'(h2) ----
-        _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) {
+        if (!(a.debug_skip & 2)) _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) {
             const float v = bufA[row * LDH + tid];
             gb3 += v;
 #pragma unroll
@@ -274,19 +276,19 @@ __global__ __launch_bounds__(256, 1) void k_agg_backward(BwdArgs a) {
             }
         }
         pn_acc_init_bias<2>(acc, nullptr, wave, lane);
-        pn_tile_gemm<2>(bufA, LDH, PN_H / 8, a.packed + PK_D3 / 4, wave, lane, acc);
+        if (!(a.debug_skip & 4)) pn_tile_gemm<2>(bufA, LDH, PN_H / 8, a.packed + PK_D3 / 4, wave, lane, acc);
         pn_store_dact<2>(acc, a.sv.h2, PN_H, bufB, LDH, a.sv.dy2, PN_H, grow0, wave, lane);
         __syncthreads();
         // ---- block1 second layer: dY1 = (dY2 @ W2) * lrelu'(h1) ----------------------------------
-        _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) gb2 += bufB[row * LDH + tid];
+        if (!(a.debug_skip & 2)) _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) gb2 += bufB[row * LDH + tid];
         pn_acc_init_bias<2>(acc, nullptr, wave, lane);
-        pn_tile_gemm<2>(bufB, LDH, PN_H / 8, a.packed + PK_D2 / 4, wave, lane, acc);
+        if (!(a.debug_skip & 4)) pn_tile_gemm<2>(bufB, LDH, PN_H / 8, a.packed + PK_D2 / 4, wave, lane, acc);
         pn_store_dact<2>(acc, a.sv.h1, PN_H, bufA, LDH, a.sv.dy1, PN_H, grow0, wave, lane);
         __syncthreads();
         // ---- block1 first layer: d X0[:, :256] = dY1 @ W1[:, :256] --------------------------------
-        _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) gb1 += bufA[row * LDH + tid];
+        if (!(a.debug_skip & 2)) _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) gb1 += bufA[row * LDH + tid];
         pn_acc_init_bias<2>(acc, nullptr, wave, lane);
-        pn_tile_gemm<2>(bufA, LDH, PN_H / 8, a.packed + PK_D1 / 4, wave, lane, acc);
+        if (!(a.debug_skip & 4)) pn_tile_gemm<2>(bufA, LDH, PN_H / 8, a.packed + PK_D1 / 4, wave, lane, acc);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void k_agg_backward(BwdArgs a) {
                             g += fr * (dx[o] * x0[o + 1] - dx[o + 1] * x0[o]);
                             fr *= 2.f;
                         }
-                        atomicAdd(&a.g_emb[(long long)p * PN_F + dd], g);
+                        if (!(a.debug_skip & 1)) atomicAdd(&a.g_emb[(long long)p * PN_F + dd], g);
                     }
                 }
             }
@@ -417,7 +419,9 @@ int launch_wgrad(const float *A, int lda, const float *B, int ldb, long long row
     if (rpc < 64) rpc = 64;
     chunks = (int)((rows + rpc - 1) / rpc);
     if (chunks < 1) chunks = 1;
-    hipLaunchKernelGGL((k_wgrad<MT, NT, WM, WN>), dim3(ntiles, chunks), dim3(WM * WN * 64), 0, s, A, lda, B, ldb, rows, (int)rpc, partial, Mtot, Ntot);
+    { PnProfScope prof(PNK_WGRAD, s);
+    hipLaunchKernelGGL((k_wgrad<MT, NT, WM, WN>), dim3(ntiles, chunks), dim3(WM * WN * 64), 0, s, A, lda, B, ldb, rows, (int)rpc, partial, Mtot, Ntot); }
+    PnProfScope prof(PNK_WGRAD_REDUCE, s);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(pn_cdiv((long long)Mtot * Ntot, 256)), dim3(256), 0, s, partial, chunks, Mtot, Ntot, Nreal, grad, dst, ldc);
     PN_CHECK_LAUNCH();
     return 0;
@@ -438,6 +442,7 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     a.pidx = d_sample_pidx; a.valid_list = d_valid_list; a.counters = d_counters;
     a.SR = SR; a.K = K; a.TS = pn_tile_samples(K); a.cap_samples = n_valid;
     a.decoded = d_decoded; a.weight = d_weight; a.grad_decoded = d_grad_decoded; a.sv = sv;
+    { const char *e = getenv("PNERF_DEBUG_SKIP"); a.debug_skip = e ? atoi(e) : 0; }
     a.gparams = d_grad_params; a.g_emb = pg->embedding; a.g_conf = pg->conf; a.g_dir = pg->dir; a.g_color = pg->color;
     if (!a.g_emb || !a.g_conf || !a.g_dir || !a.g_color) return PNERF_E_INVAL;
     int dev = 0, ncu = 256;
@@ -450,8 +455,8 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     const size_t lds_c = COLB_LDS_FLOATS * sizeof(float), lds_a = AGGB_LDS_FLOATS * sizeof(float);
     if (hipFuncSetAttribute((const void *)k_color_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipFuncSetAttribute((const void *)k_agg_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
-    hipLaunchKernelGGL(k_color_backward, dim3(grid_c), dim3(256), lds_c, s, a);
-    hipLaunchKernelGGL(k_agg_backward, dim3(grid_a), dim3(256), lds_a, s, a);
+    { PnProfScope prof(PNK_COLOR_BWD, s); hipLaunchKernelGGL(k_color_backward, dim3(grid_c), dim3(256), lds_c, s, a); }
+    { PnProfScope prof(PNK_AGG_BWD, s); hipLaunchKernelGGL(k_agg_backward, dim3(grid_a), dim3(256), lds_a, s, a); }
     PN_CHECK_LAUNCH();
     // weight gradients over the rows / samples of the tiles that actually ran
     const long long rows = tiles * PN_TILE, smp = ctiles * PN_TILE;

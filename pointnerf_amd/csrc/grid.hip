@@ -166,6 +166,7 @@ extern "C" int pnerf_grid_build(const pnerf_grid_params *gp, const float *d_xyz,
     GP g = {gp->ranges[0], gp->ranges[1], gp->ranges[2], gp->vsize[0], gp->vsize[1], gp->vsize[2],
             gp->vdim[0], gp->vdim[1], gp->vdim[2], gp->query_size[0], gp->query_size[1], gp->query_size[2]};
 
+    PnProfScope prof(PNK_GRID, s);
     hipLaunchKernelGGL(k_grid_init, dim3(1), dim3(TPB), 0, s, info);
     if (hipMemsetAsync(cursor, 0, (size_t)L.G * sizeof(int), s) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipMemsetAsync(occ, 0, (size_t)((L.G + 31) / 32) * sizeof(uint32_t), s) != hipSuccess) return PNERF_E_LAUNCH;

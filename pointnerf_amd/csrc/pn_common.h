@@ -27,6 +27,17 @@ struct PnCarver {
     bool ok() const { return off <= cap; }
 };
 
+// ---- optional per-kernel timing with HIP events on the launch stream (prof.hip) ----------------
+enum PnKernelId { PNK_GRID = 0, PNK_PROBE, PNK_NEIGHBORS, PNK_COMPACT, PNK_PACK, PNK_AGG_FWD, PNK_COLOR_FWD, PNK_RAYMARCH_FWD,
+                  PNK_RAYMARCH_BWD, PNK_COLOR_BWD, PNK_AGG_BWD, PNK_WGRAD, PNK_WGRAD_REDUCE, PNK_GATHER, PNK_COUNT };
+extern int pn_prof_enabled;
+void pn_prof_mark(int id, bool begin, hipStream_t s);
+struct PnProfScope {       // RAII: records an event pair around the launches issued while it lives
+    int id; hipStream_t s;
+    PnProfScope(int id_, hipStream_t s_) : id(id_), s(s_) { if (pn_prof_enabled) pn_prof_mark(id, true, s); }
+    ~PnProfScope() { if (pn_prof_enabled) pn_prof_mark(id, false, s); }
+};
+
 // ---- scan / compaction primitives (scan.hip) ----------------------------------------------
 // scratch needed (ints) for n elements
 size_t pn_scan_scratch_ints(long long n);

@@ -207,15 +207,19 @@ extern "C" int pnerf_query(const pnerf_grid_params *gp, const void *d_grid_ws, c
     rg.cx = campos3_host ? campos3_host[0] : 0.f; rg.cy = campos3_host ? campos3_host[1] : 0.f; rg.cz = campos3_host ? campos3_host[2] : 0.f;
     rg.near_d = near_depth; rg.jitter = jitter; rg.seed = seed;
     const int wb = pn_cdiv(R, TPB / 64);
+    { PnProfScope prof(PNK_PROBE, s);
     if (d_raypos) hipLaunchKernelGGL((k_probe<true, false>), dim3(wb), dim3(TPB), 0, s, g, rg, R, D, SR, d_sample_loc, sel_cnt);
     else if (jitter > 0.f) hipLaunchKernelGGL((k_probe<false, true>), dim3(wb), dim3(TPB), 0, s, g, rg, R, D, SR, d_sample_loc, sel_cnt);
-    else hipLaunchKernelGGL((k_probe<false, false>), dim3(wb), dim3(TPB), 0, s, g, rg, R, D, SR, d_sample_loc, sel_cnt);
+    else hipLaunchKernelGGL((k_probe<false, false>), dim3(wb), dim3(TPB), 0, s, g, rg, R, D, SR, d_sample_loc, sel_cnt); }
     const long long total = (long long)R * SR;
     const float radius2 = gp->radius * gp->radius;     // fp32 product, as .cu:410
     const int nbk = pn_cdiv(total, TPB);
+    { PnProfScope prof(PNK_NEIGHBORS, s);
     if (K <= 4) hipLaunchKernelGGL(k_neighbors<4>, dim3(nbk), dim3(TPB), 0, s, g, gp->kernel_size[0], radius2, total, SR, K, d_sample_loc, sel_cnt, d_sample_pidx, d_sample_nn);
     else if (K <= 8) hipLaunchKernelGGL(k_neighbors<8>, dim3(nbk), dim3(TPB), 0, s, g, gp->kernel_size[0], radius2, total, SR, K, d_sample_loc, sel_cnt, d_sample_pidx, d_sample_nn);
     else hipLaunchKernelGGL(k_neighbors<16>, dim3(nbk), dim3(TPB), 0, s, g, gp->kernel_size[0], radius2, total, SR, K, d_sample_loc, sel_cnt, d_sample_pidx, d_sample_nn);
+    }
+    PnProfScope prof(PNK_COMPACT, s);
     hipLaunchKernelGGL(k_ray_hit, dim3(wb), dim3(TPB), 0, s, R, SR, sel_cnt, d_sample_nn, d_ray_hit, d_counters);
     PN_CHECK_LAUNCH();
     return pn_compact_gt0_i32(d_sample_nn, total, d_valid_list, d_counters, scan, s);

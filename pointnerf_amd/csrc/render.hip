@@ -195,16 +195,27 @@ __global__ __launch_bounds__(TPB) void k_gather_rows(const float *__restrict__ s
         dst[e] = src[(long long)p * width + c];
     }
 }
+// -1 slots were gathered from point 0 (A.9 of SURVEY.md: the reference lets point 0 collect gradient from every
+// empty slot).  Those are the vast majority of the slots, all hitting ONE row: they are summed per block in LDS
+// first and leave as one atomic per column per block; real indices go straight to global atomics.
 __global__ __launch_bounds__(TPB) void k_scatter_add_rows(const float *__restrict__ grad_rows, const int *__restrict__ idx, long long n_idx,
                                                           int width, float *__restrict__ grad_src, int n_src) {
+    __shared__ float row0[64];
+    const bool use_lds = width <= 64;
+    if (use_lds && threadIdx.x < 64) row0[threadIdx.x] = 0.f;
+    __syncthreads();
     const long long total = n_idx * width;
     for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
         const long long i = e / width;
         const int c = (int)(e - i * width);
         int p = idx[i];
+        const float g = grad_rows[e];
+        if (p <= 0 && use_lds) { atomicAdd(&row0[c], g); continue; }
         p = p < 0 ? 0 : (p >= n_src ? n_src - 1 : p);
-        atomicAdd(&grad_src[(long long)p * width + c], grad_rows[e]);
+        atomicAdd(&grad_src[(long long)p * width + c], g);
     }
+    __syncthreads();
+    if (use_lds && threadIdx.x < width && row0[threadIdx.x] != 0.f) atomicAdd(&grad_src[threadIdx.x], row0[threadIdx.x]);
 }
 }  // namespace
 
@@ -213,6 +224,7 @@ extern "C" int pnerf_gather_rows(const float *d_src, int n_src, int width, const
     if (n_idx == 0) return 0;
     long long total = n_idx * width;
     int grid = (int)((total + TPB - 1) / TPB < 16384 ? (total + TPB - 1) / TPB : 16384);
+    PnProfScope prof(PNK_GATHER, (hipStream_t)stream);
     hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, d_src, n_src, width, d_idx, (long long)n_idx, d_dst);
     PN_CHECK_LAUNCH();
     return 0;
@@ -222,7 +234,8 @@ extern "C" int pnerf_scatter_add_rows(const float *d_grad_rows, const int32_t *d
     if (!d_grad_rows || !d_idx || !d_grad_src || n_src <= 0 || width <= 0 || n_idx < 0) return PNERF_E_INVAL;
     if (n_idx == 0) return 0;
     long long total = n_idx * width;
-    int grid = (int)((total + TPB - 1) / TPB < 16384 ? (total + TPB - 1) / TPB : 16384);
+    int grid = (int)((total + TPB - 1) / TPB < 4096 ? (total + TPB - 1) / TPB : 4096);
+    PnProfScope prof(PNK_GATHER, (hipStream_t)stream);
     hipLaunchKernelGGL(k_scatter_add_rows, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, d_grad_rows, d_idx, (long long)n_idx, width, d_grad_src, n_src);
     PN_CHECK_LAUNCH();
     return 0;
@@ -274,7 +287,8 @@ extern "C" int pnerf_render_forward(const pnerf_camera *cam, const pnerf_points 
     }
     RmArgs ra;
     ra.cam = *cam; ra.sample_loc = d_sample_loc; ra.decoded = d_decoded; ra.nn = d_sample_nn; ra.R = R; ra.SR = SR;
-    hipLaunchKernelGGL(k_raymarch_forward, dim3(pn_cdiv(R, TPB / 64)), dim3(TPB), 0, s, ra, d_ray_color, d_opacity, d_bg_trans, d_blend_w);
+    { PnProfScope prof(PNK_RAYMARCH_FWD, s);
+    hipLaunchKernelGGL(k_raymarch_forward, dim3(pn_cdiv(R, TPB / 64)), dim3(TPB), 0, s, ra, d_ray_color, d_opacity, d_bg_trans, d_blend_w); }
     PN_CHECK_LAUNCH();
     return 0;
 }
@@ -300,7 +314,8 @@ extern "C" int pnerf_render_backward(const pnerf_camera *cam, const pnerf_points
     float *partials = (float *)((char *)d_ws + gd_bytes);
     RmArgs ra;
     ra.cam = *cam; ra.sample_loc = d_sample_loc; ra.decoded = d_decoded; ra.nn = d_sample_nn; ra.R = R; ra.SR = SR;
-    hipLaunchKernelGGL(k_raymarch_backward, dim3(pn_cdiv(R, TPB / 64)), dim3(TPB), 0, s, ra, d_grad_ray_color, grad_decoded);
+    { PnProfScope prof(PNK_RAYMARCH_BWD, s);
+    hipLaunchKernelGGL(k_raymarch_backward, dim3(pn_cdiv(R, TPB / 64)), dim3(TPB), 0, s, ra, d_grad_ray_color, grad_decoded); }
     PN_CHECK_LAUNCH();
     PnSaved sv = pn_saved_carve(d_saved, n_valid, K);
     return pn_agg_backward_launch(cam, pts, d_params, d_packed_mlp, d_raydir, d_sample_loc, d_sample_pidx, d_valid_list, d_counters,

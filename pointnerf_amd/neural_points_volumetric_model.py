@@ -1,0 +1,112 @@
+"""Drop-in for ``NeuralPointsRayMarching`` of the reference's ``models/neural_points_volumetric_model.py``
+(:220-364) -- THE hot nn.Module (query -> aggregate -> ray_dist -> ray_march -> output dict) -- and for
+``fill_invalid`` (:87-123).
+
+``forward(**input)`` takes the reference's kwargs (``campos, raydir, gt_image, bg_color, camrotc2w, pixel_idx, near,
+far, focal, h, w, intrinsic, **kargs``) and returns the reference's dict with the reference's shapes
+(``coarse_raycolor [1,R'',3]``, ``coarse_point_opacity [1,R'',SR]``, ``coarse_is_background [1,R'',1]``,
+``ray_mask [1,R] int8``, ``queried_shading``, ``weight``, ``blend_weight``, ``conf_coefficient``).  Internally
+everything runs dense over the R submitted rays inside libpnerf_hip.so; the R'' view is produced by one
+boolean row-gather at the very end (the only host sync besides reading the valid-sample count).
+``opt.prob==1`` probe outputs (:331-362) are a "next" row and raise.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .fused import FusedRender
+
+
+def gradient_clamp(sampled_conf, lo=0.0001, hi=1.0):
+    """point_aggregators.py:722-724: clamp forward, identity backward."""
+    diff = sampled_conf - torch.clamp(sampled_conf, min=lo, max=hi)
+    return sampled_conf - diff.detach()
+
+
+class NeuralPointsRayMarching(nn.Module):
+
+    def __init__(self, tonemap_func=None, render_func=None, blend_func=None, aggregator=None, is_compute_depth=False,
+                 neural_points=None, opt=None, num_pos_freqs=0, num_viewdir_freqs=0, **kwargs):
+        super().__init__()
+        self.aggregator = aggregator
+        self.neural_points = neural_points
+        self.opt = opt
+        self.num_pos_freqs, self.num_viewdir_freqs = num_pos_freqs, num_viewdir_freqs
+        self.render_func, self.blend_func, self.tone_map = render_func, blend_func, tonemap_func
+        self.return_depth = is_compute_depth
+        self.return_color = True
+        if is_compute_depth:
+            raise NotImplementedError("compute_depth references an undefined ray_ts in the reference "
+                                      "(neural_points_volumetric_model.py:318-322); unsupported (SURVEY.md A.11 iii)")
+        if opt is not None:
+            if getattr(opt, "which_render_func", "radiance") != "radiance" or getattr(opt, "which_blend_func", "alpha") != "alpha" \
+                    or getattr(opt, "which_tonemap_func", "off") != "off":
+                raise NotImplementedError("only radiance / alpha / off (every script's setting) is implemented")
+        self.last_stats = None
+
+    def render_dense(self, campos, raydir, camrotc2w, near, far, bg_color=None, train=None):
+        """The fused step on all R rays.  Returns (ray_color [R,3], opacity, bg_trans, blend_w, decoded, weight, dense)."""
+        opt, npnt, agg = self.opt, self.neural_points, self.aggregator
+        train = torch.is_grad_enabled() if train is None else train
+        dense = npnt.query_dense(dict(campos=campos, raydir=raydir, near=near, far=far))
+        R = raydir.reshape(-1, 3).shape[0]
+        counters = dense["counters"].cpu()                    # the one sync: sizes the activation arena
+        n_valid = int(counters[0])
+        self.last_stats = dict(n_valid_samples=n_valid, rays_hit=int(counters[1]), n_selected=int(counters[2]),
+                               n_neighbor_rows=int(counters[3]), rays=R)
+        st = agg.mlp_state()
+        rw = npnt.Rw2c.detach().cpu().numpy() if isinstance(npnt.Rw2c, torch.Tensor) else None
+        cam = ops.make_camera(campos.detach().reshape(-1)[:3].cpu().numpy(), camrotc2w.detach().reshape(-1)[:9].cpu().numpy(),
+                              opt.vsize[2], opt.raydist_mode_unit,
+                              bg=None if bg_color is None else bg_color.detach().reshape(-1)[:3].cpu().numpy(), rw2c=rw)
+        mlp_params, layout = agg.ordered_params()
+        env = dict(cam=cam, xyz=npnt.xyz.detach().reshape(-1, 3).contiguous(), raydir=raydir.detach().reshape(-1, 3).contiguous().float(),
+                   dense=dense, R=R, SR=int(opt.SR), K=int(opt.K), n_valid=n_valid, flat=st.flat, packed=st.packed_image(),
+                   train=bool(train), layout=layout)
+        out = FusedRender.apply(env, npnt.points_embeding, npnt.points_conf, npnt.points_dir, npnt.points_color, *mlp_params)
+        return out + (dense,)
+
+    def forward(self, campos, raydir, gt_image=None, bg_color=None, camrotc2w=None, pixel_idx=None, near=None, far=None,
+                focal=None, h=None, w=None, intrinsic=None, **kargs):
+        opt = self.opt
+        if getattr(opt, "prob", 0) == 1:
+            raise NotImplementedError("opt.prob==1 probe outputs are a 'next' row (SURVEY.md 8f f1)")
+        if "bg_ray" in kargs:
+            bg_color = None
+        ray_color, opacity, bg_trans, blend_w, decoded, weight, dense = self.render_dense(campos, raydir, camrotc2w, near, far, bg_color)
+        hit = dense["ray_hit"] > 0
+        SR, K = int(opt.SR), int(opt.K)
+        output = {}
+        nn_hit = dense["sample_nn"][hit]
+        output["queried_shading"] = torch.logical_not(torch.any(nn_hit > 0, dim=-1, keepdim=True)).repeat(1, 3).to(torch.float32)[None]
+        output["coarse_raycolor"] = ray_color[hit][None]
+        output["coarse_point_opacity"] = opacity[hit][None]
+        output["coarse_is_background"] = bg_trans[hit][None, :, None]
+        output["ray_mask"] = hit.to(torch.int8)[None]
+        want_w = (opt.sparse_loss_weight > 0) or ("conf_coefficient" in opt.zero_one_loss_items) or getattr(opt, "prob", 0) != 0
+        if want_w:
+            output["weight"] = weight[hit][None].detach()
+            output["blend_weight"] = blend_w[hit][None, ..., None].detach()
+            conf = self.neural_points.points_conf
+            pidx_hit = dense["sample_pidx"][hit]
+            output["conf_coefficient"] = gradient_clamp(ops.gather_rows(conf.reshape(-1, 1), pidx_hit)[..., 0])[None]
+        return output
+
+
+def fill_invalid(output, bg_color, tonemap_func=None):
+    """neural_points_volumetric_model.py:87-123 for the keys the fused path emits."""
+    ray_mask = output["ray_mask"]
+    B, OR = ray_mask.shape
+    sel = ray_mask[0] > 0
+    dev = output["coarse_raycolor"].device
+    bgt = torch.ones([B, OR, 1], dtype=torch.float32, device=dev)
+    bgt[0, sel] = output["coarse_is_background"][0]
+    col = torch.ones([B, OR, 3], dtype=torch.float32, device=dev) * bg_color[None, ...].to(dev)
+    col[0, sel] = output["coarse_raycolor"][0]
+    op = torch.zeros([B, OR, output["coarse_point_opacity"].shape[2]], dtype=torch.float32, device=dev)
+    op[0, sel] = output["coarse_point_opacity"][0]
+    qs = torch.ones([B, OR, 3], dtype=torch.float32, device=dev)
+    qs[0, sel] = output["queried_shading"][0]
+    out = dict(output)
+    out.update(coarse_is_background=bgt, coarse_mask=1 - bgt, coarse_raycolor=col, coarse_point_opacity=op, queried_shading=qs)
+    return out

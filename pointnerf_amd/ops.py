@@ -187,6 +187,33 @@ def make_points(xyz, emb, conf, pdir, color):
     return p
 
 
+class Arena:
+    """Grow-only device scratch for the saved activations of one in-flight training forward.  The arena is tens of GB
+    at bench size and its exact size changes every step with the number of valid samples; letting torch's caching
+    allocator see a new size each step costs a hipMalloc/hipFree pair of that size (measured: ~1.9 s per step)."""
+
+    def __init__(self):
+        self.free, self.headroom = [], 1.15
+
+    def take(self, nbytes, device):
+        best = None
+        for t in self.free:
+            if t.numel() >= nbytes and t.device == device and (best is None or t.numel() < best.numel()):
+                best = t
+        if best is not None:
+            self.free.remove(best)
+            return best
+        self.free = [t for t in self.free if t.device != device]      # drop too-small blocks before growing
+        return torch.empty(int(nbytes * self.headroom) + 256, dtype=torch.uint8, device=device)
+
+    def give(self, t):
+        if t is not None:
+            self.free.append(t)
+
+
+ARENA = Arena()
+
+
 def render_forward(cam, pts, packed, flat, raydir, dense, R, SR, K, n_valid, train):
     """pnerf_render_forward.  n_valid = host copy of dense['counters'][0] (capacity of the scratch).
     Returns dict(decoded, weight, ray_color, opacity, bg_trans, blend_w, saved)."""
@@ -198,7 +225,7 @@ def render_forward(cam, pts, packed, flat, raydir, dense, R, SR, K, n_valid, tra
     bg_trans = torch.empty(R, **f32); blend_w = torch.empty(R, SR, **f32)
     saved = ws = None
     if train:
-        saved = torch.empty(lib.pnerf_agg_saved_bytes(n_valid, K), dtype=torch.uint8, device=dev)
+        saved = ARENA.take(lib.pnerf_agg_saved_bytes(n_valid, K), dev)
         nws = 0
     else:
         nws = lib.pnerf_agg_workspace_bytes(n_valid, K)
@@ -228,3 +255,51 @@ def render_backward(cam, pts, packed, flat, raydir, dense, R, SR, K, n_valid, fw
                                       _ptr(fwd["decoded"]), _ptr(fwd["weight"]), _ptr(fwd["opacity"]), _ptr(g),
                                       _ptr(fwd["saved"]), _ptr(grad_flat), ctypes.byref(pg), _ptr(ws), nws, _stream()),
             "pnerf_render_backward")
+
+
+# ------------------------------------------------------------------------------------------ gather (autograd)
+class GatherRows(torch.autograd.Function):
+    """rows = src[max(idx, 0)]  (NeuralPoints.forward's index_select, neural_points.py:706-717) with the
+    scatter-add backward, both in libpnerf_hip.so.  src [N,W] f32, idx [...] i32 -> [..., W]."""
+
+    @staticmethod
+    def forward(ctx, src, idx):
+        _need_cuda(src, "src")
+        s2 = src.detach().reshape(-1, src.shape[-1]).contiguous().float()
+        i2 = idx.reshape(-1).contiguous().to(torch.int32)
+        out = torch.empty(i2.numel(), s2.shape[1], dtype=torch.float32, device=src.device)
+        L.check(L.lib().pnerf_gather_rows(_ptr(s2), s2.shape[0], s2.shape[1], _ptr(i2), i2.numel(), _ptr(out), _stream()),
+                "pnerf_gather_rows")
+        ctx.save_for_backward(i2)
+        ctx.src_shape = tuple(src.shape)
+        return out.view(tuple(idx.shape) + (s2.shape[1],))
+
+    @staticmethod
+    def backward(ctx, g):
+        (i2,) = ctx.saved_tensors
+        w = ctx.src_shape[-1]
+        gs = torch.zeros(ctx.src_shape, dtype=torch.float32, device=g.device)
+        g2 = g.reshape(-1, w).contiguous().float()
+        n_src = gs.numel() // w
+        L.check(L.lib().pnerf_scatter_add_rows(_ptr(g2), _ptr(i2), i2.numel(), w, _ptr(gs), n_src, _stream()),
+                "pnerf_scatter_add_rows")
+        return gs, None
+
+
+def gather_rows(src, idx):
+    return GatherRows.apply(src, idx)
+
+
+# ------------------------------------------------------------------------------------------ profiling
+def prof_enable(on=True):
+    L.lib().pnerf_prof_enable(1 if on else 0)
+
+
+def prof_collect():
+    """{kernel name: (total ms, launches)} since the last collect; synchronises the device."""
+    lib = L.lib()
+    n = lib.pnerf_prof_kernel_count()
+    ms = (ctypes.c_double * n)()
+    cnt = (ctypes.c_int64 * n)()
+    L.check(lib.pnerf_prof_collect(ms, cnt), "pnerf_prof_collect")
+    return {lib.pnerf_prof_kernel_name(i).decode(): (ms[i], cnt[i]) for i in range(n)}
