@@ -75,19 +75,8 @@ def step_inputs(step, rank, world, rays, dev):
 
 
 def loss_fn(opt, out, inp, world):
-    """compute_losses of the reference for the lego script (models/base_rendering_model.py:543-551,630-641):
-    MSE over the hit rays (+1e-6) + 1e-4 * zero_one(conf_coefficient).  Multi-GPU: the means are taken over the
-    GLOBAL batch (one 4-float all-reduce), so that summed gradients equal the single-GPU gradients."""
-    mask = out["ray_mask"][0] > 0
-    pred, gt = out["coarse_raycolor"][0], inp["gt_image"][0][mask]
-    cc = out["conf_coefficient"]
-    n_col = torch.tensor([float(pred.numel()), float(cc.numel())], device=pred.device)
-    if world > 1:
-        torch.distributed.all_reduce(n_col)
-    sq = ((pred - gt) ** 2).sum() / n_col[0].clamp(min=1.0)
-    v = cc.clamp(1e-3, 1 - 1e-3)
-    zo = (torch.log(v) + torch.log(1 - v)).sum() / n_col[1].clamp(min=1.0)
-    return sq + 1e-6 + zo * opt.zero_one_loss_weights[0]
+    from pointnerf_amd import dist as pdist
+    return pdist.hot_path_loss(opt, out, inp["gt_image"])
 
 
 def cpu_baseline(opt, n_points, rays, threads):
@@ -123,7 +112,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation (oracle/ is the checker only)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    from pointnerf_amd import config, ops
+    from pointnerf_amd import config, ops, dist as pdist
 
     opt = config.bench_lego_opt(is_train=0)    # jitter off: every step is reproducible against the oracle
     model = build_model(opt, args.points, dev)
@@ -141,15 +130,7 @@ def main():
         out = model(**inp)
         loss = loss_fn(opt, out, inp, world)
         loss.backward()
-        if world > 1:
-            grads = [p.grad for p in mlp_params + pt_params]
-            flat = torch.cat([g.reshape(-1) for g in grads[:len(mlp_params)]])
-            torch.distributed.all_reduce(flat)                                   # 1.37 MB: one latency-bound collective
-            o = 0
-            for g in grads[:len(mlp_params)]:
-                g.copy_(flat[o:o + g.numel()].view_as(g)); o += g.numel()
-            for g in grads[len(mlp_params):]:
-                torch.distributed.all_reduce(g)                                  # dense N x (32+1+3+3) point gradients
+        pdist.allreduce_grads(mlp_params, pt_params)    # no-op at N=1; RCCL over xGMI otherwise
         opt_mlp.step(); opt_pts.step()
         return loss, model.last_stats
 

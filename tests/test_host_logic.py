@@ -1,0 +1,74 @@
+"""CPU tests of the host-side mirror of the reference interface (no kernels involved)."""
+import numpy as np
+import torch
+
+from pointnerf_amd import config, ops, scenes, dist as pdist
+from pointnerf_amd.point_aggregators import PointAggregator
+from oracle import pyref
+
+
+def test_grid_hyperparameters_match_oracle():
+    for opt, xyz in [(config.chair_opt(), scenes.chair_points()), (config.lego_opt(), scenes.lego_points(50000)),
+                     (config.lego_opt(vscale=[3, 3, 3], kernel_size=[5, 5, 5], ranges=[-0.05] * 3 + [0.05] * 3), scenes.chair_points(500))]:
+        x = torch.from_numpy(xyz)
+        hp = pyref.grid_hyperparameters(opt, x)
+        ranges, svs, svd, radius = ops.grid_hyperparameters(opt, x)
+        assert np.array_equal(ranges, hp["ranges"]) and np.array_equal(svs, hp["scaled_vsize"])
+        assert np.array_equal(svd, hp["scaled_vdim"]) and radius == hp["radius"]
+
+
+def test_mid_depths_bit_equal_to_reference_ray_generation():
+    fix = np.load(__file__.replace("test_host_logic.py", "golden/raygen_pe.npz"))
+    mid, seg = ops.mid_depths(400, 2.0, 6.0)
+    assert np.array_equal(mid.numpy(), fix["mid"])           # golden: the reference's near_far_linear_ray_generation
+    assert abs(float(seg.sum()) - 4.0) < 1e-4
+
+
+def test_aggregator_container_has_reference_state_dict():
+    opt = config.lego_opt()
+    agg = PointAggregator(opt)
+    sd = agg.state_dict()
+    shapes = pyref.mlp_param_shapes(opt)
+    assert list(sd.keys()) == list(shapes.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    assert sum(v.numel() for v in sd.values()) == 341764
+    # xavier gains of init_seq: leaky gain for layers followed by LeakyReLU, 1 for the heads; biases zero
+    g = np.sqrt(2.0 / (1 + 0.01 ** 2))
+    assert abs(float(sd["block1.0.weight"].abs().max()) - g * np.sqrt(6.0 / (284 + 256))) < 2e-3
+    assert abs(float(sd["color_branch.6.weight"].abs().max()) - np.sqrt(6.0 / (128 + 3))) < 5e-3
+    assert float(sd["block3.2.bias"].abs().max()) == 0.0
+    lay, total = ops.mlp_layout()
+    assert total == 341764 and list(lay.keys()) == list(sd.keys())
+    offs = [o for o, _ in lay.values()]
+    assert offs == sorted(offs) and lay["color_branch.6.bias"][0] + 3 == total
+
+
+def test_arena_reuses_and_grows():
+    a = ops.Arena()
+    t1 = a.take(1000, torch.device("cpu"))
+    assert t1.numel() >= 1000
+    a.give(t1)
+    t2 = a.take(900, torch.device("cpu"))
+    assert t2 is t1
+    a.give(t2)
+    t3 = a.take(5000, torch.device("cpu"))
+    assert t3.numel() >= 5000 and t3 is not t1 and not a.free
+
+
+def test_shard_slices_partition_the_batch():
+    for n, w in [(65536, 8), (1000, 3), (7, 8), (0, 2)]:
+        idx = []
+        for r in range(w):
+            s = pdist.shard_slice(n, r, w)
+            idx += list(range(n))[s]
+        assert idx == list(range(n))
+
+
+def test_scene_generators_are_deterministic():
+    a, b = scenes.lego_points(20000), scenes.lego_points(20000)
+    assert np.array_equal(a, b) and a.shape == (20000, 3) and a.dtype == np.float32
+    r1, r2 = scenes.random_rays(3, 128), scenes.random_rays(3, 128)
+    assert np.array_equal(r1["raydir"], r2["raydir"]) and r1["raydir"].shape == (1, 128, 3)
+    c2w, intr = scenes.synth_camera(30.0)
+    assert abs(intr[0, 0] - 1111.111) < 1e-2 and abs(np.linalg.norm(c2w[:3, 3]) - 4.0) < 1e-5
