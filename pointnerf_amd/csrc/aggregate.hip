@@ -113,7 +113,7 @@ namespace {
 constexpr int LDX = 292;    // X0 / colour input row stride in LDS (odd multiple of 4 floats: conflict-free b128 reads)
 constexpr int LDH = 260;    // hidden row stride
 constexpr int LDC = 132;    // colour hidden row stride
-constexpr int AGG_LDS_FLOATS = PN_TILE * LDX + PN_TILE * LDH + PN_TILE * 8 + 4 * PN_TILE + PN_H + 64;
+constexpr int AGG_LDS_FLOATS = PN_TILE * LDX + PN_TILE * 8 + PN_TILE * 8 + 4 * PN_TILE + PN_H + 64;   // 81 KB: two workgroups per CU
 
 struct FwdArgs {
     pnerf_camera cam;
@@ -134,13 +134,15 @@ __device__ __forceinline__ void rot3(const float *M /*row-major*/, float x, floa
     else { ox = x * M[0] + y * M[1] + z * M[2]; oy = x * M[3] + y * M[4] + z * M[5]; oz = x * M[6] + y * M[7] + z * M[8]; }
 }
 
+// One LDS activation buffer, updated in place (GEMM -> barrier -> epilogue -> barrier): 81 KB per workgroup, so two
+// workgroups share a CU and one's gather / epilogue latency hides under the other's MFMA phase.
 template <bool TRAIN>
-__global__ __launch_bounds__(256, 1) void k_agg_forward(FwdArgs a) {
+__global__ __launch_bounds__(256, 2) void k_agg_forward(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *bufA = smem;                         // [64][LDX]  X0, later h2 / h4 at stride LDH
-    float *bufB = bufA + PN_TILE * LDX;         // [64][LDH]  h1 / h3
-    float *exb = bufB + PN_TILE * LDH;          // [64][8]
-    float *wraw = exb + PN_TILE * 8;            // [64] raw 1/dist weights, later alpha*w
+    float *bufA = smem;                         // [64][LDX]  X0, then h1..h4 at stride LDH
+    float *exb = bufA + PN_TILE * LDX;          // [64][8]  layer-3 extras
+    float *dst = exb + PN_TILE * 8;             // [64][8]  the 6 distance components of each row
+    float *wraw = dst + PN_TILE * 8;            // [64] raw 1/dist weights, later alpha*w
     float *wrow = wraw + PN_TILE;               // [64] final weight (normalised * clamped conf)
     float *wnrm = wrow + PN_TILE;               // [64] normalised weight
     float *rawa = wnrm + PN_TILE;               // [64] alpha pre-activation
@@ -184,30 +186,32 @@ __global__ __launch_bounds__(256, 1) void k_agg_forward(FwdArgs a) {
                 // embedding + PE3(embedding)
                 const float4 e0 = *reinterpret_cast<const float4 *>(a.emb + (long long)p * PN_F + 8 * q);
                 const float4 e1 = *reinterpret_cast<const float4 *>(a.emb + (long long)p * PN_F + 8 * q + 4);
-                const float e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+                *reinterpret_cast<float4 *>(xa + 8 * q) = e0;
+                *reinterpret_cast<float4 *>(xa + 8 * q + 4) = e1;
+                if (q == 0) {
 #pragma unroll
+                    for (int j = 0; j < 6; ++j) dst[row * 8 + j] = d[j];
+                }
+#pragma unroll 2
                 for (int i = 0; i < 8; ++i) {
                     const int dd = 8 * q + i;
-                    xa[dd] = e[i];
+                    const float ev = xa[dd];
                     float fr = 1.f;
 #pragma unroll
                     for (int f = 0; f < 3; ++f) {
                         float s, c;
-                        sincosf(e[i] * fr, &s, &c);
-                        xa[PN_F + (dd * 3 + f) * 2] = s;
-                        xa[PN_F + (dd * 3 + f) * 2 + 1] = c;
+                        sincosf(ev * fr, &s, &c);
+                        *reinterpret_cast<float2 *>(xa + PN_F + (dd * 3 + f) * 2) = make_float2(s, c);
                         fr *= 2.f;
                     }
                 }
-                // PE5(dists6): 30 (sin,cos) pairs, 8 per thread (8,8,8,6)
-#pragma unroll
-                for (int j = 0; j < 30; ++j) {
-                    if ((j >> 3) == q) {
-                        float s, c;
-                        sincosf(d[j / 5] * (float)(1 << (j % 5)), &s, &c);
-                        xa[PN_F * 7 + j * 2] = s;
-                        xa[PN_F * 7 + j * 2 + 1] = c;
-                    }
+                // PE5(dists6): 30 (sin,cos) pairs, 8 per thread (8,8,8,6); d comes back from LDS (same 4 lanes wrote it)
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll 2
+                for (int j = 8 * q; j < (q == 3 ? 30 : 8 * q + 8); ++j) {
+                    float s, c;
+                    sincosf(dst[row * 8 + j / 5] * (float)(1 << (j % 5)), &s, &c);
+                    *reinterpret_cast<float2 *>(xa + PN_F * 7 + j * 2) = make_float2(s, c);
                 }
                 if (q == 3) {
 #pragma unroll
@@ -261,23 +265,27 @@ __global__ __launch_bounds__(256, 1) void k_agg_forward(FwdArgs a) {
                 *reinterpret_cast<float4 *>(a.sv.ex + (grow0 + row) * 8 + h * 4) = *reinterpret_cast<const float4 *>(exb + row * 8 + h * 4);
             }
         }
-        // ---- layers -------------------------------------------------------------------------
+        // ---- layers (in place: all waves finish reading A before anyone overwrites it) ---------------
         f32x16 acc[2][2];
         pn_acc_init_bias<2>(acc, P + PO_B1, wave, lane);
         pn_tile_gemm<2>(bufA, LDX, PN_IN1P / 8, a.packed + PK_F1 / 4, wave, lane, acc);
-        pn_store_act<2, TRAIN>(acc, bufB, LDH, a.sv.h1, PN_H, grow0, wave, lane);
+        __syncthreads();
+        pn_store_act<2, TRAIN>(acc, bufA, LDH, a.sv.h1, PN_H, grow0, wave, lane);
         __syncthreads();
         pn_acc_init_bias<2>(acc, P + PO_B2, wave, lane);
-        pn_tile_gemm<2>(bufB, LDH, PN_H / 8, a.packed + PK_F2 / 4, wave, lane, acc);
+        pn_tile_gemm<2>(bufA, LDH, PN_H / 8, a.packed + PK_F2 / 4, wave, lane, acc);
+        __syncthreads();
         pn_store_act<2, TRAIN>(acc, bufA, LDH, a.sv.h2, PN_H, grow0, wave, lane);
         __syncthreads();
         pn_acc_init_bias<2>(acc, P + PO_B3, wave, lane);
         pn_tile_gemm<2>(bufA, LDH, PN_H / 8, a.packed + PK_F3 / 4, wave, lane, acc);
         pn_tile_gemm<2>(exb, 8, 1, a.packed + PK_F3 / 4 + (PN_H / 8) * 4 * 2 * 64, wave, lane, acc);
-        pn_store_act<2, TRAIN>(acc, bufB, LDH, a.sv.h3, PN_H, grow0, wave, lane);
+        __syncthreads();
+        pn_store_act<2, TRAIN>(acc, bufA, LDH, a.sv.h3, PN_H, grow0, wave, lane);
         __syncthreads();
         pn_acc_init_bias<2>(acc, P + PO_B4, wave, lane);
-        pn_tile_gemm<2>(bufB, LDH, PN_H / 8, a.packed + PK_F4 / 4, wave, lane, acc);
+        pn_tile_gemm<2>(bufA, LDH, PN_H / 8, a.packed + PK_F4 / 4, wave, lane, acc);
+        __syncthreads();
         pn_store_act<2, TRAIN>(acc, bufA, LDH, a.sv.h4, PN_H, grow0, wave, lane);
         __syncthreads();
         // ---- P5: alpha head (256 -> 1, softplus(x - 1)) -----------------------------------------
@@ -433,7 +441,7 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     const long long tiles = (cap_samples + a.TS - 1) / a.TS;
-    const int grid_a = (int)(tiles < ncu ? (tiles > 0 ? tiles : 1) : ncu);
+    const int grid_a = (int)(tiles < 2 * ncu ? (tiles > 0 ? tiles : 1) : 2 * ncu);      // two 81 KB workgroups per CU
     const long long ctiles = (cap_samples + PN_TILE - 1) / PN_TILE;
     const int grid_c = (int)(ctiles < ncu ? (ctiles > 0 ? ctiles : 1) : ncu);
     const size_t lds_a = AGG_LDS_FLOATS * sizeof(float), lds_c = COL_LDS_FLOATS * sizeof(float);

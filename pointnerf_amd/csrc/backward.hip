@@ -11,7 +11,6 @@
 //   k_wgrad          : dW = dY^T X as split-K MFMA GEMMs over the saved activations, full dW tile
 //                      resident in accumulators, deterministic partial-sum reduction
 // LeakyReLU masks come from the saved post-activations (sign(post) == sign(pre)).
-#include <stdlib.h>
 #include "mlp_common.h"
 
 namespace {
@@ -33,7 +32,6 @@ struct BwdArgs {
     PnSaved sv;
     float *gparams;
     float *g_emb, *g_conf, *g_dir, *g_color;
-    int debug_skip;                            // dev knob (PNERF_DEBUG_SKIP): timing ablations only, results are wrong when set
 };
 
 __device__ __forceinline__ void rot3b(const float *M, float x, float y, float z, bool transpose, float &ox, float &oy, float &oz) {
@@ -120,20 +118,21 @@ __global__ __launch_bounds__(256, 1) void k_color_backward(BwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------ aggregator backward
-constexpr int AGGB_LDS_FLOATS = 2 * PN_TILE * LDH + PN_TILE * 8 + 7 * PN_H + PN_H + 5 * PN_TILE;
+// One LDS buffer updated in place (GEMM -> barrier -> epilogue -> barrier), 79 KB per workgroup: two workgroups per
+// CU, so one's global-memory phases (saved-activation reads, dY writes, atomics) hide under the other's MFMAs.
+constexpr int AGGB_LDS_FLOATS = PN_TILE * LDH + PN_TILE * 8 + 7 * PN_H + PN_H + 5 * PN_TILE;
 
-__global__ __launch_bounds__(256, 1) void k_agg_backward(BwdArgs a) {
+__global__ __launch_bounds__(256, 2) void k_agg_backward(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *bufA = smem;                        // [64][LDH]
-    float *bufB = bufA + PN_TILE * LDH;        // [64][LDH]
-    float *exs = bufB + PN_TILE * LDH;         // [64][8]
+    float *buf = smem;                         // [64][LDH]  h4 -> dY4 -> dY3 -> dY2 -> dY1 -> dX0
+    float *exs = buf + PN_TILE * LDH;          // [64][8]
     float *w3ex = exs + PN_TILE * 8;           // [7][256]  W3[o][256+j]
     float *w5s = w3ex + 7 * PN_H;              // [256]
     float *wrow = w5s + PN_H;                  // [64]
     float *wnrm = wrow + PN_TILE;              // [64]
     float *draw = wnrm + PN_TILE;              // [64] d(alpha pre-activation)
     float *dsg = draw + PN_TILE;               // [64] d sigma of the row's sample
-    int *sidx = reinterpret_cast<int *>(dsg + PN_TILE);   // [64]
+    int *sidx = reinterpret_cast<int *>(dsg + PN_TILE);   // [64] row -> sample id (or -1)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, TS = a.TS;
@@ -152,17 +151,26 @@ __global__ __launch_bounds__(256, 1) void k_agg_backward(BwdArgs a) {
             const int ls = tid / K, k = tid - ls * K;
             const long long vs = tile * TS + ls;
             const int si = (ls < TS && vs < Ns) ? a.valid_list[vs] : -1;
-            sidx[tid] = si;                                        // per ROW here (row -> its sample id)
+            sidx[tid] = si;
             wrow[tid] = si >= 0 ? a.sv.wrow[grow0 + tid] : 0.f;
             wnrm[tid] = si >= 0 ? a.weight[(long long)si * K + k] : 0.f;
             dsg[tid] = si >= 0 ? a.grad_decoded[(long long)si * 4] : 0.f;
         }
-        for (int e = tid; e < PN_TILE * 64; e += 256) {
-            const int row = e >> 6, c4 = e & 63;
-            *reinterpret_cast<float4 *>(bufA + row * LDH + c4 * 4) = *reinterpret_cast<const float4 *>(a.sv.h4 + (grow0 + row) * PN_H + c4 * 4);
+        {   // h4 tile: 16 float4 per thread, all loads issued before the first LDS store
+            float4 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int e = tid + i * 256;
+                v[i] = *reinterpret_cast<const float4 *>(a.sv.h4 + (grow0 + (e >> 6)) * PN_H + (e & 63) * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int e = tid + i * 256;
+                *reinterpret_cast<float4 *>(buf + (e >> 6) * LDH + (e & 63) * 4) = v[i];
+            }
         }
-        for (int e = tid; e < PN_TILE * 2; e += 256) {
-            const int row = e >> 1, h = e & 1;
+        if (tid < PN_TILE * 2) {
+            const int row = tid >> 1, h = tid & 1;
             *reinterpret_cast<float4 *>(exs + row * 8 + h * 4) = *reinterpret_cast<const float4 *>(a.sv.ex + (grow0 + row) * 8 + h * 4);
         }
         __syncthreads();
@@ -172,11 +180,11 @@ __global__ __launch_bounds__(256, 1) void k_agg_backward(BwdArgs a) {
             const int si = sidx[row];
             const int ls = row / K;
             const long long vs = tile * TS + ls;
-            const float *h = bufA + row * LDH + q * 64;
+            const float *h = buf + row * LDH + q * 64;
             float s = 0.f, dotf = 0.f;
             if (si >= 0) {
                 const float *df = a.sv.dfs + vs * PN_H + q * 64;
-#pragma unroll
+#pragma unroll 4
                 for (int c = 0; c < 64; c += 4) {
                     const float4 v = *reinterpret_cast<const float4 *>(h + c);
                     const float4 g = *reinterpret_cast<const float4 *>(df + c);
@@ -205,20 +213,24 @@ __global__ __launch_bounds__(256, 1) void k_agg_backward(BwdArgs a) {
             }
         }
         __syncthreads();
-        // ---- d W5 / d b5 (column tid), then dY4 = (w * d f + d raw * w5) * lrelu'(h4) ----------
+        // ---- d W5 / d b5 (column tid) ------------------------------------------------------------
         {
             float accw = 0.f;
-            _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) accw += draw[row] * bufA[row * LDH + tid];
+            _Pragma("unroll 8") for (int row = 0; row < PN_TILE; ++row) accw += draw[row] * buf[row * LDH + tid];
             gw5 += accw;
-            if (tid == 0) _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) gb5 += draw[row];
+            if (tid == 0) _Pragma("unroll 8") for (int row = 0; row < PN_TILE; ++row) gb5 += draw[row];
         }
-        for (int e = tid; e < PN_TILE * 64; e += 256) {
+        __syncthreads();
+        // ---- dY4 = (w * d f + d raw * w5) * lrelu'(h4), in place ---------------------------------
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int e = tid + i * 256;
             const int row = e >> 6, c4 = e & 63;
             const int si = sidx[row];
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (si >= 0) {
                 const long long vs = tile * TS + row / K;
-                const float4 hv = *reinterpret_cast<const float4 *>(bufA + row * LDH + c4 * 4);
+                const float4 hv = *reinterpret_cast<const float4 *>(buf + row * LDH + c4 * 4);
                 const float4 g = *reinterpret_cast<const float4 *>(a.sv.dfs + vs * PN_H + c4 * 4);
                 const float w = wrow[row], dr = draw[row];
                 o.x = (w * g.x + dr * w5s[c4 * 4]) * pn_lrelu_grad(hv.x);
@@ -226,20 +238,21 @@ __global__ __launch_bounds__(256, 1) void k_agg_backward(BwdArgs a) {
                 o.z = (w * g.z + dr * w5s[c4 * 4 + 2]) * pn_lrelu_grad(hv.z);
                 o.w = (w * g.w + dr * w5s[c4 * 4 + 3]) * pn_lrelu_grad(hv.w);
             }
-            *reinterpret_cast<float4 *>(bufB + row * LDH + c4 * 4) = o;
+            *reinterpret_cast<float4 *>(buf + row * LDH + c4 * 4) = o;
             *reinterpret_cast<float4 *>(a.sv.dy4 + (grow0 + row) * PN_H + c4 * 4) = o;
         }
         __syncthreads();
         // ---- block3 second layer: dY3 = (dY4 @ W4) * lrelu'(h3) ----------------------------------
-        if (!(a.debug_skip & 2)) _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) gb4 += bufB[row * LDH + tid];
+        _Pragma("unroll 8") for (int row = 0; row < PN_TILE; ++row) gb4 += buf[row * LDH + tid];
         f32x16 acc[2][2];
         pn_acc_init_bias<2>(acc, nullptr, wave, lane);
-        if (!(a.debug_skip & 4)) pn_tile_gemm<2>(bufB, LDH, PN_H / 8, a.packed + PK_D4 / 4, wave, lane, acc);
-        pn_store_dact<2>(acc, a.sv.h3, PN_H, bufA, LDH, a.sv.dy3, PN_H, grow0, wave, lane);
+        pn_tile_gemm<2>(buf, LDH, PN_H / 8, a.packed + PK_D4 / 4, wave, lane, acc);
+        __syncthreads();
+        pn_store_dact<2>(acc, a.sv.h3, PN_H, buf, LDH, a.sv.dy3, PN_H, grow0, wave, lane);
         __syncthreads();
         // ---- block3 first layer: extras (colour, dir) + dY2 = (dY3 @ W3[:, :256]) * lrelu'(h2) ----
-        if (!(a.debug_skip & 2)) _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) {
-            const float v = bufA[row * LDH + tid];
+        _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) {
+            const float v = buf[row * LDH + tid];
             gb3 += v;
 #pragma unroll
             for (int j = 0; j < 7; ++j) gw3e[j] += v * exs[row * 8 + j];
@@ -249,13 +262,13 @@ __global__ __launch_bounds__(256, 1) void k_agg_backward(BwdArgs a) {
             const int si = sidx[row];
             float dex[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (si >= 0) {
-                const float *dy = bufA + row * LDH + q * 64;
+                const float *dy = buf + row * LDH + q * 64;
                 _Pragma("unroll 2") for (int c = 0; c < 64; c += 4) {
                     const float4 v = *reinterpret_cast<const float4 *>(dy + c);
 #pragma unroll
                     for (int j = 0; j < 7; ++j) {
-                        const float *w = w3ex + j * PN_H + q * 64 + c;
-                        dex[j] += v.x * w[0] + v.y * w[1] + v.z * w[2] + v.w * w[3];
+                        const float4 w = *reinterpret_cast<const float4 *>(w3ex + j * PN_H + q * 64 + c);
+                        dex[j] += v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
                     }
                 }
             }
@@ -276,26 +289,29 @@ __global__ __launch_bounds__(256, 1) void k_agg_backward(BwdArgs a) {
             }
         }
         pn_acc_init_bias<2>(acc, nullptr, wave, lane);
-        if (!(a.debug_skip & 4)) pn_tile_gemm<2>(bufA, LDH, PN_H / 8, a.packed + PK_D3 / 4, wave, lane, acc);
-        pn_store_dact<2>(acc, a.sv.h2, PN_H, bufB, LDH, a.sv.dy2, PN_H, grow0, wave, lane);
+        pn_tile_gemm<2>(buf, LDH, PN_H / 8, a.packed + PK_D3 / 4, wave, lane, acc);
+        __syncthreads();
+        pn_store_dact<2>(acc, a.sv.h2, PN_H, buf, LDH, a.sv.dy2, PN_H, grow0, wave, lane);
         __syncthreads();
         // ---- block1 second layer: dY1 = (dY2 @ W2) * lrelu'(h1) ----------------------------------
-        if (!(a.debug_skip & 2)) _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) gb2 += bufB[row * LDH + tid];
+        _Pragma("unroll 8") for (int row = 0; row < PN_TILE; ++row) gb2 += buf[row * LDH + tid];
         pn_acc_init_bias<2>(acc, nullptr, wave, lane);
-        if (!(a.debug_skip & 4)) pn_tile_gemm<2>(bufB, LDH, PN_H / 8, a.packed + PK_D2 / 4, wave, lane, acc);
-        pn_store_dact<2>(acc, a.sv.h1, PN_H, bufA, LDH, a.sv.dy1, PN_H, grow0, wave, lane);
+        pn_tile_gemm<2>(buf, LDH, PN_H / 8, a.packed + PK_D2 / 4, wave, lane, acc);
+        __syncthreads();
+        pn_store_dact<2>(acc, a.sv.h1, PN_H, buf, LDH, a.sv.dy1, PN_H, grow0, wave, lane);
         __syncthreads();
         // ---- block1 first layer: d X0[:, :256] = dY1 @ W1[:, :256] --------------------------------
-        if (!(a.debug_skip & 2)) _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) gb1 += bufA[row * LDH + tid];
+        _Pragma("unroll 8") for (int row = 0; row < PN_TILE; ++row) gb1 += buf[row * LDH + tid];
         pn_acc_init_bias<2>(acc, nullptr, wave, lane);
-        if (!(a.debug_skip & 4)) pn_tile_gemm<2>(bufA, LDH, PN_H / 8, a.packed + PK_D1 / 4, wave, lane, acc);
+        pn_tile_gemm<2>(buf, LDH, PN_H / 8, a.packed + PK_D1 / 4, wave, lane, acc);
+        __syncthreads();
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 const int col = pn_acc_col<2>(wave, ct, lane);
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) bufB[pn_acc_row(rt, reg, lane) * LDH + col] = acc[rt][ct][reg];
+                for (int reg = 0; reg < 16; ++reg) buf[pn_acc_row(rt, reg, lane) * LDH + col] = acc[rt][ct][reg];
             }
         __syncthreads();
         // ---- embedding gradient through [e | PE3(e)]: d e = dX[e] + sum_f 2^f (dX[sin] cos - dX[cos] sin)
@@ -306,19 +322,23 @@ __global__ __launch_bounds__(256, 1) void k_agg_backward(BwdArgs a) {
                 const int ls = row / K, k = row - ls * K;
                 const int p = a.pidx[(long long)si * K + k];
                 if (p >= 0) {
-                    const float *dx = bufB + row * LDH;
-                    const float *x0 = a.sv.x0 + (grow0 + row) * PN_IN1P;
+                    const float *dx = buf + row * LDH;
+                    const float *x0 = a.sv.x0 + (grow0 + row) * PN_IN1P + PN_F + 48 * q;      // 48 = 8 dims * 3 freqs * 2
+                    float4 xs[12];
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) xs[i] = *reinterpret_cast<const float4 *>(x0 + 4 * i);
+                    const float *xf = reinterpret_cast<const float *>(xs);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int dd = 8 * q + i;
                         float g = dx[dd], fr = 1.f;
 #pragma unroll
                         for (int f = 0; f < 3; ++f) {
-                            const int o = PN_F + (dd * 3 + f) * 2;
-                            g += fr * (dx[o] * x0[o + 1] - dx[o + 1] * x0[o]);
+                            const int o = PN_F + (dd * 3 + f) * 2, l = (i * 3 + f) * 2;
+                            g += fr * (dx[o] * xf[l + 1] - dx[o + 1] * xf[l]);
                             fr *= 2.f;
                         }
-                        if (!(a.debug_skip & 1)) atomicAdd(&a.g_emb[(long long)p * PN_F + dd], g);
+                        atomicAdd(&a.g_emb[(long long)p * PN_F + dd], g);
                     }
                 }
             }
@@ -396,6 +416,92 @@ __global__ __launch_bounds__(WM *WN * 64) void k_wgrad(const float *__restrict__
             }
 }
 
+// Same GEMM with both operands staged through LDS (each element leaves L2 once per workgroup instead of once per
+// wave that needs it): KB rows of A [KB x Mtot] and B [KB x Ntile] per stage, double-buffered, next stage's global
+// loads in flight during the current stage's MFMAs.  Row strides are exact multiples of 32 floats, so the fragment
+// reads (lane -> column) are conflict-free and lanes l / l+32 (adjacent rows) never share a service group.
+template <int MT, int NT, int WM, int WN, int KB>
+__global__ __launch_bounds__(WM *WN * 64) void k_wgrad_lds(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+                                                           long long rows, int rows_per_chunk, float *__restrict__ partial, int Ntot) {
+    constexpr int NTHR = WM * WN * 64, MTOT = WM * MT * 32, NTILE = WN * NT * 32;
+    constexpr int A4 = KB * MTOT / 4 / NTHR, B4 = KB * NTILE / 4 / NTHR;      // float4 per thread per stage
+    static_assert(A4 * 4 * NTHR == KB * MTOT && B4 * 4 * NTHR == KB * NTILE, "stage must divide evenly");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                           // [2][KB][MTOT]
+    float *Bs = smem + 2 * KB * MTOT;           // [2][KB][NTILE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = wm * MT * 32, n0l = wn * NT * 32, n0 = blockIdx.x * NTILE;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+    long long r1 = r0 + rows_per_chunk;
+    if (r1 > rows) r1 = rows;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) acc[mt][nt][reg] = 0.f;
+    float4 ra[A4], rb[B4];
+    auto gload = [&](long long r) {
+#pragma unroll
+        for (int i = 0; i < A4; ++i) {
+            const int e = (tid + i * NTHR) * 4, kr = e / MTOT, c = e - kr * MTOT;
+            ra[i] = (r + kr < r1) ? *reinterpret_cast<const float4 *>(A + (r + kr) * lda + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < B4; ++i) {
+            const int e = (tid + i * NTHR) * 4, kr = e / NTILE, c = e - kr * NTILE;
+            rb[i] = (r + kr < r1) ? *reinterpret_cast<const float4 *>(B + (r + kr) * ldb + n0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](int bufi) {
+#pragma unroll
+        for (int i = 0; i < A4; ++i) *reinterpret_cast<float4 *>(As + bufi * KB * MTOT + (tid + i * NTHR) * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B4; ++i) *reinterpret_cast<float4 *>(Bs + bufi * KB * NTILE + (tid + i * NTHR) * 4) = rb[i];
+    };
+    if (r0 < r1) {
+        gload(r0);
+        lstore(0);
+        __syncthreads();
+        int cur = 0;
+        for (long long r = r0; r < r1; r += KB) {
+            const bool more = r + KB < r1;
+            if (more) gload(r + KB);
+            const float *ap = As + cur * KB * MTOT + (lane >> 5) * MTOT + m0 + (lane & 31);
+            const float *bp = Bs + cur * KB * NTILE + (lane >> 5) * NTILE + n0l + (lane & 31);
+#pragma unroll 4
+            for (int k = 0; k < KB; k += 2) {
+                float av[MT], bv[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) av[mt] = ap[k * MTOT + mt * 32];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = bp[k * NTILE + nt * 32];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+            }
+            if (more) lstore(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    float *out = partial + (size_t)blockIdx.y * MTOT * Ntot;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = m0 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                const int n = n0 + n0l + nt * 32 + (lane & 31);
+                out[(size_t)m * Ntot + n] = acc[mt][nt][reg];
+            }
+}
+
 // grad[dst + m*ldc + n] += sum_chunk partial[chunk][m][n]   for n < Nreal
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial, int chunks, int Mtot, int Ntot, int Nreal,
                                                       float *__restrict__ grad, int dst, int ldc) {
@@ -406,6 +512,27 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
     float s = 0.f;
     for (int c = 0; c < chunks; ++c) s += partial[(size_t)c * Mtot * Ntot + e];
     grad[dst + m * ldc + n] += s;
+}
+
+template <int MT, int NT, int WM, int WN, int KB>
+int launch_wgrad_lds(const float *A, int lda, const float *B, int ldb, long long rows, float *partial, int Ntot, int Nreal,
+                     float *grad, int dst, int ldc, hipStream_t s) {
+    constexpr int Mtot = WM * MT * 32, NTILE = WN * NT * 32;
+    const int ntiles = Ntot / NTILE;
+    int chunks = WG_CHUNKS / ntiles;
+    long long rpc = (rows + chunks - 1) / chunks;
+    rpc = (rpc + 63) / 64 * 64;
+    if (rpc < 64) rpc = 64;
+    chunks = (int)((rows + rpc - 1) / rpc);
+    if (chunks < 1) chunks = 1;
+    const size_t lds = (size_t)2 * KB * (Mtot + NTILE) * sizeof(float);
+    if (hipFuncSetAttribute((const void *)k_wgrad_lds<MT, NT, WM, WN, KB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PNERF_E_LAUNCH;
+    { PnProfScope prof(PNK_WGRAD, s);
+    hipLaunchKernelGGL((k_wgrad_lds<MT, NT, WM, WN, KB>), dim3(ntiles, chunks), dim3(WM * WN * 64), lds, s, A, lda, B, ldb, rows, (int)rpc, partial, Ntot); }
+    PnProfScope prof(PNK_WGRAD_REDUCE, s);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(pn_cdiv((long long)Mtot * Ntot, 256)), dim3(256), 0, s, partial, chunks, Mtot, Ntot, Nreal, grad, dst, ldc);
+    PN_CHECK_LAUNCH();
+    return 0;
 }
 
 template <int MT, int NT, int WM, int WN>
@@ -442,7 +569,6 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     a.pidx = d_sample_pidx; a.valid_list = d_valid_list; a.counters = d_counters;
     a.SR = SR; a.K = K; a.TS = pn_tile_samples(K); a.cap_samples = n_valid;
     a.decoded = d_decoded; a.weight = d_weight; a.grad_decoded = d_grad_decoded; a.sv = sv;
-    { const char *e = getenv("PNERF_DEBUG_SKIP"); a.debug_skip = e ? atoi(e) : 0; }
     a.gparams = d_grad_params; a.g_emb = pg->embedding; a.g_conf = pg->conf; a.g_dir = pg->dir; a.g_color = pg->color;
     if (!a.g_emb || !a.g_conf || !a.g_dir || !a.g_color) return PNERF_E_INVAL;
     int dev = 0, ncu = 256;
@@ -450,7 +576,7 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
     const long long tiles = (n_valid + a.TS - 1) / a.TS;
     const long long ctiles = (n_valid + PN_TILE - 1) / PN_TILE;
-    const int grid_a = (int)(tiles < ncu ? (tiles > 0 ? tiles : 1) : ncu);
+    const int grid_a = (int)(tiles < 2 * ncu ? (tiles > 0 ? tiles : 1) : 2 * ncu);      // two 79 KB workgroups per CU
     const int grid_c = (int)(ctiles < ncu ? (ctiles > 0 ? ctiles : 1) : ncu);
     const size_t lds_c = COLB_LDS_FLOATS * sizeof(float), lds_a = AGGB_LDS_FLOATS * sizeof(float);
     if (hipFuncSetAttribute((const void *)k_color_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
@@ -462,14 +588,14 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     const long long rows = tiles * PN_TILE, smp = ctiles * PN_TILE;
     int rc;
     float *g = d_grad_params;
-    if ((rc = launch_wgrad<4, 2, 2, 4>(sv.dy1, PN_H, sv.x0, PN_IN1P, rows, d_partials, 256, 256, g, PO_W1, PN_IN1, s))) return rc;
+    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16>(sv.dy1, PN_H, sv.x0, PN_IN1P, rows, d_partials, 256, 256, g, PO_W1, PN_IN1, s))) return rc;
     if ((rc = launch_wgrad<1, 1, 8, 1>(sv.dy1, PN_H, sv.x0 + 256, PN_IN1P, rows, d_partials, 32, PN_IN1 - 256, g, PO_W1 + 256, PN_IN1, s))) return rc;
-    if ((rc = launch_wgrad<4, 2, 2, 4>(sv.dy2, PN_H, sv.h1, PN_H, rows, d_partials, 256, 256, g, PO_W2, PN_H, s))) return rc;
-    if ((rc = launch_wgrad<4, 2, 2, 4>(sv.dy3, PN_H, sv.h2, PN_H, rows, d_partials, 256, 256, g, PO_W3, PN_IN3, s))) return rc;
-    if ((rc = launch_wgrad<4, 2, 2, 4>(sv.dy4, PN_H, sv.h3, PN_H, rows, d_partials, 256, 256, g, PO_W4, PN_H, s))) return rc;
-    if ((rc = launch_wgrad<2, 2, 2, 4>(sv.dc1, PN_HC, sv.fs, PN_H, smp, d_partials, 256, 256, g, PO_WC1, PN_INC, s))) return rc;
+    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16>(sv.dy2, PN_H, sv.h1, PN_H, rows, d_partials, 256, 256, g, PO_W2, PN_H, s))) return rc;
+    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16>(sv.dy3, PN_H, sv.h2, PN_H, rows, d_partials, 256, 256, g, PO_W3, PN_IN3, s))) return rc;
+    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16>(sv.dy4, PN_H, sv.h3, PN_H, rows, d_partials, 256, 256, g, PO_W4, PN_H, s))) return rc;
+    if ((rc = launch_wgrad_lds<2, 2, 2, 4, 16>(sv.dc1, PN_HC, sv.fs, PN_H, smp, d_partials, 256, 256, g, PO_WC1, PN_INC, s))) return rc;
     if ((rc = launch_wgrad<1, 1, 4, 1>(sv.dc1, PN_HC, sv.pe, 32, smp, d_partials, 32, PN_INC - 256, g, PO_WC1 + 256, PN_INC, s))) return rc;
-    if ((rc = launch_wgrad<2, 1, 2, 4>(sv.dc2, PN_HC, sv.c1, PN_HC, smp, d_partials, 128, 128, g, PO_WC2, PN_HC, s))) return rc;
-    if ((rc = launch_wgrad<2, 1, 2, 4>(sv.dc3, PN_HC, sv.c2, PN_HC, smp, d_partials, 128, 128, g, PO_WC3, PN_HC, s))) return rc;
+    if ((rc = launch_wgrad_lds<2, 1, 2, 4, 16>(sv.dc2, PN_HC, sv.c1, PN_HC, smp, d_partials, 128, 128, g, PO_WC2, PN_HC, s))) return rc;
+    if ((rc = launch_wgrad_lds<2, 1, 2, 4, 16>(sv.dc3, PN_HC, sv.c2, PN_HC, smp, d_partials, 128, 128, g, PO_WC3, PN_HC, s))) return rc;
     return 0;
 }
