@@ -172,6 +172,36 @@ int pnerf_render_backward(const pnerf_camera *cam, const pnerf_points *pts, cons
                           void *d_saved, float *d_grad_params, const pnerf_point_grads *pg,
                           void *d_ws, size_t ws_bytes, void *stream);
 
+/* ---- stand-alone (level-1) forms of the same kernels, for callers that use the reference's modules one by one ---- */
+
+/* work list from a caller-supplied per-sample neighbor count (ray_valid = any_K(sample_pnt_mask),
+ * models/aggregators/point_aggregators.py:741): d_list = ascending i with d_nn[i] > 0, d_counters[0] = count */
+size_t pnerf_compact_workspace_bytes(int64_t n);
+int pnerf_compact_valid(const int32_t *d_nn, int64_t n, int32_t *d_list, int32_t *d_counters, void *d_ws, size_t ws_bytes, void *stream);
+
+/* PointAggregator.forward (point_aggregators.py:727-814) on its own: -> d_decoded [R,SR,4], d_weight [R,SR,K].
+ * d_xyz_pers [N,3] / d_loc_pers [R,SR,3]: the caller's perspective coordinates (sampled_xyz_pers, sample_loc); both
+ * NULL = project from cam.  Scratch/saved sizing as pnerf_render_forward. */
+int pnerf_agg_forward(const pnerf_camera *cam, const pnerf_points *pts, const void *d_packed_mlp, const float *d_params,
+                      const float *d_raydir, const float *d_sample_loc, const float *d_xyz_pers, const float *d_loc_pers,
+                      const int32_t *d_sample_pidx, const int32_t *d_valid_list, const int32_t *d_counters,
+                      int R, int SR, int K, float *d_decoded, float *d_weight,
+                      void *d_saved, int64_t n_valid_max, void *d_ws, size_t ws_bytes, void *stream);
+/* its backward for dL/d(decoded) = d_grad_decoded [R,SR,4]; d_ws holds pnerf_render_backward_workspace_bytes(0, 1) */
+int pnerf_agg_backward(const pnerf_camera *cam, const pnerf_points *pts, const void *d_packed_mlp, const float *d_params,
+                       const float *d_raydir, const float *d_sample_loc, const int32_t *d_sample_pidx,
+                       const int32_t *d_valid_list, const int32_t *d_counters, int R, int SR, int K, int64_t n_valid,
+                       const float *d_decoded, const float *d_weight, const float *d_grad_decoded,
+                       void *d_saved, float *d_grad_params, const pnerf_point_grads *pg, void *d_ws, size_t ws_bytes, void *stream);
+
+/* ray_march(ray_dist, ray_valid, ray_features, radiance, alpha, bg) (models/rendering/diff_ray_marching.py:508-554):
+ * d_ray_dist [R,SR] f32, d_ray_valid [R,SR] u8, d_features [R,SR,4] (sigma,r,g,b), bg3_host NULL = no background. */
+int pnerf_raymarch_forward(const float *d_ray_dist, const uint8_t *d_ray_valid, const float *d_features, const float *bg3_host,
+                           int R, int SR, float *d_ray_color, float *d_opacity, float *d_acc_trans, float *d_blend_w,
+                           float *d_bg_trans, void *stream);
+int pnerf_raymarch_backward(const float *d_ray_dist, const uint8_t *d_ray_valid, const float *d_features, const float *bg3_host,
+                            int R, int SR, const float *d_grad_ray_color, float *d_grad_features, void *stream);
+
 /* ---- per-kernel timing (HIP events recorded on the launch stream; off by default) --------------- */
 int pnerf_prof_enable(int on);
 int pnerf_prof_kernel_count(void);

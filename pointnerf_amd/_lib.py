@@ -67,6 +67,19 @@ PROTOTYPES = {
                                      c_int, c_int, c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_i64, c_void_p, c_size_t, c_void_p]),
+    "pnerf_compact_workspace_bytes": (c_size_t, [c_i64]),
+    "pnerf_compact_valid": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pnerf_agg_forward": (c_int, [ctypes.POINTER(Camera), ctypes.POINTER(Points), c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_size_t, c_void_p]),
+    "pnerf_agg_backward": (c_int, [ctypes.POINTER(Camera), ctypes.POINTER(Points), c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_i64,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(PointGrads),
+                                   c_void_p, c_size_t, c_void_p]),
+    "pnerf_raymarch_forward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_f32), c_int, c_int,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pnerf_raymarch_backward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_f32), c_int, c_int,
+                                        c_void_p, c_void_p, c_void_p]),
     "pnerf_prof_enable": (c_int, [c_int]),
     "pnerf_prof_kernel_count": (c_int, []),
     "pnerf_prof_kernel_name": (ctypes.c_char_p, [c_int]),

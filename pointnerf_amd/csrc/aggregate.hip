@@ -121,6 +121,7 @@ struct FwdArgs {
     const float *params;
     const float4 *packed;
     const float *raydir, *sample_loc;
+    const float *xyz_pers, *loc_pers;   // optional: perspective coords supplied by the caller (stand-alone aggregator)
     const int *pidx, *valid_list, *counters;
     int R, SR, K, TS;
     long long cap_samples;      // capacity (in valid samples) of fs / saved buffers
@@ -176,10 +177,16 @@ __global__ __launch_bounds__(256, 2) void k_agg_forward(FwdArgs a) {
                 const float lx = a.sample_loc[(long long)si * 3], ly = a.sample_loc[(long long)si * 3 + 1], lz = a.sample_loc[(long long)si * 3 + 2];
                 const float px = a.xyz[3 * p], py = a.xyz[3 * p + 1], pz = a.xyz[3 * p + 2];
                 const float dwx = px - lx, dwy = py - ly, dwz = pz - lz;
-                float pcx, pcy, pcz, scx, scy, scz;
-                rot3(a.cam.camrot, px - a.cam.campos[0], py - a.cam.campos[1], pz - a.cam.campos[2], false, pcx, pcy, pcz);
-                rot3(a.cam.camrot, lx - a.cam.campos[0], ly - a.cam.campos[1], lz - a.cam.campos[2], false, scx, scy, scz);
-                const float ppx = pcx / pcz, ppy = pcy / pcz, spx = scx / scz, spy = scy / scz;
+                float ppx, ppy, pcz, spx, spy, scz;
+                if (a.xyz_pers) {                      // PointAggregator.forward(sampled_xyz_pers, sample_loc) inputs
+                    ppx = a.xyz_pers[3 * p]; ppy = a.xyz_pers[3 * p + 1]; pcz = a.xyz_pers[3 * p + 2];
+                    spx = a.loc_pers[(long long)si * 3]; spy = a.loc_pers[(long long)si * 3 + 1]; scz = a.loc_pers[(long long)si * 3 + 2];
+                } else {                               // fused path: project in-kernel (neural_points.py:604-610)
+                    float pcx, pcy, scx, scy;
+                    rot3(a.cam.camrot, px - a.cam.campos[0], py - a.cam.campos[1], pz - a.cam.campos[2], false, pcx, pcy, pcz);
+                    rot3(a.cam.camrot, lx - a.cam.campos[0], ly - a.cam.campos[1], lz - a.cam.campos[2], false, scx, scy, scz);
+                    ppx = pcx / pcz; ppy = pcy / pcz; spx = scx / scz; spy = scy / scz;
+                }
                 float d[6];
                 rot3(a.cam.rw2c, dwx, dwy, dwz, true, d[0], d[1], d[2]);            // dists[:3] @ Rw2c^T (point_aggregators.py:526)
                 d[3] = ppx * pcz - spx * scz; d[4] = ppy * pcz - spy * scz; d[5] = pcz - scz;   // :775-777
@@ -425,7 +432,8 @@ __global__ __launch_bounds__(256, 1) void k_color_forward(FwdArgs a) {
 
 // shared with render.hip
 int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, const float *d_params, const void *d_packed,
-                          const float *d_raydir, const float *d_sample_loc, const int32_t *d_sample_pidx,
+                          const float *d_raydir, const float *d_sample_loc, const float *d_xyz_pers, const float *d_loc_pers,
+                          const int32_t *d_sample_pidx,
                           const int32_t *d_valid_list, const int32_t *d_counters, int R, int SR, int K,
                           float *d_decoded, float *d_weight, const PnSaved &sv, long long cap_samples, bool train,
                           hipStream_t s) {
@@ -433,7 +441,7 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     a.cam = *cam;
     a.xyz = pts->xyz; a.emb = pts->embedding; a.conf = pts->conf; a.dir = pts->dir; a.color = pts->color;
     a.params = d_params; a.packed = (const float4 *)d_packed;
-    a.raydir = d_raydir; a.sample_loc = d_sample_loc; a.pidx = d_sample_pidx; a.valid_list = d_valid_list; a.counters = d_counters;
+    a.raydir = d_raydir; a.sample_loc = d_sample_loc; a.xyz_pers = d_xyz_pers; a.loc_pers = d_loc_pers; a.pidx = d_sample_pidx; a.valid_list = d_valid_list; a.counters = d_counters;
     a.R = R; a.SR = SR; a.K = K; a.TS = pn_tile_samples(K);
     a.cap_samples = cap_samples;
     a.decoded = d_decoded; a.weight = d_weight; a.sv = sv;

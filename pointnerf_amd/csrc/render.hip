@@ -11,7 +11,8 @@
 #include "mlp_common.h"
 
 int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, const float *d_params, const void *d_packed,
-                          const float *d_raydir, const float *d_sample_loc, const int32_t *d_sample_pidx,
+                          const float *d_raydir, const float *d_sample_loc, const float *d_xyz_pers, const float *d_loc_pers,
+                          const int32_t *d_sample_pidx,
                           const int32_t *d_valid_list, const int32_t *d_counters, int R, int SR, int K,
                           float *d_decoded, float *d_weight, const PnSaved &sv, long long cap_samples, bool train,
                           hipStream_t s);
@@ -30,6 +31,8 @@ struct RmArgs {
     pnerf_camera cam;
     const float *sample_loc, *decoded;
     const int *nn;
+    const float *ray_dist;            // stand-alone ray_march(): distances and validity supplied by the caller
+    const unsigned char *valid8;
     int R, SR;
 };
 
@@ -63,6 +66,11 @@ __device__ __forceinline__ float pers_z(const pnerf_camera &c, const float *p) {
 // chunk.  Returns delta (ray_dist), valid flag, and updates cm_prev.
 __device__ __forceinline__ void chunk_raydist(const RmArgs &a, int r, int s, int lane, float &cm_prev, float &delta, bool &valid) {
     const int SR = a.SR;
+    if (a.ray_dist) {
+        valid = s < SR && a.valid8[(long long)r * SR + s] != 0;
+        delta = s < SR ? a.ray_dist[(long long)r * SR + s] : 0.f;
+        return;
+    }
     float z = -INFINITY, znext = -INFINITY;
     if (s < SR) z = pers_z(a.cam, a.sample_loc + ((long long)r * SR + s) * 3);
     if (s + 1 < SR) znext = pers_z(a.cam, a.sample_loc + ((long long)r * SR + s + 1) * 3);
@@ -78,7 +86,8 @@ __device__ __forceinline__ void chunk_raydist(const RmArgs &a, int r, int s, int
 }
 
 __global__ __launch_bounds__(TPB) void k_raymarch_forward(RmArgs a, float *__restrict__ ray_color, float *__restrict__ opacity_out,
-                                                          float *__restrict__ bg_trans, float *__restrict__ blend_w) {
+                                                          float *__restrict__ bg_trans, float *__restrict__ blend_w,
+                                                          float *__restrict__ acc_trans) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
     if (r >= a.R) return;
@@ -104,6 +113,7 @@ __global__ __launch_bounds__(TPB) void k_raymarch_forward(RmArgs a, float *__res
         if (s < SR) {
             opacity_out[(long long)r * SR + s] = op;
             blend_w[(long long)r * SR + s] = bw;
+            if (acc_trans) acc_trans[(long long)r * SR + s] = Tx;
         }
         cr += bw * rr; cg += bw * gg; cb += bw * bb;
         T_carry *= __shfl(incl, 63, 64);
@@ -281,14 +291,14 @@ extern "C" int pnerf_render_forward(const pnerf_camera *cam, const pnerf_points 
     if (hipMemsetAsync(d_decoded, 0, (size_t)R * SR * 4 * sizeof(float), s) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipMemsetAsync(d_weight, 0, (size_t)R * SR * K * sizeof(float), s) != hipSuccess) return PNERF_E_LAUNCH;
     if (n_valid_max > 0) {
-        rc = pn_agg_forward_launch(cam, pts, d_params, d_packed_mlp, d_raydir, d_sample_loc, d_sample_pidx, d_valid_list, d_counters,
+        rc = pn_agg_forward_launch(cam, pts, d_params, d_packed_mlp, d_raydir, d_sample_loc, nullptr, nullptr, d_sample_pidx, d_valid_list, d_counters,
                                    R, SR, K, d_decoded, d_weight, sv, n_valid_max, train, s);
         if (rc) return rc;
     }
     RmArgs ra;
-    ra.cam = *cam; ra.sample_loc = d_sample_loc; ra.decoded = d_decoded; ra.nn = d_sample_nn; ra.R = R; ra.SR = SR;
+    ra.cam = *cam; ra.sample_loc = d_sample_loc; ra.decoded = d_decoded; ra.nn = d_sample_nn; ra.ray_dist = nullptr; ra.valid8 = nullptr; ra.R = R; ra.SR = SR;
     { PnProfScope prof(PNK_RAYMARCH_FWD, s);
-    hipLaunchKernelGGL(k_raymarch_forward, dim3(pn_cdiv(R, TPB / 64)), dim3(TPB), 0, s, ra, d_ray_color, d_opacity, d_bg_trans, d_blend_w); }
+    hipLaunchKernelGGL(k_raymarch_forward, dim3(pn_cdiv(R, TPB / 64)), dim3(TPB), 0, s, ra, d_ray_color, d_opacity, d_bg_trans, d_blend_w, (float *)nullptr); }
     PN_CHECK_LAUNCH();
     return 0;
 }
@@ -313,7 +323,7 @@ extern "C" int pnerf_render_backward(const pnerf_camera *cam, const pnerf_points
     float *grad_decoded = (float *)d_ws;
     float *partials = (float *)((char *)d_ws + gd_bytes);
     RmArgs ra;
-    ra.cam = *cam; ra.sample_loc = d_sample_loc; ra.decoded = d_decoded; ra.nn = d_sample_nn; ra.R = R; ra.SR = SR;
+    ra.cam = *cam; ra.sample_loc = d_sample_loc; ra.decoded = d_decoded; ra.nn = d_sample_nn; ra.ray_dist = nullptr; ra.valid8 = nullptr; ra.R = R; ra.SR = SR;
     { PnProfScope prof(PNK_RAYMARCH_BWD, s);
     hipLaunchKernelGGL(k_raymarch_backward, dim3(pn_cdiv(R, TPB / 64)), dim3(TPB), 0, s, ra, d_grad_ray_color, grad_decoded); }
     PN_CHECK_LAUNCH();
@@ -324,4 +334,96 @@ extern "C" int pnerf_render_backward(const pnerf_camera *cam, const pnerf_points
 
 extern "C" size_t pnerf_render_backward_workspace_bytes(int R, int SR) {
     return pn_align((size_t)R * SR * 4 * sizeof(float)) + pn_wgrad_partials_bytes();
+}
+
+// ================================ stand-alone (level-1) entry points ================================
+
+extern "C" size_t pnerf_compact_workspace_bytes(int64_t n) { return pn_align(pn_scan_scratch_ints(n) * sizeof(int)); }
+
+// d_list = ascending indices i with d_nn[i] > 0, d_counters[0] = their number (builds the aggregator's work list from
+// a caller-supplied validity array: PointAggregator.forward's ray_valid = any_K(sample_pnt_mask), point_aggregators.py:741)
+extern "C" int pnerf_compact_valid(const int32_t *d_nn, int64_t n, int32_t *d_list, int32_t *d_counters, void *d_ws, size_t ws_bytes, void *stream) {
+    if (!d_nn || !d_list || !d_counters || !d_ws || n < 0) return PNERF_E_INVAL;
+    if (ws_bytes < pnerf_compact_workspace_bytes(n)) return PNERF_E_WS;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(d_counters, 0, 8 * sizeof(int), s) != hipSuccess) return PNERF_E_LAUNCH;
+    if (n == 0) return 0;
+    PnProfScope prof(PNK_COMPACT, s);
+    return pn_compact_gt0_i32(d_nn, n, d_list, d_counters, (int *)d_ws, s);
+}
+
+extern "C" int pnerf_agg_forward(const pnerf_camera *cam, const pnerf_points *pts, const void *d_packed_mlp, const float *d_params,
+                                 const float *d_raydir, const float *d_sample_loc, const float *d_xyz_pers, const float *d_loc_pers,
+                                 const int32_t *d_sample_pidx, const int32_t *d_valid_list, const int32_t *d_counters,
+                                 int R, int SR, int K, float *d_decoded, float *d_weight,
+                                 void *d_saved, int64_t n_valid_max, void *d_ws, size_t ws_bytes, void *stream) {
+    int rc = check_common(cam, pts, R, SR, K);
+    if (rc) return rc;
+    if (!d_packed_mlp || !d_params || !d_raydir || !d_sample_loc || !d_sample_pidx || !d_valid_list || !d_counters || !d_decoded || !d_weight) return PNERF_E_INVAL;
+    if ((d_xyz_pers == nullptr) != (d_loc_pers == nullptr)) return PNERF_E_INVAL;
+    if (R == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    PnSaved sv;
+    const bool train = d_saved != nullptr;
+    if (train) sv = pn_saved_carve(d_saved, n_valid_max, K);
+    else {
+        if (!d_ws || ws_bytes < pnerf_agg_workspace_bytes(n_valid_max, K)) return PNERF_E_WS;
+        sv = PnSaved();
+        pn_saved_bytes(n_valid_max, K, &sv.rows, &sv.samples);
+        sv.fs = (float *)d_ws;
+    }
+    if (hipMemsetAsync(d_decoded, 0, (size_t)R * SR * 4 * sizeof(float), s) != hipSuccess) return PNERF_E_LAUNCH;
+    if (hipMemsetAsync(d_weight, 0, (size_t)R * SR * K * sizeof(float), s) != hipSuccess) return PNERF_E_LAUNCH;
+    if (n_valid_max == 0) return 0;
+    return pn_agg_forward_launch(cam, pts, d_params, d_packed_mlp, d_raydir, d_sample_loc, d_xyz_pers, d_loc_pers, d_sample_pidx,
+                                 d_valid_list, d_counters, R, SR, K, d_decoded, d_weight, sv, n_valid_max, train, s);
+}
+
+extern "C" int pnerf_agg_backward(const pnerf_camera *cam, const pnerf_points *pts, const void *d_packed_mlp, const float *d_params,
+                                  const float *d_raydir, const float *d_sample_loc, const int32_t *d_sample_pidx,
+                                  const int32_t *d_valid_list, const int32_t *d_counters, int R, int SR, int K, int64_t n_valid,
+                                  const float *d_decoded, const float *d_weight, const float *d_grad_decoded,
+                                  void *d_saved, float *d_grad_params, const pnerf_point_grads *pg, void *d_ws, size_t ws_bytes, void *stream) {
+    int rc = check_common(cam, pts, R, SR, K);
+    if (rc) return rc;
+    if (!d_packed_mlp || !d_params || !d_raydir || !d_sample_loc || !d_sample_pidx || !d_valid_list || !d_counters) return PNERF_E_INVAL;
+    if (!d_decoded || !d_weight || !d_grad_decoded || !d_saved || !d_grad_params || !pg || !d_ws) return PNERF_E_INVAL;
+    if (ws_bytes < pn_wgrad_partials_bytes()) return PNERF_E_WS;
+    if (R == 0 || n_valid == 0) return 0;
+    PnSaved sv = pn_saved_carve(d_saved, n_valid, K);
+    return pn_agg_backward_launch(cam, pts, d_params, d_packed_mlp, d_raydir, d_sample_loc, d_sample_pidx, d_valid_list, d_counters,
+                                  R, SR, K, d_decoded, d_weight, d_grad_decoded, sv, n_valid, d_grad_params, pg, (float *)d_ws,
+                                  (hipStream_t)stream);
+}
+
+// ray_march(ray_dist, ray_valid, ray_features, radiance, alpha, bg_color)   models/rendering/diff_ray_marching.py:508-554
+extern "C" int pnerf_raymarch_forward(const float *d_ray_dist, const uint8_t *d_ray_valid, const float *d_features, const float *bg3_host,
+                                      int R, int SR, float *d_ray_color, float *d_opacity, float *d_acc_trans, float *d_blend_w,
+                                      float *d_bg_trans, void *stream) {
+    if (!d_ray_dist || !d_ray_valid || !d_features || !d_ray_color || !d_opacity || !d_acc_trans || !d_blend_w || !d_bg_trans || R < 0 || SR <= 0) return PNERF_E_INVAL;
+    if (R == 0) return 0;
+    RmArgs ra = {};
+    ra.decoded = d_features; ra.ray_dist = d_ray_dist; ra.valid8 = d_ray_valid; ra.R = R; ra.SR = SR;
+    ra.cam.has_bg = bg3_host ? 1 : 0;
+    if (bg3_host) { ra.cam.bg[0] = bg3_host[0]; ra.cam.bg[1] = bg3_host[1]; ra.cam.bg[2] = bg3_host[2]; }
+    hipStream_t s = (hipStream_t)stream;
+    PnProfScope prof(PNK_RAYMARCH_FWD, s);
+    hipLaunchKernelGGL(k_raymarch_forward, dim3(pn_cdiv(R, TPB / 64)), dim3(TPB), 0, s, ra, d_ray_color, d_opacity, d_bg_trans, d_blend_w, d_acc_trans);
+    PN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pnerf_raymarch_backward(const float *d_ray_dist, const uint8_t *d_ray_valid, const float *d_features, const float *bg3_host,
+                                       int R, int SR, const float *d_grad_ray_color, float *d_grad_features, void *stream) {
+    if (!d_ray_dist || !d_ray_valid || !d_features || !d_grad_ray_color || !d_grad_features || R < 0 || SR <= 0) return PNERF_E_INVAL;
+    if (R == 0) return 0;
+    RmArgs ra = {};
+    ra.decoded = d_features; ra.ray_dist = d_ray_dist; ra.valid8 = d_ray_valid; ra.R = R; ra.SR = SR;
+    ra.cam.has_bg = bg3_host ? 1 : 0;
+    if (bg3_host) { ra.cam.bg[0] = bg3_host[0]; ra.cam.bg[1] = bg3_host[1]; ra.cam.bg[2] = bg3_host[2]; }
+    hipStream_t s = (hipStream_t)stream;
+    PnProfScope prof(PNK_RAYMARCH_BWD, s);
+    hipLaunchKernelGGL(k_raymarch_backward, dim3(pn_cdiv(R, TPB / 64)), dim3(TPB), 0, s, ra, d_grad_ray_color, d_grad_features);
+    PN_CHECK_LAUNCH();
+    return 0;
 }

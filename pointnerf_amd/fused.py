@@ -65,3 +65,75 @@ class FusedRender(torch.autograd.Function):
         gm = tuple(gflat[o:o + n].view(shp) for (o, n, shp) in env["layout"])
         assert len(gm) == ctx.n_mlp
         return (None, grads["points_embeding"], grads["points_conf"], grads["points_dir"], grads["points_color"]) + gm
+
+
+class Aggregate(torch.autograd.Function):
+    """The stand-alone aggregator (PointAggregator.forward, point_aggregators.py:727-814): gathered per-neighbor
+    tensors in, (decoded [R,SR,4], weight [R,SR,K]) out.  The gathered arrays play the role of a point cloud of
+    R*SR*K "points" indexed by slot, so the same kernels run; gradients come back per slot."""
+
+    @staticmethod
+    def forward(ctx, env, emb, conf, pdir, color, *mlp_params):
+        # env: dict(cam, xyz_slots [N',3], xyz_pers [N',3], loc_w, loc_pers, raydir [R,3], pidx, nn, R, SR, K, flat, packed, train, layout)
+        import ctypes
+        from . import _lib as L
+        lib = L.lib()
+        dev = emb.device
+        R, SR, K = env["R"], env["SR"], env["K"]
+        nn = env["nn"]
+        vlist = torch.empty(max(R * SR, 1), dtype=torch.int32, device=dev)
+        counters = torch.empty(8, dtype=torch.int32, device=dev)
+        nws = lib.pnerf_compact_workspace_bytes(R * SR)
+        cws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        L.check(lib.pnerf_compact_valid(ops._ptr(nn), R * SR, ops._ptr(vlist), ops._ptr(counters), ops._ptr(cws), nws, ops._stream()),
+                "pnerf_compact_valid")
+        n_valid = int(counters[0].item())
+        pts = ops.make_points(env["xyz_slots"], emb.detach().reshape(-1, emb.shape[-1]).contiguous(), conf.detach().reshape(-1, 1).contiguous(),
+                              pdir.detach().reshape(-1, 3).contiguous(), color.detach().reshape(-1, 3).contiguous())
+        f32 = dict(dtype=torch.float32, device=dev)
+        decoded, weight = torch.empty(R, SR, 4, **f32), torch.empty(R, SR, K, **f32)
+        saved = ws = None
+        nw = 0
+        if env["train"]:
+            saved = ops.ARENA.take(lib.pnerf_agg_saved_bytes(n_valid, K), dev)
+        else:
+            nw = lib.pnerf_agg_workspace_bytes(n_valid, K)
+            ws = torch.empty(nw, dtype=torch.uint8, device=dev)
+        L.check(lib.pnerf_agg_forward(ctypes.byref(env["cam"]), ctypes.byref(pts), ops._ptr(env["packed"]), ops._ptr(env["flat"]),
+                                      ops._ptr(env["raydir"]), ops._ptr(env["loc_w"]), ops._ptr(env["xyz_pers"]), ops._ptr(env["loc_pers"]),
+                                      ops._ptr(env["pidx"]), ops._ptr(vlist), ops._ptr(counters), R, SR, K, ops._ptr(decoded), ops._ptr(weight),
+                                      ops._ptr(saved), n_valid, ops._ptr(ws), nw, ops._stream()), "pnerf_agg_forward")
+        ctx.env, ctx.pts, ctx.keep = env, pts, (vlist, counters, saved, decoded, weight, n_valid)
+        ctx.shapes = (tuple(emb.shape), tuple(conf.shape), tuple(pdir.shape), tuple(color.shape))
+        ctx.mark_non_differentiable(weight)
+        return decoded, weight
+
+    @staticmethod
+    def backward(ctx, g_decoded, *unused):
+        import ctypes
+        from . import _lib as L
+        lib = L.lib()
+        env = ctx.env
+        vlist, counters, saved, decoded, weight, n_valid = ctx.keep
+        if saved is None:
+            raise RuntimeError("pointnerf_amd: backward through an aggregator call that was run with train=False")
+        dev = g_decoded.device
+        R, SR, K = env["R"], env["SR"], env["K"]
+        gflat = torch.zeros_like(env["flat"])
+        names = ("embedding", "conf", "dir", "color")
+        grads = [torch.zeros(shp, dtype=torch.float32, device=dev) for shp in ctx.shapes]
+        pg = L.PointGrads()
+        pg.embedding, pg.conf, pg.dir, pg.color = [g.data_ptr() for g in grads]
+        nws = lib.pnerf_render_backward_workspace_bytes(0, 1)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        gd = g_decoded.reshape(R, SR, 4).contiguous().float()
+        if n_valid > 0:
+            L.check(lib.pnerf_agg_backward(ctypes.byref(env["cam"]), ctypes.byref(ctx.pts), ops._ptr(env["packed"]), ops._ptr(env["flat"]),
+                                           ops._ptr(env["raydir"]), ops._ptr(env["loc_w"]), ops._ptr(env["pidx"]), ops._ptr(vlist),
+                                           ops._ptr(counters), R, SR, K, n_valid, ops._ptr(decoded), ops._ptr(weight), ops._ptr(gd),
+                                           ops._ptr(saved), ops._ptr(gflat), ctypes.byref(pg), ops._ptr(ws), nws, ops._stream()),
+                    "pnerf_agg_backward")
+        ops.ARENA.give(saved)
+        ctx.keep = None
+        gm = tuple(gflat[o:o + n].view(shp) for (o, n, shp) in env["layout"])
+        return (None,) + tuple(grads) + gm

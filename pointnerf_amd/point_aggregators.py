@@ -111,7 +111,39 @@ class PointAggregator(nn.Module):
             if p.requires_grad:
                 p.grad = g.clone() if p.grad is None else p.grad + g
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError(
-            "The stand-alone PointAggregator.forward(sampled_*...) entry is replaced by the fused render path "
-            "(NeuralPointsRayMarching.forward -> pointnerf_amd.fused.FusedRender); see INTEGRATION.md")
+    def forward(self, sampled_color, sampled_Rw2c, sampled_dir, sampled_conf, sampled_embedding, sampled_xyz_pers, sampled_xyz,
+                sample_pnt_mask, sample_loc, sample_loc_w, sample_ray_dirs, vsize, grid_vox_sz):
+        """Reference signature (point_aggregators.py:727-814).  Returns (output [B,R,SR,4], ray_valid [B,R,SR] bool,
+        weight | None, conf_coefficient | None) with the reference's rule for the last two (:812-813)."""
+        from .fused import Aggregate
+        from .neural_points_volumetric_model import gradient_clamp
+        opt = self.opt
+        B, R, SR, K = sample_pnt_mask.shape
+        assert B == 1, "batch size 1 (every reference script)"
+        in_shape = sample_loc_w.shape
+        ray_valid = torch.any(sample_pnt_mask, dim=-1)
+        dev = sampled_embedding.device
+        if R == 0 or not bool(ray_valid.any()):
+            return torch.zeros(in_shape[:-1] + (4,), device=dev, dtype=torch.float32), ray_valid, None, None
+        if sampled_Rw2c is not None and sampled_Rw2c.dim() != 2:
+            raise NotImplementedError("per-point Rw2c (normview) is not on the scripts' path")
+        if sampled_color is None or sampled_dir is None or sampled_conf is None:
+            raise NotImplementedError("point_color/dir/conf_mode must be '1' (lego script)")
+        st = self.mlp_state()
+        mlp_params, layout = self.ordered_params()
+        rw = None if sampled_Rw2c is None else sampled_Rw2c.detach().cpu().numpy()
+        cam = ops.make_camera([0, 0, 0], np.eye(3), opt.vsize[2], 1, bg=None, rw2c=rw)     # camera unused: perspective coords supplied
+        n_slots = R * SR * K
+        slot = torch.arange(n_slots, dtype=torch.int32, device=dev).view(R, SR, K)
+        pidx = torch.where(sample_pnt_mask[0], slot, torch.full_like(slot, -1)).contiguous()
+        c = lambda t, w: t.detach().reshape(-1, w).contiguous().float()
+        env = dict(cam=cam, xyz_slots=c(sampled_xyz, 3), xyz_pers=c(sampled_xyz_pers, 3), loc_w=c(sample_loc_w, 3),
+                   loc_pers=c(sample_loc, 3), raydir=sample_ray_dirs[0, :, 0, :].detach().contiguous().float(), pidx=pidx,
+                   nn=sample_pnt_mask[0].sum(-1).to(torch.int32).contiguous(), R=R, SR=SR, K=K, flat=st.flat,
+                   packed=st.packed_image(), train=torch.is_grad_enabled(), layout=layout)
+        decoded, weight = Aggregate.apply(env, sampled_embedding, sampled_conf, sampled_dir, sampled_color, *mlp_params)
+        conf_coefficient = gradient_clamp(sampled_conf[..., 0], lo=0.0001, hi=1)
+        weight = weight.view(B, R, SR, K)
+        if (opt.sparse_loss_weight <= 0) and ("conf_coefficient" not in opt.zero_one_loss_items) and getattr(opt, "prob", 0) == 0:
+            weight, conf_coefficient = None, None
+        return decoded.view(in_shape[:-1] + (4,)), ray_valid, weight, conf_coefficient

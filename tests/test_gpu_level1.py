@@ -1,0 +1,110 @@
+"""GPU test of the level-1 drop-ins used ONE BY ONE exactly as the reference's NeuralPointsRayMarching.forward chains
+them (models/neural_points_volumetric_model.py:268-306): NeuralPoints.forward (14-tuple) -> PointAggregator.forward ->
+ray_dist -> ray_march, forward and backward, against the oracle and against the fused path."""
+import numpy as np
+import pytest
+import torch
+
+from cases import CASES, build_case
+from gpu_util import DEV
+from pointnerf_amd import config, scenes
+from pointnerf_amd.neural_points import NeuralPoints
+from pointnerf_amd.point_aggregators import PointAggregator
+from pointnerf_amd.neural_points_volumetric_model import NeuralPointsRayMarching
+from pointnerf_amd.diff_ray_marching import ray_march, near_far_linear_ray_generation
+from pointnerf_amd.diff_render_func import find_render_function, find_blend_function, find_tone_map
+from oracle import pyref
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(name):
+    opt, xyz, attrs, inp, mlp = build_case(name)
+    dev = torch.device(DEV)
+    agg = PointAggregator(opt).to(dev)
+    agg.load_state_dict(mlp)
+    agg.flatten_()
+    npnt = NeuralPoints(32, xyz.shape[0], opt, dev)
+    a = {k: v.to(dev) for k, v in attrs.items()}
+    npnt.set_points(xyz.to(dev), a["points_embeding"], points_color=a["points_color"], points_dir=a["points_dir"],
+                    points_conf=a["points_conf"], parameter=True)
+    d = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in inp.items()}
+    return opt, xyz, attrs, inp, mlp, agg, npnt, d
+
+
+def _level1_forward(opt, agg, npnt, d):
+    """The reference's forward body, verbatim in structure, on our modules."""
+    sampled_color, sampled_Rw2c, sampled_dir, sampled_conf, sampled_embedding, sampled_xyz_pers, sampled_xyz, sample_pnt_mask, \
+        sample_loc, sample_loc_w, sample_ray_dirs, ray_mask_tensor, vsize, grid_vox_sz = npnt(
+            {"pixel_idx": d["pixel_idx"], "camrotc2w": d["camrotc2w"], "campos": d["campos"], "near": d["near"], "far": d["far"],
+             "focal": None, "h": d["h"], "w": d["w"], "intrinsic": d["intrinsic"], "gt_image": d["gt_image"], "raydir": d["raydir"]})
+    decoded_features, ray_valid, weight, conf_coefficient = agg(
+        sampled_color, sampled_Rw2c, sampled_dir, sampled_conf, sampled_embedding, sampled_xyz_pers, sampled_xyz, sample_pnt_mask,
+        sample_loc, sample_loc_w, sample_ray_dirs, vsize, grid_vox_sz)
+    ray_dist = torch.cummax(sample_loc[..., 2], dim=-1)[0]
+    ray_dist = torch.cat([ray_dist[..., 1:] - ray_dist[..., :-1],
+                          torch.full((ray_dist.shape[0], ray_dist.shape[1], 1), vsize[2], device=ray_dist.device)], dim=-1)
+    mask = ray_dist < 1e-8
+    if opt.raydist_mode_unit > 0:
+        mask = torch.logical_or(mask, ray_dist > 2 * vsize[2])
+    mask = mask.to(torch.float32)
+    ray_dist = ray_dist * (1.0 - mask) + mask * vsize[2]
+    ray_dist *= ray_valid.float()
+    ray_color, point_color, opacity, acc_transmission, blend_weight, background_transmission, bg_bw = ray_march(
+        ray_dist, ray_valid, decoded_features, find_render_function("radiance"), find_blend_function("alpha"), d["bg_color"])
+    ray_color = find_tone_map("off")(ray_color)
+    return dict(coarse_raycolor=ray_color, coarse_point_opacity=opacity, coarse_is_background=background_transmission,
+                ray_mask=ray_mask_tensor, weight=weight, blend_weight=blend_weight, conf_coefficient=conf_coefficient,
+                decoded_features=decoded_features, acc_transmission=acc_transmission, point_color=point_color, bg_bw=bg_bw)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_level1_chain_matches_oracle_and_fused(name):
+    opt, xyz, attrs, inp, mlp, agg, npnt, d = _build(name)
+    out = _level1_forward(opt, agg, npnt, d)
+    om = {k: v.clone().requires_grad_(True) for k, v in mlp.items()}
+    op = dict(xyz=xyz, **{k: v.clone().requires_grad_(True) for k, v in attrs.items()})
+    ref = pyref.render(opt, op, om, inp)
+    assert torch.equal(out["ray_mask"].cpu(), ref["ray_mask"])
+    for k, rk in [("coarse_raycolor", "coarse_raycolor"), ("coarse_point_opacity", "coarse_point_opacity"),
+                  ("coarse_is_background", "coarse_is_background"), ("decoded_features", "decoded_features"),
+                  ("weight", "weight"), ("blend_weight", "blend_weight"), ("conf_coefficient", "conf_coefficient")]:
+        a, b = out[k].detach().cpu(), ref[rk].detach()
+        assert a.shape == b.shape, (k, a.shape, b.shape)
+        assert float((a - b).abs().max()) <= 1e-4, k
+    # acc_transmission: exclusive product, first entry 1
+    assert float((out["acc_transmission"][..., 0] - 1).abs().max()) == 0.0
+    assert torch.equal(out["bg_bw"], out["coarse_is_background"])
+    # gradients through the level-1 chain
+    loss = pyref.training_loss(opt, out, {"gt_image": d["gt_image"]})
+    loss.backward()
+    pyref.training_loss(opt, ref, inp).backward()
+    for n, p in agg.named_parameters():
+        g, r = p.grad.cpu(), om[n].grad
+        assert float((g - r).abs().max()) <= 2e-3 * max(float(r.abs().max()), 1e-8), n
+    for n in ("points_embeding", "points_conf", "points_color", "points_dir"):
+        g, r = getattr(npnt, n).grad.cpu(), op[n].grad
+        e = (g - r).abs()
+        assert float((e > 1e-3 * float(r.abs().max())).float().mean()) <= 1e-3, n
+    # fused path gives the same numbers
+    model = NeuralPointsRayMarching(aggregator=agg, neural_points=npnt, opt=opt)
+    with torch.no_grad():
+        fo = model(**d)
+    assert float((fo["coarse_raycolor"] - out["coarse_raycolor"].detach()).abs().max()) <= 2e-6
+    assert torch.equal(fo["ray_mask"], out["ray_mask"])
+
+
+def test_ray_generation_dropin_is_bit_exact_on_device():
+    fix = np.load(__file__.replace("test_gpu_level1.py", "golden/raygen_pe.npz"))
+    inp = pyref.to_torch_inputs(scenes.block_rays(size=4))
+    raypos, seg, valid, mid = near_far_linear_ray_generation(inp["campos"].to(DEV), inp["raydir"].to(DEV), 400, near=2.0, far=6.0, jitter=0.0)
+    assert raypos.shape == (1, 16, 400, 3)
+    # the device cumsum may round differently from the CPU one: allow 1 ulp of the depth range
+    assert np.abs(raypos.cpu().numpy() - fix["raypos"]).max() <= 2e-6
+
+
+def test_ray_march_rejects_other_funcs():
+    from pointnerf_amd.diff_render_func import white_color, alpha_blend
+    x = torch.zeros(1, 2, 4, device=DEV)
+    with pytest.raises(NotImplementedError):
+        ray_march(x, x > 0, torch.zeros(1, 2, 4, 4, device=DEV), white_color, alpha_blend)
