@@ -79,3 +79,23 @@ def bench_lego_opt(**overrides):
     kw = dict(SR=128, K=8, max_o=2000000)
     kw.update(overrides)
     return lego_opt(**kw)
+
+
+def scannet_opt(**overrides):
+    """BASELINE.json configs[3]: dev_scripts/w_scannet_etf/scene101.sh values (vsize .008, vscale 2, P=30, max_o=2e6,
+    ranges +-10, near/far 0.1/8) with the benchmark's SR=160, K=8."""
+    kw = dict(vsize=[0.008, 0.008, 0.008], vscale=[2, 2, 2], P=30, max_o=2000000, ranges=[-10.0, -10.0, -10.0, 10.0, 10.0, 10.0],
+              SR=160, K=8, near_plane=0.1, far_plane=8.0)
+    kw.update(overrides)
+    return lego_opt(**kw)
+
+
+def barn_opt(**overrides):
+    """BASELINE.json configs[4]: dev_scripts/w_tt_ft/barn.sh values (vsize .003, vscale 3, P=11, max_o=1.5e6, Barn ranges,
+    near/far 0/4.5) with the benchmark's SR=128, K=12.  The 20M-point synthetic shell puts ~18 points in a 0.009 cell,
+    i.e. beyond P=11: both the HIP path and the oracle then keep the first P by index (the reference would switch to its
+    clock-seeded reservoir there), which is still an exact HIP-vs-oracle comparison."""
+    kw = dict(vsize=[0.003, 0.003, 0.003], vscale=[3, 3, 3], P=11, max_o=1500000,
+              ranges=[-2.05965, -0.48064, -2.23660, 1.78036, 0.6094, 1.28341], SR=128, K=12, near_plane=0.01, far_plane=4.5)
+    kw.update(overrides)
+    return lego_opt(**kw)

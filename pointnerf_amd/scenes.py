@@ -113,3 +113,85 @@ def lego_points(n=2_000_000, seed=1, pitch=0.0075,
     pts = P[keep] + rng.uniform(-0.5, 0.5, size=(keep.size, 3)) * pitch
     pts = np.clip(pts, lo + 1e-4, hi - 1e-4)
     return pts.astype(np.float32)
+
+
+# ------------------------------------------------------------------ configs[3] / configs[4]
+def _face_slab(rng, lo, hi, axis, side, pitch, layers, keep):
+    """Jittered lattice on one axis-aligned face of the box [lo,hi], `layers` lattice layers thick towards the inside."""
+    a, b = [i for i in range(3) if i != axis]
+    ua = np.arange(lo[a] + 0.5 * pitch, hi[a], pitch)
+    ub = np.arange(lo[b] + 0.5 * pitch, hi[b], pitch)
+    A, B = np.meshgrid(ua, ub, indexing="ij")
+    out = []
+    for l in range(layers):
+        m = rng.random(A.shape) < keep
+        n = int(m.sum())
+        p = np.empty((n, 3))
+        p[:, a], p[:, b] = A[m], B[m]
+        p[:, axis] = (lo[axis] + (l + 0.5) * pitch) if side == 0 else (hi[axis] - (l + 0.5) * pitch)
+        out.append(p + rng.uniform(-0.5, 0.5, size=p.shape) * pitch)
+    return np.concatenate(out, 0)
+
+
+def _box_shell(rng, lo, hi, pitch, layers, keep):
+    lo, hi = np.asarray(lo, float), np.asarray(hi, float)
+    return np.concatenate([_face_slab(rng, lo, hi, ax, sd, pitch, layers, keep) for ax in range(3) for sd in (0, 1)], 0)
+
+
+def scannet_points(n=6_000_000, seed=3, pitch=0.008):
+    """configs[3]: ScanNet-scale room: inner faces of an 8.0 x 6.0 x 2.8 m box (3 lattice layers thick, as noisy COLMAP
+    surfaces are) plus 12 axis-aligned cuboids, 30 % random dropout, truncated to n points (face-major order)."""
+    rng = np.random.default_rng(seed)
+    parts = [_box_shell(rng, (-4.0, -3.0, 0.0), (4.0, 3.0, 2.8), pitch, 3, 0.7)]
+    for i in range(12):
+        c = np.array([rng.uniform(-3.2, 3.2), rng.uniform(-2.3, 2.3), 0.0])
+        sz = np.array([rng.uniform(0.5, 1.6), rng.uniform(0.5, 1.6), rng.uniform(0.4, 1.8)])
+        parts.append(_box_shell(rng, c - [sz[0] / 2, sz[1] / 2, 0], c + [sz[0] / 2, sz[1] / 2, sz[2]], pitch, 1, 0.7))
+    pts = np.concatenate(parts, 0)
+    if pts.shape[0] < n:        # densify with extra wall layers until the count is reached
+        extra = _box_shell(rng, (-3.97, -2.97, 0.03), (3.97, 2.97, 2.77), pitch, 6, 0.7)
+        pts = np.concatenate([pts, extra], 0)
+    return pts[:n].astype(np.float32)
+
+
+def scannet_rays(pose_i, R, w=640, h=480, f=577.87):
+    """configs[3] camera: 50 poses on a 1.2 m circle at height 1.4 m looking outward (OpenCV convention: +z forward, +y down)."""
+    th = 2 * np.pi * (pose_i % 50) / 50.0
+    fwd = np.array([np.cos(th), np.sin(th), 0.0]); down = np.array([0.0, 0.0, -1.0]); right = np.cross(down, fwd)
+    c2w = np.eye(4, dtype=np.float32)
+    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2] = right, down, fwd
+    c2w[:3, 3] = [1.2 * np.cos(th), 1.2 * np.sin(th), 1.4]
+    intr = np.array([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1]], dtype=np.float32)
+    rng = np.random.default_rng(300 + pose_i)
+    px = rng.integers(0, w, size=R); py = rng.integers(0, h, size=R)
+    return ray_dict(c2w, intr, px, py, near=0.1, far=8.0, w=w, h=h, gt_seed=300 + pose_i)
+
+
+BARN_RANGES = (-2.05965, -0.48064, -2.23660, 1.78036, 0.6094, 1.28341)
+
+
+def barn_points(n=20_000_000, seed=4, pitch=0.003):
+    """configs[4]: Tanks&Temples-Barn-scale shell: the faces of a box inset in the Barn `ranges`, thick enough (whole
+    lattice layers) to hold n points, truncated to n (face-major order)."""
+    rng = np.random.default_rng(seed)
+    lo = np.array(BARN_RANGES[:3]) + 0.05; hi = np.array(BARN_RANGES[3:]) - 0.05
+    ext = hi - lo
+    area = 2 * (ext[0] * ext[1] + ext[0] * ext[2] + ext[1] * ext[2])
+    layers = int(np.ceil(n / (area / pitch ** 2))) + 1
+    pts = _box_shell(rng, lo, hi, pitch, layers, 1.0)
+    return pts[:n].astype(np.float32)
+
+
+def barn_rays(pose_i, R, w=1088, h=640):
+    """configs[4] camera: 60 poses on an ellipse outside the shell, looking at its centre; focal 0.7 W."""
+    th = 2 * np.pi * (pose_i % 60) / 60.0
+    ctr = np.array([(BARN_RANGES[0] + BARN_RANGES[3]) / 2, (BARN_RANGES[1] + BARN_RANGES[4]) / 2, (BARN_RANGES[2] + BARN_RANGES[5]) / 2])
+    eye = ctr + np.array([3.2 * np.cos(th), -0.3, 3.0 * np.sin(th)])
+    fwd = ctr - eye; fwd /= np.linalg.norm(fwd)
+    up = np.array([0.0, -1.0, 0.0]); right = np.cross(fwd, up); right /= np.linalg.norm(right); down = np.cross(fwd, right)
+    c2w = np.eye(4, dtype=np.float32)
+    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, down, fwd, eye
+    intr = np.array([[0.7 * w, 0, w / 2], [0, 0.7 * w, h / 2], [0, 0, 1]], dtype=np.float32)
+    rng = np.random.default_rng(400 + pose_i)
+    px = rng.integers(0, w, size=R); py = rng.integers(0, h, size=R)
+    return ray_dict(c2w, intr, px, py, near=0.01, far=4.5, w=w, h=h, gt_seed=400 + pose_i)
