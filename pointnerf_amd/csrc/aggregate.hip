@@ -277,24 +277,28 @@ __global__ __launch_bounds__(256, 2) void k_agg_forward(FwdArgs a) {
         pn_acc_init_bias<2>(acc, P + PO_B1, wave, lane);
         pn_tile_gemm<2>(bufA, LDX, PN_IN1P / 8, a.packed + PK_F1 / 4, wave, lane, acc);
         __syncthreads();
-        pn_store_act<2, TRAIN>(acc, bufA, LDH, a.sv.h1, PN_H, grow0, wave, lane);
+        pn_acc_to_lds<2, true>(acc, bufA, LDH, wave, lane);
         __syncthreads();
+        if (TRAIN) pn_tile_copy_out<PN_H>(bufA, LDH, a.sv.h1, PN_H, grow0, tid);
         pn_acc_init_bias<2>(acc, P + PO_B2, wave, lane);
         pn_tile_gemm<2>(bufA, LDH, PN_H / 8, a.packed + PK_F2 / 4, wave, lane, acc);
         __syncthreads();
-        pn_store_act<2, TRAIN>(acc, bufA, LDH, a.sv.h2, PN_H, grow0, wave, lane);
+        pn_acc_to_lds<2, true>(acc, bufA, LDH, wave, lane);
         __syncthreads();
+        if (TRAIN) pn_tile_copy_out<PN_H>(bufA, LDH, a.sv.h2, PN_H, grow0, tid);
         pn_acc_init_bias<2>(acc, P + PO_B3, wave, lane);
         pn_tile_gemm<2>(bufA, LDH, PN_H / 8, a.packed + PK_F3 / 4, wave, lane, acc);
         pn_tile_gemm<2>(exb, 8, 1, a.packed + PK_F3 / 4 + (PN_H / 8) * 4 * 2 * 64, wave, lane, acc);
         __syncthreads();
-        pn_store_act<2, TRAIN>(acc, bufA, LDH, a.sv.h3, PN_H, grow0, wave, lane);
+        pn_acc_to_lds<2, true>(acc, bufA, LDH, wave, lane);
         __syncthreads();
+        if (TRAIN) pn_tile_copy_out<PN_H>(bufA, LDH, a.sv.h3, PN_H, grow0, tid);
         pn_acc_init_bias<2>(acc, P + PO_B4, wave, lane);
         pn_tile_gemm<2>(bufA, LDH, PN_H / 8, a.packed + PK_F4 / 4, wave, lane, acc);
         __syncthreads();
-        pn_store_act<2, TRAIN>(acc, bufA, LDH, a.sv.h4, PN_H, grow0, wave, lane);
+        pn_acc_to_lds<2, true>(acc, bufA, LDH, wave, lane);
         __syncthreads();
+        if (TRAIN) pn_tile_copy_out<PN_H>(bufA, LDH, a.sv.h4, PN_H, grow0, tid);
         // ---- P5: alpha head (256 -> 1, softplus(x - 1)) -----------------------------------------
         {
             const int row = tid >> 2, q = tid & 3;
@@ -393,16 +397,19 @@ __global__ __launch_bounds__(256, 1) void k_color_forward(FwdArgs a) {
         f32x16 acc[2][1];
         pn_acc_init_bias<1>(acc, P + PO_BC1, wave, lane);
         pn_tile_gemm<1>(X, LDX, PN_INC / 8, a.packed + PK_C1 / 4, wave, lane, acc);
-        pn_store_act<1, TRAIN>(acc, H1, LDC, a.sv.c1, PN_HC, grow0, wave, lane);
+        pn_acc_to_lds<1, true>(acc, H1, LDC, wave, lane);
         __syncthreads();
+        if (TRAIN) pn_tile_copy_out<PN_HC>(H1, LDC, a.sv.c1, PN_HC, grow0, tid);
         pn_acc_init_bias<1>(acc, P + PO_BC2, wave, lane);
         pn_tile_gemm<1>(H1, LDC, PN_HC / 8, a.packed + PK_C2 / 4, wave, lane, acc);
-        pn_store_act<1, TRAIN>(acc, H2, LDC, a.sv.c2, PN_HC, grow0, wave, lane);
+        pn_acc_to_lds<1, true>(acc, H2, LDC, wave, lane);
         __syncthreads();
+        if (TRAIN) pn_tile_copy_out<PN_HC>(H2, LDC, a.sv.c2, PN_HC, grow0, tid);
         pn_acc_init_bias<1>(acc, P + PO_BC3, wave, lane);
         pn_tile_gemm<1>(H2, LDC, PN_HC / 8, a.packed + PK_C3 / 4, wave, lane, acc);
-        pn_store_act<1, TRAIN>(acc, H1, LDC, a.sv.c3, PN_HC, grow0, wave, lane);
+        pn_acc_to_lds<1, true>(acc, H1, LDC, wave, lane);
         __syncthreads();
+        if (TRAIN) pn_tile_copy_out<PN_HC>(H1, LDC, a.sv.c3, PN_HC, grow0, tid);
         {
             const int row = tid >> 2, q = tid & 3;
             const float *h = H1 + row * LDC + q * 32;

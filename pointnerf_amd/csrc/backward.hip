@@ -87,12 +87,16 @@ __global__ __launch_bounds__(256, 1) void k_color_backward(BwdArgs a) {
         f32x16 acc[2][1];
         pn_acc_init_bias<1>(acc, nullptr, wave, lane);
         pn_tile_gemm<1>(D1, LDC, PN_HC / 8, a.packed + PK_DC3 / 4, wave, lane, acc);
-        pn_store_dact<1>(acc, a.sv.c2, PN_HC, D2, LDC, a.sv.dc2, PN_HC, grow0, wave, lane);
+        pn_acc_to_lds<1, false>(acc, D2, LDC, wave, lane);
+        __syncthreads();
+        pn_tile_mask_pass<PN_HC>(D2, LDC, a.sv.c2, PN_HC, a.sv.dc2, PN_HC, grow0, tid);
         __syncthreads();
         _Pragma("unroll 4") for (int row = half; row < PN_TILE; row += 2) gb2 += D2[row * LDC + cc];
         pn_acc_init_bias<1>(acc, nullptr, wave, lane);
         pn_tile_gemm<1>(D2, LDC, PN_HC / 8, a.packed + PK_DC2 / 4, wave, lane, acc);
-        pn_store_dact<1>(acc, a.sv.c1, PN_HC, D1, LDC, a.sv.dc1, PN_HC, grow0, wave, lane);
+        pn_acc_to_lds<1, false>(acc, D1, LDC, wave, lane);
+        __syncthreads();
+        pn_tile_mask_pass<PN_HC>(D1, LDC, a.sv.c1, PN_HC, a.sv.dc1, PN_HC, grow0, tid);
         __syncthreads();
         _Pragma("unroll 4") for (int row = half; row < PN_TILE; row += 2) gb1 += D1[row * LDC + cc];
         f32x16 acc2[2][2];
@@ -248,7 +252,9 @@ __global__ __launch_bounds__(256, 2) void k_agg_backward(BwdArgs a) {
         pn_acc_init_bias<2>(acc, nullptr, wave, lane);
         pn_tile_gemm<2>(buf, LDH, PN_H / 8, a.packed + PK_D4 / 4, wave, lane, acc);
         __syncthreads();
-        pn_store_dact<2>(acc, a.sv.h3, PN_H, buf, LDH, a.sv.dy3, PN_H, grow0, wave, lane);
+        pn_acc_to_lds<2, false>(acc, buf, LDH, wave, lane);
+        __syncthreads();
+        pn_tile_mask_pass<PN_H>(buf, LDH, a.sv.h3, PN_H, a.sv.dy3, PN_H, grow0, tid);
         __syncthreads();
         // ---- block3 first layer: extras (colour, dir) + dY2 = (dY3 @ W3[:, :256]) * lrelu'(h2) ----
         _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) {
@@ -291,28 +297,25 @@ __global__ __launch_bounds__(256, 2) void k_agg_backward(BwdArgs a) {
         pn_acc_init_bias<2>(acc, nullptr, wave, lane);
         pn_tile_gemm<2>(buf, LDH, PN_H / 8, a.packed + PK_D3 / 4, wave, lane, acc);
         __syncthreads();
-        pn_store_dact<2>(acc, a.sv.h2, PN_H, buf, LDH, a.sv.dy2, PN_H, grow0, wave, lane);
+        pn_acc_to_lds<2, false>(acc, buf, LDH, wave, lane);
+        __syncthreads();
+        pn_tile_mask_pass<PN_H>(buf, LDH, a.sv.h2, PN_H, a.sv.dy2, PN_H, grow0, tid);
         __syncthreads();
         // ---- block1 second layer: dY1 = (dY2 @ W2) * lrelu'(h1) ----------------------------------
         _Pragma("unroll 8") for (int row = 0; row < PN_TILE; ++row) gb2 += buf[row * LDH + tid];
         pn_acc_init_bias<2>(acc, nullptr, wave, lane);
         pn_tile_gemm<2>(buf, LDH, PN_H / 8, a.packed + PK_D2 / 4, wave, lane, acc);
         __syncthreads();
-        pn_store_dact<2>(acc, a.sv.h1, PN_H, buf, LDH, a.sv.dy1, PN_H, grow0, wave, lane);
+        pn_acc_to_lds<2, false>(acc, buf, LDH, wave, lane);
+        __syncthreads();
+        pn_tile_mask_pass<PN_H>(buf, LDH, a.sv.h1, PN_H, a.sv.dy1, PN_H, grow0, tid);
         __syncthreads();
         // ---- block1 first layer: d X0[:, :256] = dY1 @ W1[:, :256] --------------------------------
         _Pragma("unroll 8") for (int row = 0; row < PN_TILE; ++row) gb1 += buf[row * LDH + tid];
         pn_acc_init_bias<2>(acc, nullptr, wave, lane);
         pn_tile_gemm<2>(buf, LDH, PN_H / 8, a.packed + PK_D1 / 4, wave, lane, acc);
         __syncthreads();
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const int col = pn_acc_col<2>(wave, ct, lane);
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) buf[pn_acc_row(rt, reg, lane) * LDH + col] = acc[rt][ct][reg];
-            }
+        pn_acc_to_lds<2, false>(acc, buf, LDH, wave, lane);
         __syncthreads();
         // ---- embedding gradient through [e | PE3(e)]: d e = dX[e] + sum_f 2^f (dX[sin] cos - dX[cos] sin)
         {

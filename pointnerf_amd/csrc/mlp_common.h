@@ -136,6 +136,56 @@ __device__ __forceinline__ void pn_store_dact(f32x16 (&acc)[2][NT], const float 
         }
 }
 
+// ---- wide epilogues: accumulators -> LDS (dword, conflict-free), then whole-row float4 traffic LDS <-> HBM.
+// A C-fragment lane owns 64 scattered dwords; storing them straight to HBM costs 64 dword stores per lane per layer
+// (store-issue bound).  Going through the LDS tile that the next layer needs anyway turns that into 16 dwordx4 per lane.
+template <int NT, bool LRELU>
+__device__ __forceinline__ void pn_acc_to_lds(f32x16 (&acc)[2][NT], float *__restrict__ H, int ldh, int wave, int lane) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            const int col = pn_acc_col<NT>(wave, ct, lane);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float v = acc[rt][ct][reg];
+                H[pn_acc_row(rt, reg, lane) * ldh + col] = LRELU ? pn_lrelu(v) : v;
+            }
+        }
+}
+
+// G[grow0 + row][0..W) = H[row][0..W) for the 64 rows of the tile (W = 256 or 128), float4 per lane
+template <int W>
+__device__ __forceinline__ void pn_tile_copy_out(const float *__restrict__ H, int ldh, float *__restrict__ G, int ldg, long long grow0, int tid) {
+    constexpr int PER = PN_TILE * W / 4 / 256;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = tid + i * 256, row = e / (W / 4), c4 = e - row * (W / 4);
+        *reinterpret_cast<float4 *>(G + (grow0 + row) * ldg + c4 * 4) = *reinterpret_cast<const float4 *>(H + row * ldh + c4 * 4);
+    }
+}
+
+// in place: H = H * LeakyReLU'(S) with S the saved post-activation in HBM; the result also goes to D (HBM)
+template <int W>
+__device__ __forceinline__ void pn_tile_mask_pass(float *__restrict__ H, int ldh, const float *__restrict__ S, int lds_, float *__restrict__ D,
+                                                  int ldd, long long grow0, int tid) {
+    constexpr int PER = PN_TILE * W / 4 / 256;
+    float4 sv[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = tid + i * 256, row = e / (W / 4), c4 = e - row * (W / 4);
+        sv[i] = *reinterpret_cast<const float4 *>(S + (grow0 + row) * lds_ + c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = tid + i * 256, row = e / (W / 4), c4 = e - row * (W / 4);
+        float4 v = *reinterpret_cast<const float4 *>(H + row * ldh + c4 * 4);
+        v.x *= pn_lrelu_grad(sv[i].x); v.y *= pn_lrelu_grad(sv[i].y); v.z *= pn_lrelu_grad(sv[i].z); v.w *= pn_lrelu_grad(sv[i].w);
+        *reinterpret_cast<float4 *>(H + row * ldh + c4 * 4) = v;
+        *reinterpret_cast<float4 *>(D + (grow0 + row) * ldd + c4 * 4) = v;
+    }
+}
+
 // ---- saved-activation area (training) -------------------------------------------------------
 struct PnSaved {
     // per neighbor row (rows = row tiles * 64)
