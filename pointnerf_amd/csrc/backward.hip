@@ -592,7 +592,7 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     int rc;
     float *g = d_grad_params;
     if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16>(sv.dy1, PN_H, sv.x0, PN_IN1P, rows, d_partials, 256, 256, g, PO_W1, PN_IN1, s))) return rc;
-    if ((rc = launch_wgrad<1, 1, 8, 1>(sv.dy1, PN_H, sv.x0 + 256, PN_IN1P, rows, d_partials, 32, PN_IN1 - 256, g, PO_W1 + 256, PN_IN1, s))) return rc;
+    if ((rc = launch_wgrad_lds<4, 1, 2, 1, 16>(sv.dy1, PN_H, sv.x0 + 256, PN_IN1P, rows, d_partials, 32, PN_IN1 - 256, g, PO_W1 + 256, PN_IN1, s))) return rc;
     if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16>(sv.dy2, PN_H, sv.h1, PN_H, rows, d_partials, 256, 256, g, PO_W2, PN_H, s))) return rc;
     if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16>(sv.dy3, PN_H, sv.h2, PN_H, rows, d_partials, 256, 256, g, PO_W3, PN_IN3, s))) return rc;
     if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16>(sv.dy4, PN_H, sv.h3, PN_H, rows, d_partials, 256, 256, g, PO_W4, PN_H, s))) return rc;

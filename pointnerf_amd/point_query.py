@@ -23,14 +23,26 @@ _GRID_CACHE = {}
 _GRID_CACHE_MAX = 4
 
 
+def _cache_key(xyz, n_actual, gp_tuple):
+    return (xyz.data_ptr(), xyz._version, tuple(xyz.shape), int(n_actual), gp_tuple, xyz.device.index)
+
+
+def _cache_get(key):
+    e = _GRID_CACHE.get(key)
+    return None if e is None else e[0]
+
+
 def _cached_grid(xyz, n_actual, gp_tuple, make_gp):
-    key = (xyz.data_ptr(), xyz._version, tuple(xyz.shape), int(n_actual), gp_tuple, xyz.device.index)
-    g = _GRID_CACHE.get(key)
+    """The grid is a function of (xyz contents, parameters).  Identity of the contents = (storage address, version
+    counter); every entry keeps a reference to its xyz tensor so that the address cannot be recycled by the
+    allocator for a different cloud while the entry lives (observed: two test scenes of equal N sharing an address)."""
+    key = _cache_key(xyz, n_actual, gp_tuple)
+    g = _cache_get(key)
     if g is None:
         if len(_GRID_CACHE) >= _GRID_CACHE_MAX:
             _GRID_CACHE.pop(next(iter(_GRID_CACHE)))
         g = ops.build_grid(make_gp(), xyz.reshape(-1, 3)[:n_actual])
-        _GRID_CACHE[key] = g
+        _GRID_CACHE[key] = (g, xyz)
     return g
 
 
@@ -98,9 +110,7 @@ class lighting_fast_querier():
             return holder["gp"]
 
         # the hyper-parameters depend on min/max of xyz: compute them only on a cache miss
-        key_probe = (point_xyz_w_tensor.data_ptr(), point_xyz_w_tensor._version, tuple(point_xyz_w_tensor.shape), int(n_actual),
-                     opt_key, point_xyz_w_tensor.device.index)
-        g = _GRID_CACHE.get(key_probe)
+        g = _cache_get(_cache_key(point_xyz_w_tensor, n_actual, opt_key))
         if g is None:
             ranges, svs, svd, radius = ops.grid_hyperparameters(opt, xyz[:n_actual])
             holder["gp"] = ops.make_grid_params(ranges, svs, svd, opt.kernel_size, opt.query_size, opt.P, opt.max_o, radius)

@@ -146,3 +146,20 @@ def test_jitter_mode_statistics():
     t = ((a["sample_loc"] - inp["campos"].to(DEV)) * inp["camrotc2w"][0][:, 2].to(DEV)).sum(-1)   # camera depth
     t = t[a["sample_nn"] > 0]
     assert float(t.min()) > 2.0 - 1e-3 and float(t.max()) < 6.0 + 1e-3
+
+
+def test_grid_cache_never_serves_a_recycled_address():
+    """Regression: the grid cache is keyed on the xyz storage address + version.  Two clouds of equal N allocated one
+    after the other (the first one freed) used to collide when the caching allocator recycled the address."""
+    from pointnerf_amd.point_query import lighting_fast_querier
+    opt, _, inp = _scene(3, 600)
+    qr = lighting_fast_querier(torch.device(DEV), opt)
+    rd, cp = inp["raydir"].to(DEV), inp["campos"].to(DEV)
+    for seed in (11, 12, 13, 14):
+        xyz = torch.from_numpy(scenes.chair_points(600, seed=seed, radius=0.06))
+        q = pyref.query(opt, xyz, inp)
+        xd = xyz.to(DEV)
+        dense = qr.query_dense(xd[None], 600, 2.0, 6.0, rd, cp)
+        hit = dense["ray_hit"].cpu() > 0
+        assert torch.equal(dense["sample_pidx"].cpu()[hit][None], q["sample_pidx"]), seed
+        del xd, dense
