@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rays", type=int, default=65536, help="rays per GPU per step")
     ap.add_argument("--points", type=int, default=2_000_000)
-    ap.add_argument("--cpu-rays", type=int, default=1024, help="rays of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-rays", type=int, default=12288, help="rays of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events")
     return ap.parse_args()
 
