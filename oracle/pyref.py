@@ -285,3 +285,22 @@ def training_loss(opt, out, inp, zero_epsilon=1e-3):
 
 def to_torch_inputs(d):
     return {k: (torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v) for k, v in d.items()}
+
+
+def probe_outputs(out, points):
+    """neural_points_volumetric_model.py:331-362 (opt.prob == 1) on the oracle's render() result."""
+    q = out["query"]
+    op = out["coarse_point_opacity"]
+    mx, ind = torch.max(op, dim=-1, keepdim=True)
+    ind = ind[..., None]
+    loc_max = torch.gather(q["sample_loc_w"], 2, ind.expand(-1, -1, -1, 3)).squeeze(2)
+    w = torch.gather(out["weight"] * out["conf_coefficient"], 2, ind.expand(-1, -1, -1, out["weight"].shape[-1])).squeeze(2)[..., None]
+    pidx = torch.gather(q["sample_pidx"], 2, ind.expand(-1, -1, -1, q["sample_pidx"].shape[-1])).squeeze(2).clamp(min=0).long()
+    g = lambda t: t.reshape(-1, t.shape[-1])[pidx.view(-1)].view(pidx.shape + (t.shape[-1],))
+    xyz_max = g(points["xyz"])
+    return dict(ray_max_shading_opacity=mx, ray_max_sample_loc_w=loc_max,
+                ray_max_far_dist=torch.min(torch.norm(xyz_max - loc_max[..., None, :], dim=-1), dim=-1, keepdim=True)[0],
+                shading_avg_color=torch.sum(g(points["points_color"][0]) * w, dim=-2),
+                shading_avg_dir=torch.sum(g(points["points_dir"][0]) * w, dim=-2),
+                shading_avg_conf=torch.sum(g(points["points_conf"][0]) * w, dim=-2),
+                shading_avg_embedding=torch.sum(g(points["points_embeding"][0]) * w, dim=-2))

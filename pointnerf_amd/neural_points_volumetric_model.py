@@ -8,7 +8,9 @@ far, focal, h, w, intrinsic, **kargs``) and returns the reference's dict with th
 ``ray_mask [1,R] int8``, ``queried_shading``, ``weight``, ``blend_weight``, ``conf_coefficient``).  Internally
 everything runs dense over the R submitted rays inside libpnerf_hip.so; the R'' view is produced by one
 boolean row-gather at the very end (the only host sync besides reading the valid-sample count).
-``opt.prob==1`` probe outputs (:331-362) are a "next" row and raise.
+``opt.prob==1`` adds the probe outputs of :331-362 (per-ray argmax-opacity sample, its location, nearest-neighbor
+distance and weighted average colour/dir/conf/embedding) used by ``probe_hole`` (run/train_ft.py:417-530): they touch
+one sample per ray, so they are small gathers on top of the dense render (``pnerf_gather_rows`` for the point rows).
 """
 import torch
 import torch.nn as nn
@@ -69,8 +71,6 @@ class NeuralPointsRayMarching(nn.Module):
     def forward(self, campos, raydir, gt_image=None, bg_color=None, camrotc2w=None, pixel_idx=None, near=None, far=None,
                 focal=None, h=None, w=None, intrinsic=None, **kargs):
         opt = self.opt
-        if getattr(opt, "prob", 0) == 1:
-            raise NotImplementedError("opt.prob==1 probe outputs are a 'next' row (SURVEY.md 8f f1)")
         if "bg_ray" in kargs:
             bg_color = None
         ray_color, opacity, bg_trans, blend_w, decoded, weight, dense = self.render_dense(campos, raydir, camrotc2w, near, far, bg_color)
@@ -90,7 +90,31 @@ class NeuralPointsRayMarching(nn.Module):
             conf = self.neural_points.points_conf
             pidx_hit = dense["sample_pidx"][hit]
             output["conf_coefficient"] = gradient_clamp(ops.gather_rows(conf.reshape(-1, 1), pidx_hit)[..., 0])[None]
+        if getattr(opt, "prob", 0) == 1 and output["coarse_point_opacity"].shape[1] > 0:
+            self._probe_outputs(output, dense, hit)
         return output
+
+    def _probe_outputs(self, output, dense, hit):
+        """neural_points_volumetric_model.py:331-362, same keys and shapes."""
+        npnt = self.neural_points
+        with torch.no_grad():
+            op = output["coarse_point_opacity"][0]                                   # [R'',SR]
+            mx, ind = torch.max(op, dim=-1, keepdim=True)                            # [R'',1]
+            output["ray_max_shading_opacity"] = mx[None]
+            loc_w = dense["sample_loc"][hit]                                         # [R'',SR,3]
+            sel = lambda t: torch.gather(t, 1, ind.view(-1, 1, *([1] * (t.dim() - 2))).expand(-1, 1, *t.shape[2:])).squeeze(1)
+            loc_max = sel(loc_w)                                                     # [R'',3]
+            output["ray_max_sample_loc_w"] = loc_max[None]
+            w = sel(output["weight"][0] * output["conf_coefficient"][0].detach())    # [R'',K]
+            pidx = sel(dense["sample_pidx"][hit])                                    # [R'',K]  (-1 slots read point 0, as :708)
+            g = lambda t: ops.gather_rows(t.detach().reshape(-1, t.shape[-1]), pidx)  # [R'',K,C]
+            xyz_max = g(npnt.xyz)
+            output["ray_max_far_dist"] = torch.min(torch.norm(xyz_max - loc_max[:, None, :], dim=-1), dim=-1, keepdim=True)[0][None]
+            wk = w[..., None]
+            output["shading_avg_color"] = torch.sum(g(npnt.points_color) * wk, dim=-2)[None]
+            output["shading_avg_dir"] = torch.sum(g(npnt.points_dir) * wk, dim=-2)[None]
+            output["shading_avg_conf"] = torch.sum(g(npnt.points_conf) * wk, dim=-2)[None]
+            output["shading_avg_embedding"] = torch.sum(g(npnt.points_embeding) * wk, dim=-2)[None]
 
 
 def fill_invalid(output, bg_color, tonemap_func=None):

@@ -108,3 +108,20 @@ def test_ray_march_rejects_other_funcs():
     x = torch.zeros(1, 2, 4, device=DEV)
     with pytest.raises(NotImplementedError):
         ray_march(x, x > 0, torch.zeros(1, 2, 4, 4, device=DEV), white_color, alpha_blend)
+
+
+def test_probe_outputs_prob1():
+    """opt.prob == 1 (probe_hole, run/train_ft.py:417-530): the 7 extra outputs against the oracle."""
+    opt, xyz, attrs, inp, mlp, agg, npnt, d = _build("small_k8")
+    opt.prob = 1
+    model = NeuralPointsRayMarching(aggregator=agg, neural_points=npnt, opt=opt)
+    with torch.no_grad():
+        out = model(**d)
+        points = dict(xyz=xyz, **attrs)
+        ref = pyref.render(opt, points, mlp, inp)
+        pr = pyref.probe_outputs(ref, points)
+    for k, v in pr.items():
+        a = out[k].cpu()
+        assert a.shape == v.shape, (k, a.shape, v.shape)
+        assert float((a - v).abs().max()) <= 1e-4, k
+    opt.prob = 0
