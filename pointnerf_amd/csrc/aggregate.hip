@@ -76,7 +76,7 @@ size_t pn_saved_bytes(long long n_valid, int K, long long *rows_out, long long *
     const int TS = pn_tile_samples(K);
     const long long tiles = (n_valid + TS - 1) / TS + 1;
     const long long rows = tiles * PN_TILE;
-    const long long samples = ((tiles * TS + PN_TILE - 1) / PN_TILE + 1) * PN_TILE;
+    const long long samples = ((tiles * TS + PN_CTILE - 1) / PN_CTILE + 1) * PN_CTILE;
     if (rows_out) *rows_out = rows;
     if (samples_out) *samples_out = samples;
     size_t b = 0;
@@ -113,7 +113,12 @@ namespace {
 constexpr int LDX = 292;    // X0 / colour input row stride in LDS (odd multiple of 4 floats: conflict-free b128 reads)
 constexpr int LDH = 260;    // hidden row stride
 constexpr int LDC = 132;    // colour hidden row stride
-constexpr int AGG_LDS_FLOATS = PN_TILE * LDX + PN_TILE * 8 + PN_TILE * 8 + 4 * PN_TILE + PN_H + 64;   // 81 KB: two workgroups per CU
+constexpr int TPR = PN_TPR; // threads per tile row in the element-wise phases
+constexpr int EPT = PN_F / TPR;              // embedding dims per thread in the feature build
+constexpr int PPT = (30 + TPR - 1) / TPR;    // (sin,cos) pairs of PE5(dists6) per thread
+constexpr int CPT = PN_H / TPR;              // hidden columns per thread in the row-wise dot products
+constexpr int AGG_LDS_FLOATS = PN_TILE * LDX + PN_TILE * 8 + PN_TILE * 8 + 4 * PN_TILE + PN_H + PN_TILE;
+constexpr int AGG_WG_PER_CU = (160 * 1024) / (AGG_LDS_FLOATS * 4);
 
 struct FwdArgs {
     pnerf_camera cam;
@@ -135,20 +140,26 @@ __device__ __forceinline__ void rot3(const float *M /*row-major*/, float x, floa
     else { ox = x * M[0] + y * M[1] + z * M[2]; oy = x * M[3] + y * M[4] + z * M[5]; oz = x * M[6] + y * M[7] + z * M[8]; }
 }
 
-// One LDS activation buffer, updated in place (GEMM -> barrier -> epilogue -> barrier): 81 KB per workgroup, so two
-// workgroups share a CU and one's gather / epilogue latency hides under the other's MFMA phase.
+template <int N> __device__ __forceinline__ float group_sum(float v) {      // sum over N adjacent lanes (N = 4 or 8)
+#pragma unroll
+    for (int off = 1; off < N; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// One LDS activation buffer, updated in place (GEMM -> barrier -> epilogue -> barrier): with 32-row tiles 46 KB per
+// workgroup, so three workgroups share a CU and one's gather / epilogue latency hides under the others' MFMA phases.
 template <bool TRAIN>
-__global__ __launch_bounds__(256, 2) void k_agg_forward(FwdArgs a) {
+__global__ __launch_bounds__(256, PN_TILE == 32 ? 3 : 2) void k_agg_forward(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *bufA = smem;                         // [64][LDX]  X0, then h1..h4 at stride LDH
-    float *exb = bufA + PN_TILE * LDX;          // [64][8]  layer-3 extras
-    float *dst = exb + PN_TILE * 8;             // [64][8]  the 6 distance components of each row
-    float *wraw = dst + PN_TILE * 8;            // [64] raw 1/dist weights, later alpha*w
-    float *wrow = wraw + PN_TILE;               // [64] final weight (normalised * clamped conf)
-    float *wnrm = wrow + PN_TILE;               // [64] normalised weight
-    float *rawa = wnrm + PN_TILE;               // [64] alpha pre-activation
+    float *bufA = smem;                         // [PN_TILE][LDX]  X0, then h1..h4 at stride LDH
+    float *exb = bufA + PN_TILE * LDX;          // [PN_TILE][8]  layer-3 extras
+    float *dst = exb + PN_TILE * 8;             // [PN_TILE][8]  the 6 distance components of each row
+    float *wraw = dst + PN_TILE * 8;            // [PN_TILE] raw 1/dist weights, later alpha*w
+    float *wrow = wraw + PN_TILE;               // final weight (normalised * clamped conf)
+    float *wnrm = wrow + PN_TILE;               // normalised weight
+    float *rawa = wnrm + PN_TILE;               // (spare)
     float *w5s = rawa + PN_TILE;                // [256]
-    int *sidx = reinterpret_cast<int *>(w5s + PN_H);   // [<=64] sample ids of this tile
+    int *sidx = reinterpret_cast<int *>(w5s + PN_H);   // [<=PN_TILE] sample ids of this tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, TS = a.TS;
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void k_agg_forward(FwdArgs a) {
         __syncthreads();
         // ---- P1: gather + feature build -----------------------------------------------------
         {
-            const int row = tid >> 2, q = tid & 3;
+            const int row = tid / TPR, q = tid % TPR;
             const int ls = row / K, k = row - ls * K;
             const int si = ls < TS ? sidx[ls] : -1;
             int p = -1;
@@ -190,18 +201,17 @@ __global__ __launch_bounds__(256, 2) void k_agg_forward(FwdArgs a) {
                 float d[6];
                 rot3(a.cam.rw2c, dwx, dwy, dwz, true, d[0], d[1], d[2]);            // dists[:3] @ Rw2c^T (point_aggregators.py:526)
                 d[3] = ppx * pcz - spx * scz; d[4] = ppy * pcz - spy * scz; d[5] = pcz - scz;   // :775-777
-                // embedding + PE3(embedding)
-                const float4 e0 = *reinterpret_cast<const float4 *>(a.emb + (long long)p * PN_F + 8 * q);
-                const float4 e1 = *reinterpret_cast<const float4 *>(a.emb + (long long)p * PN_F + 8 * q + 4);
-                *reinterpret_cast<float4 *>(xa + 8 * q) = e0;
-                *reinterpret_cast<float4 *>(xa + 8 * q + 4) = e1;
                 if (q == 0) {
 #pragma unroll
                     for (int j = 0; j < 6; ++j) dst[row * 8 + j] = d[j];
                 }
+                // embedding + PE3(embedding): EPT dims per thread
+                const float *ep = a.emb + (long long)p * PN_F + EPT * q;
+#pragma unroll
+                for (int i = 0; i < EPT; i += 4) *reinterpret_cast<float4 *>(xa + EPT * q + i) = *reinterpret_cast<const float4 *>(ep + i);
 #pragma unroll 2
-                for (int i = 0; i < 8; ++i) {
-                    const int dd = 8 * q + i;
+                for (int i = 0; i < EPT; ++i) {
+                    const int dd = EPT * q + i;
                     const float ev = xa[dd];
                     float fr = 1.f;
 #pragma unroll
@@ -212,15 +222,17 @@ __global__ __launch_bounds__(256, 2) void k_agg_forward(FwdArgs a) {
                         fr *= 2.f;
                     }
                 }
-                // PE5(dists6): 30 (sin,cos) pairs, 8 per thread (8,8,8,6); d comes back from LDS (same 4 lanes wrote it)
+                // PE5(dists6): 30 (sin,cos) pairs, PPT per thread; d comes back from LDS (a lane of the same row wrote it)
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll 2
-                for (int j = 8 * q; j < (q == 3 ? 30 : 8 * q + 8); ++j) {
-                    float s, c;
-                    sincosf(dst[row * 8 + j / 5] * (float)(1 << (j % 5)), &s, &c);
-                    *reinterpret_cast<float2 *>(xa + PN_F * 7 + j * 2) = make_float2(s, c);
+                for (int j = PPT * q; j < PPT * q + PPT; ++j) {
+                    if (j < 30) {
+                        float s, c;
+                        sincosf(dst[row * 8 + j / 5] * (float)(1 << (j % 5)), &s, &c);
+                        *reinterpret_cast<float2 *>(xa + PN_F * 7 + j * 2) = make_float2(s, c);
+                    }
                 }
-                if (q == 3) {
+                if (q == TPR - 1) {
 #pragma unroll
                     for (int j = PN_IN1; j < LDX; ++j) xa[j] = 0.f;
                 }
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void k_agg_forward(FwdArgs a) {
                     wraw[row] = 1.0f / fmaxf(sqrtf(dwx * dwx + dwy * dwy + dwz * dwz), 1e-6f);                            // linear :425-428
                 }
             } else {
-                for (int j = q; j < LDX; j += 4) xa[j] = 0.f;
+                for (int j = q; j < LDX; j += TPR) xa[j] = 0.f;
                 if (q == 0) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) exb[row * 8 + j] = 0.f;
@@ -267,50 +279,49 @@ __global__ __launch_bounds__(256, 2) void k_agg_forward(FwdArgs a) {
                 const int row = e / (PN_IN1P / 4), c4 = e - row * (PN_IN1P / 4);
                 *reinterpret_cast<float4 *>(a.sv.x0 + (grow0 + row) * PN_IN1P + c4 * 4) = *reinterpret_cast<const float4 *>(bufA + row * LDX + c4 * 4);
             }
-            for (int e = tid; e < PN_TILE * 2; e += 256) {
-                const int row = e >> 1, h = e & 1;
+            if (tid < PN_TILE * 2) {
+                const int row = tid >> 1, h = tid & 1;
                 *reinterpret_cast<float4 *>(a.sv.ex + (grow0 + row) * 8 + h * 4) = *reinterpret_cast<const float4 *>(exb + row * 8 + h * 4);
             }
         }
         // ---- layers (in place: all waves finish reading A before anyone overwrites it) ---------------
-        f32x16 acc[2][2];
-        pn_acc_init_bias<2>(acc, P + PO_B1, wave, lane);
-        pn_tile_gemm<2>(bufA, LDX, PN_IN1P / 8, a.packed + PK_F1 / 4, wave, lane, acc);
+        f32x16 acc[PN_MT][2];
+        pn_acc_init_bias<PN_MT, 2>(acc, P + PO_B1, wave, lane);
+        pn_tile_gemm<PN_MT, 2>(bufA, LDX, PN_IN1P / 8, a.packed + PK_F1 / 4, wave, lane, acc);
         __syncthreads();
-        pn_acc_to_lds<2, true>(acc, bufA, LDH, wave, lane);
+        pn_acc_to_lds<PN_MT, 2, true>(acc, bufA, LDH, wave, lane);
         __syncthreads();
-        if (TRAIN) pn_tile_copy_out<PN_H>(bufA, LDH, a.sv.h1, PN_H, grow0, tid);
-        pn_acc_init_bias<2>(acc, P + PO_B2, wave, lane);
-        pn_tile_gemm<2>(bufA, LDH, PN_H / 8, a.packed + PK_F2 / 4, wave, lane, acc);
+        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H>(bufA, LDH, a.sv.h1, PN_H, grow0, tid);
+        pn_acc_init_bias<PN_MT, 2>(acc, P + PO_B2, wave, lane);
+        pn_tile_gemm<PN_MT, 2>(bufA, LDH, PN_H / 8, a.packed + PK_F2 / 4, wave, lane, acc);
         __syncthreads();
-        pn_acc_to_lds<2, true>(acc, bufA, LDH, wave, lane);
+        pn_acc_to_lds<PN_MT, 2, true>(acc, bufA, LDH, wave, lane);
         __syncthreads();
-        if (TRAIN) pn_tile_copy_out<PN_H>(bufA, LDH, a.sv.h2, PN_H, grow0, tid);
-        pn_acc_init_bias<2>(acc, P + PO_B3, wave, lane);
-        pn_tile_gemm<2>(bufA, LDH, PN_H / 8, a.packed + PK_F3 / 4, wave, lane, acc);
-        pn_tile_gemm<2>(exb, 8, 1, a.packed + PK_F3 / 4 + (PN_H / 8) * 4 * 2 * 64, wave, lane, acc);
+        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H>(bufA, LDH, a.sv.h2, PN_H, grow0, tid);
+        pn_acc_init_bias<PN_MT, 2>(acc, P + PO_B3, wave, lane);
+        pn_tile_gemm<PN_MT, 2>(bufA, LDH, PN_H / 8, a.packed + PK_F3 / 4, wave, lane, acc);
+        pn_tile_gemm<PN_MT, 2>(exb, 8, 1, a.packed + PK_F3 / 4 + (PN_H / 8) * 4 * 2 * 64, wave, lane, acc);
         __syncthreads();
-        pn_acc_to_lds<2, true>(acc, bufA, LDH, wave, lane);
+        pn_acc_to_lds<PN_MT, 2, true>(acc, bufA, LDH, wave, lane);
         __syncthreads();
-        if (TRAIN) pn_tile_copy_out<PN_H>(bufA, LDH, a.sv.h3, PN_H, grow0, tid);
-        pn_acc_init_bias<2>(acc, P + PO_B4, wave, lane);
-        pn_tile_gemm<2>(bufA, LDH, PN_H / 8, a.packed + PK_F4 / 4, wave, lane, acc);
+        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H>(bufA, LDH, a.sv.h3, PN_H, grow0, tid);
+        pn_acc_init_bias<PN_MT, 2>(acc, P + PO_B4, wave, lane);
+        pn_tile_gemm<PN_MT, 2>(bufA, LDH, PN_H / 8, a.packed + PK_F4 / 4, wave, lane, acc);
         __syncthreads();
-        pn_acc_to_lds<2, true>(acc, bufA, LDH, wave, lane);
+        pn_acc_to_lds<PN_MT, 2, true>(acc, bufA, LDH, wave, lane);
         __syncthreads();
-        if (TRAIN) pn_tile_copy_out<PN_H>(bufA, LDH, a.sv.h4, PN_H, grow0, tid);
+        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H>(bufA, LDH, a.sv.h4, PN_H, grow0, tid);
         // ---- P5: alpha head (256 -> 1, softplus(x - 1)) -----------------------------------------
         {
-            const int row = tid >> 2, q = tid & 3;
-            const float *h = bufA + row * LDH + q * 64;
+            const int row = tid / TPR, q = tid % TPR;
+            const float *h = bufA + row * LDH + q * CPT;
             float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < 64; c += 4) {
+            for (int c = 0; c < CPT; c += 4) {
                 const float4 v = *reinterpret_cast<const float4 *>(h + c);
-                s += v.x * w5s[q * 64 + c] + v.y * w5s[q * 64 + c + 1] + v.z * w5s[q * 64 + c + 2] + v.w * w5s[q * 64 + c + 3];
+                s += v.x * w5s[q * CPT + c] + v.y * w5s[q * CPT + c + 1] + v.z * w5s[q * CPT + c + 2] + v.w * w5s[q * CPT + c + 3];
             }
-            s += __shfl_xor(s, 1, 64);
-            s += __shfl_xor(s, 2, 64);
+            s = group_sum<TPR>(s);
             if (q == 0) {
                 const float x = s + b5 - 1.0f;
                 const float alpha = x > 20.f ? x : log1pf(expf(x));                                                   // raw2out_density :262-265
@@ -341,20 +352,20 @@ __global__ __launch_bounds__(256, 2) void k_agg_forward(FwdArgs a) {
     }
 }
 
-constexpr int COL_LDS_FLOATS = PN_TILE * LDX + 2 * PN_TILE * LDC + 32;
+constexpr int COL_LDS_FLOATS = PN_CTILE * LDX + 2 * PN_CTILE * LDC + 32;
 
 template <bool TRAIN>
 __global__ __launch_bounds__(256, 1) void k_color_forward(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *X = smem;                            // [64][LDX]
-    float *H1 = X + PN_TILE * LDX;              // [64][LDC]
-    float *H2 = H1 + PN_TILE * LDC;             // [64][LDC]
+    float *H1 = X + PN_CTILE * LDX;             // [64][LDC]
+    float *H2 = H1 + PN_CTILE * LDC;            // [64][LDC]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Ns = a.counters[0] < a.cap_samples ? a.counters[0] : (int)a.cap_samples;
     const float *P = a.params;
 
-    for (long long tile = blockIdx.x; tile * PN_TILE < Ns; tile += gridDim.x) {
-        const long long grow0 = tile * PN_TILE;
+    for (long long tile = blockIdx.x; tile * PN_CTILE < Ns; tile += gridDim.x) {
+        const long long grow0 = tile * PN_CTILE;
         __syncthreads();
         {
             const int row = tid >> 2, q = tid & 3;
@@ -395,21 +406,21 @@ __global__ __launch_bounds__(256, 1) void k_color_forward(FwdArgs a) {
         }
         __syncthreads();
         f32x16 acc[2][1];
-        pn_acc_init_bias<1>(acc, P + PO_BC1, wave, lane);
-        pn_tile_gemm<1>(X, LDX, PN_INC / 8, a.packed + PK_C1 / 4, wave, lane, acc);
-        pn_acc_to_lds<1, true>(acc, H1, LDC, wave, lane);
+        pn_acc_init_bias<2, 1>(acc, P + PO_BC1, wave, lane);
+        pn_tile_gemm<2, 1>(X, LDX, PN_INC / 8, a.packed + PK_C1 / 4, wave, lane, acc);
+        pn_acc_to_lds<2, 1, true>(acc, H1, LDC, wave, lane);
         __syncthreads();
-        if (TRAIN) pn_tile_copy_out<PN_HC>(H1, LDC, a.sv.c1, PN_HC, grow0, tid);
-        pn_acc_init_bias<1>(acc, P + PO_BC2, wave, lane);
-        pn_tile_gemm<1>(H1, LDC, PN_HC / 8, a.packed + PK_C2 / 4, wave, lane, acc);
-        pn_acc_to_lds<1, true>(acc, H2, LDC, wave, lane);
+        if (TRAIN) pn_tile_copy_out<PN_CTILE, PN_HC>(H1, LDC, a.sv.c1, PN_HC, grow0, tid);
+        pn_acc_init_bias<2, 1>(acc, P + PO_BC2, wave, lane);
+        pn_tile_gemm<2, 1>(H1, LDC, PN_HC / 8, a.packed + PK_C2 / 4, wave, lane, acc);
+        pn_acc_to_lds<2, 1, true>(acc, H2, LDC, wave, lane);
         __syncthreads();
-        if (TRAIN) pn_tile_copy_out<PN_HC>(H2, LDC, a.sv.c2, PN_HC, grow0, tid);
-        pn_acc_init_bias<1>(acc, P + PO_BC3, wave, lane);
-        pn_tile_gemm<1>(H2, LDC, PN_HC / 8, a.packed + PK_C3 / 4, wave, lane, acc);
-        pn_acc_to_lds<1, true>(acc, H1, LDC, wave, lane);
+        if (TRAIN) pn_tile_copy_out<PN_CTILE, PN_HC>(H2, LDC, a.sv.c2, PN_HC, grow0, tid);
+        pn_acc_init_bias<2, 1>(acc, P + PO_BC3, wave, lane);
+        pn_tile_gemm<2, 1>(H2, LDC, PN_HC / 8, a.packed + PK_C3 / 4, wave, lane, acc);
+        pn_acc_to_lds<2, 1, true>(acc, H1, LDC, wave, lane);
         __syncthreads();
-        if (TRAIN) pn_tile_copy_out<PN_HC>(H1, LDC, a.sv.c3, PN_HC, grow0, tid);
+        if (TRAIN) pn_tile_copy_out<PN_CTILE, PN_HC>(H1, LDC, a.sv.c3, PN_HC, grow0, tid);
         {
             const int row = tid >> 2, q = tid & 3;
             const float *h = H1 + row * LDC + q * 32;
@@ -421,9 +432,7 @@ __global__ __launch_bounds__(256, 1) void k_color_forward(FwdArgs a) {
                 o1 += hv * P[PO_WC4 + PN_HC + q * 32 + c];
                 o2 += hv * P[PO_WC4 + 2 * PN_HC + q * 32 + c];
             }
-            o0 += __shfl_xor(o0, 1, 64); o0 += __shfl_xor(o0, 2, 64);
-            o1 += __shfl_xor(o1, 1, 64); o1 += __shfl_xor(o1, 2, 64);
-            o2 += __shfl_xor(o2, 1, 64); o2 += __shfl_xor(o2, 2, 64);
+            o0 = group_sum<4>(o0); o1 = group_sum<4>(o1); o2 = group_sum<4>(o2);
             const long long vs = grow0 + row;
             if (q == 0 && vs < Ns) {
                 const int si = a.valid_list[vs];
@@ -456,8 +465,9 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     const long long tiles = (cap_samples + a.TS - 1) / a.TS;
-    const int grid_a = (int)(tiles < 2 * ncu ? (tiles > 0 ? tiles : 1) : 2 * ncu);      // two 81 KB workgroups per CU
-    const long long ctiles = (cap_samples + PN_TILE - 1) / PN_TILE;
+    const int wgcu = AGG_WG_PER_CU < 1 ? 1 : (AGG_WG_PER_CU > 4 ? 4 : AGG_WG_PER_CU);
+    const int grid_a = (int)(tiles < (long long)wgcu * ncu ? (tiles > 0 ? tiles : 1) : wgcu * ncu);   // as many workgroups per CU as the LDS admits
+    const long long ctiles = (cap_samples + PN_CTILE - 1) / PN_CTILE;
     const int grid_c = (int)(ctiles < ncu ? (ctiles > 0 ? ctiles : 1) : ncu);
     const size_t lds_a = AGG_LDS_FLOATS * sizeof(float), lds_c = COL_LDS_FLOATS * sizeof(float);
     if (train) {

@@ -40,23 +40,23 @@ __device__ __forceinline__ void rot3b(const float *M, float x, float y, float z,
 }
 
 // ------------------------------------------------------------------------------ colour backward
-constexpr int COLB_LDS_FLOATS = 2 * PN_TILE * LDC + PN_TILE * 4;
+constexpr int COLB_LDS_FLOATS = 2 * PN_CTILE * LDC + PN_CTILE * 4;
 
 __global__ __launch_bounds__(256, 1) void k_color_backward(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *D1 = smem;                          // [64][LDC]
-    float *D2 = D1 + PN_TILE * LDC;            // [64][LDC]
-    float *draw = D2 + PN_TILE * LDC;          // [64][4] d(pre-sigmoid colour)
+    float *D2 = D1 + PN_CTILE * LDC;            // [64][LDC]
+    float *draw = D2 + PN_CTILE * LDC;          // [64][4] d(pre-sigmoid colour)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Ns = a.counters[0] < a.cap_samples ? a.counters[0] : (int)a.cap_samples;
     const float *P = a.params;
     const int cc = tid & 127, half = tid >> 7;
     float gw4[3] = {0.f, 0.f, 0.f}, gb3 = 0.f, gb2 = 0.f, gb1 = 0.f, gb4 = 0.f;
 
-    for (long long tile = blockIdx.x; tile * PN_TILE < Ns; tile += gridDim.x) {
-        const long long grow0 = tile * PN_TILE;
+    for (long long tile = blockIdx.x; tile * PN_CTILE < Ns; tile += gridDim.x) {
+        const long long grow0 = tile * PN_CTILE;
         __syncthreads();
-        if (tid < PN_TILE) {
+        if (tid < PN_CTILE) {
             const long long vs = grow0 + tid;
             float d0 = 0.f, d1 = 0.f, d2 = 0.f;
             if (vs < Ns) {
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, 1) void k_color_backward(BwdArgs a) {
         // d c3 = (d raw @ Wc4) * lrelu'(c3) ; accumulate d Wc4, d bc4
         {
             const float w0 = P[PO_WC4 + cc], w1 = P[PO_WC4 + PN_HC + cc], w2 = P[PO_WC4 + 2 * PN_HC + cc];
-            _Pragma("unroll 4") for (int row = half; row < PN_TILE; row += 2) {
+            _Pragma("unroll 4") for (int row = half; row < PN_CTILE; row += 2) {
                 const float d0 = draw[row * 4], d1 = draw[row * 4 + 1], d2 = draw[row * 4 + 2];
                 const float c3 = a.sv.c3[(grow0 + row) * PN_HC + cc];
                 const float v = (d0 * w0 + d1 * w1 + d2 * w2) * pn_lrelu_grad(c3);
@@ -81,27 +81,27 @@ __global__ __launch_bounds__(256, 1) void k_color_backward(BwdArgs a) {
                 gw4[0] += d0 * c3; gw4[1] += d1 * c3; gw4[2] += d2 * c3;
                 gb3 += v;
             }
-            if (tid < 3) _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) gb4 += draw[row * 4 + tid];
+            if (tid < 3) _Pragma("unroll 4") for (int row = 0; row < PN_CTILE; ++row) gb4 += draw[row * 4 + tid];
         }
         __syncthreads();
         f32x16 acc[2][1];
-        pn_acc_init_bias<1>(acc, nullptr, wave, lane);
-        pn_tile_gemm<1>(D1, LDC, PN_HC / 8, a.packed + PK_DC3 / 4, wave, lane, acc);
-        pn_acc_to_lds<1, false>(acc, D2, LDC, wave, lane);
+        pn_acc_init_bias<2, 1>(acc, nullptr, wave, lane);
+        pn_tile_gemm<2, 1>(D1, LDC, PN_HC / 8, a.packed + PK_DC3 / 4, wave, lane, acc);
+        pn_acc_to_lds<2, 1, false>(acc, D2, LDC, wave, lane);
         __syncthreads();
-        pn_tile_mask_pass<PN_HC>(D2, LDC, a.sv.c2, PN_HC, a.sv.dc2, PN_HC, grow0, tid);
+        pn_tile_mask_pass<PN_CTILE, PN_HC>(D2, LDC, a.sv.c2, PN_HC, a.sv.dc2, PN_HC, grow0, tid);
         __syncthreads();
-        _Pragma("unroll 4") for (int row = half; row < PN_TILE; row += 2) gb2 += D2[row * LDC + cc];
-        pn_acc_init_bias<1>(acc, nullptr, wave, lane);
-        pn_tile_gemm<1>(D2, LDC, PN_HC / 8, a.packed + PK_DC2 / 4, wave, lane, acc);
-        pn_acc_to_lds<1, false>(acc, D1, LDC, wave, lane);
+        _Pragma("unroll 4") for (int row = half; row < PN_CTILE; row += 2) gb2 += D2[row * LDC + cc];
+        pn_acc_init_bias<2, 1>(acc, nullptr, wave, lane);
+        pn_tile_gemm<2, 1>(D2, LDC, PN_HC / 8, a.packed + PK_DC2 / 4, wave, lane, acc);
+        pn_acc_to_lds<2, 1, false>(acc, D1, LDC, wave, lane);
         __syncthreads();
-        pn_tile_mask_pass<PN_HC>(D1, LDC, a.sv.c1, PN_HC, a.sv.dc1, PN_HC, grow0, tid);
+        pn_tile_mask_pass<PN_CTILE, PN_HC>(D1, LDC, a.sv.c1, PN_HC, a.sv.dc1, PN_HC, grow0, tid);
         __syncthreads();
-        _Pragma("unroll 4") for (int row = half; row < PN_TILE; row += 2) gb1 += D1[row * LDC + cc];
+        _Pragma("unroll 4") for (int row = half; row < PN_CTILE; row += 2) gb1 += D1[row * LDC + cc];
         f32x16 acc2[2][2];
-        pn_acc_init_bias<2>(acc2, nullptr, wave, lane);
-        pn_tile_gemm<2>(D1, LDC, PN_HC / 8, a.packed + PK_DC1 / 4, wave, lane, acc2);
+        pn_acc_init_bias<2, 2>(acc2, nullptr, wave, lane);
+        pn_tile_gemm<2, 2>(D1, LDC, PN_HC / 8, a.packed + PK_DC1 / 4, wave, lane, acc2);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -122,21 +122,32 @@ __global__ __launch_bounds__(256, 1) void k_color_backward(BwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------ aggregator backward
-// One LDS buffer updated in place (GEMM -> barrier -> epilogue -> barrier), 79 KB per workgroup: two workgroups per
-// CU, so one's global-memory phases (saved-activation reads, dY writes, atomics) hide under the other's MFMAs.
+// One LDS buffer updated in place (GEMM -> barrier -> epilogue -> barrier); with 32-row tiles 42 KB per workgroup:
+// three workgroups per CU, so one's global-memory phases (saved-activation reads, dY writes, atomics) hide under the
+// others' MFMAs.
+constexpr int TPR = PN_TPR;                    // threads per tile row
+constexpr int EPT = PN_F / TPR;                // embedding dims per thread
+constexpr int CPT = PN_H / TPR;                // hidden columns per thread
 constexpr int AGGB_LDS_FLOATS = PN_TILE * LDH + PN_TILE * 8 + 7 * PN_H + PN_H + 5 * PN_TILE;
+constexpr int AGGB_WG_PER_CU = (160 * 1024) / (AGGB_LDS_FLOATS * 4);
 
-__global__ __launch_bounds__(256, 2) void k_agg_backward(BwdArgs a) {
+template <int N> __device__ __forceinline__ float group_sum_b(float v) {
+#pragma unroll
+    for (int off = 1; off < N; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256, PN_TILE == 32 ? 3 : 2) void k_agg_backward(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *buf = smem;                         // [64][LDH]  h4 -> dY4 -> dY3 -> dY2 -> dY1 -> dX0
-    float *exs = buf + PN_TILE * LDH;          // [64][8]
+    float *buf = smem;                         // [PN_TILE][LDH]  h4 -> dY4 -> dY3 -> dY2 -> dY1 -> dX0
+    float *exs = buf + PN_TILE * LDH;          // [PN_TILE][8]
     float *w3ex = exs + PN_TILE * 8;           // [7][256]  W3[o][256+j]
     float *w5s = w3ex + 7 * PN_H;              // [256]
-    float *wrow = w5s + PN_H;                  // [64]
-    float *wnrm = wrow + PN_TILE;              // [64]
-    float *draw = wnrm + PN_TILE;              // [64] d(alpha pre-activation)
-    float *dsg = draw + PN_TILE;               // [64] d sigma of the row's sample
-    int *sidx = reinterpret_cast<int *>(dsg + PN_TILE);   // [64] row -> sample id (or -1)
+    float *wrow = w5s + PN_H;                  // [PN_TILE]
+    float *wnrm = wrow + PN_TILE;
+    float *draw = wnrm + PN_TILE;              // d(alpha pre-activation)
+    float *dsg = draw + PN_TILE;               // d sigma of the row's sample
+    int *sidx = reinterpret_cast<int *>(dsg + PN_TILE);   // row -> sample id (or -1)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, TS = a.TS;
@@ -147,6 +158,7 @@ __global__ __launch_bounds__(256, 2) void k_agg_backward(BwdArgs a) {
     const float b5 = P[PO_B5];
     float gb1 = 0.f, gb2 = 0.f, gb3 = 0.f, gb4 = 0.f, gw5 = 0.f, gb5 = 0.f;
     float gw3e[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    constexpr int H4PER = PN_TILE * 64 / 256;  // float4 of an [PN_TILE x 256] tile per thread
 
     for (long long tile = blockIdx.x; tile * TS < Ns; tile += gridDim.x) {
         const long long grow0 = tile * PN_TILE;
@@ -160,15 +172,15 @@ __global__ __launch_bounds__(256, 2) void k_agg_backward(BwdArgs a) {
             wnrm[tid] = si >= 0 ? a.weight[(long long)si * K + k] : 0.f;
             dsg[tid] = si >= 0 ? a.grad_decoded[(long long)si * 4] : 0.f;
         }
-        {   // h4 tile: 16 float4 per thread, all loads issued before the first LDS store
-            float4 v[16];
+        {   // h4 tile: all loads issued before the first LDS store
+            float4 v[H4PER];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < H4PER; ++i) {
                 const int e = tid + i * 256;
                 v[i] = *reinterpret_cast<const float4 *>(a.sv.h4 + (grow0 + (e >> 6)) * PN_H + (e & 63) * 4);
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < H4PER; ++i) {
                 const int e = tid + i * 256;
                 *reinterpret_cast<float4 *>(buf + (e >> 6) * LDH + (e & 63) * 4) = v[i];
             }
@@ -180,24 +192,24 @@ __global__ __launch_bounds__(256, 2) void k_agg_backward(BwdArgs a) {
         __syncthreads();
         // ---- alpha head + weight gradient ------------------------------------------------------
         {
-            const int row = tid >> 2, q = tid & 3;
+            const int row = tid / TPR, q = tid % TPR;
             const int si = sidx[row];
             const int ls = row / K;
             const long long vs = tile * TS + ls;
-            const float *h = buf + row * LDH + q * 64;
+            const float *h = buf + row * LDH + q * CPT;
             float s = 0.f, dotf = 0.f;
             if (si >= 0) {
-                const float *df = a.sv.dfs + vs * PN_H + q * 64;
+                const float *df = a.sv.dfs + vs * PN_H + q * CPT;
 #pragma unroll 4
-                for (int c = 0; c < 64; c += 4) {
+                for (int c = 0; c < CPT; c += 4) {
                     const float4 v = *reinterpret_cast<const float4 *>(h + c);
                     const float4 g = *reinterpret_cast<const float4 *>(df + c);
-                    s += v.x * w5s[q * 64 + c] + v.y * w5s[q * 64 + c + 1] + v.z * w5s[q * 64 + c + 2] + v.w * w5s[q * 64 + c + 3];
+                    s += v.x * w5s[q * CPT + c] + v.y * w5s[q * CPT + c + 1] + v.z * w5s[q * CPT + c + 2] + v.w * w5s[q * CPT + c + 3];
                     dotf += v.x * g.x + v.y * g.y + v.z * g.z + v.w * g.w;
                 }
             }
-            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
-            dotf += __shfl_xor(dotf, 1, 64); dotf += __shfl_xor(dotf, 2, 64);
+            s = group_sum_b<TPR>(s);
+            dotf = group_sum_b<TPR>(dotf);
             if (q == 0) {
                 float dr = 0.f;
                 if (si >= 0) {
@@ -227,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void k_agg_backward(BwdArgs a) {
         __syncthreads();
         // ---- dY4 = (w * d f + d raw * w5) * lrelu'(h4), in place ---------------------------------
 #pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < H4PER; ++i) {
             const int e = tid + i * 256;
             const int row = e >> 6, c4 = e & 63;
             const int si = sidx[row];
@@ -248,13 +260,13 @@ __global__ __launch_bounds__(256, 2) void k_agg_backward(BwdArgs a) {
         __syncthreads();
         // ---- block3 second layer: dY3 = (dY4 @ W4) * lrelu'(h3) ----------------------------------
         _Pragma("unroll 8") for (int row = 0; row < PN_TILE; ++row) gb4 += buf[row * LDH + tid];
-        f32x16 acc[2][2];
-        pn_acc_init_bias<2>(acc, nullptr, wave, lane);
-        pn_tile_gemm<2>(buf, LDH, PN_H / 8, a.packed + PK_D4 / 4, wave, lane, acc);
+        f32x16 acc[PN_MT][2];
+        pn_acc_init_bias<PN_MT, 2>(acc, nullptr, wave, lane);
+        pn_tile_gemm<PN_MT, 2>(buf, LDH, PN_H / 8, a.packed + PK_D4 / 4, wave, lane, acc);
         __syncthreads();
-        pn_acc_to_lds<2, false>(acc, buf, LDH, wave, lane);
+        pn_acc_to_lds<PN_MT, 2, false>(acc, buf, LDH, wave, lane);
         __syncthreads();
-        pn_tile_mask_pass<PN_H>(buf, LDH, a.sv.h3, PN_H, a.sv.dy3, PN_H, grow0, tid);
+        pn_tile_mask_pass<PN_TILE, PN_H>(buf, LDH, a.sv.h3, PN_H, a.sv.dy3, PN_H, grow0, tid);
         __syncthreads();
         // ---- block3 first layer: extras (colour, dir) + dY2 = (dY3 @ W3[:, :256]) * lrelu'(h2) ----
         _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) {
@@ -264,22 +276,22 @@ __global__ __launch_bounds__(256, 2) void k_agg_backward(BwdArgs a) {
             for (int j = 0; j < 7; ++j) gw3e[j] += v * exs[row * 8 + j];
         }
         {
-            const int row = tid >> 2, q = tid & 3;
+            const int row = tid / TPR, q = tid % TPR;
             const int si = sidx[row];
             float dex[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (si >= 0) {
-                const float *dy = buf + row * LDH + q * 64;
-                _Pragma("unroll 2") for (int c = 0; c < 64; c += 4) {
+                const float *dy = buf + row * LDH + q * CPT;
+                _Pragma("unroll 2") for (int c = 0; c < CPT; c += 4) {
                     const float4 v = *reinterpret_cast<const float4 *>(dy + c);
 #pragma unroll
                     for (int j = 0; j < 7; ++j) {
-                        const float4 w = *reinterpret_cast<const float4 *>(w3ex + j * PN_H + q * 64 + c);
+                        const float4 w = *reinterpret_cast<const float4 *>(w3ex + j * PN_H + q * CPT + c);
                         dex[j] += v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
                     }
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 7; ++j) { dex[j] += __shfl_xor(dex[j], 1, 64); dex[j] += __shfl_xor(dex[j], 2, 64); }
+            for (int j = 0; j < 7; ++j) dex[j] = group_sum_b<TPR>(dex[j]);
             if (q == 0 && si >= 0) {
                 const int ls = row / K, k = row - ls * K;
                 const int p = a.pidx[(long long)si * K + k];
@@ -294,46 +306,46 @@ __global__ __launch_bounds__(256, 2) void k_agg_backward(BwdArgs a) {
                 }
             }
         }
-        pn_acc_init_bias<2>(acc, nullptr, wave, lane);
-        pn_tile_gemm<2>(buf, LDH, PN_H / 8, a.packed + PK_D3 / 4, wave, lane, acc);
+        pn_acc_init_bias<PN_MT, 2>(acc, nullptr, wave, lane);
+        pn_tile_gemm<PN_MT, 2>(buf, LDH, PN_H / 8, a.packed + PK_D3 / 4, wave, lane, acc);
         __syncthreads();
-        pn_acc_to_lds<2, false>(acc, buf, LDH, wave, lane);
+        pn_acc_to_lds<PN_MT, 2, false>(acc, buf, LDH, wave, lane);
         __syncthreads();
-        pn_tile_mask_pass<PN_H>(buf, LDH, a.sv.h2, PN_H, a.sv.dy2, PN_H, grow0, tid);
+        pn_tile_mask_pass<PN_TILE, PN_H>(buf, LDH, a.sv.h2, PN_H, a.sv.dy2, PN_H, grow0, tid);
         __syncthreads();
         // ---- block1 second layer: dY1 = (dY2 @ W2) * lrelu'(h1) ----------------------------------
         _Pragma("unroll 8") for (int row = 0; row < PN_TILE; ++row) gb2 += buf[row * LDH + tid];
-        pn_acc_init_bias<2>(acc, nullptr, wave, lane);
-        pn_tile_gemm<2>(buf, LDH, PN_H / 8, a.packed + PK_D2 / 4, wave, lane, acc);
+        pn_acc_init_bias<PN_MT, 2>(acc, nullptr, wave, lane);
+        pn_tile_gemm<PN_MT, 2>(buf, LDH, PN_H / 8, a.packed + PK_D2 / 4, wave, lane, acc);
         __syncthreads();
-        pn_acc_to_lds<2, false>(acc, buf, LDH, wave, lane);
+        pn_acc_to_lds<PN_MT, 2, false>(acc, buf, LDH, wave, lane);
         __syncthreads();
-        pn_tile_mask_pass<PN_H>(buf, LDH, a.sv.h1, PN_H, a.sv.dy1, PN_H, grow0, tid);
+        pn_tile_mask_pass<PN_TILE, PN_H>(buf, LDH, a.sv.h1, PN_H, a.sv.dy1, PN_H, grow0, tid);
         __syncthreads();
         // ---- block1 first layer: d X0[:, :256] = dY1 @ W1[:, :256] --------------------------------
         _Pragma("unroll 8") for (int row = 0; row < PN_TILE; ++row) gb1 += buf[row * LDH + tid];
-        pn_acc_init_bias<2>(acc, nullptr, wave, lane);
-        pn_tile_gemm<2>(buf, LDH, PN_H / 8, a.packed + PK_D1 / 4, wave, lane, acc);
+        pn_acc_init_bias<PN_MT, 2>(acc, nullptr, wave, lane);
+        pn_tile_gemm<PN_MT, 2>(buf, LDH, PN_H / 8, a.packed + PK_D1 / 4, wave, lane, acc);
         __syncthreads();
-        pn_acc_to_lds<2, false>(acc, buf, LDH, wave, lane);
+        pn_acc_to_lds<PN_MT, 2, false>(acc, buf, LDH, wave, lane);
         __syncthreads();
         // ---- embedding gradient through [e | PE3(e)]: d e = dX[e] + sum_f 2^f (dX[sin] cos - dX[cos] sin)
         {
-            const int row = tid >> 2, q = tid & 3;
+            const int row = tid / TPR, q = tid % TPR;
             const int si = sidx[row];
             if (si >= 0) {
                 const int ls = row / K, k = row - ls * K;
                 const int p = a.pidx[(long long)si * K + k];
                 if (p >= 0) {
                     const float *dx = buf + row * LDH;
-                    const float *x0 = a.sv.x0 + (grow0 + row) * PN_IN1P + PN_F + 48 * q;      // 48 = 8 dims * 3 freqs * 2
-                    float4 xs[12];
+                    const float *x0 = a.sv.x0 + (grow0 + row) * PN_IN1P + PN_F + 6 * EPT * q;      // EPT dims * 3 freqs * 2
+                    float4 xs[6 * EPT / 4];
 #pragma unroll
-                    for (int i = 0; i < 12; ++i) xs[i] = *reinterpret_cast<const float4 *>(x0 + 4 * i);
+                    for (int i = 0; i < 6 * EPT / 4; ++i) xs[i] = *reinterpret_cast<const float4 *>(x0 + 4 * i);
                     const float *xf = reinterpret_cast<const float *>(xs);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int dd = 8 * q + i;
+                    for (int i = 0; i < EPT; ++i) {
+                        const int dd = EPT * q + i;
                         float g = dx[dd], fr = 1.f;
 #pragma unroll
                         for (int f = 0; f < 3; ++f) {
@@ -578,8 +590,9 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     if (hipGetDevice(&dev) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
     const long long tiles = (n_valid + a.TS - 1) / a.TS;
-    const long long ctiles = (n_valid + PN_TILE - 1) / PN_TILE;
-    const int grid_a = (int)(tiles < 2 * ncu ? (tiles > 0 ? tiles : 1) : 2 * ncu);      // two 79 KB workgroups per CU
+    const long long ctiles = (n_valid + PN_CTILE - 1) / PN_CTILE;
+    const int wgcu = AGGB_WG_PER_CU < 1 ? 1 : (AGGB_WG_PER_CU > 4 ? 4 : AGGB_WG_PER_CU);
+    const int grid_a = (int)(tiles < (long long)wgcu * ncu ? (tiles > 0 ? tiles : 1) : wgcu * ncu);
     const int grid_c = (int)(ctiles < ncu ? (ctiles > 0 ? ctiles : 1) : ncu);
     const size_t lds_c = COLB_LDS_FLOATS * sizeof(float), lds_a = AGGB_LDS_FLOATS * sizeof(float);
     if (hipFuncSetAttribute((const void *)k_color_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
@@ -588,7 +601,7 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     { PnProfScope prof(PNK_AGG_BWD, s); hipLaunchKernelGGL(k_agg_backward, dim3(grid_a), dim3(256), lds_a, s, a); }
     PN_CHECK_LAUNCH();
     // weight gradients over the rows / samples of the tiles that actually ran
-    const long long rows = tiles * PN_TILE, smp = ctiles * PN_TILE;
+    const long long rows = tiles * PN_TILE, smp = ctiles * PN_CTILE;
     int rc;
     float *g = d_grad_params;
     if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16>(sv.dy1, PN_H, sv.x0, PN_IN1P, rows, d_partials, 256, 256, g, PO_W1, PN_IN1, s))) return rc;

@@ -12,7 +12,12 @@
 #define PN_IN3    263                // 256 + colour 3 + (dir - view) 3 + dir.view 1
 #define PN_INC    280                // 256 + view PE 24
 #define PN_HC     128
-#define PN_TILE   64                 // rows per GEMM tile (2 MFMA row tiles)
+#ifndef PN_TILE
+#define PN_TILE   64                 // neighbor rows per aggregator tile (MT = PN_TILE/32 MFMA row tiles): 64 -> 2 WGs/CU. Measured: 32 (3 WGs/CU) is 10 % slower (twice the weight-fragment traffic per MFMA)
+#endif
+#define PN_MT     (PN_TILE / 32)
+#define PN_TPR    (256 / PN_TILE)    // threads per tile row in the element-wise phases (256-thread workgroups)
+#define PN_CTILE  64                 // valid samples per colour-MLP tile
 
 // flat parameter vector (state_dict order, torch [out,in] row-major)
 enum : int {
@@ -40,43 +45,47 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float pn_lrelu(float v) { return v > 0.f ? v : 0.01f * v; }
 __device__ __forceinline__ float pn_lrelu_grad(float post) { return post > 0.f ? 1.f : 0.01f; }
 
-// C[64 x (4 waves * NT * 32)] += A[64 x 8*nchunks] * B   (A in LDS, row stride lda floats, lda % 4 == 0;
-// B = packed image).  Each wave owns NT column tiles x both row tiles.  K order inside a chunk is
+// C[(MT*32) x (4 waves * NT * 32)] += A[(MT*32) x 8*nchunks] * B   (A in LDS, row stride lda floats, lda % 4 == 0;
+// B = packed image).  Each wave owns NT column tiles x all MT row tiles.  K order inside a chunk is
 // {0,4},{1,5},{2,6},{3,7} (lanes 0-31 / 32-63), identical for A and B, so the sum is a permutation of the
-// textbook order.  One chunk is prefetched ahead (one wave per SIMD: the MFMA pipe is the only latency cover).
-template <int NT>
+// textbook order.  One chunk is prefetched ahead.
+template <int MT, int NT>
 __device__ __forceinline__ void pn_tile_gemm(const float *__restrict__ A, int lda, int nchunks,
-                                             const float4 *__restrict__ Wp, int wave, int lane, f32x16 (&acc)[2][NT]) {
-    const float *a0p = A + (lane & 31) * lda + 4 * (lane >> 5);
-    const float *a1p = a0p + 32 * lda;
+                                             const float4 *__restrict__ Wp, int wave, int lane, f32x16 (&acc)[MT][NT]) {
+    const float *ap = A + (lane & 31) * lda + 4 * (lane >> 5);
     const float4 *wp = Wp + (wave * NT) * 64 + lane;
-    float4 a0 = *reinterpret_cast<const float4 *>(a0p);
-    float4 a1 = *reinterpret_cast<const float4 *>(a1p);
-    float4 b[NT];
+    float4 a[MT], b[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4 *>(ap + mt * 32 * lda);
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) b[ct] = wp[ct * 64];
 #pragma unroll 1
     for (int c = 0; c < nchunks; ++c) {
-        float4 na0 = a0, na1 = a1, nb[NT];
+        float4 na[MT], nb[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) na[mt] = a[mt];
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) nb[ct] = b[ct];
         if (c + 1 < nchunks) {
-            na0 = *reinterpret_cast<const float4 *>(a0p + 8 * (c + 1));
-            na1 = *reinterpret_cast<const float4 *>(a1p + 8 * (c + 1));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) na[mt] = *reinterpret_cast<const float4 *>(ap + mt * 32 * lda + 8 * (c + 1));
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) nb[ct] = wp[((c + 1) * 4 * NT + ct) * 64];
         }
-        const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
                 const float bv = i == 0 ? b[ct].x : (i == 1 ? b[ct].y : (i == 2 ? b[ct].z : b[ct].w));
-                acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[i], bv, acc[0][ct], 0, 0, 0);
-                acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[i], bv, acc[1][ct], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float av = i == 0 ? a[mt].x : (i == 1 ? a[mt].y : (i == 2 ? a[mt].z : a[mt].w));
+                    acc[mt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt][ct], 0, 0, 0);
+                }
             }
         }
-        a0 = na0; a1 = na1;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = na[mt];
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) b[ct] = nb[ct];
     }
@@ -86,63 +95,26 @@ __device__ __forceinline__ void pn_tile_gemm(const float *__restrict__ A, int ld
 __device__ __forceinline__ int pn_acc_row(int rt, int reg, int lane) { return rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 template <int NT> __device__ __forceinline__ int pn_acc_col(int wave, int ct, int lane) { return wave * NT * 32 + ct * 32 + (lane & 31); }
 
-template <int NT>
-__device__ __forceinline__ void pn_acc_init_bias(f32x16 (&acc)[2][NT], const float *__restrict__ bias, int wave, int lane) {
+template <int MT, int NT>
+__device__ __forceinline__ void pn_acc_init_bias(f32x16 (&acc)[MT][NT], const float *__restrict__ bias, int wave, int lane) {
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) {
         const float bv = bias ? bias[pn_acc_col<NT>(wave, ct, lane)] : 0.f;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) { acc[0][ct][reg] = bv; acc[1][ct][reg] = bv; }
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) acc[mt][ct][reg] = bv;
     }
 }
 
-// Forward epilogue: LeakyReLU, write the tile to LDS (row stride ldh) and optionally to a saved
-// activation matrix in HBM (row stride ldg, rows g_row0 .. g_row0+63).
-template <int NT, bool SAVE>
-__device__ __forceinline__ void pn_store_act(f32x16 (&acc)[2][NT], float *__restrict__ H, int ldh,
-                                             float *__restrict__ G, int ldg, long long g_row0, int wave, int lane) {
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
-            const int col = pn_acc_col<NT>(wave, ct, lane);
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int row = pn_acc_row(rt, reg, lane);
-                const float v = pn_lrelu(acc[rt][ct][reg]);
-                H[row * ldh + col] = v;
-                if (SAVE) G[(g_row0 + row) * ldg + col] = v;
-            }
-        }
-}
-
-// Backward epilogue: dY = dH (acc) * LeakyReLU'(saved post-activation), to LDS and to HBM.
-template <int NT>
-__device__ __forceinline__ void pn_store_dact(f32x16 (&acc)[2][NT], const float *__restrict__ Hsaved, int ldhs,
-                                              float *__restrict__ Dlds, int ldd, float *__restrict__ Dg, int ldg,
-                                              long long g_row0, int wave, int lane) {
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
-            const int col = pn_acc_col<NT>(wave, ct, lane);
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int row = pn_acc_row(rt, reg, lane);
-                const float v = acc[rt][ct][reg] * pn_lrelu_grad(Hsaved[(g_row0 + row) * ldhs + col]);
-                Dlds[row * ldd + col] = v;
-                Dg[(g_row0 + row) * ldg + col] = v;
-            }
-        }
-}
-
 // ---- wide epilogues: accumulators -> LDS (dword, conflict-free), then whole-row float4 traffic LDS <-> HBM.
-// A C-fragment lane owns 64 scattered dwords; storing them straight to HBM costs 64 dword stores per lane per layer
-// (store-issue bound).  Going through the LDS tile that the next layer needs anyway turns that into 16 dwordx4 per lane.
-template <int NT, bool LRELU>
-__device__ __forceinline__ void pn_acc_to_lds(f32x16 (&acc)[2][NT], float *__restrict__ H, int ldh, int wave, int lane) {
+// A C-fragment lane owns 16*MT*NT scattered dwords; storing them straight to HBM costs that many dword stores per lane
+// per layer (store-issue bound).  Going through the LDS tile that the next layer needs anyway turns that into
+// dwordx4 traffic.
+template <int MT, int NT, bool LRELU>
+__device__ __forceinline__ void pn_acc_to_lds(f32x16 (&acc)[MT][NT], float *__restrict__ H, int ldh, int wave, int lane) {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < MT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
             const int col = pn_acc_col<NT>(wave, ct, lane);
@@ -154,10 +126,10 @@ __device__ __forceinline__ void pn_acc_to_lds(f32x16 (&acc)[2][NT], float *__res
         }
 }
 
-// G[grow0 + row][0..W) = H[row][0..W) for the 64 rows of the tile (W = 256 or 128), float4 per lane
-template <int W>
+// G[grow0 + row][0..W) = H[row][0..W) for the ROWS rows of the tile (W = 256 or 128), float4 per lane
+template <int ROWS, int W>
 __device__ __forceinline__ void pn_tile_copy_out(const float *__restrict__ H, int ldh, float *__restrict__ G, int ldg, long long grow0, int tid) {
-    constexpr int PER = PN_TILE * W / 4 / 256;
+    constexpr int PER = ROWS * W / 4 / 256;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int e = tid + i * 256, row = e / (W / 4), c4 = e - row * (W / 4);
@@ -166,10 +138,10 @@ __device__ __forceinline__ void pn_tile_copy_out(const float *__restrict__ H, in
 }
 
 // in place: H = H * LeakyReLU'(S) with S the saved post-activation in HBM; the result also goes to D (HBM)
-template <int W>
+template <int ROWS, int W>
 __device__ __forceinline__ void pn_tile_mask_pass(float *__restrict__ H, int ldh, const float *__restrict__ S, int lds_, float *__restrict__ D,
                                                   int ldd, long long grow0, int tid) {
-    constexpr int PER = PN_TILE * W / 4 / 256;
+    constexpr int PER = ROWS * W / 4 / 256;
     float4 sv[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
