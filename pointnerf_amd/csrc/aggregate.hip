@@ -462,8 +462,8 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     a.cap_samples = cap_samples;
     a.decoded = d_decoded; a.weight = d_weight; a.sv = sv;
     int dev = 0, ncu = 256;
-    hipGetDevice(&dev);
-    hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipGetDevice(&dev) != hipSuccess) return PNERF_E_LAUNCH;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
     const long long tiles = (cap_samples + a.TS - 1) / a.TS;
     const int wgcu = AGG_WG_PER_CU < 1 ? 1 : (AGG_WG_PER_CU > 4 ? 4 : AGG_WG_PER_CU);
     const int grid_a = (int)(tiles < (long long)wgcu * ncu ? (tiles > 0 ? tiles : 1) : wgcu * ncu);   // as many workgroups per CU as the LDS admits
@@ -471,13 +471,13 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     const int grid_c = (int)(ctiles < ncu ? (ctiles > 0 ? ctiles : 1) : ncu);
     const size_t lds_a = AGG_LDS_FLOATS * sizeof(float), lds_c = COL_LDS_FLOATS * sizeof(float);
     if (train) {
-        hipFuncSetAttribute((const void *)k_agg_forward<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
-        hipFuncSetAttribute((const void *)k_color_forward<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+        if (hipFuncSetAttribute((const void *)k_agg_forward<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
+        if (hipFuncSetAttribute((const void *)k_color_forward<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
         { PnProfScope prof(PNK_AGG_FWD, s); hipLaunchKernelGGL(k_agg_forward<true>, dim3(grid_a), dim3(256), lds_a, s, a); }
         { PnProfScope prof(PNK_COLOR_FWD, s); hipLaunchKernelGGL(k_color_forward<true>, dim3(grid_c), dim3(256), lds_c, s, a); }
     } else {
-        hipFuncSetAttribute((const void *)k_agg_forward<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
-        hipFuncSetAttribute((const void *)k_color_forward<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+        if (hipFuncSetAttribute((const void *)k_agg_forward<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
+        if (hipFuncSetAttribute((const void *)k_color_forward<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
         { PnProfScope prof(PNK_AGG_FWD, s); hipLaunchKernelGGL(k_agg_forward<false>, dim3(grid_a), dim3(256), lds_a, s, a); }
         { PnProfScope prof(PNK_COLOR_FWD, s); hipLaunchKernelGGL(k_color_forward<false>, dim3(grid_c), dim3(256), lds_c, s, a); }
     }

@@ -21,7 +21,6 @@ constexpr size_t PARTIAL_FLOATS = (size_t)WG_CHUNKS * PN_H * PN_H;
 
 struct BwdArgs {
     pnerf_camera cam;
-    const float *dir;                          // point dirs (for nothing but symmetry with forward; grads only need idx)
     const float *params;
     const float4 *packed;
     const float *raydir;
@@ -580,7 +579,7 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
                            float *d_partials, hipStream_t s) {
     (void)d_sample_loc; (void)R;
     BwdArgs a;
-    a.cam = *cam; a.dir = pts->dir; a.params = d_params; a.packed = (const float4 *)d_packed; a.raydir = d_raydir;
+    a.cam = *cam; a.params = d_params; a.packed = (const float4 *)d_packed; a.raydir = d_raydir;
     a.pidx = d_sample_pidx; a.valid_list = d_valid_list; a.counters = d_counters;
     a.SR = SR; a.K = K; a.TS = pn_tile_samples(K); a.cap_samples = n_valid;
     a.decoded = d_decoded; a.weight = d_weight; a.grad_decoded = d_grad_decoded; a.sv = sv;
