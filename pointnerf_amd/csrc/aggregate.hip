@@ -149,7 +149,7 @@ template <int N> __device__ __forceinline__ float group_sum(float v) {      // s
 // One LDS activation buffer, updated in place (GEMM -> barrier -> epilogue -> barrier): with 32-row tiles 46 KB per
 // workgroup, so three workgroups share a CU and one's gather / epilogue latency hides under the others' MFMA phases.
 template <bool TRAIN>
-__global__ __launch_bounds__(256, PN_TILE == 32 ? 3 : 2) void k_agg_forward(FwdArgs a) {
+__global__ __launch_bounds__(PN_NTHR, PN_NTHR == 512 ? 4 : (PN_TILE == 32 ? 3 : 2)) void k_agg_forward(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *bufA = smem;                         // [PN_TILE][LDX]  X0, then h1..h4 at stride LDH
     float *exb = bufA + PN_TILE * LDX;          // [PN_TILE][8]  layer-3 extras
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, PN_TILE == 32 ? 3 : 2) void k_agg_forward(FwdA
     const int K = a.K, TS = a.TS;
     const int Ns = a.counters[0] < a.cap_samples ? a.counters[0] : (int)a.cap_samples;
     const float *P = a.params;
-    w5s[tid] = P[PO_W5 + tid];
+    if (tid < PN_H) w5s[tid] = P[PO_W5 + tid];
     const float b5 = P[PO_B5];
 
     for (long long tile = blockIdx.x; tile * TS < Ns; tile += gridDim.x) {
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256, PN_TILE == 32 ? 3 : 2) void k_agg_forward(FwdA
             if (TRAIN) a.sv.wrow[grow0 + row] = w;
         }
         if (TRAIN) {
-            for (int e = tid; e < PN_TILE * (PN_IN1P / 4); e += 256) {
+            for (int e = tid; e < PN_TILE * (PN_IN1P / 4); e += PN_NTHR) {
                 const int row = e / (PN_IN1P / 4), c4 = e - row * (PN_IN1P / 4);
                 *reinterpret_cast<float4 *>(a.sv.x0 + (grow0 + row) * PN_IN1P + c4 * 4) = *reinterpret_cast<const float4 *>(bufA + row * LDX + c4 * 4);
             }
@@ -285,32 +285,32 @@ __global__ __launch_bounds__(256, PN_TILE == 32 ? 3 : 2) void k_agg_forward(FwdA
             }
         }
         // ---- layers (in place: all waves finish reading A before anyone overwrites it) ---------------
-        f32x16 acc[PN_MT][2];
-        pn_acc_init_bias<PN_MT, 2>(acc, P + PO_B1, wave, lane);
-        pn_tile_gemm<PN_MT, 2>(bufA, LDX, PN_IN1P / 8, a.packed + PK_F1 / 4, wave, lane, acc);
+        f32x16 acc[PN_MT][PN_NT];
+        pn_acc_init_bias<PN_MT, PN_NT>(acc, P + PO_B1, wave, lane);
+        pn_tile_gemm<PN_MT, PN_NT, PN_NW>(bufA, LDX, PN_IN1P / 8, a.packed + PK_F1 / 4, wave, lane, acc);
         __syncthreads();
-        pn_acc_to_lds<PN_MT, 2, true>(acc, bufA, LDH, wave, lane);
+        pn_acc_to_lds<PN_MT, PN_NT, true>(acc, bufA, LDH, wave, lane);
         __syncthreads();
-        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H>(bufA, LDH, a.sv.h1, PN_H, grow0, tid);
-        pn_acc_init_bias<PN_MT, 2>(acc, P + PO_B2, wave, lane);
-        pn_tile_gemm<PN_MT, 2>(bufA, LDH, PN_H / 8, a.packed + PK_F2 / 4, wave, lane, acc);
+        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h1, PN_H, grow0, tid);
+        pn_acc_init_bias<PN_MT, PN_NT>(acc, P + PO_B2, wave, lane);
+        pn_tile_gemm<PN_MT, PN_NT, PN_NW>(bufA, LDH, PN_H / 8, a.packed + PK_F2 / 4, wave, lane, acc);
         __syncthreads();
-        pn_acc_to_lds<PN_MT, 2, true>(acc, bufA, LDH, wave, lane);
+        pn_acc_to_lds<PN_MT, PN_NT, true>(acc, bufA, LDH, wave, lane);
         __syncthreads();
-        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H>(bufA, LDH, a.sv.h2, PN_H, grow0, tid);
-        pn_acc_init_bias<PN_MT, 2>(acc, P + PO_B3, wave, lane);
-        pn_tile_gemm<PN_MT, 2>(bufA, LDH, PN_H / 8, a.packed + PK_F3 / 4, wave, lane, acc);
-        pn_tile_gemm<PN_MT, 2>(exb, 8, 1, a.packed + PK_F3 / 4 + (PN_H / 8) * 4 * 2 * 64, wave, lane, acc);
+        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h2, PN_H, grow0, tid);
+        pn_acc_init_bias<PN_MT, PN_NT>(acc, P + PO_B3, wave, lane);
+        pn_tile_gemm<PN_MT, PN_NT, PN_NW>(bufA, LDH, PN_H / 8, a.packed + PK_F3 / 4, wave, lane, acc);
+        pn_tile_gemm<PN_MT, PN_NT, PN_NW>(exb, 8, 1, a.packed + PK_F3 / 4 + (PN_H / 8) * (PN_H / 32) * 64, wave, lane, acc);
         __syncthreads();
-        pn_acc_to_lds<PN_MT, 2, true>(acc, bufA, LDH, wave, lane);
+        pn_acc_to_lds<PN_MT, PN_NT, true>(acc, bufA, LDH, wave, lane);
         __syncthreads();
-        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H>(bufA, LDH, a.sv.h3, PN_H, grow0, tid);
-        pn_acc_init_bias<PN_MT, 2>(acc, P + PO_B4, wave, lane);
-        pn_tile_gemm<PN_MT, 2>(bufA, LDH, PN_H / 8, a.packed + PK_F4 / 4, wave, lane, acc);
+        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h3, PN_H, grow0, tid);
+        pn_acc_init_bias<PN_MT, PN_NT>(acc, P + PO_B4, wave, lane);
+        pn_tile_gemm<PN_MT, PN_NT, PN_NW>(bufA, LDH, PN_H / 8, a.packed + PK_F4 / 4, wave, lane, acc);
         __syncthreads();
-        pn_acc_to_lds<PN_MT, 2, true>(acc, bufA, LDH, wave, lane);
+        pn_acc_to_lds<PN_MT, PN_NT, true>(acc, bufA, LDH, wave, lane);
         __syncthreads();
-        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H>(bufA, LDH, a.sv.h4, PN_H, grow0, tid);
+        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h4, PN_H, grow0, tid);
         // ---- P5: alpha head (256 -> 1, softplus(x - 1)) -----------------------------------------
         {
             const int row = tid / TPR, q = tid % TPR;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256, PN_TILE == 32 ? 3 : 2) void k_agg_forward(FwdA
         }
         __syncthreads();
         // ---- P6: K-weighted sums -> sigma, f[256] -------------------------------------------------
-        for (int e = tid; e < TS * 64; e += 256) {
+        for (int e = tid; e < TS * 64; e += PN_NTHR) {
             const int ls = e >> 6, c4 = e & 63;
             float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int k = 0; k < K; ++k) {
@@ -473,12 +473,12 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     if (train) {
         if (hipFuncSetAttribute((const void *)k_agg_forward<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
         if (hipFuncSetAttribute((const void *)k_color_forward<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
-        { PnProfScope prof(PNK_AGG_FWD, s); hipLaunchKernelGGL(k_agg_forward<true>, dim3(grid_a), dim3(256), lds_a, s, a); }
+        { PnProfScope prof(PNK_AGG_FWD, s); hipLaunchKernelGGL(k_agg_forward<true>, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a); }
         { PnProfScope prof(PNK_COLOR_FWD, s); hipLaunchKernelGGL(k_color_forward<true>, dim3(grid_c), dim3(256), lds_c, s, a); }
     } else {
         if (hipFuncSetAttribute((const void *)k_agg_forward<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
         if (hipFuncSetAttribute((const void *)k_color_forward<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
-        { PnProfScope prof(PNK_AGG_FWD, s); hipLaunchKernelGGL(k_agg_forward<false>, dim3(grid_a), dim3(256), lds_a, s, a); }
+        { PnProfScope prof(PNK_AGG_FWD, s); hipLaunchKernelGGL(k_agg_forward<false>, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a); }
         { PnProfScope prof(PNK_COLOR_FWD, s); hipLaunchKernelGGL(k_color_forward<false>, dim3(grid_c), dim3(256), lds_c, s, a); }
     }
     PN_CHECK_LAUNCH();

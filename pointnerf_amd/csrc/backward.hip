@@ -136,7 +136,7 @@ template <int N> __device__ __forceinline__ float group_sum_b(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256, PN_TILE == 32 ? 3 : 2) void k_agg_backward(BwdArgs a) {
+__global__ __launch_bounds__(PN_NTHR, PN_NTHR == 512 ? 4 : (PN_TILE == 32 ? 3 : 2)) void k_agg_backward(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *buf = smem;                         // [PN_TILE][LDH]  h4 -> dY4 -> dY3 -> dY2 -> dY1 -> dX0
     float *exs = buf + PN_TILE * LDH;          // [PN_TILE][8]
@@ -152,12 +152,17 @@ __global__ __launch_bounds__(256, PN_TILE == 32 ? 3 : 2) void k_agg_backward(Bwd
     const int K = a.K, TS = a.TS;
     const int Ns = a.counters[0] < a.cap_samples ? a.counters[0] : (int)a.cap_samples;
     const float *P = a.params;
-    w5s[tid] = P[PO_W5 + tid];
-    for (int j = 0; j < 7; ++j) w3ex[j * PN_H + tid] = P[PO_W3 + tid * PN_IN3 + PN_H + j];
+    if (tid < PN_H) {
+        w5s[tid] = P[PO_W5 + tid];
+        for (int j = 0; j < 7; ++j) w3ex[j * PN_H + tid] = P[PO_W3 + tid * PN_IN3 + PN_H + j];
+    }
+    // column sums (bias / alpha-head / extras gradients): thread = (column cc, row group cg)
+    constexpr int CG = PN_NTHR / PN_H, RPG = PN_TILE / CG;
+    const int cc = tid % PN_H, row_lo = (tid / PN_H) * RPG, row_hi = row_lo + RPG;
     const float b5 = P[PO_B5];
     float gb1 = 0.f, gb2 = 0.f, gb3 = 0.f, gb4 = 0.f, gw5 = 0.f, gb5 = 0.f;
     float gw3e[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    constexpr int H4PER = PN_TILE * 64 / 256;  // float4 of an [PN_TILE x 256] tile per thread
+    constexpr int H4PER = PN_TILE * 64 / PN_NTHR;  // float4 of an [PN_TILE x 256] tile per thread
 
     for (long long tile = blockIdx.x; tile * TS < Ns; tile += gridDim.x) {
         const long long grow0 = tile * PN_TILE;
@@ -175,12 +180,12 @@ __global__ __launch_bounds__(256, PN_TILE == 32 ? 3 : 2) void k_agg_backward(Bwd
             float4 v[H4PER];
 #pragma unroll
             for (int i = 0; i < H4PER; ++i) {
-                const int e = tid + i * 256;
+                const int e = tid + i * PN_NTHR;
                 v[i] = *reinterpret_cast<const float4 *>(a.sv.h4 + (grow0 + (e >> 6)) * PN_H + (e & 63) * 4);
             }
 #pragma unroll
             for (int i = 0; i < H4PER; ++i) {
-                const int e = tid + i * 256;
+                const int e = tid + i * PN_NTHR;
                 *reinterpret_cast<float4 *>(buf + (e >> 6) * LDH + (e & 63) * 4) = v[i];
             }
         }
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(256, PN_TILE == 32 ? 3 : 2) void k_agg_backward(Bwd
         // ---- d W5 / d b5 (column tid) ------------------------------------------------------------
         {
             float accw = 0.f;
-            _Pragma("unroll 8") for (int row = 0; row < PN_TILE; ++row) accw += draw[row] * buf[row * LDH + tid];
+            _Pragma("unroll 8") for (int row = row_lo; row < row_hi; ++row) accw += draw[row] * buf[row * LDH + cc];
             gw5 += accw;
             if (tid == 0) _Pragma("unroll 8") for (int row = 0; row < PN_TILE; ++row) gb5 += draw[row];
         }
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(256, PN_TILE == 32 ? 3 : 2) void k_agg_backward(Bwd
         // ---- dY4 = (w * d f + d raw * w5) * lrelu'(h4), in place ---------------------------------
 #pragma unroll 4
         for (int i = 0; i < H4PER; ++i) {
-            const int e = tid + i * 256;
+            const int e = tid + i * PN_NTHR;
             const int row = e >> 6, c4 = e & 63;
             const int si = sidx[row];
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -258,18 +263,18 @@ __global__ __launch_bounds__(256, PN_TILE == 32 ? 3 : 2) void k_agg_backward(Bwd
         }
         __syncthreads();
         // ---- block3 second layer: dY3 = (dY4 @ W4) * lrelu'(h3) ----------------------------------
-        _Pragma("unroll 8") for (int row = 0; row < PN_TILE; ++row) gb4 += buf[row * LDH + tid];
-        f32x16 acc[PN_MT][2];
-        pn_acc_init_bias<PN_MT, 2>(acc, nullptr, wave, lane);
-        pn_tile_gemm<PN_MT, 2>(buf, LDH, PN_H / 8, a.packed + PK_D4 / 4, wave, lane, acc);
+        _Pragma("unroll 8") for (int row = row_lo; row < row_hi; ++row) gb4 += buf[row * LDH + cc];
+        f32x16 acc[PN_MT][PN_NT];
+        pn_acc_init_bias<PN_MT, PN_NT>(acc, nullptr, wave, lane);
+        pn_tile_gemm<PN_MT, PN_NT, PN_NW>(buf, LDH, PN_H / 8, a.packed + PK_D4 / 4, wave, lane, acc);
         __syncthreads();
-        pn_acc_to_lds<PN_MT, 2, false>(acc, buf, LDH, wave, lane);
+        pn_acc_to_lds<PN_MT, PN_NT, false>(acc, buf, LDH, wave, lane);
         __syncthreads();
-        pn_tile_mask_pass<PN_TILE, PN_H>(buf, LDH, a.sv.h3, PN_H, a.sv.dy3, PN_H, grow0, tid);
+        pn_tile_mask_pass<PN_TILE, PN_H, PN_NTHR>(buf, LDH, a.sv.h3, PN_H, a.sv.dy3, PN_H, grow0, tid);
         __syncthreads();
         // ---- block3 first layer: extras (colour, dir) + dY2 = (dY3 @ W3[:, :256]) * lrelu'(h2) ----
-        _Pragma("unroll 4") for (int row = 0; row < PN_TILE; ++row) {
-            const float v = buf[row * LDH + tid];
+        _Pragma("unroll 4") for (int row = row_lo; row < row_hi; ++row) {
+            const float v = buf[row * LDH + cc];
             gb3 += v;
 #pragma unroll
             for (int j = 0; j < 7; ++j) gw3e[j] += v * exs[row * 8 + j];
@@ -305,28 +310,28 @@ __global__ __launch_bounds__(256, PN_TILE == 32 ? 3 : 2) void k_agg_backward(Bwd
                 }
             }
         }
-        pn_acc_init_bias<PN_MT, 2>(acc, nullptr, wave, lane);
-        pn_tile_gemm<PN_MT, 2>(buf, LDH, PN_H / 8, a.packed + PK_D3 / 4, wave, lane, acc);
+        pn_acc_init_bias<PN_MT, PN_NT>(acc, nullptr, wave, lane);
+        pn_tile_gemm<PN_MT, PN_NT, PN_NW>(buf, LDH, PN_H / 8, a.packed + PK_D3 / 4, wave, lane, acc);
         __syncthreads();
-        pn_acc_to_lds<PN_MT, 2, false>(acc, buf, LDH, wave, lane);
+        pn_acc_to_lds<PN_MT, PN_NT, false>(acc, buf, LDH, wave, lane);
         __syncthreads();
-        pn_tile_mask_pass<PN_TILE, PN_H>(buf, LDH, a.sv.h2, PN_H, a.sv.dy2, PN_H, grow0, tid);
+        pn_tile_mask_pass<PN_TILE, PN_H, PN_NTHR>(buf, LDH, a.sv.h2, PN_H, a.sv.dy2, PN_H, grow0, tid);
         __syncthreads();
         // ---- block1 second layer: dY1 = (dY2 @ W2) * lrelu'(h1) ----------------------------------
-        _Pragma("unroll 8") for (int row = 0; row < PN_TILE; ++row) gb2 += buf[row * LDH + tid];
-        pn_acc_init_bias<PN_MT, 2>(acc, nullptr, wave, lane);
-        pn_tile_gemm<PN_MT, 2>(buf, LDH, PN_H / 8, a.packed + PK_D2 / 4, wave, lane, acc);
+        _Pragma("unroll 8") for (int row = row_lo; row < row_hi; ++row) gb2 += buf[row * LDH + cc];
+        pn_acc_init_bias<PN_MT, PN_NT>(acc, nullptr, wave, lane);
+        pn_tile_gemm<PN_MT, PN_NT, PN_NW>(buf, LDH, PN_H / 8, a.packed + PK_D2 / 4, wave, lane, acc);
         __syncthreads();
-        pn_acc_to_lds<PN_MT, 2, false>(acc, buf, LDH, wave, lane);
+        pn_acc_to_lds<PN_MT, PN_NT, false>(acc, buf, LDH, wave, lane);
         __syncthreads();
-        pn_tile_mask_pass<PN_TILE, PN_H>(buf, LDH, a.sv.h1, PN_H, a.sv.dy1, PN_H, grow0, tid);
+        pn_tile_mask_pass<PN_TILE, PN_H, PN_NTHR>(buf, LDH, a.sv.h1, PN_H, a.sv.dy1, PN_H, grow0, tid);
         __syncthreads();
         // ---- block1 first layer: d X0[:, :256] = dY1 @ W1[:, :256] --------------------------------
-        _Pragma("unroll 8") for (int row = 0; row < PN_TILE; ++row) gb1 += buf[row * LDH + tid];
-        pn_acc_init_bias<PN_MT, 2>(acc, nullptr, wave, lane);
-        pn_tile_gemm<PN_MT, 2>(buf, LDH, PN_H / 8, a.packed + PK_D1 / 4, wave, lane, acc);
+        _Pragma("unroll 8") for (int row = row_lo; row < row_hi; ++row) gb1 += buf[row * LDH + cc];
+        pn_acc_init_bias<PN_MT, PN_NT>(acc, nullptr, wave, lane);
+        pn_tile_gemm<PN_MT, PN_NT, PN_NW>(buf, LDH, PN_H / 8, a.packed + PK_D1 / 4, wave, lane, acc);
         __syncthreads();
-        pn_acc_to_lds<PN_MT, 2, false>(acc, buf, LDH, wave, lane);
+        pn_acc_to_lds<PN_MT, PN_NT, false>(acc, buf, LDH, wave, lane);
         __syncthreads();
         // ---- embedding gradient through [e | PE3(e)]: d e = dX[e] + sum_f 2^f (dX[sin] cos - dX[cos] sin)
         {
@@ -358,14 +363,14 @@ __global__ __launch_bounds__(256, PN_TILE == 32 ? 3 : 2) void k_agg_backward(Bwd
             }
         }
     }
-    atomicAdd(&a.gparams[PO_B1 + tid], gb1);
-    atomicAdd(&a.gparams[PO_B2 + tid], gb2);
-    atomicAdd(&a.gparams[PO_B3 + tid], gb3);
-    atomicAdd(&a.gparams[PO_B4 + tid], gb4);
-    atomicAdd(&a.gparams[PO_W5 + tid], gw5);
+    atomicAdd(&a.gparams[PO_B1 + cc], gb1);
+    atomicAdd(&a.gparams[PO_B2 + cc], gb2);
+    atomicAdd(&a.gparams[PO_B3 + cc], gb3);
+    atomicAdd(&a.gparams[PO_B4 + cc], gb4);
+    atomicAdd(&a.gparams[PO_W5 + cc], gw5);
     if (tid == 0) atomicAdd(&a.gparams[PO_B5], gb5);
 #pragma unroll
-    for (int j = 0; j < 7; ++j) atomicAdd(&a.gparams[PO_W3 + tid * PN_IN3 + PN_H + j], gw3e[j]);
+    for (int j = 0; j < 7; ++j) atomicAdd(&a.gparams[PO_W3 + cc * PN_IN3 + PN_H + j], gw3e[j]);
 }
 
 // ------------------------------------------------------------------------------ weight gradients
@@ -597,7 +602,7 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     if (hipFuncSetAttribute((const void *)k_color_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipFuncSetAttribute((const void *)k_agg_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
     { PnProfScope prof(PNK_COLOR_BWD, s); hipLaunchKernelGGL(k_color_backward, dim3(grid_c), dim3(256), lds_c, s, a); }
-    { PnProfScope prof(PNK_AGG_BWD, s); hipLaunchKernelGGL(k_agg_backward, dim3(grid_a), dim3(256), lds_a, s, a); }
+    { PnProfScope prof(PNK_AGG_BWD, s); hipLaunchKernelGGL(k_agg_backward, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a); }
     PN_CHECK_LAUNCH();
     // weight gradients over the rows / samples of the tiles that actually ran
     const long long rows = tiles * PN_TILE, smp = ctiles * PN_CTILE;

@@ -16,7 +16,13 @@
 #define PN_TILE   64                 // neighbor rows per aggregator tile (MT = PN_TILE/32 MFMA row tiles): 64 -> 2 WGs/CU. Measured: 32 (3 WGs/CU) is 10 % slower (twice the weight-fragment traffic per MFMA)
 #endif
 #define PN_MT     (PN_TILE / 32)
-#define PN_TPR    (256 / PN_TILE)    // threads per tile row in the element-wise phases (256-thread workgroups)
+#ifndef PN_NTHR
+#define PN_NTHR   256                // threads per aggregator workgroup.  256 = 4 waves x (64 rows x 64 cols).  Measured: 512
+                                     // (8 waves x 32 cols, 128-VGPR cap, 16 waves/CU) is 8-12 % slower (spills, 2x LDS A-reads)
+#endif
+#define PN_NW     (PN_NTHR / 64)     // waves per aggregator workgroup
+#define PN_NT     (PN_H / (PN_NW * 32))   // MFMA column tiles per wave (1 with 8 waves, 2 with 4)
+#define PN_TPR    (PN_NTHR / PN_TILE)     // threads per tile row in the element-wise phases
 #define PN_CTILE  64                 // valid samples per colour-MLP tile
 
 // flat parameter vector (state_dict order, torch [out,in] row-major)
@@ -31,6 +37,7 @@ static_assert(PO_TOTAL == 341764, "parameter count of the lego-script aggregator
 
 // packed images (float offsets).  An image of a B operand [Kpad x N] is stored as
 //   float4 img[c][w][ct][lane] ,  element i = B[8c + 4*(lane>>5) + i][w*NT*32 + ct*32 + (lane&31)]
+// (the same bytes serve 4 waves x NT=2 and 8 waves x NT=1: fragment index = column / 32)
 // i.e. exactly what lane `lane` of wave `w` feeds to 4 consecutive 32x32x2 MFMAs of column tile ct.
 enum : int {
     PK_F1 = 0, PK_F2 = PK_F1 + PN_IN1P * PN_H, PK_F3 = PK_F2 + PN_H * PN_H, PK_F4 = PK_F3 + (PN_H + 8) * PN_H,
@@ -49,7 +56,7 @@ __device__ __forceinline__ float pn_lrelu_grad(float post) { return post > 0.f ?
 // B = packed image).  Each wave owns NT column tiles x all MT row tiles.  K order inside a chunk is
 // {0,4},{1,5},{2,6},{3,7} (lanes 0-31 / 32-63), identical for A and B, so the sum is a permutation of the
 // textbook order.  One chunk is prefetched ahead.
-template <int MT, int NT>
+template <int MT, int NT, int NW = 4>
 __device__ __forceinline__ void pn_tile_gemm(const float *__restrict__ A, int lda, int nchunks,
                                              const float4 *__restrict__ Wp, int wave, int lane, f32x16 (&acc)[MT][NT]) {
     const float *ap = A + (lane & 31) * lda + 4 * (lane >> 5);
@@ -70,7 +77,7 @@ __device__ __forceinline__ void pn_tile_gemm(const float *__restrict__ A, int ld
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) na[mt] = *reinterpret_cast<const float4 *>(ap + mt * 32 * lda + 8 * (c + 1));
 #pragma unroll
-            for (int ct = 0; ct < NT; ++ct) nb[ct] = wp[((c + 1) * 4 * NT + ct) * 64];
+            for (int ct = 0; ct < NT; ++ct) nb[ct] = wp[((c + 1) * NW * NT + ct) * 64];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -127,30 +134,30 @@ __device__ __forceinline__ void pn_acc_to_lds(f32x16 (&acc)[MT][NT], float *__re
 }
 
 // G[grow0 + row][0..W) = H[row][0..W) for the ROWS rows of the tile (W = 256 or 128), float4 per lane
-template <int ROWS, int W>
+template <int ROWS, int W, int NTHR = 256>
 __device__ __forceinline__ void pn_tile_copy_out(const float *__restrict__ H, int ldh, float *__restrict__ G, int ldg, long long grow0, int tid) {
-    constexpr int PER = ROWS * W / 4 / 256;
+    constexpr int PER = ROWS * W / 4 / NTHR;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int e = tid + i * 256, row = e / (W / 4), c4 = e - row * (W / 4);
+        const int e = tid + i * NTHR, row = e / (W / 4), c4 = e - row * (W / 4);
         *reinterpret_cast<float4 *>(G + (grow0 + row) * ldg + c4 * 4) = *reinterpret_cast<const float4 *>(H + row * ldh + c4 * 4);
     }
 }
 
 // in place: H = H * LeakyReLU'(S) with S the saved post-activation in HBM; the result also goes to D (HBM)
-template <int ROWS, int W>
+template <int ROWS, int W, int NTHR = 256>
 __device__ __forceinline__ void pn_tile_mask_pass(float *__restrict__ H, int ldh, const float *__restrict__ S, int lds_, float *__restrict__ D,
                                                   int ldd, long long grow0, int tid) {
-    constexpr int PER = ROWS * W / 4 / 256;
+    constexpr int PER = ROWS * W / 4 / NTHR;
     float4 sv[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int e = tid + i * 256, row = e / (W / 4), c4 = e - row * (W / 4);
+        const int e = tid + i * NTHR, row = e / (W / 4), c4 = e - row * (W / 4);
         sv[i] = *reinterpret_cast<const float4 *>(S + (grow0 + row) * lds_ + c4 * 4);
     }
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int e = tid + i * 256, row = e / (W / 4), c4 = e - row * (W / 4);
+        const int e = tid + i * NTHR, row = e / (W / 4), c4 = e - row * (W / 4);
         float4 v = *reinterpret_cast<const float4 *>(H + row * ldh + c4 * 4);
         v.x *= pn_lrelu_grad(sv[i].x); v.y *= pn_lrelu_grad(sv[i].y); v.z *= pn_lrelu_grad(sv[i].z); v.w *= pn_lrelu_grad(sv[i].w);
         *reinterpret_cast<float4 *>(H + row * ldh + c4 * 4) = v;
