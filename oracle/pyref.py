@@ -242,7 +242,7 @@ def ray_march(rdist, ray_valid, feats, bg_color=None):
     return color, rgb, opacity, acc, bw, bg_t
 
 
-def render(opt, points, mlp, inp, impl="oracle", q=None, nthreads=1):
+def render(opt, points, mlp, inp, impl="oracle", q=None, nthreads=1, Rw2c=None):
     """NeuralPointsRayMarching.forward (neural_points_volumetric_model.py:252-329) on CPU.
     points: dict xyz [N,3], points_embeding [1,N,F], points_conf [1,N,1], points_dir/color [1,N,3]."""
     if q is None:
@@ -250,7 +250,7 @@ def render(opt, points, mlp, inp, impl="oracle", q=None, nthreads=1):
             q = query(opt, points["xyz"].detach(), inp, impl=impl, nthreads=nthreads)
     camrot, campos = inp["camrotc2w"][0], inp["campos"][0]
     nb = gather_neighbors(points, q["sample_pidx"], camrot, campos)
-    feats, ray_valid, w, conf_c = aggregate(opt, mlp, nb, q["sample_loc"], q["sample_loc_w"], q["sample_ray_dirs"])
+    feats, ray_valid, w, conf_c = aggregate(opt, mlp, nb, q["sample_loc"], q["sample_loc_w"], q["sample_ray_dirs"], Rw2c=Rw2c)
     rd = ray_dist(opt, q["sample_loc"], ray_valid)
     color, _, opacity, acc, bw, bg_t = ray_march(rd, ray_valid, feats, inp["bg_color"])
     return dict(coarse_raycolor=color, coarse_point_opacity=opacity, coarse_is_background=bg_t,

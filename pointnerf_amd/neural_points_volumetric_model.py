@@ -50,6 +50,9 @@ class NeuralPointsRayMarching(nn.Module):
         """The fused step on all R rays.  Returns (ray_color [R,3], opacity, bg_trans, blend_w, decoded, weight, dense)."""
         opt, npnt, agg = self.opt, self.neural_points, self.aggregator
         train = torch.is_grad_enabled() if train is None else train
+        if train and getattr(opt, "xyz_grad", 0) > 0:
+            raise NotImplementedError("xyz_grad > 0 (optimising point positions) is not on any reference script's path and the "
+                                      "fused backward produces no d/d xyz")
         dense = npnt.query_dense(dict(campos=campos, raydir=raydir, near=near, far=far))
         R = raydir.reshape(-1, 3).shape[0]
         counters = dense["counters"].cpu()                    # the one sync: sizes the activation arena

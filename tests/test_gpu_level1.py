@@ -125,3 +125,28 @@ def test_probe_outputs_prob1():
         assert a.shape == v.shape, (k, a.shape, v.shape)
         assert float((a - v).abs().max()) <= 1e-4, k
     opt.prob = 0
+
+
+def test_normview_rotation_rw2c_and_no_background():
+    """NeuralPoints.Rw2c != identity (scenes initialised with normview, point_aggregators.py:492-496,506,526,566) and
+    bg_color=None ('bg_ray' callers): forward + gradients against the oracle."""
+    opt, xyz, attrs, inp, mlp, agg, npnt, d = _build("small_k4")
+    g = torch.Generator().manual_seed(5)
+    qm, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+    npnt.Rw2c = qm.to(DEV)
+    model = NeuralPointsRayMarching(aggregator=agg, neural_points=npnt, opt=opt)
+    d2 = dict(d); d2["bg_ray"] = torch.zeros(1, d["raydir"].shape[1], 3, device=DEV)      # forward() then ignores bg_color
+    out = model(**d2)
+    om = {k: v.clone().requires_grad_(True) for k, v in mlp.items()}
+    op = dict(xyz=xyz, **{k: v.clone().requires_grad_(True) for k, v in attrs.items()})
+    inp2 = dict(inp); inp2["bg_color"] = None
+    ref = pyref.render(opt, op, om, inp2, Rw2c=qm)
+    assert float((out["coarse_raycolor"].cpu() - ref["coarse_raycolor"]).abs().max()) <= 1e-4
+    (out["coarse_raycolor"].sum() * 1.0).backward()
+    ref["coarse_raycolor"].sum().backward()
+    for n, p in agg.named_parameters():
+        gh, r = p.grad.cpu(), om[n].grad
+        assert float((gh - r).abs().max()) <= 2e-3 * max(float(r.abs().max()), 1e-8), n
+    for n in ("points_dir", "points_color", "points_conf"):
+        gh, r = getattr(npnt, n).grad.cpu(), op[n].grad
+        assert float((gh - r).abs().max()) <= 2e-3 * max(float(r.abs().max()), 1e-8), n
