@@ -1,0 +1,49 @@
+"""Roofline numbers of the HBM-bound kernels of the path, measured in isolation with the library's HIP-event profiler:
+the per-neighbor gather (pnerf_gather_rows, the stand-alone form of NeuralPoints.forward's index_select), the ray probe,
+the neighbor query and the ray-march, at BASELINE configs[1] size.  Prints one JSON object (goes to profiles/)."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from pointnerf_amd import config, ops, scenes
+
+dev = torch.device("cuda:0")
+opt = config.bench_lego_opt(is_train=0)
+model = bench.build_model(opt, 2_000_000, dev)
+npnt = model.neural_points
+inp = bench.step_inputs(0, 0, 1, 65536, dev)
+res = {}
+ops.prof_enable(True)
+with torch.no_grad():
+    for _ in range(3):
+        out = model(**inp)
+    ops.prof_collect()
+    for _ in range(10):
+        out = model(**inp)
+    st = model.last_stats
+    prof = ops.prof_collect()
+    dense = npnt.querier.last_dense
+    R, SR, K, D = 65536, opt.SR, opt.K, opt.z_depth_dim
+    nsel, nrows, nval = st["n_selected"], st["n_neighbor_rows"], st["n_valid_samples"]
+    ms = lambda k: prof[k][0] / prof[k][1]
+    # algorithmic bytes
+    res["probe"] = dict(ms=ms("probe"), bytes=R * 24 + R * D / 8 + R * SR * 12 + R * 4)
+    res["neighbors"] = dict(ms=ms("neighbors"), bytes=nsel * 27 * 8 + nrows * 16 * 2 + R * SR * (12 + 4 * K + 4))
+    res["raymarch_forward"] = dict(ms=ms("raymarch_forward"), bytes=R * SR * (16 + 12 + 4 + 4 + 4) + R * 16)
+    # stand-alone gather of the 32-float embedding rows for every neighbor slot of the hit rays
+    hit = dense["ray_hit"] > 0
+    pidx = dense["sample_pidx"][hit].contiguous()
+    emb = npnt.points_embeding.detach().reshape(-1, 32)
+    for _ in range(3):
+        g = ops.gather_rows(emb, pidx)
+    ops.prof_collect()
+    for _ in range(10):
+        g = ops.gather_rows(emb, pidx)
+    p2 = ops.prof_collect()
+    n = pidx.numel()
+    valid = int((pidx >= 0).sum())
+    res["gather_rows_emb32"] = dict(ms=p2["gather"][0] / p2["gather"][1], bytes=n * (4 + 128 + 128), slots=n, valid_slots=valid)
+for k, v in res.items():
+    v["GBps"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+    v["frac_of_8TBps"] = v["GBps"] / 8000.0
+print(json.dumps(res, indent=1))
