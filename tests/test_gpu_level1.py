@@ -150,3 +150,26 @@ def test_normview_rotation_rw2c_and_no_background():
     for n in ("points_dir", "points_color", "points_conf"):
         gh, r = getattr(npnt, n).grad.cpu(), op[n].grad
         assert float((gh - r).abs().max()) <= 2e-3 * max(float(r.abs().max()), 1e-8), n
+
+
+def test_full_image_eval_loop_matches_oracle():
+    """pointnerf_amd.eval_loop.render_image (chunked, canvas on the device) == the oracle rendered ray by ray."""
+    from pointnerf_amd import eval_loop
+    opt, xyz, attrs, inp, mlp, agg, npnt, d = _build("small_k8")
+    model = NeuralPointsRayMarching(aggregator=agg, neural_points=npnt, opt=opt)
+    # a 24x20 window of the 800x800 camera: shift the principal point so that window pixel (0,0) is image pixel (388,390)
+    intr = inp["intrinsic"][0].clone()
+    intr[0, 2] -= 388.0; intr[1, 2] -= 390.0
+    h, w = 20, 24
+    img, hit = eval_loop.render_image(model, d["campos"], d["camrotc2w"], intr, h, w, d["near"], d["far"], d["bg_color"], chunk=157)
+    pix = eval_loop.pixel_grid(h, w, torch.device("cpu"))
+    sub = dict(inp)
+    sub["raydir"] = eval_loop.rays_from_pixels(pix, intr, inp["camrotc2w"])
+    with torch.no_grad():
+        ref = pyref.render(opt, dict(xyz=xyz, **attrs), mlp, sub)
+        full = pyref.fill_invalid(ref, sub)
+    assert torch.equal(hit.cpu(), ref["ray_mask"][0] > 0)
+    assert float((img.cpu().reshape(-1, 3) - full["coarse_raycolor"][0]).abs().max()) <= 1e-4
+    gt = torch.rand(h, w, 3, generator=torch.Generator().manual_seed(0))
+    p1 = float(eval_loop.psnr(img, gt)); p2 = float(-10 * torch.log10(torch.mean((full["coarse_raycolor"][0] - gt.reshape(-1, 3)) ** 2)))
+    assert abs(p1 - p2) < 1e-3
