@@ -63,17 +63,18 @@ def ray_march(ray_dist, ray_valid, ray_features, render_func, blend_func, bg_col
 
 
 def near_far_linear_ray_generation(campos, raydir, point_count, near=0.1, far=10, jitter=0., **kargs):
-    """diff_ray_marching.py:349-392 (plain tensor expressions; returns raypos, segment_length, valid, middle_point_ts)."""
-    tvals = torch.linspace(0, 1, point_count + 1, device=campos.device).view(1, -1)
-    tvals = near * (1 - tvals) + far * tvals
-    segment_length = (tvals[..., 1:] - tvals[..., :-1]) * (1 + jitter * (torch.rand(
-        (raydir.shape[0], raydir.shape[1], point_count), device=campos.device) - 0.5))
-    end_point_ts = torch.cumsum(segment_length, dim=2)
-    end_point_ts = torch.cat([torch.zeros((end_point_ts.shape[0], end_point_ts.shape[1], 1), device=end_point_ts.device),
-                              end_point_ts], dim=2)
-    end_point_ts = near + end_point_ts
-    middle_point_ts = (end_point_ts[:, :, :-1] + end_point_ts[:, :, 1:]) / 2
-    raypos = campos[:, None, None, :] + raydir[:, :, None, :] * middle_point_ts[:, :, :, None]
-    valid = torch.ones_like(middle_point_ts)
-    segment_length = segment_length * torch.linalg.norm(raydir[..., None, :], axis=-1)
-    return raypos, segment_length, valid, middle_point_ts
+    """Reference signature (diff_ray_marching.py:349-392): returns (raypos [N,R,S,3], segment_length [N,R,S], valid,
+    middle_point_ts).  Depth range split into S equal segments, optionally jittered by +-jitter/2 of their length,
+    samples at the segment mid-points; ``raydir`` is used un-normalised, so depths are camera-z depths."""
+    dev = campos.device
+    N, R = raydir.shape[0], raydir.shape[1]
+    u = torch.linspace(0, 1, point_count + 1, device=dev).view(1, -1)
+    edges = near * (1 - u) + far * u
+    seg = edges[..., 1:] - edges[..., :-1]
+    noise = torch.rand((N, R, point_count), device=dev) - 0.5
+    seg = seg * (1 + jitter * noise)                                   # [N,R,S]
+    ends = near + torch.cat([seg.new_zeros(N, R, 1), torch.cumsum(seg, dim=2)], dim=2)
+    mid = 0.5 * (ends[..., :-1] + ends[..., 1:])
+    raypos = campos[:, None, None, :] + raydir[:, :, None, :] * mid[..., None]
+    seg_len = seg * torch.linalg.norm(raydir, dim=-1, keepdim=True)
+    return raypos, seg_len, torch.ones_like(mid), mid

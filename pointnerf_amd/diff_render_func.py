@@ -1,61 +1,59 @@
-"""Drop-in for ``models/rendering/diff_render_func.py`` (:8-67): the lookup functions the model shell calls
-(``base_rendering_model.py:314-337``) and the three functions every script selects (radiance / alpha / off).  The
-functions are tiny tensor expressions, kept so that reference code that calls them directly still works; the fused
-renderer (``diff_ray_marching.ray_march``) recognises them by identity and runs them inside its HIP kernel."""
+"""Render / blend / tone-map lookups of the reference (``models/rendering/diff_render_func.py:8-67``), kept so that
+host code which resolves them by name (``base_rendering_model.py:314-337``) keeps working.  Every reference script
+selects ``radiance`` / ``alpha`` / ``off``; ``diff_ray_marching.ray_march`` recognises exactly those three objects and
+evaluates them inside its HIP kernel -- the Python bodies below only run if somebody calls them directly."""
 import torch
-import torch.nn.functional as F
 
 
 def radiance_render(ray_feature):
+    """Per-sample colour = channels 1..3 of the decoded features."""
     return ray_feature[..., 1:4]
 
 
 def white_color(ray_feature):
-    albedo = ray_feature[..., 1:4].clamp(0., 1.)
-    return torch.ones_like(albedo)
+    return torch.ones_like(ray_feature[..., 1:4])
 
 
 def alpha_blend(opacity, acc_transmission):
+    """Front-to-back compositing weight."""
     return opacity * acc_transmission
 
 
 def alpha2_blend(opacity, acc_transmission):
-    return opacity * acc_transmission * acc_transmission
-
-
-def simple_tone_map(color, gamma=2.2, exposure=1):
-    return torch.pow(color * exposure + 1e-5, 1 / gamma).clamp_(0, 1)
+    """Round-trip (collocated light) variant: transmission applied twice."""
+    return alpha_blend(opacity, acc_transmission) * acc_transmission
 
 
 def no_tone_map(color, gamma=2.2, exposure=1):
     return color
 
 
+def simple_tone_map(color, gamma=2.2, exposure=1):
+    return (color * exposure + 1e-5).pow(1.0 / gamma).clamp_(0, 1)
+
+
 def normalize_tone_map(color):
-    return F.normalize(color, dim=-1) * 0.5 + 0.5
+    return 0.5 * torch.nn.functional.normalize(color, dim=-1) + 0.5
+
+
+_RENDER = {"radiance": radiance_render, "white": white_color}
+_BLEND = {"alpha": alpha_blend, "alpha2": alpha2_blend}
+_TONEMAP = {"off": no_tone_map, "gamma": simple_tone_map, "normalize": normalize_tone_map}
+
+
+def _lookup(table, kind, name):
+    if name not in table:
+        raise RuntimeError("Unknown %s function: %s" % (kind, name))
+    return table[name]
 
 
 def find_render_function(name):
-    if name == 'radiance':
-        return radiance_render
-    elif name == 'white':
-        return white_color
-    raise RuntimeError('Unknown render function: ' + name)
+    return _lookup(_RENDER, "render", name)
 
 
 def find_blend_function(name):
-    if name == 'alpha':
-        return alpha_blend
-    elif name == 'alpha2':
-        return alpha2_blend
-    raise RuntimeError('Unknown blend function: ' + name)
+    return _lookup(_BLEND, "blend", name)
 
 
 def find_tone_map(name):
-    if name == 'gamma':
-        return simple_tone_map
-    elif name == 'normalize':
-        return normalize_tone_map
-    elif name == 'off':
-        return no_tone_map
-    raise RuntimeError('Unknown blend function: ' + name)
+    return _lookup(_TONEMAP, "tone-map", name)

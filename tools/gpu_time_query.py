@@ -4,12 +4,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pointnerf_amd import config, scenes
 from pointnerf_amd.point_query import lighting_fast_querier, clear_grid_cache
-from oracle import pyref
 print([l.split()[-1] for l in open('/proc/self/maps') if 'amdhip' in l or 'pnerf' in l][:4])
 dev = torch.device('cuda:0')
 opt = config.bench_lego_opt()
 xyz = torch.from_numpy(scenes.lego_points()).to(dev)
-inp = pyref.to_torch_inputs(scenes.random_rays(3, 65536))
+inp = {k: (torch.from_numpy(v) if hasattr(v, 'dtype') else v) for k, v in scenes.random_rays(3, 65536).items()}
 qr = lighting_fast_querier(dev, opt)
 rd, cp = inp['raydir'].to(dev), inp['campos'].to(dev)
 for it in range(3):
