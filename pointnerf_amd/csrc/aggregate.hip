@@ -115,7 +115,6 @@ constexpr int LDH = 260;    // hidden row stride
 constexpr int LDC = 132;    // colour hidden row stride
 constexpr int TPR = PN_TPR; // threads per tile row in the element-wise phases
 constexpr int EPT = PN_F / TPR;              // embedding dims per thread in the feature build
-constexpr int PPT = (30 + TPR - 1) / TPR;    // (sin,cos) pairs of PE5(dists6) per thread
 constexpr int CPT = PN_H / TPR;              // hidden columns per thread in the row-wise dot products
 constexpr int AGG_LDS_FLOATS = PN_TILE * LDX + PN_TILE * 8 + PN_TILE * 8 + 4 * PN_TILE + PN_H + PN_TILE;
 constexpr int AGG_WG_PER_CU = (160 * 1024) / (AGG_LDS_FLOATS * 4);
@@ -209,27 +208,31 @@ __global__ __launch_bounds__(PN_NTHR, PN_NTHR == 512 ? 4 : (PN_TILE == 32 ? 3 : 
                 const float *ep = a.emb + (long long)p * PN_F + EPT * q;
 #pragma unroll
                 for (int i = 0; i < EPT; i += 4) *reinterpret_cast<float4 *>(xa + EPT * q + i) = *reinterpret_cast<const float4 *>(ep + i);
+                // sin/cos(e 2^f): one accurate sincosf at the base frequency, then exact double-angle steps
+                // (sin 2x = 2 s c, cos 2x = 1 - 2 s^2): 38 instead of 126 sincosf per row; |error| grows ~2x per octave
+                // from <= 1 ulp, i.e. <= 2e-6 at the 16x band, far inside the 1e-4 bar.
 #pragma unroll 2
                 for (int i = 0; i < EPT; ++i) {
                     const int dd = EPT * q + i;
-                    const float ev = xa[dd];
-                    float fr = 1.f;
+                    float s, c;
+                    sincosf(xa[dd], &s, &c);
 #pragma unroll
                     for (int f = 0; f < 3; ++f) {
-                        float s, c;
-                        sincosf(ev * fr, &s, &c);
                         *reinterpret_cast<float2 *>(xa + PN_F + (dd * 3 + f) * 2) = make_float2(s, c);
-                        fr *= 2.f;
+                        const float s2 = 2.f * s * c;
+                        c = 1.f - 2.f * s * s; s = s2;
                     }
                 }
-                // PE5(dists6): 30 (sin,cos) pairs, PPT per thread; d comes back from LDS (a lane of the same row wrote it)
+                // PE5(dists6): 6 components x 5 octaves = 30 (sin,cos) pairs; thread q takes components q, q+TPR, ...
                 __builtin_amdgcn_wave_barrier();
-#pragma unroll 2
-                for (int j = PPT * q; j < PPT * q + PPT; ++j) {
-                    if (j < 30) {
-                        float s, c;
-                        sincosf(dst[row * 8 + j / 5] * (float)(1 << (j % 5)), &s, &c);
-                        *reinterpret_cast<float2 *>(xa + PN_F * 7 + j * 2) = make_float2(s, c);
+                for (int comp = q; comp < 6; comp += TPR) {
+                    float s, c;
+                    sincosf(dst[row * 8 + comp], &s, &c);
+#pragma unroll
+                    for (int f = 0; f < 5; ++f) {
+                        *reinterpret_cast<float2 *>(xa + PN_F * 7 + (comp * 5 + f) * 2) = make_float2(s, c);
+                        const float s2 = 2.f * s * c;
+                        c = 1.f - 2.f * s * s; s = s2;
                     }
                 }
                 if (q == TPR - 1) {

@@ -56,45 +56,45 @@ __device__ __forceinline__ float pn_lrelu_grad(float post) { return post > 0.f ?
 // B = packed image).  Each wave owns NT column tiles x all MT row tiles.  K order inside a chunk is
 // {0,4},{1,5},{2,6},{3,7} (lanes 0-31 / 32-63), identical for A and B, so the sum is a permutation of the
 // textbook order.  One chunk is prefetched ahead.
+template <int MT, int NT>
+__device__ __forceinline__ void pn_mfma_chunk(const float4 (&a)[MT], const float4 (&b)[NT], f32x16 (&acc)[MT][NT]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            const float bv = i == 0 ? b[ct].x : (i == 1 ? b[ct].y : (i == 2 ? b[ct].z : b[ct].w));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float av = i == 0 ? a[mt].x : (i == 1 ? a[mt].y : (i == 2 ? a[mt].z : a[mt].w));
+                acc[mt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt][ct], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// Two explicit register sets, the loop unrolled by two: chunk c+1's operands are requested before chunk c's 16 MFMAs
+// and first used after them, with no register copies in between.  (A single-set "next = load; ...; cur = next" form made
+// hipcc sink the copies into the middle of the MFMA block behind s_waitcnt vmcnt(0): every chunk then waited for an L2
+// round trip after ~6 MFMAs, and a workgroup running alone reached only ~80 % of the MFMA rate.)
 template <int MT, int NT, int NW = 4>
 __device__ __forceinline__ void pn_tile_gemm(const float *__restrict__ A, int lda, int nchunks,
                                              const float4 *__restrict__ Wp, int wave, int lane, f32x16 (&acc)[MT][NT]) {
     const float *ap = A + (lane & 31) * lda + 4 * (lane >> 5);
     const float4 *wp = Wp + (wave * NT) * 64 + lane;
-    float4 a[MT], b[NT];
+    float4 a0[MT], b0[NT], a1[MT], b1[NT];
+    auto load = [&](int c, float4 (&a)[MT], float4 (&b)[NT]) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4 *>(ap + mt * 32 * lda);
+        for (int ct = 0; ct < NT; ++ct) b[ct] = wp[(c * NW * NT + ct) * 64];
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct) b[ct] = wp[ct * 64];
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4 *>(ap + mt * 32 * lda + 8 * c);
+    };
+    load(0, a0, b0);
 #pragma unroll 1
-    for (int c = 0; c < nchunks; ++c) {
-        float4 na[MT], nb[NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) na[mt] = a[mt];
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) nb[ct] = b[ct];
-        if (c + 1 < nchunks) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) na[mt] = *reinterpret_cast<const float4 *>(ap + mt * 32 * lda + 8 * (c + 1));
-#pragma unroll
-            for (int ct = 0; ct < NT; ++ct) nb[ct] = wp[((c + 1) * NW * NT + ct) * 64];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int ct = 0; ct < NT; ++ct) {
-                const float bv = i == 0 ? b[ct].x : (i == 1 ? b[ct].y : (i == 2 ? b[ct].z : b[ct].w));
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const float av = i == 0 ? a[mt].x : (i == 1 ? a[mt].y : (i == 2 ? a[mt].z : a[mt].w));
-                    acc[mt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt][ct], 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = na[mt];
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) b[ct] = nb[ct];
+    for (int c = 0; c < nchunks; c += 2) {
+        if (c + 1 < nchunks) load(c + 1, a1, b1);
+        pn_mfma_chunk<MT, NT>(a0, b0, acc);
+        if (c + 2 < nchunks) load(c + 2, a0, b0);
+        if (c + 1 < nchunks) pn_mfma_chunk<MT, NT>(a1, b1, acc);
     }
 }
 
