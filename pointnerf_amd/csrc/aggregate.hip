@@ -80,7 +80,8 @@ size_t pn_saved_bytes(long long n_valid, int K, long long *rows_out, long long *
     if (rows_out) *rows_out = rows;
     if (samples_out) *samples_out = samples;
     size_t b = 0;
-    b += pn_align((size_t)rows * PN_IN1P * 4) + 8 * pn_align((size_t)rows * PN_H * 4) + pn_align((size_t)rows * 8 * 4) + pn_align((size_t)rows * 4);
+    b += pn_align((size_t)rows * PN_IN1P * 4) + 8 * pn_align((size_t)rows * PN_H * 4) + pn_align((size_t)rows * 8 * 4) + pn_align((size_t)rows * 16);
+    b += pn_align((size_t)tiles * 3 * PN_NTHR * 8);
     b += 2 * pn_align((size_t)samples * PN_H * 4) + pn_align((size_t)samples * 32 * 4) + 6 * pn_align((size_t)samples * PN_HC * 4);
     return b;
 }
@@ -94,7 +95,8 @@ PnSaved pn_saved_carve(void *base, long long n_valid, int K) {
     s.h3 = cv.take<float>((size_t)s.rows * PN_H); s.h4 = cv.take<float>((size_t)s.rows * PN_H);
     s.dy1 = cv.take<float>((size_t)s.rows * PN_H); s.dy2 = cv.take<float>((size_t)s.rows * PN_H);
     s.dy3 = cv.take<float>((size_t)s.rows * PN_H); s.dy4 = cv.take<float>((size_t)s.rows * PN_H);
-    s.ex = cv.take<float>((size_t)s.rows * 8); s.wrow = cv.take<float>((size_t)s.rows);
+    s.ex = cv.take<float>((size_t)s.rows * 8); s.rmeta = cv.take<int4>((size_t)s.rows);
+    s.lmask = cv.take<unsigned long long>((size_t)(s.rows / PN_TILE) * 3 * PN_NTHR);
     s.fs = cv.take<float>((size_t)s.samples * PN_H); s.dfs = cv.take<float>((size_t)s.samples * PN_H);
     s.pe = cv.take<float>((size_t)s.samples * 32);
     s.c1 = cv.take<float>((size_t)s.samples * PN_HC); s.c2 = cv.take<float>((size_t)s.samples * PN_HC);
@@ -147,6 +149,9 @@ template <int N> __device__ __forceinline__ float group_sum(float v) {      // s
 
 // One LDS activation buffer, updated in place (GEMM -> barrier -> epilogue -> barrier): with 32-row tiles 46 KB per
 // workgroup, so three workgroups share a CU and one's gather / epilogue latency hides under the others' MFMA phases.
+#ifdef PN_PHASE_TRACE
+PN_TR_DECL(pn_trace_fwd);
+#endif
 template <bool TRAIN>
 __global__ __launch_bounds__(PN_NTHR, PN_NTHR == 512 ? 4 : (PN_TILE == 32 ? 3 : 2)) void k_agg_forward(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -167,9 +172,16 @@ __global__ __launch_bounds__(PN_NTHR, PN_NTHR == 512 ? 4 : (PN_TILE == 32 ? 3 : 
     if (tid < PN_H) w5s[tid] = P[PO_W5 + tid];
     const float b5 = P[PO_B5];
 
+#ifdef PN_PHASE_TRACE
+    int titer = -1;
+#endif
     for (long long tile = blockIdx.x; tile * TS < Ns; tile += gridDim.x) {
         const long long grow0 = tile * PN_TILE;
+#ifdef PN_PHASE_TRACE
+        ++titer;
+#endif
         __syncthreads();
+        PN_TR(pn_trace_fwd, 0); PN_TR_HWID(pn_trace_fwd);
         if (tid < PN_TILE) {
             const long long vs = tile * TS + tid;
             sidx[tid] = (tid < TS && vs < Ns) ? a.valid_list[vs] : -1;
@@ -260,22 +272,24 @@ __global__ __launch_bounds__(PN_NTHR, PN_NTHR == 512 ? 4 : (PN_TILE == 32 ? 3 : 
             }
         }
         __syncthreads();
+        PN_TR(pn_trace_fwd, 1);
         // ---- P2: normalise weights over the K slots, multiply by the clamped confidence -------
         if (tid < PN_TILE) {
             const int row = tid, ls = row / K, k = row - ls * K;
             const int si = ls < TS ? sidx[ls] : -1;
             float wn = 0.f, w = 0.f;
+            int p = -1;
             if (si >= 0) {
                 float sum = 0.f;
                 for (int kk = 0; kk < K; ++kk) sum += wraw[ls * K + kk];
                 wn = wraw[row] / fmaxf(sum, 1e-8f);                                                                   // :801-802
-                const int p = a.pidx[(long long)si * K + k];
+                p = a.pidx[(long long)si * K + k];
                 const float cf = a.conf[p >= 0 ? p : 0];
                 w = wn * fminf(fmaxf(cf, 1e-4f), 1.0f);                                                               // :807-811
                 a.weight[(long long)si * K + k] = wn;
             }
             wnrm[row] = wn; wrow[row] = w;
-            if (TRAIN) a.sv.wrow[grow0 + row] = w;
+            if (TRAIN) a.sv.rmeta[grow0 + row] = make_int4(si, p, __float_as_int(wn), __float_as_int(w));
         }
         if (TRAIN) {
             for (int e = tid; e < PN_TILE * (PN_IN1P / 4); e += PN_NTHR) {
@@ -289,31 +303,44 @@ __global__ __launch_bounds__(PN_NTHR, PN_NTHR == 512 ? 4 : (PN_TILE == 32 ? 3 : 
         }
         // ---- layers (in place: all waves finish reading A before anyone overwrites it) ---------------
         f32x16 acc[PN_MT][PN_NT];
+        PN_TR(pn_trace_fwd, 2);
         pn_acc_init_bias<PN_MT, PN_NT>(acc, P + PO_B1, wave, lane);
         pn_tile_gemm<PN_MT, PN_NT, PN_NW>(bufA, LDX, PN_IN1P / 8, a.packed + PK_F1 / 4, wave, lane, acc);
+        PN_TR(pn_trace_fwd, 3);
         __syncthreads();
         pn_acc_to_lds<PN_MT, PN_NT, true>(acc, bufA, LDH, wave, lane);
         __syncthreads();
-        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h1, PN_H, grow0, tid);
+        PN_TR(pn_trace_fwd, 4);
+        if (TRAIN) a.sv.lmask[(tile * 3 + 0) * PN_NTHR + tid] = pn_tile_copy_out_bits<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h1, PN_H, grow0, tid);
+        PN_TR(pn_trace_fwd, 5);
         pn_acc_init_bias<PN_MT, PN_NT>(acc, P + PO_B2, wave, lane);
         pn_tile_gemm<PN_MT, PN_NT, PN_NW>(bufA, LDH, PN_H / 8, a.packed + PK_F2 / 4, wave, lane, acc);
+        PN_TR(pn_trace_fwd, 6);
         __syncthreads();
         pn_acc_to_lds<PN_MT, PN_NT, true>(acc, bufA, LDH, wave, lane);
         __syncthreads();
-        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h2, PN_H, grow0, tid);
+        PN_TR(pn_trace_fwd, 7);
+        if (TRAIN) a.sv.lmask[(tile * 3 + 1) * PN_NTHR + tid] = pn_tile_copy_out_bits<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h2, PN_H, grow0, tid);
+        PN_TR(pn_trace_fwd, 8);
         pn_acc_init_bias<PN_MT, PN_NT>(acc, P + PO_B3, wave, lane);
         pn_tile_gemm<PN_MT, PN_NT, PN_NW>(bufA, LDH, PN_H / 8, a.packed + PK_F3 / 4, wave, lane, acc);
         pn_tile_gemm<PN_MT, PN_NT, PN_NW>(exb, 8, 1, a.packed + PK_F3 / 4 + (PN_H / 8) * (PN_H / 32) * 64, wave, lane, acc);
+        PN_TR(pn_trace_fwd, 9);
         __syncthreads();
         pn_acc_to_lds<PN_MT, PN_NT, true>(acc, bufA, LDH, wave, lane);
         __syncthreads();
-        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h3, PN_H, grow0, tid);
+        PN_TR(pn_trace_fwd, 10);
+        if (TRAIN) a.sv.lmask[(tile * 3 + 2) * PN_NTHR + tid] = pn_tile_copy_out_bits<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h3, PN_H, grow0, tid);
+        PN_TR(pn_trace_fwd, 11);
         pn_acc_init_bias<PN_MT, PN_NT>(acc, P + PO_B4, wave, lane);
         pn_tile_gemm<PN_MT, PN_NT, PN_NW>(bufA, LDH, PN_H / 8, a.packed + PK_F4 / 4, wave, lane, acc);
+        PN_TR(pn_trace_fwd, 12);
         __syncthreads();
         pn_acc_to_lds<PN_MT, PN_NT, true>(acc, bufA, LDH, wave, lane);
         __syncthreads();
+        PN_TR(pn_trace_fwd, 13);
         if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h4, PN_H, grow0, tid);
+        PN_TR(pn_trace_fwd, 14);
         // ---- P5: alpha head (256 -> 1, softplus(x - 1)) -----------------------------------------
         {
             const int row = tid / TPR, q = tid % TPR;
@@ -332,6 +359,7 @@ __global__ __launch_bounds__(PN_NTHR, PN_NTHR == 512 ? 4 : (PN_TILE == 32 ? 3 : 
             }
         }
         __syncthreads();
+        PN_TR(pn_trace_fwd, 15);
         // ---- P6: K-weighted sums -> sigma, f[256] -------------------------------------------------
         for (int e = tid; e < TS * 64; e += PN_NTHR) {
             const int ls = e >> 6, c4 = e & 63;
@@ -352,6 +380,7 @@ __global__ __launch_bounds__(PN_NTHR, PN_NTHR == 512 ? 4 : (PN_TILE == 32 ? 3 : 
                 a.decoded[(long long)si * 4] = sg;
             }
         }
+        PN_TR(pn_trace_fwd, 16);
     }
 }
 
@@ -487,3 +516,9 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     PN_CHECK_LAUNCH();
     return 0;
 }
+
+#ifdef PN_PHASE_TRACE
+extern "C" int pnerf_debug_trace_fwd(void *host, size_t bytes) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(pn_trace_fwd), bytes < sizeof(pn_trace_fwd) ? bytes : sizeof(pn_trace_fwd)) == hipSuccess ? 0 : -1;
+}
+#endif

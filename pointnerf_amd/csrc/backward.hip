@@ -121,13 +121,17 @@ __global__ __launch_bounds__(256, 1) void k_color_backward(BwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------ aggregator backward
-// One LDS buffer updated in place (GEMM -> barrier -> epilogue -> barrier); with 32-row tiles 42 KB per workgroup:
-// three workgroups per CU, so one's global-memory phases (saved-activation reads, dY writes, atomics) hide under the
-// others' MFMAs.
+// One LDS buffer updated in place (GEMM -> barrier -> epilogue -> barrier), two workgroups per CU.  A workgroup running
+// alone already keeps the MFMA pipe ~86 % busy (tools/mfma_probe.hip), so what matters is how long a workgroup spends
+// OUTSIDE its four GEMMs: the phase timeline (tools/gpu_phase_trace.py) showed 102 us of latency-bound element-wise
+// phases against 64 us of GEMM per tile.  Hence everything an element-wise phase needs from HBM/L2 is requested at the top
+// of the tile (row metadata written by the forward, LeakyReLU sign words, the d f tile, the ray direction) and only
+// LDS, registers and fire-and-forget stores/atomics remain after each GEMM.
 constexpr int TPR = PN_TPR;                    // threads per tile row
 constexpr int EPT = PN_F / TPR;                // embedding dims per thread
 constexpr int CPT = PN_H / TPR;                // hidden columns per thread
-constexpr int AGGB_LDS_FLOATS = PN_TILE * LDH + PN_TILE * 8 + 7 * PN_H + PN_H + 5 * PN_TILE;
+constexpr int AGGB_UNION_FLOATS = 8 * PN_H;    // d f tile [TS <= 8][256] until dY4 is formed, then W3[:, 256:263] as [7][256]
+constexpr int AGGB_LDS_FLOATS = PN_TILE * LDH + PN_TILE * 8 + AGGB_UNION_FLOATS + PN_H + 6 * PN_TILE;
 constexpr int AGGB_WG_PER_CU = (160 * 1024) / (AGGB_LDS_FLOATS * 4);
 
 template <int N> __device__ __forceinline__ float group_sum_b(float v) {
@@ -136,103 +140,136 @@ template <int N> __device__ __forceinline__ float group_sum_b(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(PN_NTHR, PN_NTHR == 512 ? 4 : (PN_TILE == 32 ? 3 : 2)) void k_agg_backward(BwdArgs a) {
+#ifdef PN_PHASE_TRACE
+PN_TR_DECL(pn_trace_bwd);
+#endif
+// DFS_LDS: the tile's d f rows (TS x 256 floats) fit the 8 KB union region (K >= 8); otherwise they are read from HBM/L2.
+template <bool DFS_LDS>
+__global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *buf = smem;                         // [PN_TILE][LDH]  h4 -> dY4 -> dY3 -> dY2 -> dY1 -> dX0
     float *exs = buf + PN_TILE * LDH;          // [PN_TILE][8]
-    float *w3ex = exs + PN_TILE * 8;           // [7][256]  W3[o][256+j]
-    float *w5s = w3ex + 7 * PN_H;              // [256]
+    float *uni = exs + PN_TILE * 8;            // [8][256] d f tile, later [7][256] W3[o][256+j]
+    float *w5s = uni + AGGB_UNION_FLOATS;      // [256]
     float *wrow = w5s + PN_H;                  // [PN_TILE]
     float *wnrm = wrow + PN_TILE;
     float *draw = wnrm + PN_TILE;              // d(alpha pre-activation)
     float *dsg = draw + PN_TILE;               // d sigma of the row's sample
     int *sidx = reinterpret_cast<int *>(dsg + PN_TILE);   // row -> sample id (or -1)
+    int *prow = sidx + PN_TILE;                            // row -> point id (or -1)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int K = a.K, TS = a.TS;
     const int Ns = a.counters[0] < a.cap_samples ? a.counters[0] : (int)a.cap_samples;
     const float *P = a.params;
-    if (tid < PN_H) {
-        w5s[tid] = P[PO_W5 + tid];
-        for (int j = 0; j < 7; ++j) w3ex[j * PN_H + tid] = P[PO_W3 + tid * PN_IN3 + PN_H + j];
-    }
+    if (tid < PN_H) w5s[tid] = P[PO_W5 + tid];
     // column sums (bias / alpha-head / extras gradients): thread = (column cc, row group cg)
     constexpr int CG = PN_NTHR / PN_H, RPG = PN_TILE / CG;
-    const int cc = tid % PN_H, row_lo = (tid / PN_H) * RPG, row_hi = row_lo + RPG;
+    const int cc0 = tid % PN_H;
     const float b5 = P[PO_B5];
     float gb1 = 0.f, gb2 = 0.f, gb3 = 0.f, gb4 = 0.f, gw5 = 0.f, gb5 = 0.f;
     float gw3e[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     constexpr int H4PER = PN_TILE * 64 / PN_NTHR;  // float4 of an [PN_TILE x 256] tile per thread
 
+#ifdef PN_PHASE_TRACE
+    int titer = -1;
+#endif
     for (long long tile = blockIdx.x; tile * TS < Ns; tile += gridDim.x) {
         const long long grow0 = tile * PN_TILE;
+#ifdef PN_PHASE_TRACE
+        ++titer;
+#endif
+        // thread-index-derived offsets are recomputed per tile (a few VALU ops) instead of living in registers across the
+        // whole loop: hipcc otherwise hoists ~60 of them, spills, and the scratch reloads queue behind the atomics
+        int tl = threadIdx.x;
+        asm volatile("" : "+v"(tl));
+        const int cc = tl % PN_H, row_lo = (tl / PN_H) * RPG, row_hi = row_lo + RPG;
+        const int rrow = tl / TPR, rq = tl % TPR;      // (row, quarter) of the row-wise phases
+        const int rls = rrow / K;
+        const int lane = tl & 63, wave = tl >> 6;
         __syncthreads();
+        PN_TR(pn_trace_bwd, 0); PN_TR_HWID(pn_trace_bwd);
+        // ---- everything this tile needs from memory, requested up front ---------------------------
+        const unsigned long long m1 = a.sv.lmask[(tile * 3 + 0) * PN_NTHR + tl];
+        const unsigned long long m2 = a.sv.lmask[(tile * 3 + 1) * PN_NTHR + tl];
+        const unsigned long long m3 = a.sv.lmask[(tile * 3 + 2) * PN_NTHR + tl];
         if (tid < PN_TILE) {
-            const int ls = tid / K, k = tid - ls * K;
-            const long long vs = tile * TS + ls;
-            const int si = (ls < TS && vs < Ns) ? a.valid_list[vs] : -1;
-            sidx[tid] = si;
-            wrow[tid] = si >= 0 ? a.sv.wrow[grow0 + tid] : 0.f;
-            wnrm[tid] = si >= 0 ? a.weight[(long long)si * K + k] : 0.f;
-            dsg[tid] = si >= 0 ? a.grad_decoded[(long long)si * 4] : 0.f;
+            const int4 rm = a.sv.rmeta[grow0 + tl];
+            const int si = rm.x;
+            sidx[tl] = si; prow[tl] = rm.y;
+            wnrm[tl] = __int_as_float(rm.z); wrow[tl] = __int_as_float(rm.w);
+            dsg[tl] = si >= 0 ? a.grad_decoded[(long long)si * 4] : 0.f;
         }
-        {   // h4 tile: all loads issued before the first LDS store
-            float4 v[H4PER];
+        {   // h4 tile (+ d f tile): all loads issued before the first LDS store
+            float4 v[H4PER], g[2];
 #pragma unroll
             for (int i = 0; i < H4PER; ++i) {
-                const int e = tid + i * PN_NTHR;
+                const int e = tl + i * PN_NTHR;
                 v[i] = *reinterpret_cast<const float4 *>(a.sv.h4 + (grow0 + (e >> 6)) * PN_H + (e & 63) * 4);
+            }
+            if (DFS_LDS) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int e = tl + i * PN_NTHR;       // float4 e of the [TS x 256] block (rows past TS: the next tile's, unused)
+                    g[i] = (e >> 6) < TS ? *reinterpret_cast<const float4 *>(a.sv.dfs + (tile * TS + (e >> 6)) * PN_H + (e & 63) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
 #pragma unroll
             for (int i = 0; i < H4PER; ++i) {
-                const int e = tid + i * PN_NTHR;
+                const int e = tl + i * PN_NTHR;
                 *reinterpret_cast<float4 *>(buf + (e >> 6) * LDH + (e & 63) * 4) = v[i];
+            }
+            if (DFS_LDS) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) *reinterpret_cast<float4 *>(uni + (tl + i * PN_NTHR) * 4) = g[i];
             }
         }
         if (tid < PN_TILE * 2) {
-            const int row = tid >> 1, h = tid & 1;
+            const int row = tl >> 1, h = tl & 1;
             *reinterpret_cast<float4 *>(exs + row * 8 + h * 4) = *reinterpret_cast<const float4 *>(a.sv.ex + (grow0 + row) * 8 + h * 4);
         }
         __syncthreads();
+        PN_TR(pn_trace_bwd, 1);
         // ---- alpha head + weight gradient ------------------------------------------------------
+        const int rsi = sidx[rrow], rp = prow[rrow];
+        float rdx = 0.f, rdy = 0.f, rdz = 0.f;        // ray direction of the row's sample: used after the next GEMM
+        if (rq == 0 && rp >= 0) {
+            const int r = rsi / a.SR;
+            rdx = a.raydir[3 * r]; rdy = a.raydir[3 * r + 1]; rdz = a.raydir[3 * r + 2];
+        }
         {
-            const int row = tid / TPR, q = tid % TPR;
-            const int si = sidx[row];
-            const int ls = row / K;
-            const long long vs = tile * TS + ls;
-            const float *h = buf + row * LDH + q * CPT;
+            const float *h = buf + rrow * LDH + rq * CPT;
             float s = 0.f, dotf = 0.f;
-            if (si >= 0) {
-                const float *df = a.sv.dfs + vs * PN_H + q * CPT;
+            if (rsi >= 0) {
+                const float *df = DFS_LDS ? uni + rls * PN_H + rq * CPT : a.sv.dfs + (tile * TS + rls) * PN_H + rq * CPT;
 #pragma unroll 4
                 for (int c = 0; c < CPT; c += 4) {
                     const float4 v = *reinterpret_cast<const float4 *>(h + c);
                     const float4 g = *reinterpret_cast<const float4 *>(df + c);
-                    s += v.x * w5s[q * CPT + c] + v.y * w5s[q * CPT + c + 1] + v.z * w5s[q * CPT + c + 2] + v.w * w5s[q * CPT + c + 3];
+                    s += v.x * w5s[rq * CPT + c] + v.y * w5s[rq * CPT + c + 1] + v.z * w5s[rq * CPT + c + 2] + v.w * w5s[rq * CPT + c + 3];
                     dotf += v.x * g.x + v.y * g.y + v.z * g.z + v.w * g.w;
                 }
             }
             s = group_sum_b<TPR>(s);
             dotf = group_sum_b<TPR>(dotf);
-            if (q == 0) {
+            if (rq == 0) {
                 float dr = 0.f;
-                if (si >= 0) {
+                if (rsi >= 0) {
                     const float x = s + b5 - 1.0f;
                     const float alpha = x > 20.f ? x : log1pf(expf(x));
                     const float sg = x > 20.f ? 1.f : 1.0f / (1.0f + expf(-x));
-                    const int k = row - ls * K;
-                    const int p = a.pidx[(long long)si * K + k];
-                    if (p >= 0) {
+                    if (rp >= 0) {
                         // w = wn * clamp(conf) with a straight-through clamp (gradiant_clamp, point_aggregators.py:722-724)
-                        const float dw = dsg[row] * alpha + dotf;
-                        atomicAdd(&a.g_conf[p], dw * wnrm[row]);
+                        const float dw = dsg[rrow] * alpha + dotf;
+                        atomicAdd(&a.g_conf[rp], dw * wnrm[rrow]);
                     }
-                    dr = dsg[row] * wrow[row] * sg;
+                    dr = dsg[rrow] * wrow[rrow] * sg;
                 }
-                draw[row] = dr;
+                draw[rrow] = dr;
             }
         }
         __syncthreads();
+        PN_TR(pn_trace_bwd, 2);
         // ---- d W5 / d b5 (column tid) ------------------------------------------------------------
         {
             float accw = 0.f;
@@ -241,17 +278,24 @@ __global__ __launch_bounds__(PN_NTHR, PN_NTHR == 512 ? 4 : (PN_TILE == 32 ? 3 : 
             if (tid == 0) _Pragma("unroll 8") for (int row = 0; row < PN_TILE; ++row) gb5 += draw[row];
         }
         __syncthreads();
+        PN_TR(pn_trace_bwd, 3);
         // ---- dY4 = (w * d f + d raw * w5) * lrelu'(h4), in place ---------------------------------
+        float w3r[7];                              // W3[o][256 + j] of column o = tid: into the union region once d f is dead
+        if (tid < PN_H) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) w3r[j] = P[PO_W3 + tl * PN_IN3 + PN_H + j];
+        }
 #pragma unroll 4
         for (int i = 0; i < H4PER; ++i) {
-            const int e = tid + i * PN_NTHR;
+            const int e = tl + i * PN_NTHR;
             const int row = e >> 6, c4 = e & 63;
             const int si = sidx[row];
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (si >= 0) {
-                const long long vs = tile * TS + row / K;
+                const int ls = row / K;
                 const float4 hv = *reinterpret_cast<const float4 *>(buf + row * LDH + c4 * 4);
-                const float4 g = *reinterpret_cast<const float4 *>(a.sv.dfs + vs * PN_H + c4 * 4);
+                const float4 g = DFS_LDS ? *reinterpret_cast<const float4 *>(uni + ls * PN_H + c4 * 4)
+                                         : *reinterpret_cast<const float4 *>(a.sv.dfs + (tile * TS + ls) * PN_H + c4 * 4);
                 const float w = wrow[row], dr = draw[row];
                 o.x = (w * g.x + dr * w5s[c4 * 4]) * pn_lrelu_grad(hv.x);
                 o.y = (w * g.y + dr * w5s[c4 * 4 + 1]) * pn_lrelu_grad(hv.y);
@@ -262,16 +306,25 @@ __global__ __launch_bounds__(PN_NTHR, PN_NTHR == 512 ? 4 : (PN_TILE == 32 ? 3 : 
             *reinterpret_cast<float4 *>(a.sv.dy4 + (grow0 + row) * PN_H + c4 * 4) = o;
         }
         __syncthreads();
+        PN_TR(pn_trace_bwd, 4);
+        if (tid < PN_H) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) uni[j * PN_H + tl] = w3r[j];
+        }
         // ---- block3 second layer: dY3 = (dY4 @ W4) * lrelu'(h3) ----------------------------------
         _Pragma("unroll 8") for (int row = row_lo; row < row_hi; ++row) gb4 += buf[row * LDH + cc];
         f32x16 acc[PN_MT][PN_NT];
+        PN_TR(pn_trace_bwd, 5);
         pn_acc_init_bias<PN_MT, PN_NT>(acc, nullptr, wave, lane);
         pn_tile_gemm<PN_MT, PN_NT, PN_NW>(buf, LDH, PN_H / 8, a.packed + PK_D4 / 4, wave, lane, acc);
+        PN_TR(pn_trace_bwd, 6);
         __syncthreads();
         pn_acc_to_lds<PN_MT, PN_NT, false>(acc, buf, LDH, wave, lane);
         __syncthreads();
-        pn_tile_mask_pass<PN_TILE, PN_H, PN_NTHR>(buf, LDH, a.sv.h3, PN_H, a.sv.dy3, PN_H, grow0, tid);
+        PN_TR(pn_trace_bwd, 7);
+        pn_tile_mask_bits<PN_TILE, PN_H, PN_NTHR>(buf, LDH, m3, a.sv.dy3, PN_H, grow0, tl);
         __syncthreads();
+        PN_TR(pn_trace_bwd, 8);
         // ---- block3 first layer: extras (colour, dir) + dY2 = (dY3 @ W3[:, :256]) * lrelu'(h2) ----
         _Pragma("unroll 4") for (int row = row_lo; row < row_hi; ++row) {
             const float v = buf[row * LDH + cc];
@@ -280,89 +333,87 @@ __global__ __launch_bounds__(PN_NTHR, PN_NTHR == 512 ? 4 : (PN_TILE == 32 ? 3 : 
             for (int j = 0; j < 7; ++j) gw3e[j] += v * exs[row * 8 + j];
         }
         {
-            const int row = tid / TPR, q = tid % TPR;
-            const int si = sidx[row];
             float dex[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (si >= 0) {
-                const float *dy = buf + row * LDH + q * CPT;
+            if (rp >= 0) {
+                const float *dy = buf + rrow * LDH + rq * CPT;
                 _Pragma("unroll 2") for (int c = 0; c < CPT; c += 4) {
                     const float4 v = *reinterpret_cast<const float4 *>(dy + c);
 #pragma unroll
                     for (int j = 0; j < 7; ++j) {
-                        const float4 w = *reinterpret_cast<const float4 *>(w3ex + j * PN_H + q * CPT + c);
+                        const float4 w = *reinterpret_cast<const float4 *>(uni + j * PN_H + rq * CPT + c);
                         dex[j] += v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
                     }
                 }
             }
 #pragma unroll
             for (int j = 0; j < 7; ++j) dex[j] = group_sum_b<TPR>(dex[j]);
-            if (q == 0 && si >= 0) {
-                const int ls = row / K, k = row - ls * K;
-                const int p = a.pidx[(long long)si * K + k];
-                if (p >= 0) {
-                    atomicAdd(&a.g_color[3 * p], dex[0]); atomicAdd(&a.g_color[3 * p + 1], dex[1]); atomicAdd(&a.g_color[3 * p + 2], dex[2]);
-                    const int r = si / a.SR;
-                    float vx, vy, vz, gx, gy, gz;
-                    rot3b(a.cam.rw2c, a.raydir[3 * r], a.raydir[3 * r + 1], a.raydir[3 * r + 2], true, vx, vy, vz);
-                    // features (q - v, q . v) with q = dir @ Rw2c^T  ->  d q = dex[3:6] + dex[6] * v ; d dir = d q @ Rw2c
-                    rot3b(a.cam.rw2c, dex[3] + dex[6] * vx, dex[4] + dex[6] * vy, dex[5] + dex[6] * vz, false, gx, gy, gz);
-                    atomicAdd(&a.g_dir[3 * p], gx); atomicAdd(&a.g_dir[3 * p + 1], gy); atomicAdd(&a.g_dir[3 * p + 2], gz);
-                }
+            if (rq == 0 && rp >= 0) {
+                atomicAdd(&a.g_color[3 * rp], dex[0]); atomicAdd(&a.g_color[3 * rp + 1], dex[1]); atomicAdd(&a.g_color[3 * rp + 2], dex[2]);
+                float vx, vy, vz, gx, gy, gz;
+                rot3b(a.cam.rw2c, rdx, rdy, rdz, true, vx, vy, vz);
+                // features (q - v, q . v) with q = dir @ Rw2c^T  ->  d q = dex[3:6] + dex[6] * v ; d dir = d q @ Rw2c
+                rot3b(a.cam.rw2c, dex[3] + dex[6] * vx, dex[4] + dex[6] * vy, dex[5] + dex[6] * vz, false, gx, gy, gz);
+                atomicAdd(&a.g_dir[3 * rp], gx); atomicAdd(&a.g_dir[3 * rp + 1], gy); atomicAdd(&a.g_dir[3 * rp + 2], gz);
             }
         }
+        PN_TR(pn_trace_bwd, 9);
         pn_acc_init_bias<PN_MT, PN_NT>(acc, nullptr, wave, lane);
         pn_tile_gemm<PN_MT, PN_NT, PN_NW>(buf, LDH, PN_H / 8, a.packed + PK_D3 / 4, wave, lane, acc);
+        PN_TR(pn_trace_bwd, 10);
         __syncthreads();
         pn_acc_to_lds<PN_MT, PN_NT, false>(acc, buf, LDH, wave, lane);
         __syncthreads();
-        pn_tile_mask_pass<PN_TILE, PN_H, PN_NTHR>(buf, LDH, a.sv.h2, PN_H, a.sv.dy2, PN_H, grow0, tid);
+        PN_TR(pn_trace_bwd, 11);
+        pn_tile_mask_bits<PN_TILE, PN_H, PN_NTHR>(buf, LDH, m2, a.sv.dy2, PN_H, grow0, tl);
         __syncthreads();
+        PN_TR(pn_trace_bwd, 12);
         // ---- block1 second layer: dY1 = (dY2 @ W2) * lrelu'(h1) ----------------------------------
         _Pragma("unroll 8") for (int row = row_lo; row < row_hi; ++row) gb2 += buf[row * LDH + cc];
+        PN_TR(pn_trace_bwd, 13);
         pn_acc_init_bias<PN_MT, PN_NT>(acc, nullptr, wave, lane);
         pn_tile_gemm<PN_MT, PN_NT, PN_NW>(buf, LDH, PN_H / 8, a.packed + PK_D2 / 4, wave, lane, acc);
+        PN_TR(pn_trace_bwd, 14);
         __syncthreads();
         pn_acc_to_lds<PN_MT, PN_NT, false>(acc, buf, LDH, wave, lane);
         __syncthreads();
-        pn_tile_mask_pass<PN_TILE, PN_H, PN_NTHR>(buf, LDH, a.sv.h1, PN_H, a.sv.dy1, PN_H, grow0, tid);
+        PN_TR(pn_trace_bwd, 15);
+        pn_tile_mask_bits<PN_TILE, PN_H, PN_NTHR>(buf, LDH, m1, a.sv.dy1, PN_H, grow0, tl);
         __syncthreads();
+        PN_TR(pn_trace_bwd, 16);
         // ---- block1 first layer: d X0[:, :256] = dY1 @ W1[:, :256] --------------------------------
         _Pragma("unroll 8") for (int row = row_lo; row < row_hi; ++row) gb1 += buf[row * LDH + cc];
+        PN_TR(pn_trace_bwd, 17);
         pn_acc_init_bias<PN_MT, PN_NT>(acc, nullptr, wave, lane);
         pn_tile_gemm<PN_MT, PN_NT, PN_NW>(buf, LDH, PN_H / 8, a.packed + PK_D1 / 4, wave, lane, acc);
+        PN_TR(pn_trace_bwd, 18);
         __syncthreads();
         pn_acc_to_lds<PN_MT, PN_NT, false>(acc, buf, LDH, wave, lane);
         __syncthreads();
+        PN_TR(pn_trace_bwd, 19);
         // ---- embedding gradient through [e | PE3(e)]: d e = dX[e] + sum_f 2^f (dX[sin] cos - dX[cos] sin)
-        {
-            const int row = tid / TPR, q = tid % TPR;
-            const int si = sidx[row];
-            if (si >= 0) {
-                const int ls = row / K, k = row - ls * K;
-                const int p = a.pidx[(long long)si * K + k];
-                if (p >= 0) {
-                    const float *dx = buf + row * LDH;
-                    const float *x0 = a.sv.x0 + (grow0 + row) * PN_IN1P + PN_F + 6 * EPT * q;      // EPT dims * 3 freqs * 2
-                    float4 xs[6 * EPT / 4];
+        if (rp >= 0) {
+            const float *dx = buf + rrow * LDH;
+            const float *x0 = a.sv.x0 + (grow0 + rrow) * PN_IN1P + PN_F + 6 * EPT * rq;          // EPT dims * 3 freqs * 2
+            float4 xs[6 * EPT / 4];
 #pragma unroll
-                    for (int i = 0; i < 6 * EPT / 4; ++i) xs[i] = *reinterpret_cast<const float4 *>(x0 + 4 * i);
-                    const float *xf = reinterpret_cast<const float *>(xs);
+            for (int i = 0; i < 6 * EPT / 4; ++i) xs[i] = *reinterpret_cast<const float4 *>(x0 + 4 * i);
+            const float *xf = reinterpret_cast<const float *>(xs);
 #pragma unroll
-                    for (int i = 0; i < EPT; ++i) {
-                        const int dd = EPT * q + i;
-                        float g = dx[dd], fr = 1.f;
+            for (int i = 0; i < EPT; ++i) {
+                const int dd = EPT * rq + i;
+                float g = dx[dd], fr = 1.f;
 #pragma unroll
-                        for (int f = 0; f < 3; ++f) {
-                            const int o = PN_F + (dd * 3 + f) * 2, l = (i * 3 + f) * 2;
-                            g += fr * (dx[o] * xf[l + 1] - dx[o + 1] * xf[l]);
-                            fr *= 2.f;
-                        }
-                        atomicAdd(&a.g_emb[(long long)p * PN_F + dd], g);
-                    }
+                for (int f = 0; f < 3; ++f) {
+                    const int o = PN_F + (dd * 3 + f) * 2, l = (i * 3 + f) * 2;
+                    g += fr * (dx[o] * xf[l + 1] - dx[o + 1] * xf[l]);
+                    fr *= 2.f;
                 }
+                atomicAdd(&a.g_emb[(long long)rp * PN_F + dd], g);
             }
         }
+        PN_TR(pn_trace_bwd, 20);
     }
+    const int cc = cc0;
     atomicAdd(&a.gparams[PO_B1 + cc], gb1);
     atomicAdd(&a.gparams[PO_B2 + cc], gb2);
     atomicAdd(&a.gparams[PO_B3 + cc], gb3);
@@ -600,9 +651,13 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     const int grid_c = (int)(ctiles < ncu ? (ctiles > 0 ? ctiles : 1) : ncu);
     const size_t lds_c = COLB_LDS_FLOATS * sizeof(float), lds_a = AGGB_LDS_FLOATS * sizeof(float);
     if (hipFuncSetAttribute((const void *)k_color_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
-    if (hipFuncSetAttribute((const void *)k_agg_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
+    const bool dfs_lds = a.TS * PN_H <= AGGB_UNION_FLOATS;
+    const void *kfn = dfs_lds ? (const void *)k_agg_backward<true> : (const void *)k_agg_backward<false>;
+    if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
     { PnProfScope prof(PNK_COLOR_BWD, s); hipLaunchKernelGGL(k_color_backward, dim3(grid_c), dim3(256), lds_c, s, a); }
-    { PnProfScope prof(PNK_AGG_BWD, s); hipLaunchKernelGGL(k_agg_backward, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a); }
+    { PnProfScope prof(PNK_AGG_BWD, s);
+      if (dfs_lds) hipLaunchKernelGGL(k_agg_backward<true>, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+      else hipLaunchKernelGGL(k_agg_backward<false>, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a); }
     PN_CHECK_LAUNCH();
     // weight gradients over the rows / samples of the tiles that actually ran
     const long long rows = tiles * PN_TILE, smp = ctiles * PN_CTILE;
@@ -619,3 +674,9 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     if ((rc = launch_wgrad_lds<2, 1, 2, 4, 16>(sv.dc3, PN_HC, sv.c2, PN_HC, smp, d_partials, 128, 128, g, PO_WC3, PN_HC, s))) return rc;
     return 0;
 }
+
+#ifdef PN_PHASE_TRACE
+extern "C" int pnerf_debug_trace_bwd(void *host, size_t bytes) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(pn_trace_bwd), bytes < sizeof(pn_trace_bwd) ? bytes : sizeof(pn_trace_bwd)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -165,10 +165,49 @@ __device__ __forceinline__ void pn_tile_mask_pass(float *__restrict__ H, int ldh
     }
 }
 
+// ---- 1-bit LeakyReLU masks.  The element-wise tile passes of forward and backward use the same thread -> element map
+// (float4 number e = tid + i * NTHR of the [ROWS x W] tile, i < 16), so the sign bits of the 64 floats a thread copies
+// out in the forward are exactly the 64 bits it needs in the backward: one 8-byte word per thread per layer, written
+// and read fully coalesced.  The backward fetches its words at the top of the tile, long before the GEMM whose result
+// they mask -- the 64 KB fp32 read it replaces sat on the critical path after every GEMM (latency-, not bandwidth-bound).
+template <int ROWS, int W, int NTHR = 256>
+__device__ __forceinline__ unsigned long long pn_tile_copy_out_bits(const float *__restrict__ H, int ldh, float *__restrict__ G, int ldg,
+                                                                    long long grow0, int tid) {
+    constexpr int PER = ROWS * W / 4 / NTHR;
+    static_assert(PER * 4 == 64, "one 64-bit mask word per thread");
+    unsigned long long m = 0ull;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = tid + i * NTHR, row = e / (W / 4), c4 = e - row * (W / 4);
+        const float4 v = *reinterpret_cast<const float4 *>(H + row * ldh + c4 * 4);
+        *reinterpret_cast<float4 *>(G + (grow0 + row) * ldg + c4 * 4) = v;
+        m |= (unsigned long long)((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << (4 * i);
+    }
+    return m;
+}
+
+template <int ROWS, int W, int NTHR = 256>
+__device__ __forceinline__ void pn_tile_mask_bits(float *__restrict__ H, int ldh, unsigned long long m, float *__restrict__ D, int ldd,
+                                                  long long grow0, int tid) {
+    constexpr int PER = ROWS * W / 4 / NTHR;
+    static_assert(PER * 4 == 64, "one 64-bit mask word per thread");
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = tid + i * NTHR, row = e / (W / 4), c4 = e - row * (W / 4);
+        const unsigned b = (unsigned)(m >> (4 * i));
+        float4 v = *reinterpret_cast<const float4 *>(H + row * ldh + c4 * 4);
+        v.x *= (b & 1u) ? 1.f : 0.01f; v.y *= (b & 2u) ? 1.f : 0.01f; v.z *= (b & 4u) ? 1.f : 0.01f; v.w *= (b & 8u) ? 1.f : 0.01f;
+        *reinterpret_cast<float4 *>(H + row * ldh + c4 * 4) = v;
+        *reinterpret_cast<float4 *>(D + (grow0 + row) * ldd + c4 * 4) = v;
+    }
+}
+
 // ---- saved-activation area (training) -------------------------------------------------------
 struct PnSaved {
     // per neighbor row (rows = row tiles * 64)
-    float *x0, *h1, *h2, *h3, *h4, *ex, *wrow, *dy1, *dy2, *dy3, *dy4;
+    float *x0, *h1, *h2, *h3, *h4, *ex, *dy1, *dy2, *dy3, *dy4;
+    int4 *rmeta;                        // per row: {sample id or -1, point id or -1, bits(normalised weight), bits(final weight)}
+    unsigned long long *lmask;          // [row tiles][3 layers h1..h3][PN_NTHR]: LeakyReLU sign bits (pn_tile_copy_out_bits)
     // per valid sample (padded to colour tiles * 64)
     float *fs, *pe, *c1, *c2, *c3, *dfs, *dc1, *dc2, *dc3;
     long long rows, samples;
@@ -177,3 +216,27 @@ size_t pn_saved_bytes(long long n_valid, int K, long long *rows_out, long long *
 PnSaved pn_saved_carve(void *base, long long n_valid, int K);
 
 __host__ __device__ inline int pn_tile_samples(int K) { return PN_TILE / K; }
+
+// ---- dev-only phase timeline (build with EXTRA_DEFS=-DPN_PHASE_TRACE; tools/gpu_phase_trace.py reads it) ----------
+#ifdef PN_PHASE_TRACE
+#define PN_TR_WGS   512
+#define PN_TR_IT0   20
+#define PN_TR_ITERS 6
+#define PN_TR_SLOTS 24
+#define PN_TR_DECL(name) __device__ unsigned long long name[PN_TR_WGS * PN_TR_ITERS * PN_TR_SLOTS]
+#define PN_TR(buf, ph)                                                                                              \
+    do {                                                                                                            \
+        if (tid == 0 && blockIdx.x < PN_TR_WGS && titer >= PN_TR_IT0 && titer < PN_TR_IT0 + PN_TR_ITERS)           \
+            buf[((size_t)blockIdx.x * PN_TR_ITERS + (titer - PN_TR_IT0)) * PN_TR_SLOTS + (ph)] = wall_clock64();    \
+    } while (0)
+#define PN_TR_HWID(buf)                                                                                             \
+    do {                                                                                                            \
+        if (tid == 0 && blockIdx.x < PN_TR_WGS && titer >= PN_TR_IT0 && titer < PN_TR_IT0 + PN_TR_ITERS)           \
+            buf[((size_t)blockIdx.x * PN_TR_ITERS + (titer - PN_TR_IT0)) * PN_TR_SLOTS + PN_TR_SLOTS - 1] =         \
+                (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |                                    \
+                ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);                             \
+    } while (0)
+#else
+#define PN_TR(buf, ph)
+#define PN_TR_HWID(buf)
+#endif
