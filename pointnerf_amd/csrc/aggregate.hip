@@ -308,29 +308,38 @@ __global__ __launch_bounds__(PN_NTHR, PN_NTHR == 512 ? 4 : (PN_TILE == 32 ? 3 : 
         pn_tile_gemm<PN_MT, PN_NT, PN_NW>(bufA, LDX, PN_IN1P / 8, a.packed + PK_F1 / 4, wave, lane, acc);
         PN_TR(pn_trace_fwd, 3);
         __syncthreads();
-        pn_acc_to_lds<PN_MT, PN_NT, true>(acc, bufA, LDH, wave, lane);
+        {
+            const unsigned long long mbits = pn_acc_to_lds_bits<true>(acc, bufA, LDH, wave, lane);
+            if (TRAIN) a.sv.lmask[(tile * 3 + 0) * PN_NTHR + tid] = mbits;
+        }
         __syncthreads();
         PN_TR(pn_trace_fwd, 4);
-        if (TRAIN) a.sv.lmask[(tile * 3 + 0) * PN_NTHR + tid] = pn_tile_copy_out_bits<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h1, PN_H, grow0, tid);
+        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h1, PN_H, grow0, tid);
         PN_TR(pn_trace_fwd, 5);
         pn_acc_init_bias<PN_MT, PN_NT>(acc, P + PO_B2, wave, lane);
         pn_tile_gemm<PN_MT, PN_NT, PN_NW>(bufA, LDH, PN_H / 8, a.packed + PK_F2 / 4, wave, lane, acc);
         PN_TR(pn_trace_fwd, 6);
         __syncthreads();
-        pn_acc_to_lds<PN_MT, PN_NT, true>(acc, bufA, LDH, wave, lane);
+        {
+            const unsigned long long mbits = pn_acc_to_lds_bits<true>(acc, bufA, LDH, wave, lane);
+            if (TRAIN) a.sv.lmask[(tile * 3 + 1) * PN_NTHR + tid] = mbits;
+        }
         __syncthreads();
         PN_TR(pn_trace_fwd, 7);
-        if (TRAIN) a.sv.lmask[(tile * 3 + 1) * PN_NTHR + tid] = pn_tile_copy_out_bits<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h2, PN_H, grow0, tid);
+        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h2, PN_H, grow0, tid);
         PN_TR(pn_trace_fwd, 8);
         pn_acc_init_bias<PN_MT, PN_NT>(acc, P + PO_B3, wave, lane);
         pn_tile_gemm<PN_MT, PN_NT, PN_NW>(bufA, LDH, PN_H / 8, a.packed + PK_F3 / 4, wave, lane, acc);
         pn_tile_gemm<PN_MT, PN_NT, PN_NW>(exb, 8, 1, a.packed + PK_F3 / 4 + (PN_H / 8) * (PN_H / 32) * 64, wave, lane, acc);
         PN_TR(pn_trace_fwd, 9);
         __syncthreads();
-        pn_acc_to_lds<PN_MT, PN_NT, true>(acc, bufA, LDH, wave, lane);
+        {
+            const unsigned long long mbits = pn_acc_to_lds_bits<true>(acc, bufA, LDH, wave, lane);
+            if (TRAIN) a.sv.lmask[(tile * 3 + 2) * PN_NTHR + tid] = mbits;
+        }
         __syncthreads();
         PN_TR(pn_trace_fwd, 10);
-        if (TRAIN) a.sv.lmask[(tile * 3 + 2) * PN_NTHR + tid] = pn_tile_copy_out_bits<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h3, PN_H, grow0, tid);
+        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h3, PN_H, grow0, tid);
         PN_TR(pn_trace_fwd, 11);
         pn_acc_init_bias<PN_MT, PN_NT>(acc, P + PO_B4, wave, lane);
         pn_tile_gemm<PN_MT, PN_NT, PN_NW>(bufA, LDH, PN_H / 8, a.packed + PK_F4 / 4, wave, lane, acc);

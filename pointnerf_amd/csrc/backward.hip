@@ -121,18 +121,23 @@ __global__ __launch_bounds__(256, 1) void k_color_backward(BwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------ aggregator backward
-// One LDS buffer updated in place (GEMM -> barrier -> epilogue -> barrier), two workgroups per CU.  A workgroup running
-// alone already keeps the MFMA pipe ~86 % busy (tools/mfma_probe.hip), so what matters is how long a workgroup spends
-// OUTSIDE its four GEMMs: the phase timeline (tools/gpu_phase_trace.py) showed 102 us of latency-bound element-wise
-// phases against 64 us of GEMM per tile.  Hence everything an element-wise phase needs from HBM/L2 is requested at the top
-// of the tile (row metadata written by the forward, LeakyReLU sign words, the d f tile, the ray direction) and only
-// LDS, registers and fire-and-forget stores/atomics remain after each GEMM.
-constexpr int TPR = PN_TPR;                    // threads per tile row
+// One workgroup (4 waves, one per SIMD) per CU keeps TWO tiles (A, B) in flight and alternates their layer GEMMs:
+//   G(A,4) G(B,4) G(A,3) G(B,3) G(A,2) G(B,2) G(A,1) G(B,1)
+// While tile X's GEMM streams through the MFMA pipe, the same wave issues, in the shadow of its own MFMAs
+// (pn_tile_gemm_side), the other tile's epilogue (accumulators x LeakyReLU' -> LDS, bias column sums) and the copy-out of
+// X's finished dY rows to HBM (plus the W3-extras gradient, which needs exactly those rows).  The phase timeline of the
+// previous design (two single-tile workgroups per CU, tools/gpu_phase_trace.py) showed why: a workgroup spent 80-100 us per
+// tile outside its 64 us of GEMM, because VALU work of one wave crawls (1 instruction / ~84 cycles) while another wave of
+// the same SIMD streams MFMAs -- a second workgroup cannot hide element-wise phases on this hardware, the GEMM wave itself can.
+// Everything a tile needs from HBM/L2 is requested at its start (row metadata and 1-bit LeakyReLU masks written by the
+// forward, the d f tile, the ray direction).
+constexpr int TPR = PN_TPR;                    // threads per tile row in the row-wise phases
 constexpr int EPT = PN_F / TPR;                // embedding dims per thread
-constexpr int CPT = PN_H / TPR;                // hidden columns per thread
-constexpr int AGGB_UNION_FLOATS = 8 * PN_H;    // d f tile [TS <= 8][256] until dY4 is formed, then W3[:, 256:263] as [7][256]
-constexpr int AGGB_LDS_FLOATS = PN_TILE * LDH + PN_TILE * 8 + AGGB_UNION_FLOATS + PN_H + 6 * PN_TILE;
-constexpr int AGGB_WG_PER_CU = (160 * 1024) / (AGGB_LDS_FLOATS * 4);
+constexpr int B2_DFS_FLOATS = 8 * PN_H;        // d f tile [TS <= 8][256]
+constexpr int B2_TILE_FLOATS = PN_TILE * LDH + B2_DFS_FLOATS + 6 * PN_TILE;
+constexpr int AGGB_LDS_FLOATS = 2 * B2_TILE_FLOATS + PN_H + 7 * PN_H;
+static_assert(AGGB_LDS_FLOATS * 4 <= 160 * 1024, "two tiles must fit the 160 KB LDS");
+static_assert(PN_TILE == 64 && PN_NTHR == 256, "the two-tile backward is written for 64-row tiles and 4 waves");
 
 template <int N> __device__ __forceinline__ float group_sum_b(float v) {
 #pragma unroll
@@ -140,288 +145,347 @@ template <int N> __device__ __forceinline__ float group_sum_b(float v) {
     return v;
 }
 
+struct B2Tile {            // LDS of one in-flight tile
+    float *buf;            // [64][LDH]  h4 -> dY4 -> dY3 -> dY2 -> dY1 -> dX0
+    float *dfs;            // [8][256]   d f rows of the tile's samples
+    float *wrow, *wnrm, *draw, *dsg;
+    int *sidx, *prow;
+};
+struct B2State {           // registers of one in-flight tile
+    unsigned long long m1, m2, m3;
+    float rdx, rdy, rdz;
+    int rsi, rp;
+    long long tile;
+    bool valid;
+};
+
+__device__ __forceinline__ B2Tile b2_carve(float *base) {
+    B2Tile t;
+    t.buf = base; t.dfs = t.buf + PN_TILE * LDH;
+    t.wrow = t.dfs + B2_DFS_FLOATS; t.wnrm = t.wrow + PN_TILE; t.draw = t.wnrm + PN_TILE; t.dsg = t.draw + PN_TILE;
+    t.sidx = reinterpret_cast<int *>(t.dsg + PN_TILE); t.prow = t.sidx + PN_TILE;
+    return t;
+}
+
+// P0: request everything the tile needs from memory; h4 / d f / row metadata land in LDS
+template <bool DFS_LDS>
+__device__ __forceinline__ void b2_load(const BwdArgs &a, const B2Tile &T, B2State &S, long long tile, long long ntiles, int tl, int TS) {
+    S.tile = tile; S.valid = tile < ntiles;
+    S.rdx = S.rdy = S.rdz = 0.f;
+    const long long grow0 = tile * PN_TILE;
+    if (S.valid) {
+        S.m1 = a.sv.lmask[(tile * 3 + 0) * PN_NTHR + tl];
+        S.m2 = a.sv.lmask[(tile * 3 + 1) * PN_NTHR + tl];
+        S.m3 = a.sv.lmask[(tile * 3 + 2) * PN_NTHR + tl];
+        if (tl < PN_TILE) {
+            const int4 rm = a.sv.rmeta[grow0 + tl];
+            T.sidx[tl] = rm.x; T.prow[tl] = rm.y;
+            T.wnrm[tl] = __int_as_float(rm.z); T.wrow[tl] = __int_as_float(rm.w);
+            T.dsg[tl] = rm.x >= 0 ? a.grad_decoded[(long long)rm.x * 4] : 0.f;
+        }
+        // (no staging arrays: hipcc hoists the 16 + 2 loads of the unrolled bodies above the first LDS store by itself)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float4 v = *reinterpret_cast<const float4 *>(a.sv.h4 + (grow0 + (tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4);
+            *reinterpret_cast<float4 *>(T.buf + ((tl >> 6) + 4 * i) * LDH + (tl & 63) * 4) = v;
+        }
+        if (DFS_LDS) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = (tl >> 6) + 4 * i;            // row of the [TS x 256] block
+                const float4 g = r < TS ? *reinterpret_cast<const float4 *>(a.sv.dfs + (tile * TS + r) * PN_H + (tl & 63) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(T.dfs + r * PN_H + (tl & 63) * 4) = g;
+            }
+        }
+    } else {                                               // the partner slot of the last odd tile: an all-invalid tile of zeros
+        S.m1 = S.m2 = S.m3 = 0ull;
+        if (tl < PN_TILE) { T.sidx[tl] = -1; T.prow[tl] = -1; T.wnrm[tl] = 0.f; T.wrow[tl] = 0.f; T.dsg[tl] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *reinterpret_cast<float4 *>(T.buf + ((tl >> 6) + 4 * i) * LDH + (tl & 63) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// P1: alpha head (softplus'), d conf, d(alpha pre-activation) per row.  Row-wise: 4 threads per row, float4 columns interleaved
+// (thread q takes float4 q, q+4, ...: conflict-free LDS reads; contiguous 64-column quarters were 8-way bank conflicts)
+template <bool DFS_LDS>
+__device__ __forceinline__ void b2_alpha(const BwdArgs &a, const B2Tile &T, B2State &S, const float *w5s, float b5, int tl, int TS, int K) {
+    const int rrow = tl / TPR, rq = tl % TPR, rls = rrow / K;
+    S.rsi = T.sidx[rrow]; S.rp = T.prow[rrow];
+    if (rq == 0 && S.rp >= 0) {
+        const int r = S.rsi / a.SR;
+        S.rdx = a.raydir[3 * r]; S.rdy = a.raydir[3 * r + 1]; S.rdz = a.raydir[3 * r + 2];
+    }
+    float s = 0.f, dotf = 0.f;
+    if (S.rsi >= 0) {
+        const float *h = T.buf + rrow * LDH + rq * 4;
+        const float *df = DFS_LDS ? T.dfs + rls * PN_H + rq * 4 : a.sv.dfs + (S.tile * TS + rls) * PN_H + rq * 4;
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            const float4 v = *reinterpret_cast<const float4 *>(h + 16 * j);
+            const float4 g = *reinterpret_cast<const float4 *>(df + 16 * j);
+            const float4 w = *reinterpret_cast<const float4 *>(w5s + rq * 4 + 16 * j);
+            s += v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
+            dotf += v.x * g.x + v.y * g.y + v.z * g.z + v.w * g.w;
+        }
+    }
+    s = group_sum_b<TPR>(s);
+    dotf = group_sum_b<TPR>(dotf);
+    if (rq == 0) {
+        float dr = 0.f;
+        if (S.rsi >= 0) {
+            const float x = s + b5 - 1.0f;
+            const float alpha = x > 20.f ? x : log1pf(expf(x));
+            const float sg = x > 20.f ? 1.f : 1.0f / (1.0f + expf(-x));
+            if (S.rp >= 0) {
+                // w = wn * clamp(conf) with a straight-through clamp (gradiant_clamp, point_aggregators.py:722-724)
+                const float dw = T.dsg[rrow] * alpha + dotf;
+                atomicAdd(&a.g_conf[S.rp], dw * T.wnrm[rrow]);
+            }
+            dr = T.dsg[rrow] * T.wrow[rrow] * sg;
+        }
+        T.draw[rrow] = dr;
+    }
+}
+
+// P2: dY4 = (w * d f + d raw * w5) * lrelu'(h4) in place + HBM; d W5 / d b4 / d b5 partial sums ride along
+template <bool DFS_LDS>
+__device__ __forceinline__ void b2_dy4(const BwdArgs &a, const B2Tile &T, const B2State &S, const float *w5s, int tl, int TS, int K,
+                                       float4 &gb4v, float4 &gw5v, float &gb5t) {
+    const int c4 = tl & 63;
+    const float4 w5 = *reinterpret_cast<const float4 *>(w5s + c4 * 4);
+    const long long grow0 = S.tile * PN_TILE;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int row = (tl >> 6) + 4 * i;
+        const int si = T.sidx[row];
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (si >= 0) {
+            const int ls = row / K;
+            const float4 hv = *reinterpret_cast<const float4 *>(T.buf + row * LDH + c4 * 4);
+            const float4 g = DFS_LDS ? *reinterpret_cast<const float4 *>(T.dfs + ls * PN_H + c4 * 4)
+                                     : *reinterpret_cast<const float4 *>(a.sv.dfs + (S.tile * TS + ls) * PN_H + c4 * 4);
+            const float w = T.wrow[row], dr = T.draw[row];
+            o.x = (w * g.x + dr * w5.x) * pn_lrelu_grad(hv.x);
+            o.y = (w * g.y + dr * w5.y) * pn_lrelu_grad(hv.y);
+            o.z = (w * g.z + dr * w5.z) * pn_lrelu_grad(hv.z);
+            o.w = (w * g.w + dr * w5.w) * pn_lrelu_grad(hv.w);
+            gw5v.x += dr * hv.x; gw5v.y += dr * hv.y; gw5v.z += dr * hv.z; gw5v.w += dr * hv.w;
+            gb4v.x += o.x; gb4v.y += o.y; gb4v.z += o.z; gb4v.w += o.w;
+        }
+        *reinterpret_cast<float4 *>(T.buf + row * LDH + c4 * 4) = o;
+        *reinterpret_cast<float4 *>(a.sv.dy4 + (grow0 + row) * PN_H + c4 * 4) = o;     // an invalid partner tile writes zeros into the padding tile
+    }
+    if (tl < PN_TILE) gb5t += T.draw[tl];
+}
+
+// P4: extras of block3's first layer: d colour, d dir from dY3 (row-wise, interleaved columns)
+__device__ __forceinline__ void b2_extras(const BwdArgs &a, const B2Tile &T, const B2State &S, const float *w3ex, int tl) {
+    const int rrow = tl / TPR, rq = tl % TPR;
+    float dex[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (S.rp >= 0) {
+        const float *dy = T.buf + rrow * LDH + rq * 4;
+        _Pragma("unroll 2") for (int j = 0; j < 16; ++j) {
+            const float4 v = *reinterpret_cast<const float4 *>(dy + 16 * j);
+#pragma unroll
+            for (int jj = 0; jj < 7; ++jj) {
+                const float4 w = *reinterpret_cast<const float4 *>(w3ex + jj * PN_H + rq * 4 + 16 * j);
+                dex[jj] += v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 7; ++jj) dex[jj] = group_sum_b<TPR>(dex[jj]);
+    if (rq == 0 && S.rp >= 0) {
+        const int rp = S.rp;
+        atomicAdd(&a.g_color[3 * rp], dex[0]); atomicAdd(&a.g_color[3 * rp + 1], dex[1]); atomicAdd(&a.g_color[3 * rp + 2], dex[2]);
+        float vx, vy, vz, gx, gy, gz;
+        rot3b(a.cam.rw2c, S.rdx, S.rdy, S.rdz, true, vx, vy, vz);
+        // features (q - v, q . v) with q = dir @ Rw2c^T  ->  d q = dex[3:6] + dex[6] * v ; d dir = d q @ Rw2c
+        rot3b(a.cam.rw2c, dex[3] + dex[6] * vx, dex[4] + dex[6] * vy, dex[5] + dex[6] * vz, false, gx, gy, gz);
+        atomicAdd(&a.g_dir[3 * rp], gx); atomicAdd(&a.g_dir[3 * rp + 1], gy); atomicAdd(&a.g_dir[3 * rp + 2], gz);
+    }
+}
+
+// P8: embedding gradient through [e | PE3(e)]: d e = dX[e] + sum_f 2^f (dX[sin] cos - dX[cos] sin)
+__device__ __forceinline__ void b2_emb(const BwdArgs &a, const B2Tile &T, const B2State &S, int tl) {
+    const int rrow = tl / TPR, rq = tl % TPR;
+    if (S.rp >= 0) {
+        const float *dx = T.buf + rrow * LDH;
+        const float *x0 = a.sv.x0 + (S.tile * PN_TILE + rrow) * PN_IN1P + PN_F + 6 * EPT * rq;          // EPT dims * 3 freqs * 2
+        float4 xs[6 * EPT / 4];
+#pragma unroll
+        for (int i = 0; i < 6 * EPT / 4; ++i) xs[i] = *reinterpret_cast<const float4 *>(x0 + 4 * i);
+        const float *xf = reinterpret_cast<const float *>(xs);
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int dd = EPT * rq + i;
+            float g = dx[dd], fr = 1.f;
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                const int o = PN_F + (dd * 3 + f) * 2, l = (i * 3 + f) * 2;
+                g += fr * (dx[o] * xf[l + 1] - dx[o + 1] * xf[l]);
+                fr *= 2.f;
+            }
+            atomicAdd(&a.g_emb[(long long)S.rp * PN_F + dd], g);
+        }
+    }
+}
+
+// Epilogue pieces that run in the MFMA shadow.
+// E: element r of the finished accumulators of tile Y, times LeakyReLU' (bit r of m), into Y's LDS tile; bias column sums
+template <int R, bool MASK>
+__device__ __forceinline__ void b2_epi_piece(const f32x16 (&acc)[2][2], unsigned mlo, unsigned mhi, float *wy, float (&gb)[2]) {
+    constexpr int mt = R >> 5, ct = (R >> 4) & 1, reg = R & 15;
+    float v = acc[mt][ct][reg];
+    if (MASK) {
+        const unsigned bit = ((R < 32 ? mlo : mhi) >> (R & 31)) & 1u;
+        v *= bit ? 1.f : 0.01f;
+        gb[ct] += v;
+        asm volatile("" : "+v"(gb[ct]));       // pin the accumulation to this MFMA shadow (pure arithmetic is otherwise sunk to its use)
+    }
+    wy[(mt * 32 + (reg & 3) + 8 * (reg >> 2)) * LDH + ct * 32] = v;
+}
+
 #ifdef PN_PHASE_TRACE
 PN_TR_DECL(pn_trace_bwd);
 #endif
-// DFS_LDS: the tile's d f rows (TS x 256 floats) fit the 8 KB union region (K >= 8); otherwise they are read from HBM/L2.
+// DFS_LDS: the tile's d f rows (TS x 256 floats) fit the 8 KB LDS region (K >= 8); otherwise they are read from HBM/L2.
 template <bool DFS_LDS>
-__global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
+__global__ __launch_bounds__(PN_NTHR, 1) void k_agg_backward(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *buf = smem;                         // [PN_TILE][LDH]  h4 -> dY4 -> dY3 -> dY2 -> dY1 -> dX0
-    float *exs = buf + PN_TILE * LDH;          // [PN_TILE][8]
-    float *uni = exs + PN_TILE * 8;            // [8][256] d f tile, later [7][256] W3[o][256+j]
-    float *w5s = uni + AGGB_UNION_FLOATS;      // [256]
-    float *wrow = w5s + PN_H;                  // [PN_TILE]
-    float *wnrm = wrow + PN_TILE;
-    float *draw = wnrm + PN_TILE;              // d(alpha pre-activation)
-    float *dsg = draw + PN_TILE;               // d sigma of the row's sample
-    int *sidx = reinterpret_cast<int *>(dsg + PN_TILE);   // row -> sample id (or -1)
-    int *prow = sidx + PN_TILE;                            // row -> point id (or -1)
-
+    const B2Tile TA = b2_carve(smem), TB = b2_carve(smem + B2_TILE_FLOATS);
+    float *w5s = smem + 2 * B2_TILE_FLOATS;    // [256]
+    float *w3ex = w5s + PN_H;                  // [7][256]  W3[o][256+j]
     const int tid = threadIdx.x;
     const int K = a.K, TS = a.TS;
     const int Ns = a.counters[0] < a.cap_samples ? a.counters[0] : (int)a.cap_samples;
+    const long long ntiles = ((long long)Ns + TS - 1) / TS;
     const float *P = a.params;
-    if (tid < PN_H) w5s[tid] = P[PO_W5 + tid];
-    // column sums (bias / alpha-head / extras gradients): thread = (column cc, row group cg)
-    constexpr int CG = PN_NTHR / PN_H, RPG = PN_TILE / CG;
-    const int cc0 = tid % PN_H;
+    if (tid < PN_H) {
+        w5s[tid] = P[PO_W5 + tid];
+        for (int j = 0; j < 7; ++j) w3ex[j * PN_H + tid] = P[PO_W3 + tid * PN_IN3 + PN_H + j];
+    }
     const float b5 = P[PO_B5];
-    float gb1 = 0.f, gb2 = 0.f, gb3 = 0.f, gb4 = 0.f, gw5 = 0.f, gb5 = 0.f;
-    float gw3e[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    constexpr int H4PER = PN_TILE * 64 / PN_NTHR;  // float4 of an [PN_TILE x 256] tile per thread
+    // gradient partial sums that live in registers for the whole kernel
+    float gb[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};      // d b1..b3: accumulator layout, columns wave*64 + ct*32 + (lane&31)
+    float4 gb4v = make_float4(0.f, 0.f, 0.f, 0.f), gw5v = gb4v;  // d b4, d W5: columns 4*lane .. 4*lane+3
+    float gw3e[7][4];                                            // d W3[col][256 + j], columns 4*lane .. +3
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gw3e[j][c] = 0.f;
+    float gb5t = 0.f;
+    f32x16 accA[2][2], accB[2][2];
+    B2State SA, SB;
 
 #ifdef PN_PHASE_TRACE
     int titer = -1;
 #endif
-    for (long long tile = blockIdx.x; tile * TS < Ns; tile += gridDim.x) {
-        const long long grow0 = tile * PN_TILE;
+    for (long long pair = blockIdx.x; pair * 2 < ntiles; pair += gridDim.x) {
 #ifdef PN_PHASE_TRACE
         ++titer;
 #endif
-        // thread-index-derived offsets are recomputed per tile (a few VALU ops) instead of living in registers across the
-        // whole loop: hipcc otherwise hoists ~60 of them, spills, and the scratch reloads queue behind the atomics
+        // thread-index-derived offsets are recomputed per pair (a few VALU ops) instead of living in registers across the loop
         int tl = threadIdx.x;
         asm volatile("" : "+v"(tl));
-        const int cc = tl % PN_H, row_lo = (tl / PN_H) * RPG, row_hi = row_lo + RPG;
-        const int rrow = tl / TPR, rq = tl % TPR;      // (row, quarter) of the row-wise phases
-        const int rls = rrow / K;
         const int lane = tl & 63, wave = tl >> 6;
         __syncthreads();
         PN_TR(pn_trace_bwd, 0); PN_TR_HWID(pn_trace_bwd);
-        // ---- everything this tile needs from memory, requested up front ---------------------------
-        const unsigned long long m1 = a.sv.lmask[(tile * 3 + 0) * PN_NTHR + tl];
-        const unsigned long long m2 = a.sv.lmask[(tile * 3 + 1) * PN_NTHR + tl];
-        const unsigned long long m3 = a.sv.lmask[(tile * 3 + 2) * PN_NTHR + tl];
-        if (tid < PN_TILE) {
-            const int4 rm = a.sv.rmeta[grow0 + tl];
-            const int si = rm.x;
-            sidx[tl] = si; prow[tl] = rm.y;
-            wnrm[tl] = __int_as_float(rm.z); wrow[tl] = __int_as_float(rm.w);
-            dsg[tl] = si >= 0 ? a.grad_decoded[(long long)si * 4] : 0.f;
-        }
-        {   // h4 tile (+ d f tile): all loads issued before the first LDS store
-            float4 v[H4PER], g[2];
-#pragma unroll
-            for (int i = 0; i < H4PER; ++i) {
-                const int e = tl + i * PN_NTHR;
-                v[i] = *reinterpret_cast<const float4 *>(a.sv.h4 + (grow0 + (e >> 6)) * PN_H + (e & 63) * 4);
-            }
-            if (DFS_LDS) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int e = tl + i * PN_NTHR;       // float4 e of the [TS x 256] block (rows past TS: the next tile's, unused)
-                    g[i] = (e >> 6) < TS ? *reinterpret_cast<const float4 *>(a.sv.dfs + (tile * TS + (e >> 6)) * PN_H + (e & 63) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < H4PER; ++i) {
-                const int e = tl + i * PN_NTHR;
-                *reinterpret_cast<float4 *>(buf + (e >> 6) * LDH + (e & 63) * 4) = v[i];
-            }
-            if (DFS_LDS) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) *reinterpret_cast<float4 *>(uni + (tl + i * PN_NTHR) * 4) = g[i];
-            }
-        }
-        if (tid < PN_TILE * 2) {
-            const int row = tl >> 1, h = tl & 1;
-            *reinterpret_cast<float4 *>(exs + row * 8 + h * 4) = *reinterpret_cast<const float4 *>(a.sv.ex + (grow0 + row) * 8 + h * 4);
-        }
+        b2_load<DFS_LDS>(a, TA, SA, 2 * pair, ntiles, tl, TS);
+        b2_load<DFS_LDS>(a, TB, SB, 2 * pair + 1, ntiles, tl, TS);
         __syncthreads();
         PN_TR(pn_trace_bwd, 1);
-        // ---- alpha head + weight gradient ------------------------------------------------------
-        const int rsi = sidx[rrow], rp = prow[rrow];
-        float rdx = 0.f, rdy = 0.f, rdz = 0.f;        // ray direction of the row's sample: used after the next GEMM
-        if (rq == 0 && rp >= 0) {
-            const int r = rsi / a.SR;
-            rdx = a.raydir[3 * r]; rdy = a.raydir[3 * r + 1]; rdz = a.raydir[3 * r + 2];
-        }
-        {
-            const float *h = buf + rrow * LDH + rq * CPT;
-            float s = 0.f, dotf = 0.f;
-            if (rsi >= 0) {
-                const float *df = DFS_LDS ? uni + rls * PN_H + rq * CPT : a.sv.dfs + (tile * TS + rls) * PN_H + rq * CPT;
-#pragma unroll 4
-                for (int c = 0; c < CPT; c += 4) {
-                    const float4 v = *reinterpret_cast<const float4 *>(h + c);
-                    const float4 g = *reinterpret_cast<const float4 *>(df + c);
-                    s += v.x * w5s[rq * CPT + c] + v.y * w5s[rq * CPT + c + 1] + v.z * w5s[rq * CPT + c + 2] + v.w * w5s[rq * CPT + c + 3];
-                    dotf += v.x * g.x + v.y * g.y + v.z * g.z + v.w * g.w;
-                }
-            }
-            s = group_sum_b<TPR>(s);
-            dotf = group_sum_b<TPR>(dotf);
-            if (rq == 0) {
-                float dr = 0.f;
-                if (rsi >= 0) {
-                    const float x = s + b5 - 1.0f;
-                    const float alpha = x > 20.f ? x : log1pf(expf(x));
-                    const float sg = x > 20.f ? 1.f : 1.0f / (1.0f + expf(-x));
-                    if (rp >= 0) {
-                        // w = wn * clamp(conf) with a straight-through clamp (gradiant_clamp, point_aggregators.py:722-724)
-                        const float dw = dsg[rrow] * alpha + dotf;
-                        atomicAdd(&a.g_conf[rp], dw * wnrm[rrow]);
-                    }
-                    dr = dsg[rrow] * wrow[rrow] * sg;
-                }
-                draw[rrow] = dr;
-            }
-        }
+        b2_alpha<DFS_LDS>(a, TA, SA, w5s, b5, tl, TS, K);
+        b2_alpha<DFS_LDS>(a, TB, SB, w5s, b5, tl, TS, K);
         __syncthreads();
         PN_TR(pn_trace_bwd, 2);
-        // ---- d W5 / d b5 (column tid) ------------------------------------------------------------
-        {
-            float accw = 0.f;
-            _Pragma("unroll 8") for (int row = row_lo; row < row_hi; ++row) accw += draw[row] * buf[row * LDH + cc];
-            gw5 += accw;
-            if (tid == 0) _Pragma("unroll 8") for (int row = 0; row < PN_TILE; ++row) gb5 += draw[row];
-        }
+        b2_dy4<DFS_LDS>(a, TA, SA, w5s, tl, TS, K, gb4v, gw5v, gb5t);
+        b2_dy4<DFS_LDS>(a, TB, SB, w5s, tl, TS, K, gb4v, gw5v, gb5t);
         __syncthreads();
         PN_TR(pn_trace_bwd, 3);
-        // ---- dY4 = (w * d f + d raw * w5) * lrelu'(h4), in place ---------------------------------
-        float w3r[7];                              // W3[o][256 + j] of column o = tid: into the union region once d f is dead
-        if (tid < PN_H) {
-#pragma unroll
-            for (int j = 0; j < 7; ++j) w3r[j] = P[PO_W3 + tl * PN_IN3 + PN_H + j];
+
+        float *wyA = TA.buf + (4 * (lane >> 5)) * LDH + wave * 64 + (lane & 31);     // accumulator-layout write base
+        float *wyB = TB.buf + (4 * (lane >> 5)) * LDH + wave * 64 + (lane & 31);
+        const float *rxA = TA.buf + wave * LDH + lane * 4, *rxB = TB.buf + wave * LDH + lane * 4;   // copy-out read base (+ 4*i rows)
+        const long long gA = SA.tile * PN_TILE + wave, gB = SB.tile * PN_TILE + wave;           // copy-out row base (+ 4*i)
+        float4 cpv = make_float4(0.f, 0.f, 0.f, 0.f), exa = cpv, exb2 = cpv;
+
+        // one G step: GEMM of tile X (LDS XB, accumulators ACCX, weight image PK) with, in the MFMA shadows,
+        //   E (MASKED: x LeakyReLU' of mask word MY, column sums into GBY) of the other tile's accumulators ACCY -> WY, and
+        //   the copy-out of X's own finished rows RX -> DST (COPY), plus the W3-extras gradient (EXTRAS)
+#define B2_STEP(XB, ACCX, PK, ACCY, MY, WY, GBY, EPI, MASKED, COPY, EXTRAS, RX, DST, GROW, XVALID)                                   \
+        {                                                                                                                           \
+            const unsigned mlo_ = (unsigned)(MY), mhi_ = (unsigned)((MY) >> 32);                                                    \
+            pn_acc_zero(ACCX);                                                                                                      \
+            pn_tile_gemm_side<PN_H / 8>(XB, LDH, a.packed + (PK) / 4, wave, lane, ACCX, [&](auto ss) {                              \
+                constexpr int s = decltype(ss)::value;                                                                              \
+                if constexpr (EPI && s % 8 == 0) b2_epi_piece<s / 8, MASKED>(ACCY, mlo_, mhi_, WY, GBY);                            \
+                if constexpr (COPY && EXTRAS && s % 32 == 2) {                                                                      \
+                    const float *exr = a.sv.ex + ((GROW) + 4 * (s / 32)) * 8;                                                       \
+                    exa = *reinterpret_cast<const float4 *>(exr); exb2 = *reinterpret_cast<const float4 *>(exr + 4);                \
+                }                                                                                                                   \
+                if constexpr (COPY && s % 32 == 4) cpv = *reinterpret_cast<const float4 *>((RX) + 4 * (s / 32) * LDH);              \
+                if constexpr (COPY && s % 32 == 20) *reinterpret_cast<float4 *>((DST) + ((GROW) + 4 * (s / 32)) * PN_H + lane * 4) = cpv; \
+                if constexpr (COPY && EXTRAS && s % 32 >= 21 && s % 32 < 28) {                                                      \
+                    constexpr int j_ = s % 32 - 21;                                                                                 \
+                    const float e_ = j_ == 0 ? exa.x : j_ == 1 ? exa.y : j_ == 2 ? exa.z : j_ == 3 ? exa.w : j_ == 4 ? exb2.x : j_ == 5 ? exb2.y : exb2.z; \
+                    gw3e[j_][0] += cpv.x * e_; gw3e[j_][1] += cpv.y * e_; gw3e[j_][2] += cpv.z * e_; gw3e[j_][3] += cpv.w * e_;      \
+                    asm volatile("" : "+v"(gw3e[j_][0]), "+v"(gw3e[j_][1]), "+v"(gw3e[j_][2]), "+v"(gw3e[j_][3]));                    \
+                }                                                                                                                   \
+            });                                                                                                                     \
+            __syncthreads();                                                                                                        \
         }
-#pragma unroll 4
-        for (int i = 0; i < H4PER; ++i) {
-            const int e = tl + i * PN_NTHR;
-            const int row = e >> 6, c4 = e & 63;
-            const int si = sidx[row];
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (si >= 0) {
-                const int ls = row / K;
-                const float4 hv = *reinterpret_cast<const float4 *>(buf + row * LDH + c4 * 4);
-                const float4 g = DFS_LDS ? *reinterpret_cast<const float4 *>(uni + ls * PN_H + c4 * 4)
-                                         : *reinterpret_cast<const float4 *>(a.sv.dfs + (tile * TS + ls) * PN_H + c4 * 4);
-                const float w = wrow[row], dr = draw[row];
-                o.x = (w * g.x + dr * w5s[c4 * 4]) * pn_lrelu_grad(hv.x);
-                o.y = (w * g.y + dr * w5s[c4 * 4 + 1]) * pn_lrelu_grad(hv.y);
-                o.z = (w * g.z + dr * w5s[c4 * 4 + 2]) * pn_lrelu_grad(hv.z);
-                o.w = (w * g.w + dr * w5s[c4 * 4 + 3]) * pn_lrelu_grad(hv.w);
-            }
-            *reinterpret_cast<float4 *>(buf + row * LDH + c4 * 4) = o;
-            *reinterpret_cast<float4 *>(a.sv.dy4 + (grow0 + row) * PN_H + c4 * 4) = o;
-        }
-        __syncthreads();
+        float gnone[2] = {0.f, 0.f};
+        //      X-tile   accX  image  accY  maskY  writeY gbY    EPI    MASK   COPY   EXTRAS readX dst        rowbase valid
+        B2_STEP(TA.buf, accA, PK_D4, accB, 0ull, wyB, gnone, false, false, false, false, rxA, a.sv.dy3, gA, SA.valid)
         PN_TR(pn_trace_bwd, 4);
-        if (tid < PN_H) {
-#pragma unroll
-            for (int j = 0; j < 7; ++j) uni[j * PN_H + tl] = w3r[j];
-        }
-        // ---- block3 second layer: dY3 = (dY4 @ W4) * lrelu'(h3) ----------------------------------
-        _Pragma("unroll 8") for (int row = row_lo; row < row_hi; ++row) gb4 += buf[row * LDH + cc];
-        f32x16 acc[PN_MT][PN_NT];
+        B2_STEP(TB.buf, accB, PK_D4, accA, SA.m3, wyA, gb[2], true, true, false, false, rxB, a.sv.dy3, gB, SB.valid)
         PN_TR(pn_trace_bwd, 5);
-        pn_acc_init_bias<PN_MT, PN_NT>(acc, nullptr, wave, lane);
-        pn_tile_gemm<PN_MT, PN_NT, PN_NW>(buf, LDH, PN_H / 8, a.packed + PK_D4 / 4, wave, lane, acc);
+        b2_extras(a, TA, SA, w3ex, tl);
         PN_TR(pn_trace_bwd, 6);
-        __syncthreads();
-        pn_acc_to_lds<PN_MT, PN_NT, false>(acc, buf, LDH, wave, lane);
-        __syncthreads();
+        B2_STEP(TA.buf, accA, PK_D3, accB, SB.m3, wyB, gb[2], true, true, true, true, rxA, a.sv.dy3, gA, SA.valid)
         PN_TR(pn_trace_bwd, 7);
-        pn_tile_mask_bits<PN_TILE, PN_H, PN_NTHR>(buf, LDH, m3, a.sv.dy3, PN_H, grow0, tl);
-        __syncthreads();
+        b2_extras(a, TB, SB, w3ex, tl);
         PN_TR(pn_trace_bwd, 8);
-        // ---- block3 first layer: extras (colour, dir) + dY2 = (dY3 @ W3[:, :256]) * lrelu'(h2) ----
-        _Pragma("unroll 4") for (int row = row_lo; row < row_hi; ++row) {
-            const float v = buf[row * LDH + cc];
-            gb3 += v;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) gw3e[j] += v * exs[row * 8 + j];
-        }
-        {
-            float dex[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (rp >= 0) {
-                const float *dy = buf + rrow * LDH + rq * CPT;
-                _Pragma("unroll 2") for (int c = 0; c < CPT; c += 4) {
-                    const float4 v = *reinterpret_cast<const float4 *>(dy + c);
-#pragma unroll
-                    for (int j = 0; j < 7; ++j) {
-                        const float4 w = *reinterpret_cast<const float4 *>(uni + j * PN_H + rq * CPT + c);
-                        dex[j] += v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 7; ++j) dex[j] = group_sum_b<TPR>(dex[j]);
-            if (rq == 0 && rp >= 0) {
-                atomicAdd(&a.g_color[3 * rp], dex[0]); atomicAdd(&a.g_color[3 * rp + 1], dex[1]); atomicAdd(&a.g_color[3 * rp + 2], dex[2]);
-                float vx, vy, vz, gx, gy, gz;
-                rot3b(a.cam.rw2c, rdx, rdy, rdz, true, vx, vy, vz);
-                // features (q - v, q . v) with q = dir @ Rw2c^T  ->  d q = dex[3:6] + dex[6] * v ; d dir = d q @ Rw2c
-                rot3b(a.cam.rw2c, dex[3] + dex[6] * vx, dex[4] + dex[6] * vy, dex[5] + dex[6] * vz, false, gx, gy, gz);
-                atomicAdd(&a.g_dir[3 * rp], gx); atomicAdd(&a.g_dir[3 * rp + 1], gy); atomicAdd(&a.g_dir[3 * rp + 2], gz);
-            }
-        }
+        B2_STEP(TB.buf, accB, PK_D3, accA, SA.m2, wyA, gb[1], true, true, true, true, rxB, a.sv.dy3, gB, SB.valid)
         PN_TR(pn_trace_bwd, 9);
-        pn_acc_init_bias<PN_MT, PN_NT>(acc, nullptr, wave, lane);
-        pn_tile_gemm<PN_MT, PN_NT, PN_NW>(buf, LDH, PN_H / 8, a.packed + PK_D3 / 4, wave, lane, acc);
+        B2_STEP(TA.buf, accA, PK_D2, accB, SB.m2, wyB, gb[1], true, true, true, false, rxA, a.sv.dy2, gA, SA.valid)
         PN_TR(pn_trace_bwd, 10);
-        __syncthreads();
-        pn_acc_to_lds<PN_MT, PN_NT, false>(acc, buf, LDH, wave, lane);
-        __syncthreads();
+        B2_STEP(TB.buf, accB, PK_D2, accA, SA.m1, wyA, gb[0], true, true, true, false, rxB, a.sv.dy2, gB, SB.valid)
         PN_TR(pn_trace_bwd, 11);
-        pn_tile_mask_bits<PN_TILE, PN_H, PN_NTHR>(buf, LDH, m2, a.sv.dy2, PN_H, grow0, tl);
-        __syncthreads();
+        B2_STEP(TA.buf, accA, PK_D1, accB, SB.m1, wyB, gb[0], true, true, true, false, rxA, a.sv.dy1, gA, SA.valid)
         PN_TR(pn_trace_bwd, 12);
-        // ---- block1 second layer: dY1 = (dY2 @ W2) * lrelu'(h1) ----------------------------------
-        _Pragma("unroll 8") for (int row = row_lo; row < row_hi; ++row) gb2 += buf[row * LDH + cc];
+        B2_STEP(TB.buf, accB, PK_D1, accA, 0ull, wyA, gnone, true, false, true, false, rxB, a.sv.dy1, gB, SB.valid)
         PN_TR(pn_trace_bwd, 13);
-        pn_acc_init_bias<PN_MT, PN_NT>(acc, nullptr, wave, lane);
-        pn_tile_gemm<PN_MT, PN_NT, PN_NW>(buf, LDH, PN_H / 8, a.packed + PK_D2 / 4, wave, lane, acc);
+#undef B2_STEP
+        // d X0 of tile B: plain epilogue, then the embedding gradients of both tiles
+        pn_static_for<64>([&](auto rr) { b2_epi_piece<decltype(rr)::value, false>(accB, 0u, 0u, wyB, gnone); });
+        __syncthreads();
         PN_TR(pn_trace_bwd, 14);
-        __syncthreads();
-        pn_acc_to_lds<PN_MT, PN_NT, false>(acc, buf, LDH, wave, lane);
-        __syncthreads();
+        b2_emb(a, TA, SA, tl);
+        b2_emb(a, TB, SB, tl);
         PN_TR(pn_trace_bwd, 15);
-        pn_tile_mask_bits<PN_TILE, PN_H, PN_NTHR>(buf, LDH, m1, a.sv.dy1, PN_H, grow0, tl);
-        __syncthreads();
-        PN_TR(pn_trace_bwd, 16);
-        // ---- block1 first layer: d X0[:, :256] = dY1 @ W1[:, :256] --------------------------------
-        _Pragma("unroll 8") for (int row = row_lo; row < row_hi; ++row) gb1 += buf[row * LDH + cc];
-        PN_TR(pn_trace_bwd, 17);
-        pn_acc_init_bias<PN_MT, PN_NT>(acc, nullptr, wave, lane);
-        pn_tile_gemm<PN_MT, PN_NT, PN_NW>(buf, LDH, PN_H / 8, a.packed + PK_D1 / 4, wave, lane, acc);
-        PN_TR(pn_trace_bwd, 18);
-        __syncthreads();
-        pn_acc_to_lds<PN_MT, PN_NT, false>(acc, buf, LDH, wave, lane);
-        __syncthreads();
-        PN_TR(pn_trace_bwd, 19);
-        // ---- embedding gradient through [e | PE3(e)]: d e = dX[e] + sum_f 2^f (dX[sin] cos - dX[cos] sin)
-        if (rp >= 0) {
-            const float *dx = buf + rrow * LDH;
-            const float *x0 = a.sv.x0 + (grow0 + rrow) * PN_IN1P + PN_F + 6 * EPT * rq;          // EPT dims * 3 freqs * 2
-            float4 xs[6 * EPT / 4];
-#pragma unroll
-            for (int i = 0; i < 6 * EPT / 4; ++i) xs[i] = *reinterpret_cast<const float4 *>(x0 + 4 * i);
-            const float *xf = reinterpret_cast<const float *>(xs);
-#pragma unroll
-            for (int i = 0; i < EPT; ++i) {
-                const int dd = EPT * rq + i;
-                float g = dx[dd], fr = 1.f;
-#pragma unroll
-                for (int f = 0; f < 3; ++f) {
-                    const int o = PN_F + (dd * 3 + f) * 2, l = (i * 3 + f) * 2;
-                    g += fr * (dx[o] * xf[l + 1] - dx[o + 1] * xf[l]);
-                    fr *= 2.f;
-                }
-                atomicAdd(&a.g_emb[(long long)rp * PN_F + dd], g);
-            }
-        }
-        PN_TR(pn_trace_bwd, 20);
     }
-    const int cc = cc0;
-    atomicAdd(&a.gparams[PO_B1 + cc], gb1);
-    atomicAdd(&a.gparams[PO_B2 + cc], gb2);
-    atomicAdd(&a.gparams[PO_B3 + cc], gb3);
-    atomicAdd(&a.gparams[PO_B4 + cc], gb4);
-    atomicAdd(&a.gparams[PO_W5 + cc], gw5);
-    if (tid == 0) atomicAdd(&a.gparams[PO_B5], gb5);
+    // flush the register-resident partial sums
+    {
+        const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int j = 0; j < 7; ++j) atomicAdd(&a.gparams[PO_W3 + cc * PN_IN3 + PN_H + j], gw3e[j]);
+        for (int ct = 0; ct < 2; ++ct) {
+            const int col = wave * 64 + ct * 32 + (lane & 31);
+            atomicAdd(&a.gparams[PO_B1 + col], gb[0][ct]);
+            atomicAdd(&a.gparams[PO_B2 + col], gb[1][ct]);
+            atomicAdd(&a.gparams[PO_B3 + col], gb[2][ct]);
+        }
+        const float g4[4] = {gb4v.x, gb4v.y, gb4v.z, gb4v.w}, g5[4] = {gw5v.x, gw5v.y, gw5v.z, gw5v.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            atomicAdd(&a.gparams[PO_B4 + lane * 4 + c], g4[c]);
+            atomicAdd(&a.gparams[PO_W5 + lane * 4 + c], g5[c]);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) atomicAdd(&a.gparams[PO_W3 + (lane * 4 + c) * PN_IN3 + PN_H + j], gw3e[j][c]);
+        }
+        if (tid < PN_TILE) atomicAdd(&a.gparams[PO_B5], gb5t);
+    }
 }
 
 // ------------------------------------------------------------------------------ weight gradients
@@ -646,12 +710,12 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
     const long long tiles = (n_valid + a.TS - 1) / a.TS;
     const long long ctiles = (n_valid + PN_CTILE - 1) / PN_CTILE;
-    const int wgcu = AGGB_WG_PER_CU < 1 ? 1 : (AGGB_WG_PER_CU > 4 ? 4 : AGGB_WG_PER_CU);
-    const int grid_a = (int)(tiles < (long long)wgcu * ncu ? (tiles > 0 ? tiles : 1) : wgcu * ncu);
+    const long long pairs = (tiles + 1) / 2;          // one workgroup per CU, two tiles in flight each
+    const int grid_a = (int)(pairs < (long long)ncu ? (pairs > 0 ? pairs : 1) : ncu);
     const int grid_c = (int)(ctiles < ncu ? (ctiles > 0 ? ctiles : 1) : ncu);
     const size_t lds_c = COLB_LDS_FLOATS * sizeof(float), lds_a = AGGB_LDS_FLOATS * sizeof(float);
     if (hipFuncSetAttribute((const void *)k_color_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
-    const bool dfs_lds = a.TS * PN_H <= AGGB_UNION_FLOATS;
+    const bool dfs_lds = a.TS * PN_H <= B2_DFS_FLOATS;
     const void *kfn = dfs_lds ? (const void *)k_agg_backward<true> : (const void *)k_agg_backward<false>;
     if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
     { PnProfScope prof(PNK_COLOR_BWD, s); hipLaunchKernelGGL(k_color_backward, dim3(grid_c), dim3(256), lds_c, s, a); }

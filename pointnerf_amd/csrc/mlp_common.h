@@ -3,6 +3,8 @@
 // reference rules out plain bf16 inputs; see DESIGN.md "precision").
 #pragma once
 #include "pn_common.h"
+#include <type_traits>
+#include <utility>
 
 // ---- architecture (reference viewmlp_init, models/aggregators/point_aggregators.py:276-348, lego flags)
 #define PN_F      32                 // point_features_dim
@@ -165,41 +167,72 @@ __device__ __forceinline__ void pn_tile_mask_pass(float *__restrict__ H, int ldh
     }
 }
 
-// ---- 1-bit LeakyReLU masks.  The element-wise tile passes of forward and backward use the same thread -> element map
-// (float4 number e = tid + i * NTHR of the [ROWS x W] tile, i < 16), so the sign bits of the 64 floats a thread copies
-// out in the forward are exactly the 64 bits it needs in the backward: one 8-byte word per thread per layer, written
-// and read fully coalesced.  The backward fetches its words at the top of the tile, long before the GEMM whose result
-// they mask -- the 64 KB fp32 read it replaces sat on the critical path after every GEMM (latency-, not bandwidth-bound).
-template <int ROWS, int W, int NTHR = 256>
-__device__ __forceinline__ unsigned long long pn_tile_copy_out_bits(const float *__restrict__ H, int ldh, float *__restrict__ G, int ldg,
-                                                                    long long grow0, int tid) {
-    constexpr int PER = ROWS * W / 4 / NTHR;
-    static_assert(PER * 4 == 64, "one 64-bit mask word per thread");
-    unsigned long long m = 0ull;
+// ---- 1-bit LeakyReLU masks, in the accumulator layout.  A lane owns the same 64 (row, col) elements of a layer's output in
+// the forward (where it applies bias + LeakyReLU to its accumulators) and in the backward (where it multiplies its dgrad
+// accumulators by LeakyReLU'), so the sign bits travel as ONE 8-byte word per thread per layer: bit r = mt*32 + ct*16 + reg.
+// Written and read fully coalesced ([tile][layer][thread]); the backward fetches its words at the top of the tile.  The 64 KB
+// fp32 read this replaces sat on the critical path after every GEMM (latency-, not bandwidth-bound).
+template <bool LRELU>
+__device__ __forceinline__ unsigned long long pn_acc_to_lds_bits(f32x16 (&acc)[2][2], float *__restrict__ H, int ldh, int wave, int lane) {
+    unsigned lo = 0u, hi = 0u;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int e = tid + i * NTHR, row = e / (W / 4), c4 = e - row * (W / 4);
-        const float4 v = *reinterpret_cast<const float4 *>(H + row * ldh + c4 * 4);
-        *reinterpret_cast<float4 *>(G + (grow0 + row) * ldg + c4 * 4) = v;
-        m |= (unsigned long long)((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << (4 * i);
-    }
-    return m;
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int col = pn_acc_col<2>(wave, ct, lane);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float v = acc[rt][ct][reg];
+                if (rt == 0) lo |= (v > 0.f ? 1u : 0u) << (ct * 16 + reg);
+                else hi |= (v > 0.f ? 1u : 0u) << (ct * 16 + reg);
+                H[pn_acc_row(rt, reg, lane) * ldh + col] = LRELU ? pn_lrelu(v) : v;
+            }
+        }
+    return ((unsigned long long)hi << 32) | lo;
 }
 
-template <int ROWS, int W, int NTHR = 256>
-__device__ __forceinline__ void pn_tile_mask_bits(float *__restrict__ H, int ldh, unsigned long long m, float *__restrict__ D, int ldd,
-                                                  long long grow0, int tid) {
-    constexpr int PER = ROWS * W / 4 / NTHR;
-    static_assert(PER * 4 == 64, "one 64-bit mask word per thread");
+// ---- side-job GEMM --------------------------------------------------------------------------------------------------
+// Measured on MI355X (tools/mfma_probe.hip): while one wave streams v_mfma_f32_32x32x2_f32 back to back, ANOTHER wave on the
+// same SIMD gets one VALU instruction through per ~84 cycles (s_setprio does not change it), but the streaming wave's OWN
+// independent VALU / LDS / VMEM instructions issue for free in the 64-cycle shadow of each MFMA (<= ~15 per MFMA).  So
+// element-wise work is hidden by the wave that runs the GEMM, not by a second workgroup: the chunk loop is fully unrolled
+// and after every MFMA a hook `side(slot)` (slot = compile-time constant 0 .. 16*NCH-1) may issue a few instructions that
+// belong to a DIFFERENT tile (or to finished rows of this one).  sched_barrier keeps hipcc from regrouping them.
+template <int... I, class F> __device__ __forceinline__ void pn_static_for_impl(std::integer_sequence<int, I...>, F &&f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void pn_static_for(F &&f) { pn_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+template <int NCH, class Side>
+__device__ __forceinline__ void pn_tile_gemm_side(const float *__restrict__ A, int lda, const float4 *__restrict__ Wp, int wave, int lane,
+                                                  f32x16 (&acc)[2][2], Side &&side) {
+    const float *ap = A + (lane & 31) * lda + 4 * (lane >> 5);
+    const float4 *wp = Wp + (wave * 2) * 64 + lane;
+    float4 a[2][2], b[2][2];
+    b[0][0] = wp[0]; b[0][1] = wp[64];
+    a[0][0] = *reinterpret_cast<const float4 *>(ap); a[0][1] = *reinterpret_cast<const float4 *>(ap + 32 * lda);
+    pn_static_for<NCH>([&](auto cc) {
+        constexpr int c = decltype(cc)::value, cur = c & 1, nxt = cur ^ 1;
+        if constexpr (c + 1 < NCH) {
+            b[nxt][0] = wp[((c + 1) * 8) * 64]; b[nxt][1] = wp[((c + 1) * 8 + 1) * 64];
+            a[nxt][0] = *reinterpret_cast<const float4 *>(ap + 8 * (c + 1)); a[nxt][1] = *reinterpret_cast<const float4 *>(ap + 32 * lda + 8 * (c + 1));
+        }
+        pn_static_for<16>([&](auto jj) {
+            constexpr int j = decltype(jj)::value, i = j >> 2, ct = (j >> 1) & 1, mt = j & 1;
+            const float av = i == 0 ? a[cur][mt].x : (i == 1 ? a[cur][mt].y : (i == 2 ? a[cur][mt].z : a[cur][mt].w));
+            const float bv = i == 0 ? b[cur][ct].x : (i == 1 ? b[cur][ct].y : (i == 2 ? b[cur][ct].z : b[cur][ct].w));
+            acc[mt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt][ct], 0, 0, 0);
+            side(std::integral_constant<int, c * 16 + j>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    });
+}
+
+__device__ __forceinline__ void pn_acc_zero(f32x16 (&acc)[2][2]) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int e = tid + i * NTHR, row = e / (W / 4), c4 = e - row * (W / 4);
-        const unsigned b = (unsigned)(m >> (4 * i));
-        float4 v = *reinterpret_cast<const float4 *>(H + row * ldh + c4 * 4);
-        v.x *= (b & 1u) ? 1.f : 0.01f; v.y *= (b & 2u) ? 1.f : 0.01f; v.z *= (b & 4u) ? 1.f : 0.01f; v.w *= (b & 8u) ? 1.f : 0.01f;
-        *reinterpret_cast<float4 *>(H + row * ldh + c4 * 4) = v;
-        *reinterpret_cast<float4 *>(D + (grow0 + row) * ldd + c4 * 4) = v;
-    }
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) acc[mt][ct][reg] = 0.f;
 }
 
 // ---- saved-activation area (training) -------------------------------------------------------
@@ -207,7 +240,7 @@ struct PnSaved {
     // per neighbor row (rows = row tiles * 64)
     float *x0, *h1, *h2, *h3, *h4, *ex, *dy1, *dy2, *dy3, *dy4;
     int4 *rmeta;                        // per row: {sample id or -1, point id or -1, bits(normalised weight), bits(final weight)}
-    unsigned long long *lmask;          // [row tiles][3 layers h1..h3][PN_NTHR]: LeakyReLU sign bits (pn_tile_copy_out_bits)
+    unsigned long long *lmask;          // [row tiles][3 layers h1..h3][PN_NTHR]: LeakyReLU sign bits (pn_acc_to_lds_bits)
     // per valid sample (padded to colour tiles * 64)
     float *fs, *pe, *c1, *c2, *c3, *dfs, *dc1, *dc2, *dc3;
     long long rows, samples;

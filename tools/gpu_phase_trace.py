@@ -38,15 +38,14 @@ def read(name):
 
 
 FWD_GEMM = [(2, 3), (5, 6), (8, 9), (11, 12)]
-BWD_GEMM = [(5, 6), (9, 10), (13, 14), (17, 18)]
+BWD_GEMM = [(3, 4), (4, 5), (6, 7), (8, 9), (9, 10), (10, 11), (11, 12), (12, 13)]
 FWD_NAMES = {(0, 1): "sidx+gather+PE", (1, 2): "weights+x0 copy-out", (2, 3): "GEMM1", (3, 4): "acc->lds", (4, 5): "copy-out h1", (5, 6): "GEMM2",
              (6, 7): "acc->lds", (7, 8): "copy-out h2", (8, 9): "GEMM3", (9, 10): "acc->lds", (10, 11): "copy-out h3", (11, 12): "GEMM4",
              (12, 13): "acc->lds", (13, 14): "copy-out h4", (14, 15): "alpha head", (15, 16): "K-sums"}
-BWD_NAMES = {(0, 1): "load h4/meta", (1, 2): "alpha head+conf atomics", (2, 3): "dW5", (3, 4): "dY4 pass", (4, 5): "colsum b4", (5, 6): "GEMM4",
-             (6, 7): "acc->lds", (7, 8): "mask pass h3", (8, 9): "colsum+extras+atomics", (9, 10): "GEMM3", (10, 11): "acc->lds", (11, 12): "mask pass h2",
-             (12, 13): "colsum b2", (13, 14): "GEMM2", (14, 15): "acc->lds", (15, 16): "mask pass h1", (16, 17): "colsum b1", (17, 18): "GEMM1",
-             (18, 19): "acc->lds", (19, 20): "emb grad atomics"}
-
+BWD_NAMES = {(0, 1): "load A,B", (1, 2): "alpha head A,B", (2, 3): "dY4 pass A,B", (3, 4): "G(A,4)", (4, 5): "G(B,4) | E(A)", (5, 6): "extras A",
+             (6, 7): "G(A,3) | E(B), copy A", (7, 8): "extras B", (8, 9): "G(B,3) | E(A), copy B", (9, 10): "G(A,2) | E(B), copy A",
+             (10, 11): "G(B,2) | E(A), copy B", (11, 12): "G(A,1) | E(B), copy A", (12, 13): "G(B,1) | E(A), copy B", (13, 14): "E1(B) plain",
+             (14, 15): "emb grad A,B"}
 
 def analyse(tr, names, gemm, last):
     t = tr[:, :, :last + 1].astype(np.int64)
@@ -60,7 +59,7 @@ def analyse(tr, names, gemm, last):
         dur["%02d-%02d %s" % (a, b, n)] = [round(float(d.mean()), 2), round(float(np.percentile(d, 90)), 2)]
     res["phase_us_mean_p90"] = dur
     it = (t[:, 1:, 0] - t[:, :-1, 0]).astype(np.float64) * 0.01
-    res["tile_iteration_us_mean"] = round(float(it.mean()), 2)
+    res["tile_iteration_us_mean"] = round(float(it.mean()), 2)       # backward: one iteration = a PAIR of tiles
     res["gemm_us_per_tile"] = round(float(sum((t[:, :, b] - t[:, :, a]).mean() for a, b in gemm) * 0.01), 2)
     # pair workgroups by CU: xcc id (high word) + HW_ID bits 8..15 (cu, sh, se)
     key = ((hw >> np.uint64(32)) & np.uint64(0xF)) * np.uint64(65536) + (hw & np.uint64(0xFF00))
@@ -100,4 +99,4 @@ def analyse(tr, names, gemm, last):
 fwd, bwd = read("pnerf_debug_trace_fwd"), read("pnerf_debug_trace_bwd")
 os.makedirs("gpurun_out", exist_ok=True)
 np.savez_compressed("gpurun_out/phase_trace.npz", fwd=fwd, bwd=bwd)
-print(json.dumps({"forward": analyse(fwd, FWD_NAMES, FWD_GEMM, 16), "backward": analyse(bwd, BWD_NAMES, BWD_GEMM, 20)}, indent=1))
+print(json.dumps({"forward": analyse(fwd, FWD_NAMES, FWD_GEMM, 16), "backward": analyse(bwd, BWD_NAMES, BWD_GEMM, 15)}, indent=1))
