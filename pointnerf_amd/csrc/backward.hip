@@ -349,6 +349,209 @@ __device__ __forceinline__ void b2_epi_piece(const f32x16 (&acc)[2][2], unsigned
 #ifdef PN_PHASE_TRACE
 PN_TR_DECL(pn_trace_bwd);
 #endif
+// ---- the tile-boundary program, one slot at a time in the MFMA shadows of the OTHER tile's GEMM --------------------------
+// Between a tile's last GEMM (layer 1) and the first GEMM of the tile that replaces it in the same LDS buffer lie: E1
+// (d X0 accumulators -> LDS), the embedding gradient, the next tile's loads, its alpha head and its dY4 pass -- four
+// workgroup barriers and ~1300 instructions.  All of it is issued by the waves that run the other tile's 512-MFMA GEMM.
+// Everything from HBM is requested in ONE burst at slot 0 (a second burst would stall the GEMM's own operand loads a second
+// time: vmcnt retires in order).  Slot map:
+//   0..8   burst: saved sin/cos of the finished tile (for the embedding gradient), next tile's masks / row metadata / h4 / d f
+//   10..73 E1: accumulator element s-10 -> LDS                                  75: barrier
+//   77..140 embedding gradient, one embedding dim per 8 slots                   141: barrier (buffer free)
+//   143..161 next tile: state, metadata and the staged h4 / d f rows -> LDS     240: d sigma -> LDS   244: barrier
+//   246..312 alpha head (one float4 column group per 4 slots, loads two slots ahead of use)  314, 316: reduce, softplus', d conf   320: barrier
+//   322..449 dY4 pass (one tile row group per 8 slots)         452: d b5
+// A piece never consumes an LDS / HBM value in the slot that requested it (the wave would wait, and the MFMA stream with it),
+// and stays under ~12 instructions (the shadow of one MFMA).
+struct B2Bnd {
+    float4 xs[6 * EPT / 4];      // saved (sin, cos) x 3 octaves x EPT dims of this thread's row of the finished tile
+    float4 h4[16], df[2];        // staged rows of the next tile
+    unsigned long long nm1, nm2, nm3;
+    int4 rm;
+    float dsgv, s, dotf;
+    float4 hv, g4, o;            // dY4 pass registers
+    float wv, drv; int siv;
+    float dxv[7];
+    long long ntile; bool nvalid;
+#ifdef PN_PHASE_TRACE
+    int titer, trbase;
+#endif
+};
+
+template <int SLOT, bool DFS_LDS>
+__device__ __forceinline__ void b2_boundary_slot(const BwdArgs &a, const B2Tile &T, B2State &S, const f32x16 (&acc)[2][2], float *wy, B2Bnd &C,
+                                                 long long next_tile, long long ntiles, const float *w5s, float b5, int tl, int TS, int K,
+                                                 float4 &gb4v, float4 &gw5v, float &gb5t) {
+    const int rrow = tl / TPR, rq = tl % TPR;
+    constexpr int S_E1 = 10, S_EMB = 77, S_NEXT = 143, S_ALPHA = 246, S_DY4 = 322;
+    // ---- one burst of requests
+    if constexpr (SLOT < 3) {
+        const float *x0 = a.sv.x0 + (S.tile * PN_TILE + rrow) * PN_IN1P + PN_F + 6 * EPT * rq;
+#pragma unroll
+        for (int i = SLOT * 4; i < SLOT * 4 + 4; ++i) C.xs[i] = *reinterpret_cast<const float4 *>(x0 + 4 * i);
+        if (SLOT == 0) { C.ntile = next_tile; C.nvalid = next_tile < ntiles; }
+    }
+    if constexpr (SLOT == 3) {
+        const long long te = C.nvalid ? C.ntile : ntiles;          // an invalid tile reads the (allocated) padding tile and is masked out below
+        C.nm1 = a.sv.lmask[(te * 3 + 0) * PN_NTHR + tl];
+        C.nm2 = a.sv.lmask[(te * 3 + 1) * PN_NTHR + tl];
+        C.nm3 = a.sv.lmask[(te * 3 + 2) * PN_NTHR + tl];
+        C.rm = a.sv.rmeta[te * PN_TILE + (tl & 63)];
+    }
+    if constexpr (SLOT >= 4 && SLOT < 8) {
+        const long long te = C.nvalid ? C.ntile : ntiles;
+#pragma unroll
+        for (int i = (SLOT - 4) * 4; i < (SLOT - 4) * 4 + 4; ++i)
+            C.h4[i] = *reinterpret_cast<const float4 *>(a.sv.h4 + (te * PN_TILE + (tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4);
+    }
+    if constexpr (DFS_LDS && SLOT == 8) {
+        const long long te = C.nvalid ? C.ntile : ntiles;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) C.df[i] = *reinterpret_cast<const float4 *>(a.sv.dfs + (te * TS + (tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4);
+    }
+    // ---- E1 of the finished tile
+    if constexpr (SLOT >= S_E1 && SLOT < S_E1 + 64) {
+        float gd[2] = {0.f, 0.f};
+        b2_epi_piece<SLOT - S_E1, false>(acc, 0u, 0u, wy, gd);
+    }
+    if constexpr (SLOT == 75 || SLOT == 141 || SLOT == 244 || SLOT == 320) __syncthreads();
+#ifdef PN_PHASE_TRACE
+    if constexpr (SLOT == 0 || SLOT == 3 || SLOT == 9 || SLOT == 17 || SLOT == 34 || SLOT == 50 || SLOT == 74 || SLOT == 140 || SLOT == 243 || SLOT == 319) {
+        constexpr int k = SLOT == 0 ? 0 : SLOT == 3 ? 1 : SLOT == 9 ? 2 : SLOT == 17 ? 3 : SLOT == 34 ? 4 : SLOT == 50 ? 5 : SLOT == 74 ? 6 : SLOT == 140 ? 7 : SLOT == 243 ? 8 : 9;
+        const int tid = threadIdx.x, titer = C.titer;
+        if (C.trbase >= 0) PN_TR(pn_trace_bwd, C.trbase + k);
+    }
+#endif
+    // ---- embedding gradient of the finished tile: dim i of this thread at slots S_EMB + 8 i (+0 LDS reads, +3 / +5 math, +6 atomic)
+    if constexpr (SLOT >= S_EMB && SLOT < S_EMB + 64 && (SLOT - S_EMB) % 8 == 0) {
+        constexpr int i = (SLOT - S_EMB) / 8;
+        const float *dx = T.buf + rrow * LDH;
+        const int dd = EPT * rq + i;
+        C.dxv[0] = dx[dd];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            const float2 t = *reinterpret_cast<const float2 *>(dx + PN_F + dd * 6 + 2 * f);
+            C.dxv[1 + 2 * f] = t.x; C.dxv[2 + 2 * f] = t.y;
+        }
+    }
+    if constexpr (SLOT >= S_EMB && SLOT < S_EMB + 64 && (SLOT - S_EMB) % 8 == 3) {
+        constexpr int i = (SLOT - S_EMB) / 8;
+        const float *xf = reinterpret_cast<const float *>(C.xs);
+        C.dxv[0] += (C.dxv[1] * xf[(i * 3) * 2 + 1] - C.dxv[2] * xf[(i * 3) * 2]) + 2.f * (C.dxv[3] * xf[(i * 3 + 1) * 2 + 1] - C.dxv[4] * xf[(i * 3 + 1) * 2]);
+        asm volatile("" : "+v"(C.dxv[0]));
+    }
+    if constexpr (SLOT >= S_EMB && SLOT < S_EMB + 64 && (SLOT - S_EMB) % 8 == 5) {
+        constexpr int i = (SLOT - S_EMB) / 8;
+        const float *xf = reinterpret_cast<const float *>(C.xs);
+        const float g = C.dxv[0] + 4.f * (C.dxv[5] * xf[(i * 3 + 2) * 2 + 1] - C.dxv[6] * xf[(i * 3 + 2) * 2]);
+        if (S.rp >= 0) atomicAdd(&a.g_emb[(long long)S.rp * PN_F + EPT * rq + i], g);
+    }
+    // ---- the next tile takes over the buffer
+    if constexpr (SLOT == S_NEXT) {
+        S.tile = C.nvalid ? C.ntile : ntiles; S.valid = C.nvalid;      // an invalid tile lives on the padding tile's storage
+        S.m1 = C.nvalid ? C.nm1 : 0ull; S.m2 = C.nvalid ? C.nm2 : 0ull; S.m3 = C.nvalid ? C.nm3 : 0ull;
+        S.rdx = S.rdy = S.rdz = 0.f;
+        const int si = C.nvalid ? C.rm.x : -1;
+        C.dsgv = 0.f;
+        if (si >= 0) C.dsgv = a.grad_decoded[(long long)si * 4];
+        if (tl < PN_TILE) {
+            T.sidx[tl] = si; T.prow[tl] = C.nvalid ? C.rm.y : -1;
+            T.wnrm[tl] = C.nvalid ? __int_as_float(C.rm.z) : 0.f; T.wrow[tl] = C.nvalid ? __int_as_float(C.rm.w) : 0.f;
+        }
+    }
+    if constexpr (SLOT > S_NEXT && SLOT <= S_NEXT + 16) {
+        constexpr int i = SLOT - S_NEXT - 1;
+        *reinterpret_cast<float4 *>(T.buf + ((tl >> 6) + 4 * i) * LDH + (tl & 63) * 4) = C.h4[i];
+    }
+    if constexpr (DFS_LDS && (SLOT == S_NEXT + 17 || SLOT == S_NEXT + 18)) {
+        constexpr int i = SLOT - S_NEXT - 17;
+        *reinterpret_cast<float4 *>(T.dfs + ((tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4) = C.df[i];
+    }
+    if constexpr (SLOT == 240) {
+        if (tl < PN_TILE) T.dsg[tl] = C.dsgv;
+    }
+    // ---- alpha head of the next tile: float4 column group j loaded at S_ALPHA + 1 + 4 j, consumed two slots later
+    if constexpr (SLOT == S_ALPHA) {
+        S.rsi = T.sidx[rrow]; S.rp = T.prow[rrow];
+        C.s = 0.f; C.dotf = 0.f;
+        if (rq == 0 && S.rp >= 0) {
+            const int r = S.rsi / a.SR;
+            S.rdx = a.raydir[3 * r]; S.rdy = a.raydir[3 * r + 1]; S.rdz = a.raydir[3 * r + 2];
+        }
+    }
+    if constexpr (SLOT > S_ALPHA && SLOT <= S_ALPHA + 64 && (SLOT - S_ALPHA - 1) % 4 == 0) {
+        constexpr int j = (SLOT - S_ALPHA - 1) / 4;
+        const int rls = rrow / K;
+        C.hv = *reinterpret_cast<const float4 *>(T.buf + rrow * LDH + rq * 4 + 16 * j);
+        C.g4 = DFS_LDS ? *reinterpret_cast<const float4 *>(T.dfs + rls * PN_H + rq * 4 + 16 * j)
+                       : *reinterpret_cast<const float4 *>(a.sv.dfs + (S.tile * TS + rls) * PN_H + rq * 4 + 16 * j);
+        C.o = *reinterpret_cast<const float4 *>(w5s + rq * 4 + 16 * j);
+    }
+    if constexpr (SLOT > S_ALPHA && SLOT <= S_ALPHA + 66 && (SLOT - S_ALPHA - 1) % 4 == 2) {
+        C.s += C.hv.x * C.o.x + C.hv.y * C.o.y + C.hv.z * C.o.z + C.hv.w * C.o.w;
+        C.dotf += C.hv.x * C.g4.x + C.hv.y * C.g4.y + C.hv.z * C.g4.z + C.hv.w * C.g4.w;
+        asm volatile("" : "+v"(C.s), "+v"(C.dotf));
+    }
+    if constexpr (SLOT == 314) {
+        C.s = group_sum_b<TPR>(C.s);
+        C.dotf = group_sum_b<TPR>(C.dotf);
+    }
+    if constexpr (SLOT == 316) {
+        if (rq == 0) {
+            float dr = 0.f;
+            if (S.rsi >= 0) {
+                const float x = C.s + b5 - 1.0f;
+                const float alpha = x > 20.f ? x : log1pf(expf(x));
+                const float sg = x > 20.f ? 1.f : 1.0f / (1.0f + expf(-x));
+                if (S.rp >= 0) atomicAdd(&a.g_conf[S.rp], (T.dsg[rrow] * alpha + C.dotf) * T.wnrm[rrow]);
+                dr = T.dsg[rrow] * T.wrow[rrow] * sg;
+            }
+            T.draw[rrow] = dr;
+        }
+    }
+    // ---- dY4 pass of the next tile: row group i at slots S_DY4 + 8 i: +0 LDS reads, +2 / +3 math, +4 partial sums, +5 LDS write, +6 HBM store
+    if constexpr (SLOT >= S_DY4 && SLOT < S_DY4 + 128 && (SLOT - S_DY4) % 8 == 0) {
+        constexpr int i = (SLOT - S_DY4) / 8;
+        const int row = (tl >> 6) + 4 * i, c4 = tl & 63;
+        C.siv = T.sidx[row];
+        C.hv = *reinterpret_cast<const float4 *>(T.buf + row * LDH + c4 * 4);
+        C.g4 = DFS_LDS ? *reinterpret_cast<const float4 *>(T.dfs + (row / K) * PN_H + c4 * 4)
+                       : *reinterpret_cast<const float4 *>(a.sv.dfs + (S.tile * TS + row / K) * PN_H + c4 * 4);
+        C.wv = T.wrow[row]; C.drv = T.draw[row];
+    }
+    if constexpr (SLOT >= S_DY4 && SLOT < S_DY4 + 128 && ((SLOT - S_DY4) % 8 == 2 || (SLOT - S_DY4) % 8 == 3)) {
+        const float4 w5 = *reinterpret_cast<const float4 *>(w5s + (tl & 63) * 4);
+        const float m = C.siv >= 0 ? 1.f : 0.f;                     // invalid rows: kills garbage d f / h4 of the padding tile too
+        const float w = C.wv * m, dr = C.drv * m;
+        if ((SLOT - S_DY4) % 8 == 2) {
+            C.o.x = C.siv >= 0 ? (w * C.g4.x + dr * w5.x) * pn_lrelu_grad(C.hv.x) : 0.f;
+            C.o.y = C.siv >= 0 ? (w * C.g4.y + dr * w5.y) * pn_lrelu_grad(C.hv.y) : 0.f;
+            asm volatile("" : "+v"(C.o.x), "+v"(C.o.y));
+        } else {
+            C.o.z = C.siv >= 0 ? (w * C.g4.z + dr * w5.z) * pn_lrelu_grad(C.hv.z) : 0.f;
+            C.o.w = C.siv >= 0 ? (w * C.g4.w + dr * w5.w) * pn_lrelu_grad(C.hv.w) : 0.f;
+            asm volatile("" : "+v"(C.o.z), "+v"(C.o.w));
+        }
+    }
+    if constexpr (SLOT >= S_DY4 && SLOT < S_DY4 + 128 && (SLOT - S_DY4) % 8 == 4) {
+        const float dr = C.siv >= 0 ? C.drv : 0.f;
+        gw5v.x += dr * C.hv.x; gw5v.y += dr * C.hv.y; gw5v.z += dr * C.hv.z; gw5v.w += dr * C.hv.w;
+        gb4v.x += C.o.x; gb4v.y += C.o.y; gb4v.z += C.o.z; gb4v.w += C.o.w;
+        asm volatile("" : "+v"(gw5v.x), "+v"(gw5v.y), "+v"(gw5v.z), "+v"(gw5v.w), "+v"(gb4v.x), "+v"(gb4v.y), "+v"(gb4v.z), "+v"(gb4v.w));
+    }
+    if constexpr (SLOT >= S_DY4 && SLOT < S_DY4 + 128 && (SLOT - S_DY4) % 8 == 5) {
+        constexpr int i = (SLOT - S_DY4) / 8;
+        *reinterpret_cast<float4 *>(T.buf + ((tl >> 6) + 4 * i) * LDH + (tl & 63) * 4) = C.o;
+    }
+    if constexpr (SLOT >= S_DY4 && SLOT < S_DY4 + 128 && (SLOT - S_DY4) % 8 == 6) {
+        constexpr int i = (SLOT - S_DY4) / 8;
+        *reinterpret_cast<float4 *>(a.sv.dy4 + (S.tile * PN_TILE + (tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4) = C.o;
+    }
+    if constexpr (SLOT == 452) {
+        if (tl < PN_TILE) gb5t += T.draw[tl];
+    }
+}
+
 // DFS_LDS: the tile's d f rows (TS x 256 floats) fit the 8 KB LDS region (K >= 8); otherwise they are read from HBM/L2.
 template <bool DFS_LDS>
 __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_backward(BwdArgs a) {
@@ -376,8 +579,19 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_backward(BwdArgs a) {
         for (int c = 0; c < 4; ++c) gw3e[j][c] = 0.f;
     float gb5t = 0.f;
     f32x16 accA[2][2], accB[2][2];
+    pn_acc_zero(accA); pn_acc_zero(accB);
     B2State SA, SB;
-
+    B2Bnd CB;
+    float4 bpre[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};   // chunk-0 weight fragments of the next GEMM
+    if ((long long)blockIdx.x * 2 < ntiles) {
+        // prologue: the first tile of buffer A, plain; buffer B starts as an empty finished tile (zero accumulators, no rows)
+        b2_load<DFS_LDS>(a, TA, SA, 2 * (long long)blockIdx.x, ntiles, tid, TS);
+        SB.tile = ntiles; SB.valid = false; SB.m1 = SB.m2 = SB.m3 = 0ull; SB.rdx = SB.rdy = SB.rdz = 0.f; SB.rsi = -1; SB.rp = -1;
+        __syncthreads();
+        b2_alpha<DFS_LDS>(a, TA, SA, w5s, b5, tid, TS, K);
+        __syncthreads();
+        b2_dy4<DFS_LDS>(a, TA, SA, w5s, tid, TS, K, gb4v, gw5v, gb5t);
+    }
 #ifdef PN_PHASE_TRACE
     int titer = -1;
 #endif
@@ -391,33 +605,30 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_backward(BwdArgs a) {
         const int lane = tl & 63, wave = tl >> 6;
         __syncthreads();
         PN_TR(pn_trace_bwd, 0); PN_TR_HWID(pn_trace_bwd);
-        b2_load<DFS_LDS>(a, TA, SA, 2 * pair, ntiles, tl, TS);
-        b2_load<DFS_LDS>(a, TB, SB, 2 * pair + 1, ntiles, tl, TS);
-        __syncthreads();
-        PN_TR(pn_trace_bwd, 1);
-        b2_alpha<DFS_LDS>(a, TA, SA, w5s, b5, tl, TS, K);
-        b2_alpha<DFS_LDS>(a, TB, SB, w5s, b5, tl, TS, K);
-        __syncthreads();
-        PN_TR(pn_trace_bwd, 2);
-        b2_dy4<DFS_LDS>(a, TA, SA, w5s, tl, TS, K, gb4v, gw5v, gb5t);
-        b2_dy4<DFS_LDS>(a, TB, SB, w5s, tl, TS, K, gb4v, gw5v, gb5t);
-        __syncthreads();
-        PN_TR(pn_trace_bwd, 3);
-
         float *wyA = TA.buf + (4 * (lane >> 5)) * LDH + wave * 64 + (lane & 31);     // accumulator-layout write base
         float *wyB = TB.buf + (4 * (lane >> 5)) * LDH + wave * 64 + (lane & 31);
         const float *rxA = TA.buf + wave * LDH + lane * 4, *rxB = TB.buf + wave * LDH + lane * 4;   // copy-out read base (+ 4*i rows)
-        const long long gA = SA.tile * PN_TILE + wave, gB = SB.tile * PN_TILE + wave;           // copy-out row base (+ 4*i)
+        const long long gA = SA.tile * PN_TILE + wave;                                  // copy-out row base (+ 4*i)
+        const long long nextB = 2 * pair + 1, nextA = 2 * (pair + gridDim.x);
         float4 cpv = make_float4(0.f, 0.f, 0.f, 0.f), exa = cpv, exb2 = cpv;
+        float gnone[2] = {0.f, 0.f};
+        if (pair == (long long)blockIdx.x) pn_gemm_prefetch_b0(a.packed + PK_D4 / 4, wave, lane, bpre);
+#ifdef PN_PHASE_TRACE
+        CB.titer = titer; CB.trbase = 11;
+#endif
 
         // one G step: GEMM of tile X (LDS XB, accumulators ACCX, weight image PK) with, in the MFMA shadows,
-        //   E (MASKED: x LeakyReLU' of mask word MY, column sums into GBY) of the other tile's accumulators ACCY -> WY, and
-        //   the copy-out of X's own finished rows RX -> DST (COPY), plus the W3-extras gradient (EXTRAS)
-#define B2_STEP(XB, ACCX, PK, ACCY, MY, WY, GBY, EPI, MASKED, COPY, EXTRAS, RX, DST, GROW, XVALID)                                   \
+        //   E (MASKED: x LeakyReLU' of mask word MY, column sums into GBY) of the other tile's accumulators ACCY -> WY,
+        //   the copy-out of X's own finished rows RX -> DST (COPY), plus the W3-extras gradient (EXTRAS), and
+        //   optionally the whole boundary program of the other tile (BND)
+#define B2_NOBND(s_) (void)0
+#define B2_BND_B(s_) b2_boundary_slot<s_, DFS_LDS>(a, TB, SB, accB, wyB, CB, nextB, ntiles, w5s, b5, tl, TS, K, gb4v, gw5v, gb5t)
+#define B2_BND_A(s_) b2_boundary_slot<s_, DFS_LDS>(a, TA, SA, accA, wyA, CB, nextA, ntiles, w5s, b5, tl, TS, K, gb4v, gw5v, gb5t)
+#define B2_STEP(XB, ACCX, PK, PKNEXT, ACCY, MY, WY, GBY, EPI, MASKED, COPY, EXTRAS, RX, DST, GROW, BND)                              \
         {                                                                                                                           \
             const unsigned mlo_ = (unsigned)(MY), mhi_ = (unsigned)((MY) >> 32);                                                    \
             pn_acc_zero(ACCX);                                                                                                      \
-            pn_tile_gemm_side<PN_H / 8>(XB, LDH, a.packed + (PK) / 4, wave, lane, ACCX, [&](auto ss) {                              \
+            pn_tile_gemm_side<PN_H / 8>(XB, LDH, a.packed + (PK) / 4, wave, lane, ACCX, bpre, a.packed + (PKNEXT) / 4, [&](auto ss) { \
                 constexpr int s = decltype(ss)::value;                                                                              \
                 if constexpr (EPI && s % 8 == 0) b2_epi_piece<s / 8, MASKED>(ACCY, mlo_, mhi_, WY, GBY);                            \
                 if constexpr (COPY && EXTRAS && s % 32 == 2) {                                                                      \
@@ -432,39 +643,48 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_backward(BwdArgs a) {
                     gw3e[j_][0] += cpv.x * e_; gw3e[j_][1] += cpv.y * e_; gw3e[j_][2] += cpv.z * e_; gw3e[j_][3] += cpv.w * e_;      \
                     asm volatile("" : "+v"(gw3e[j_][0]), "+v"(gw3e[j_][1]), "+v"(gw3e[j_][2]), "+v"(gw3e[j_][3]));                    \
                 }                                                                                                                   \
+                BND(s);                                                                                                             \
             });                                                                                                                     \
             __syncthreads();                                                                                                        \
         }
-        float gnone[2] = {0.f, 0.f};
-        //      X-tile   accX  image  accY  maskY  writeY gbY    EPI    MASK   COPY   EXTRAS readX dst        rowbase valid
-        B2_STEP(TA.buf, accA, PK_D4, accB, 0ull, wyB, gnone, false, false, false, false, rxA, a.sv.dy3, gA, SA.valid)
-        PN_TR(pn_trace_bwd, 4);
-        B2_STEP(TB.buf, accB, PK_D4, accA, SA.m3, wyA, gb[2], true, true, false, false, rxB, a.sv.dy3, gB, SB.valid)
-        PN_TR(pn_trace_bwd, 5);
+        //      X-tile   accX  image  accY  maskY  writeY gbY    EPI    MASK   COPY   EXTRAS readX dst        rowbase boundary
+        B2_STEP(TA.buf, accA, PK_D4, PK_D4, accB, 0ull, wyB, gnone, false, false, false, false, rxA, a.sv.dy3, gA, B2_BND_B)
+        PN_TR(pn_trace_bwd, 1);
+        const long long gB = SB.tile * PN_TILE + wave;
+        B2_STEP(TB.buf, accB, PK_D4, PK_D3, accA, SA.m3, wyA, gb[2], true, true, false, false, rxB, a.sv.dy3, gB, B2_NOBND)
+        PN_TR(pn_trace_bwd, 2);
         b2_extras(a, TA, SA, w3ex, tl);
-        PN_TR(pn_trace_bwd, 6);
-        B2_STEP(TA.buf, accA, PK_D3, accB, SB.m3, wyB, gb[2], true, true, true, true, rxA, a.sv.dy3, gA, SA.valid)
-        PN_TR(pn_trace_bwd, 7);
+        PN_TR(pn_trace_bwd, 3);
+        B2_STEP(TA.buf, accA, PK_D3, PK_D3, accB, SB.m3, wyB, gb[2], true, true, true, true, rxA, a.sv.dy3, gA, B2_NOBND)
+        PN_TR(pn_trace_bwd, 4);
         b2_extras(a, TB, SB, w3ex, tl);
+        PN_TR(pn_trace_bwd, 5);
+        B2_STEP(TB.buf, accB, PK_D3, PK_D2, accA, SA.m2, wyA, gb[1], true, true, true, true, rxB, a.sv.dy3, gB, B2_NOBND)
+        PN_TR(pn_trace_bwd, 6);
+        B2_STEP(TA.buf, accA, PK_D2, PK_D2, accB, SB.m2, wyB, gb[1], true, true, true, false, rxA, a.sv.dy2, gA, B2_NOBND)
+        PN_TR(pn_trace_bwd, 7);
+        B2_STEP(TB.buf, accB, PK_D2, PK_D1, accA, SA.m1, wyA, gb[0], true, true, true, false, rxB, a.sv.dy2, gB, B2_NOBND)
         PN_TR(pn_trace_bwd, 8);
-        B2_STEP(TB.buf, accB, PK_D3, accA, SA.m2, wyA, gb[1], true, true, true, true, rxB, a.sv.dy3, gB, SB.valid)
+        B2_STEP(TA.buf, accA, PK_D1, PK_D1, accB, SB.m1, wyB, gb[0], true, true, true, false, rxA, a.sv.dy1, gA, B2_NOBND)
         PN_TR(pn_trace_bwd, 9);
-        B2_STEP(TA.buf, accA, PK_D2, accB, SB.m2, wyB, gb[1], true, true, true, false, rxA, a.sv.dy2, gA, SA.valid)
+#ifdef PN_PHASE_TRACE
+        CB.trbase = -1;
+#endif
+        B2_STEP(TB.buf, accB, PK_D1, PK_D4, accA, 0ull, wyA, gnone, false, false, true, false, rxB, a.sv.dy1, gB, B2_BND_A)
         PN_TR(pn_trace_bwd, 10);
-        B2_STEP(TB.buf, accB, PK_D2, accA, SA.m1, wyA, gb[0], true, true, true, false, rxB, a.sv.dy2, gB, SB.valid)
-        PN_TR(pn_trace_bwd, 11);
-        B2_STEP(TA.buf, accA, PK_D1, accB, SB.m1, wyB, gb[0], true, true, true, false, rxA, a.sv.dy1, gA, SA.valid)
-        PN_TR(pn_trace_bwd, 12);
-        B2_STEP(TB.buf, accB, PK_D1, accA, 0ull, wyA, gnone, true, false, true, false, rxB, a.sv.dy1, gB, SB.valid)
-        PN_TR(pn_trace_bwd, 13);
 #undef B2_STEP
-        // d X0 of tile B: plain epilogue, then the embedding gradients of both tiles
+#undef B2_BND_A
+#undef B2_BND_B
+#undef B2_NOBND
+    }
+    if ((long long)blockIdx.x * 2 < ntiles) {
+        // epilogue: d X0 of the last B tile and its embedding gradient (A's were done inside the last step)
+        const int lane = tid & 63, wave = tid >> 6;
+        float *wyB = TB.buf + (4 * (lane >> 5)) * LDH + wave * 64 + (lane & 31);
+        float gnone[2] = {0.f, 0.f};
         pn_static_for<64>([&](auto rr) { b2_epi_piece<decltype(rr)::value, false>(accB, 0u, 0u, wyB, gnone); });
         __syncthreads();
-        PN_TR(pn_trace_bwd, 14);
-        b2_emb(a, TA, SA, tl);
-        b2_emb(a, TB, SB, tl);
-        PN_TR(pn_trace_bwd, 15);
+        b2_emb(a, TB, SB, tid);
     }
     // flush the register-resident partial sums
     {

@@ -201,19 +201,24 @@ __device__ __forceinline__ unsigned long long pn_acc_to_lds_bits(f32x16 (&acc)[2
 template <int... I, class F> __device__ __forceinline__ void pn_static_for_impl(std::integer_sequence<int, I...>, F &&f) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void pn_static_for(F &&f) { pn_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
+// `bpre` holds this GEMM's chunk-0 weight fragments on entry (requested during the previous GEMM: a step would otherwise
+// start with an exposed L2 round trip) and, on exit, chunk 0 of the NEXT GEMM's image `Wnext` (nullptr: none).
 template <int NCH, class Side>
 __device__ __forceinline__ void pn_tile_gemm_side(const float *__restrict__ A, int lda, const float4 *__restrict__ Wp, int wave, int lane,
-                                                  f32x16 (&acc)[2][2], Side &&side) {
+                                                  f32x16 (&acc)[2][2], float4 (&bpre)[2], const float4 *__restrict__ Wnext, Side &&side) {
     const float *ap = A + (lane & 31) * lda + 4 * (lane >> 5);
     const float4 *wp = Wp + (wave * 2) * 64 + lane;
     float4 a[2][2], b[2][2];
-    b[0][0] = wp[0]; b[0][1] = wp[64];
+    b[0][0] = bpre[0]; b[0][1] = bpre[1];
     a[0][0] = *reinterpret_cast<const float4 *>(ap); a[0][1] = *reinterpret_cast<const float4 *>(ap + 32 * lda);
     pn_static_for<NCH>([&](auto cc) {
         constexpr int c = decltype(cc)::value, cur = c & 1, nxt = cur ^ 1;
         if constexpr (c + 1 < NCH) {
             b[nxt][0] = wp[((c + 1) * 8) * 64]; b[nxt][1] = wp[((c + 1) * 8 + 1) * 64];
             a[nxt][0] = *reinterpret_cast<const float4 *>(ap + 8 * (c + 1)); a[nxt][1] = *reinterpret_cast<const float4 *>(ap + 32 * lda + 8 * (c + 1));
+        } else if (Wnext) {
+            const float4 *wn = Wnext + (wave * 2) * 64 + lane;
+            bpre[0] = wn[0]; bpre[1] = wn[64];
         }
         pn_static_for<16>([&](auto jj) {
             constexpr int j = decltype(jj)::value, i = j >> 2, ct = (j >> 1) & 1, mt = j & 1;
@@ -224,6 +229,11 @@ __device__ __forceinline__ void pn_tile_gemm_side(const float *__restrict__ A, i
             __builtin_amdgcn_sched_barrier(0);
         });
     });
+}
+
+__device__ __forceinline__ void pn_gemm_prefetch_b0(const float4 *__restrict__ Wp, int wave, int lane, float4 (&bpre)[2]) {
+    const float4 *wp = Wp + (wave * 2) * 64 + lane;
+    bpre[0] = wp[0]; bpre[1] = wp[64];
 }
 
 __device__ __forceinline__ void pn_acc_zero(f32x16 (&acc)[2][2]) {

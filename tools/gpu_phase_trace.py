@@ -38,17 +38,19 @@ def read(name):
 
 
 FWD_GEMM = [(2, 3), (5, 6), (8, 9), (11, 12)]
-BWD_GEMM = [(3, 4), (4, 5), (6, 7), (8, 9), (9, 10), (10, 11), (11, 12), (12, 13)]
+BWD_GEMM = [(0, 1), (1, 2), (3, 4), (5, 6), (6, 7), (7, 8), (8, 9), (9, 10)]
 FWD_NAMES = {(0, 1): "sidx+gather+PE", (1, 2): "weights+x0 copy-out", (2, 3): "GEMM1", (3, 4): "acc->lds", (4, 5): "copy-out h1", (5, 6): "GEMM2",
              (6, 7): "acc->lds", (7, 8): "copy-out h2", (8, 9): "GEMM3", (9, 10): "acc->lds", (10, 11): "copy-out h3", (11, 12): "GEMM4",
              (12, 13): "acc->lds", (13, 14): "copy-out h4", (14, 15): "alpha head", (15, 16): "K-sums"}
-BWD_NAMES = {(0, 1): "load A,B", (1, 2): "alpha head A,B", (2, 3): "dY4 pass A,B", (3, 4): "G(A,4)", (4, 5): "G(B,4) | E(A)", (5, 6): "extras A",
-             (6, 7): "G(A,3) | E(B), copy A", (7, 8): "extras B", (8, 9): "G(B,3) | E(A), copy B", (9, 10): "G(A,2) | E(B), copy A",
-             (10, 11): "G(B,2) | E(A), copy B", (11, 12): "G(A,1) | E(B), copy A", (12, 13): "G(B,1) | E(A), copy B", (13, 14): "E1(B) plain",
-             (14, 15): "emb grad A,B"}
+BWD_NAMES = {(0, 1): "G(A,4) | boundary B", (1, 2): "G(B,4) | E(A)", (2, 3): "extras A", (3, 4): "G(A,3) | E(B), copy A", (4, 5): "extras B",
+             (5, 6): "G(B,3) | E(A), copy B", (6, 7): "G(A,2) | E(B), copy A", (7, 8): "G(B,2) | E(A), copy B", (8, 9): "G(A,1) | E(B), copy A",
+             (9, 10): "G(B,1) | copy B, boundary A",
+             (0, 11): "  S1: start -> slot 0", (11, 12): "  S1: slots 0-3", (12, 13): "  S1: slots 3-9", (13, 14): "  S1: slots 9-17", (14, 15): "  S1: slots 17-34",
+             (15, 16): "  S1: slots 34-50", (16, 17): "  S1: slots 50-74", (17, 18): "  S1: slots 74-140", (18, 19): "  S1: slots 140-243",
+             (19, 20): "  S1: slots 243-319", (20, 1): "  S1: slots 319-511 + barrier"}
 
 def analyse(tr, names, gemm, last):
-    t = tr[:, :, :last + 1].astype(np.int64)
+    t = tr[:, :, :max(last, max(max(k) for k in names)) + 1].astype(np.int64)
     ok = (t[:, :, 0] > 0).all(axis=1) & (t[:, :, last] > 0).all(axis=1)
     t = t[ok]
     hw = tr[ok, 0, SLOTS - 1]
@@ -99,4 +101,4 @@ def analyse(tr, names, gemm, last):
 fwd, bwd = read("pnerf_debug_trace_fwd"), read("pnerf_debug_trace_bwd")
 os.makedirs("gpurun_out", exist_ok=True)
 np.savez_compressed("gpurun_out/phase_trace.npz", fwd=fwd, bwd=bwd)
-print(json.dumps({"forward": analyse(fwd, FWD_NAMES, FWD_GEMM, 16), "backward": analyse(bwd, BWD_NAMES, BWD_GEMM, 15)}, indent=1))
+print(json.dumps({"forward": analyse(fwd, FWD_NAMES, FWD_GEMM, 16), "backward": analyse(bwd, BWD_NAMES, BWD_GEMM, 10)}, indent=1))
