@@ -171,6 +171,8 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    if not np.isfinite(float(loss.item())):
+        raise SystemExit("bench.py: non-finite loss after %d steps -- the timed path produced NaN/Inf, the number would be meaningless" % total)
     if rank == 0:
         rays_total = args.rays * world * args.steps
         rows = float(np.mean([s["n_neighbor_rows"] for s in stats])); smp = float(np.mean([s["n_valid_samples"] for s in stats]))

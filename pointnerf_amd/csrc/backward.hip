@@ -8,7 +8,7 @@
 //   k_agg_backward   : TS samples x K rows per tile; (d sigma, d f) -> alpha head, K-weighted sums,
 //                      block3/block1 dgrad on MFMA, PE chain rule, atomic scatter-add into the
 //                      embedding / colour / dir / conf gradients of the touched points only
-//   k_wgrad          : dW = dY^T X as split-K MFMA GEMMs over the saved activations, full dW tile
+//   k_wgrad_lds      : dW = dY^T X as split-K MFMA GEMMs over the saved activations, full dW tile
 //                      resident in accumulators, deterministic partial-sum reduction
 // LeakyReLU masks come from the saved post-activations (sign(post) == sign(pre)).
 #include "mlp_common.h"
@@ -17,7 +17,7 @@ namespace {
 constexpr int LDH = 260;
 constexpr int LDC = 132;
 constexpr int WG_CHUNKS = 256;                 // split-K factor of the wgrad GEMMs
-constexpr size_t PARTIAL_FLOATS = (size_t)WG_CHUNKS * PN_H * PN_H;
+constexpr size_t PARTIAL_FLOATS = (size_t)WG_CHUNKS * PN_H * PN_IN1P;
 
 struct BwdArgs {
     pnerf_camera cam;
@@ -401,13 +401,18 @@ __device__ __forceinline__ void b2_boundary_slot(const BwdArgs &a, const B2Tile 
     if constexpr (SLOT >= 4 && SLOT < 8) {
         const long long te = C.nvalid ? C.ntile : ntiles;
 #pragma unroll
-        for (int i = (SLOT - 4) * 4; i < (SLOT - 4) * 4 + 4; ++i)
-            C.h4[i] = *reinterpret_cast<const float4 *>(a.sv.h4 + (te * PN_TILE + (tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4);
+        for (int i = (SLOT - 4) * 4; i < (SLOT - 4) * 4 + 4; ++i) {
+            C.h4[i] = make_float4(0.f, 0.f, 0.f, 0.f);     // (an invalid tile must not bring the padding tile's garbage in: 0 * NaN)
+            if (C.nvalid) C.h4[i] = *reinterpret_cast<const float4 *>(a.sv.h4 + (te * PN_TILE + (tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4);
+        }
     }
     if constexpr (DFS_LDS && SLOT == 8) {
         const long long te = C.nvalid ? C.ntile : ntiles;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) C.df[i] = *reinterpret_cast<const float4 *>(a.sv.dfs + (te * TS + (tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4);
+        for (int i = 0; i < 2; ++i) {
+            C.df[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (C.nvalid) C.df[i] = *reinterpret_cast<const float4 *>(a.sv.dfs + (te * TS + (tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4);
+        }
     }
     // ---- E1 of the finished tile
     if constexpr (SLOT >= S_E1 && SLOT < S_E1 + 64) {
@@ -624,7 +629,7 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_backward(BwdArgs a) {
 #define B2_NOBND(s_) (void)0
 #define B2_BND_B(s_) b2_boundary_slot<s_, DFS_LDS>(a, TB, SB, accB, wyB, CB, nextB, ntiles, w5s, b5, tl, TS, K, gb4v, gw5v, gb5t)
 #define B2_BND_A(s_) b2_boundary_slot<s_, DFS_LDS>(a, TA, SA, accA, wyA, CB, nextA, ntiles, w5s, b5, tl, TS, K, gb4v, gw5v, gb5t)
-#define B2_STEP(XB, ACCX, PK, PKNEXT, ACCY, MY, WY, GBY, EPI, MASKED, COPY, EXTRAS, RX, DST, GROW, BND)                              \
+#define B2_STEP(XB, ACCX, PK, PKNEXT, ACCY, MY, WY, GBY, EPI, MASKED, COPY, EXTRAS, RX, DST, GROW, XVALID, BND)                      \
         {                                                                                                                           \
             const unsigned mlo_ = (unsigned)(MY), mhi_ = (unsigned)((MY) >> 32);                                                    \
             pn_acc_zero(ACCX);                                                                                                      \
@@ -633,7 +638,8 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_backward(BwdArgs a) {
                 if constexpr (EPI && s % 8 == 0) b2_epi_piece<s / 8, MASKED>(ACCY, mlo_, mhi_, WY, GBY);                            \
                 if constexpr (COPY && EXTRAS && s % 32 == 2) {                                                                      \
                     const float *exr = a.sv.ex + ((GROW) + 4 * (s / 32)) * 8;                                                       \
-                    exa = *reinterpret_cast<const float4 *>(exr); exb2 = *reinterpret_cast<const float4 *>(exr + 4);                \
+                    exa = exb2 = make_float4(0.f, 0.f, 0.f, 0.f);                                                                   \
+                    if (XVALID) { exa = *reinterpret_cast<const float4 *>(exr); exb2 = *reinterpret_cast<const float4 *>(exr + 4); } \
                 }                                                                                                                   \
                 if constexpr (COPY && s % 32 == 4) cpv = *reinterpret_cast<const float4 *>((RX) + 4 * (s / 32) * LDH);              \
                 if constexpr (COPY && s % 32 == 20) *reinterpret_cast<float4 *>((DST) + ((GROW) + 4 * (s / 32)) * PN_H + lane * 4) = cpv; \
@@ -648,29 +654,29 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_backward(BwdArgs a) {
             __syncthreads();                                                                                                        \
         }
         //      X-tile   accX  image  accY  maskY  writeY gbY    EPI    MASK   COPY   EXTRAS readX dst        rowbase boundary
-        B2_STEP(TA.buf, accA, PK_D4, PK_D4, accB, 0ull, wyB, gnone, false, false, false, false, rxA, a.sv.dy3, gA, B2_BND_B)
+        B2_STEP(TA.buf, accA, PK_D4, PK_D4, accB, 0ull, wyB, gnone, false, false, false, false, rxA, a.sv.dy3, gA, SA.valid, B2_BND_B)
         PN_TR(pn_trace_bwd, 1);
         const long long gB = SB.tile * PN_TILE + wave;
-        B2_STEP(TB.buf, accB, PK_D4, PK_D3, accA, SA.m3, wyA, gb[2], true, true, false, false, rxB, a.sv.dy3, gB, B2_NOBND)
+        B2_STEP(TB.buf, accB, PK_D4, PK_D3, accA, SA.m3, wyA, gb[2], true, true, false, false, rxB, a.sv.dy3, gB, SB.valid, B2_NOBND)
         PN_TR(pn_trace_bwd, 2);
         b2_extras(a, TA, SA, w3ex, tl);
         PN_TR(pn_trace_bwd, 3);
-        B2_STEP(TA.buf, accA, PK_D3, PK_D3, accB, SB.m3, wyB, gb[2], true, true, true, true, rxA, a.sv.dy3, gA, B2_NOBND)
+        B2_STEP(TA.buf, accA, PK_D3, PK_D3, accB, SB.m3, wyB, gb[2], true, true, true, true, rxA, a.sv.dy3, gA, SA.valid, B2_NOBND)
         PN_TR(pn_trace_bwd, 4);
         b2_extras(a, TB, SB, w3ex, tl);
         PN_TR(pn_trace_bwd, 5);
-        B2_STEP(TB.buf, accB, PK_D3, PK_D2, accA, SA.m2, wyA, gb[1], true, true, true, true, rxB, a.sv.dy3, gB, B2_NOBND)
+        B2_STEP(TB.buf, accB, PK_D3, PK_D2, accA, SA.m2, wyA, gb[1], true, true, true, true, rxB, a.sv.dy3, gB, SB.valid, B2_NOBND)
         PN_TR(pn_trace_bwd, 6);
-        B2_STEP(TA.buf, accA, PK_D2, PK_D2, accB, SB.m2, wyB, gb[1], true, true, true, false, rxA, a.sv.dy2, gA, B2_NOBND)
+        B2_STEP(TA.buf, accA, PK_D2, PK_D2, accB, SB.m2, wyB, gb[1], true, true, true, false, rxA, a.sv.dy2, gA, SA.valid, B2_NOBND)
         PN_TR(pn_trace_bwd, 7);
-        B2_STEP(TB.buf, accB, PK_D2, PK_D1, accA, SA.m1, wyA, gb[0], true, true, true, false, rxB, a.sv.dy2, gB, B2_NOBND)
+        B2_STEP(TB.buf, accB, PK_D2, PK_D1, accA, SA.m1, wyA, gb[0], true, true, true, false, rxB, a.sv.dy2, gB, SB.valid, B2_NOBND)
         PN_TR(pn_trace_bwd, 8);
-        B2_STEP(TA.buf, accA, PK_D1, PK_D1, accB, SB.m1, wyB, gb[0], true, true, true, false, rxA, a.sv.dy1, gA, B2_NOBND)
+        B2_STEP(TA.buf, accA, PK_D1, PK_D1, accB, SB.m1, wyB, gb[0], true, true, true, false, rxA, a.sv.dy1, gA, SA.valid, B2_NOBND)
         PN_TR(pn_trace_bwd, 9);
 #ifdef PN_PHASE_TRACE
         CB.trbase = -1;
 #endif
-        B2_STEP(TB.buf, accB, PK_D1, PK_D4, accA, 0ull, wyA, gnone, false, false, true, false, rxB, a.sv.dy1, gB, B2_BND_A)
+        B2_STEP(TB.buf, accB, PK_D1, PK_D4, accA, 0ull, wyA, gnone, false, false, true, false, rxB, a.sv.dy1, gB, SB.valid, B2_BND_A)
         PN_TR(pn_trace_bwd, 10);
 #undef B2_STEP
 #undef B2_BND_A
@@ -710,93 +716,43 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_backward(BwdArgs a) {
 
 // ------------------------------------------------------------------------------ weight gradients
 // partial[chunk][m][n] = sum_{r in chunk} A[r][m] B[r][n]   (A = dY [rows,lda], B = X [rows,ldb])
-// Block tile (WM*MT*32) x (WN*NT*32); the whole tile lives in MFMA accumulators, operands stream
-// straight from HBM/L2 in the MFMA fragment layout (lane l: row r + (l>>5), column base + (l&31):
-// two 128-byte segments per load).
-template <int MT, int NT, int WM, int WN>
-__global__ __launch_bounds__(WM *WN * 64) void k_wgrad(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
-                                                       long long rows, int rows_per_chunk, float *__restrict__ partial, int Mtot, int Ntot) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int m0 = wm * MT * 32, n0 = blockIdx.x * (WN * NT * 32) + wn * NT * 32;
-    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
-    long long r1 = r0 + rows_per_chunk;
-    if (r1 > rows) r1 = rows;
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) acc[mt][nt][reg] = 0.f;
-    const float *ap = A + m0 + (lane & 31) + (long long)(lane >> 5) * lda;
-    const float *bp = B + n0 + (lane & 31) + (long long)(lane >> 5) * ldb;
-    constexpr int U = 4;                       // k-steps (2 rows each) per unrolled body
-    long long r = r0;
-    for (; r + 2 * U <= r1; r += 2 * U) {
-        float av[U][MT], bv[U][NT];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[u][mt] = ap[(r + 2 * u) * lda + mt * 32];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[u][nt] = bp[(r + 2 * u) * ldb + nt * 32];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][mt], bv[u][nt], acc[mt][nt], 0, 0, 0);
-    }
-    for (; r + 2 <= r1; r += 2) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[r * lda + mt * 32], bp[r * ldb + nt * 32], acc[mt][nt], 0, 0, 0);
-    }
-    float *out = partial + (size_t)blockIdx.y * Mtot * Ntot;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int m = m0 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                const int n = n0 + nt * 32 + (lane & 31);
-                out[(size_t)m * Ntot + n] = acc[mt][nt][reg];
-            }
-}
-
-// Same GEMM with both operands staged through LDS (each element leaves L2 once per workgroup instead of once per
-// wave that needs it): KB rows of A [KB x Mtot] and B [KB x Ntile] per stage, double-buffered, next stage's global
+// Block tile (WM*MT*32) x (WN*NT*32); the whole tile lives in MFMA accumulators.  Both operands are staged through LDS
+// (each element leaves L2 once per workgroup instead of once per wave that needs it): KB rows of A [KB x Mtot] and B [KB x Ntile] per stage, double-buffered, next stage's global
 // loads in flight during the current stage's MFMAs.  Row strides are exact multiples of 32 floats, so the fragment
 // reads (lane -> column) are conflict-free and lanes l / l+32 (adjacent rows) never share a service group.
-template <int MT, int NT, int WM, int WN, int KB>
+// TAIL: the B operand has 32 more columns in a second array Bt (x0[:, 256:288] for W1, the view PE for the colour layer).
+// They ride in the same pass over A instead of a second kernel that re-reads all of dY: wave w (< MTOT/32) owns the extra
+// 32 x 32 tile of row tile w -- one more MFMA per k-step next to its MT*NT.
+template <int MT, int NT, int WM, int WN, int KB, bool TAIL>
 __global__ __launch_bounds__(WM *WN * 64) void k_wgrad_lds(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+                                                           const float *__restrict__ Bt, int ldbt,
                                                            long long rows, int rows_per_chunk, float *__restrict__ partial, int Ntot) {
     constexpr int NTHR = WM * WN * 64, MTOT = WM * MT * 32, NTILE = WN * NT * 32;
     constexpr int A4 = KB * MTOT / 4 / NTHR, B4 = KB * NTILE / 4 / NTHR;      // float4 per thread per stage
+    constexpr int T4 = KB * 32 / 4;                                            // float4 of the tail stage (threads < T4 carry one)
     static_assert(A4 * 4 * NTHR == KB * MTOT && B4 * 4 * NTHR == KB * NTILE, "stage must divide evenly");
+    static_assert(T4 <= NTHR, "tail stage: one float4 per thread");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                           // [2][KB][MTOT]
     float *Bs = smem + 2 * KB * MTOT;           // [2][KB][NTILE]
+    float *Ts = Bs + 2 * KB * NTILE;            // [2][KB][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = wm * MT * 32, n0l = wn * NT * 32, n0 = blockIdx.x * NTILE;
+    const bool tail_wave = TAIL && wave < MTOT / 32;
     const long long r0 = (long long)blockIdx.y * rows_per_chunk;
     long long r1 = r0 + rows_per_chunk;
     if (r1 > rows) r1 = rows;
-    f32x16 acc[MT][NT];
+    f32x16 acc[MT][NT], acct;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) acct[reg] = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) acc[mt][nt][reg] = 0.f;
-    float4 ra[A4], rb[B4];
+    float4 ra[A4], rb[B4], rt = make_float4(0.f, 0.f, 0.f, 0.f);
     auto gload = [&](long long r) {
 #pragma unroll
         for (int i = 0; i < A4; ++i) {
@@ -808,12 +764,17 @@ __global__ __launch_bounds__(WM *WN * 64) void k_wgrad_lds(const float *__restri
             const int e = (tid + i * NTHR) * 4, kr = e / NTILE, c = e - kr * NTILE;
             rb[i] = (r + kr < r1) ? *reinterpret_cast<const float4 *>(B + (r + kr) * ldb + n0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        if (TAIL && tid < T4) {
+            const int kr = tid / 8, c = (tid % 8) * 4;
+            rt = (r + kr < r1) ? *reinterpret_cast<const float4 *>(Bt + (r + kr) * ldbt + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     };
     auto lstore = [&](int bufi) {
 #pragma unroll
         for (int i = 0; i < A4; ++i) *reinterpret_cast<float4 *>(As + bufi * KB * MTOT + (tid + i * NTHR) * 4) = ra[i];
 #pragma unroll
         for (int i = 0; i < B4; ++i) *reinterpret_cast<float4 *>(Bs + bufi * KB * NTILE + (tid + i * NTHR) * 4) = rb[i];
+        if (TAIL && tid < T4) *reinterpret_cast<float4 *>(Ts + bufi * KB * 32 + tid * 4) = rt;
     };
     if (r0 < r1) {
         gload(r0);
@@ -825,6 +786,8 @@ __global__ __launch_bounds__(WM *WN * 64) void k_wgrad_lds(const float *__restri
             if (more) gload(r + KB);
             const float *ap = As + cur * KB * MTOT + (lane >> 5) * MTOT + m0 + (lane & 31);
             const float *bp = Bs + cur * KB * NTILE + (lane >> 5) * NTILE + n0l + (lane & 31);
+            const float *atp = As + cur * KB * MTOT + (lane >> 5) * MTOT + wave * 32 + (lane & 31);
+            const float *tp = Ts + cur * KB * 32 + (lane >> 5) * 32 + (lane & 31);
 #pragma unroll 4
             for (int k = 0; k < KB; k += 2) {
                 float av[MT], bv[NT];
@@ -837,6 +800,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_wgrad_lds(const float *__restri
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+                if (tail_wave) acct = __builtin_amdgcn_mfma_f32_32x32x2f32(atp[k * MTOT], tp[k * 32], acct, 0, 0, 0);
             }
             if (more) lstore(cur ^ 1);
             __syncthreads();
@@ -854,12 +818,18 @@ __global__ __launch_bounds__(WM *WN * 64) void k_wgrad_lds(const float *__restri
                 const int n = n0 + n0l + nt * 32 + (lane & 31);
                 out[(size_t)m * Ntot + n] = acc[mt][nt][reg];
             }
+    if (tail_wave) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int m = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            out[(size_t)m * Ntot + NTILE + (lane & 31)] = acct[reg];        // TAIL kernels run with a single column block (gridDim.x == 1)
+        }
+    }
 }
 
-// grad[dst + m*ldc + n] += sum_chunk partial[chunk][m][n]   for n < Nreal
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial, int chunks, int Mtot, int Ntot, int Nreal,
-                                                      float *__restrict__ grad, int dst, int ldc) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+// sum the split-K partials: grad[dst + m*ldc + n] += sum_c partial[c][m][n]   (n < Nreal)
+__global__ void k_wgrad_reduce(const float *__restrict__ partial, int chunks, int Mtot, int Ntot, int Nreal, float *__restrict__ grad, int dst, int ldc) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= Mtot * Ntot) return;
     const int m = e / Ntot, n = e - m * Ntot;
     if (n >= Nreal) return;
@@ -868,45 +838,31 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
     grad[dst + m * ldc + n] += s;
 }
 
-template <int MT, int NT, int WM, int WN, int KB>
-int launch_wgrad_lds(const float *A, int lda, const float *B, int ldb, long long rows, float *partial, int Ntot, int Nreal,
+// Ntot / Nreal: padded / real number of B columns INCLUDING the 32-column tail when Bt != nullptr
+template <int MT, int NT, int WM, int WN, int KB, bool TAIL>
+int launch_wgrad_lds(const float *A, int lda, const float *B, int ldb, const float *Bt, int ldbt, long long rows, float *partial, int Ntot, int Nreal,
                      float *grad, int dst, int ldc, hipStream_t s) {
     constexpr int Mtot = WM * MT * 32, NTILE = WN * NT * 32;
-    const int ntiles = Ntot / NTILE;
+    const int ntiles = TAIL ? 1 : Ntot / NTILE;
+    if (TAIL && Ntot != NTILE + 32) return PNERF_E_INVAL;
     int chunks = WG_CHUNKS / ntiles;
+    if ((size_t)chunks * Mtot * Ntot > PARTIAL_FLOATS) chunks = (int)(PARTIAL_FLOATS / ((size_t)Mtot * Ntot));     // the tail widens the tile
     long long rpc = (rows + chunks - 1) / chunks;
     rpc = (rpc + 63) / 64 * 64;
     if (rpc < 64) rpc = 64;
     chunks = (int)((rows + rpc - 1) / rpc);
     if (chunks < 1) chunks = 1;
-    const size_t lds = (size_t)2 * KB * (Mtot + NTILE) * sizeof(float);
-    if (hipFuncSetAttribute((const void *)k_wgrad_lds<MT, NT, WM, WN, KB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PNERF_E_LAUNCH;
+    if ((size_t)chunks * Mtot * Ntot > PARTIAL_FLOATS) return PNERF_E_WS;
+    const size_t lds = (size_t)2 * KB * (Mtot + NTILE + (TAIL ? 32 : 0)) * sizeof(float);
+    if (hipFuncSetAttribute((const void *)k_wgrad_lds<MT, NT, WM, WN, KB, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PNERF_E_LAUNCH;
     { PnProfScope prof(PNK_WGRAD, s);
-    hipLaunchKernelGGL((k_wgrad_lds<MT, NT, WM, WN, KB>), dim3(ntiles, chunks), dim3(WM * WN * 64), lds, s, A, lda, B, ldb, rows, (int)rpc, partial, Ntot); }
+    hipLaunchKernelGGL((k_wgrad_lds<MT, NT, WM, WN, KB, TAIL>), dim3(ntiles, chunks), dim3(WM * WN * 64), lds, s, A, lda, B, ldb, Bt, ldbt, rows, (int)rpc, partial, Ntot); }
     PnProfScope prof(PNK_WGRAD_REDUCE, s);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(pn_cdiv((long long)Mtot * Ntot, 256)), dim3(256), 0, s, partial, chunks, Mtot, Ntot, Nreal, grad, dst, ldc);
     PN_CHECK_LAUNCH();
     return 0;
 }
 
-template <int MT, int NT, int WM, int WN>
-int launch_wgrad(const float *A, int lda, const float *B, int ldb, long long rows, float *partial, int Ntot, int Nreal,
-                 float *grad, int dst, int ldc, hipStream_t s) {
-    constexpr int Mtot = WM * MT * 32;
-    const int ntiles = Ntot / (WN * NT * 32);
-    int chunks = WG_CHUNKS / ntiles;
-    long long rpc = (rows + chunks - 1) / chunks;
-    rpc = (rpc + 63) / 64 * 64;                       // whole row tiles per chunk
-    if (rpc < 64) rpc = 64;
-    chunks = (int)((rows + rpc - 1) / rpc);
-    if (chunks < 1) chunks = 1;
-    { PnProfScope prof(PNK_WGRAD, s);
-    hipLaunchKernelGGL((k_wgrad<MT, NT, WM, WN>), dim3(ntiles, chunks), dim3(WM * WN * 64), 0, s, A, lda, B, ldb, rows, (int)rpc, partial, Mtot, Ntot); }
-    PnProfScope prof(PNK_WGRAD_REDUCE, s);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(pn_cdiv((long long)Mtot * Ntot, 256)), dim3(256), 0, s, partial, chunks, Mtot, Ntot, Nreal, grad, dst, ldc);
-    PN_CHECK_LAUNCH();
-    return 0;
-}
 }  // namespace
 
 size_t pn_wgrad_partials_bytes() { return pn_align(PARTIAL_FLOATS * sizeof(float)); }
@@ -944,18 +900,18 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
       else hipLaunchKernelGGL(k_agg_backward<false>, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a); }
     PN_CHECK_LAUNCH();
     // weight gradients over the rows / samples of the tiles that actually ran
-    const long long rows = tiles * PN_TILE, smp = ctiles * PN_CTILE;
+    // rows: every row of a processed tile was written by the forward (invalid rows included); samples: only the first n_valid
+    // rows of fs / pe / c1.. exist -- the GEMM masks the rest of the last colour tile (0 * stale bits could be NaN)
+    const long long rows = tiles * PN_TILE, smp = n_valid;
     int rc;
     float *g = d_grad_params;
-    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16>(sv.dy1, PN_H, sv.x0, PN_IN1P, rows, d_partials, 256, 256, g, PO_W1, PN_IN1, s))) return rc;
-    if ((rc = launch_wgrad_lds<4, 1, 2, 1, 16>(sv.dy1, PN_H, sv.x0 + 256, PN_IN1P, rows, d_partials, 32, PN_IN1 - 256, g, PO_W1 + 256, PN_IN1, s))) return rc;
-    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16>(sv.dy2, PN_H, sv.h1, PN_H, rows, d_partials, 256, 256, g, PO_W2, PN_H, s))) return rc;
-    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16>(sv.dy3, PN_H, sv.h2, PN_H, rows, d_partials, 256, 256, g, PO_W3, PN_IN3, s))) return rc;
-    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16>(sv.dy4, PN_H, sv.h3, PN_H, rows, d_partials, 256, 256, g, PO_W4, PN_H, s))) return rc;
-    if ((rc = launch_wgrad_lds<2, 2, 2, 4, 16>(sv.dc1, PN_HC, sv.fs, PN_H, smp, d_partials, 256, 256, g, PO_WC1, PN_INC, s))) return rc;
-    if ((rc = launch_wgrad<1, 1, 4, 1>(sv.dc1, PN_HC, sv.pe, 32, smp, d_partials, 32, PN_INC - 256, g, PO_WC1 + 256, PN_INC, s))) return rc;
-    if ((rc = launch_wgrad_lds<2, 1, 2, 4, 16>(sv.dc2, PN_HC, sv.c1, PN_HC, smp, d_partials, 128, 128, g, PO_WC2, PN_HC, s))) return rc;
-    if ((rc = launch_wgrad_lds<2, 1, 2, 4, 16>(sv.dc3, PN_HC, sv.c2, PN_HC, smp, d_partials, 128, 128, g, PO_WC3, PN_HC, s))) return rc;
+    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16, true>(sv.dy1, PN_H, sv.x0, PN_IN1P, sv.x0 + 256, PN_IN1P, rows, d_partials, PN_IN1P, PN_IN1, g, PO_W1, PN_IN1, s))) return rc;
+    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16, false>(sv.dy2, PN_H, sv.h1, PN_H, nullptr, 0, rows, d_partials, 256, 256, g, PO_W2, PN_H, s))) return rc;
+    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16, false>(sv.dy3, PN_H, sv.h2, PN_H, nullptr, 0, rows, d_partials, 256, 256, g, PO_W3, PN_IN3, s))) return rc;
+    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16, false>(sv.dy4, PN_H, sv.h3, PN_H, nullptr, 0, rows, d_partials, 256, 256, g, PO_W4, PN_H, s))) return rc;
+    if ((rc = launch_wgrad_lds<2, 2, 2, 4, 16, true>(sv.dc1, PN_HC, sv.fs, PN_H, sv.pe, 32, smp, d_partials, 288, PN_INC, g, PO_WC1, PN_INC, s))) return rc;
+    if ((rc = launch_wgrad_lds<2, 1, 2, 4, 16, false>(sv.dc2, PN_HC, sv.c1, PN_HC, nullptr, 0, smp, d_partials, 128, 128, g, PO_WC2, PN_HC, s))) return rc;
+    if ((rc = launch_wgrad_lds<2, 1, 2, 4, 16, false>(sv.dc3, PN_HC, sv.c2, PN_HC, nullptr, 0, smp, d_partials, 128, 128, g, PO_WC3, PN_HC, s))) return rc;
     return 0;
 }
 

@@ -27,6 +27,7 @@ def test_bench_json_contract_single_gpu():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "rays/s" and d["value"] > 0 and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["final_loss"] == d["config"]["final_loss"] and abs(d["config"]["final_loss"]) < 1e3      # finite: a NaN step is not a step
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["peak"] > 0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c = d["cpu_baseline"]
