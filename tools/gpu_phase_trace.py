@@ -37,11 +37,13 @@ def read(name):
     return buf.reshape(WGS, ITERS, SLOTS)
 
 
-FWD_GEMM = [(2, 3), (5, 6), (8, 9), (11, 12)]
+FWD_GEMM = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8)]
 BWD_GEMM = [(0, 1), (1, 2), (3, 4), (5, 6), (6, 7), (7, 8), (8, 9), (9, 10)]
-FWD_NAMES = {(0, 1): "sidx+gather+PE", (1, 2): "weights+x0 copy-out", (2, 3): "GEMM1", (3, 4): "acc->lds", (4, 5): "copy-out h1", (5, 6): "GEMM2",
-             (6, 7): "acc->lds", (7, 8): "copy-out h2", (8, 9): "GEMM3", (9, 10): "acc->lds", (10, 11): "copy-out h3", (11, 12): "GEMM4",
-             (12, 13): "acc->lds", (13, 14): "copy-out h4", (14, 15): "alpha head", (15, 16): "K-sums"}
+FWD_NAMES = {(0, 1): "G1(A) | boundary B", (1, 2): "G1(B) | E1(A)", (2, 3): "G2(A) | E1(B), copy A", (3, 4): "G2(B) | E2(A), copy B",
+             (4, 5): "G3(A) | E2(B), copy A", (5, 6): "G3(B) | E3(A), copy B", (6, 7): "G4(A) | E3(B), copy A", (7, 8): "G4(B) | copy B, boundary A",
+             (0, 9): "  S1: start -> slot 1 (requests)", (9, 10): "  S1: slots 1-3", (10, 11): "  S1: E4 (4-67)", (11, 12): "  S1: alpha head (68-141)", (12, 13): "  S1: K-sums + h4 copy (142-215)",
+             (13, 14): "  S1: barrier + geometry (216-223)", (14, 15): "  S1: embedding PE (224-271)", (15, 16): "  S1: distance PE + pad (272-295)", (16, 17): "  S1: barrier + weights (296-299)",
+             (17, 18): "  S1: x0 copy-out (300-375)", (18, 1): "  S1: tail (375-575) + barrier"}
 BWD_NAMES = {(0, 1): "G(A,4) | boundary B", (1, 2): "G(B,4) | E(A)", (2, 3): "extras A", (3, 4): "G(A,3) | E(B), copy A", (4, 5): "extras B",
              (5, 6): "G(B,3) | E(A), copy B", (6, 7): "G(A,2) | E(B), copy A", (7, 8): "G(B,2) | E(A), copy B", (8, 9): "G(A,1) | E(B), copy A",
              (9, 10): "G(B,1) | copy B, boundary A",
@@ -101,4 +103,4 @@ def analyse(tr, names, gemm, last):
 fwd, bwd = read("pnerf_debug_trace_fwd"), read("pnerf_debug_trace_bwd")
 os.makedirs("gpurun_out", exist_ok=True)
 np.savez_compressed("gpurun_out/phase_trace.npz", fwd=fwd, bwd=bwd)
-print(json.dumps({"forward": analyse(fwd, FWD_NAMES, FWD_GEMM, 16), "backward": analyse(bwd, BWD_NAMES, BWD_GEMM, 10)}, indent=1))
+print(json.dumps({"forward": analyse(fwd, FWD_NAMES, FWD_GEMM, 8), "backward": analyse(bwd, BWD_NAMES, BWD_GEMM, 10)}, indent=1))
