@@ -113,13 +113,9 @@ extern "C" size_t pnerf_agg_saved_bytes(int64_t n_valid_samples, int K) {
 // ------------------------------------------------------------------------------ forward kernels
 namespace {
 constexpr int LDX = 292;    // X0 / colour input row stride in LDS (odd multiple of 4 floats: conflict-free b128 reads)
-constexpr int LDH = 260;    // hidden row stride
 constexpr int LDC = 132;    // colour hidden row stride
 constexpr int TPR = PN_TPR; // threads per tile row in the element-wise phases
 constexpr int EPT = PN_F / TPR;              // embedding dims per thread in the feature build
-constexpr int CPT = PN_H / TPR;              // hidden columns per thread in the row-wise dot products
-constexpr int AGG_LDS_FLOATS = PN_TILE * LDX + PN_TILE * 8 + PN_TILE * 8 + 4 * PN_TILE + PN_H + PN_TILE;
-constexpr int AGG_WG_PER_CU = (160 * 1024) / (AGG_LDS_FLOATS * 4);
 
 struct FwdArgs {
     pnerf_camera cam;
@@ -147,265 +143,7 @@ template <int N> __device__ __forceinline__ float group_sum(float v) {      // s
     return v;
 }
 
-// One LDS activation buffer, updated in place (GEMM -> barrier -> epilogue -> barrier): with 32-row tiles 46 KB per
-// workgroup, so three workgroups share a CU and one's gather / epilogue latency hides under the others' MFMA phases.
-#ifdef PN_PHASE_TRACE
-PN_TR_DECL(pn_trace_fwd);
-#endif
-template <bool TRAIN>
-__global__ __launch_bounds__(PN_NTHR, PN_NTHR == 512 ? 4 : (PN_TILE == 32 ? 3 : 2)) void k_agg_forward(FwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *bufA = smem;                         // [PN_TILE][LDX]  X0, then h1..h4 at stride LDH
-    float *exb = bufA + PN_TILE * LDX;          // [PN_TILE][8]  layer-3 extras
-    float *dst = exb + PN_TILE * 8;             // [PN_TILE][8]  the 6 distance components of each row
-    float *wraw = dst + PN_TILE * 8;            // [PN_TILE] raw 1/dist weights, later alpha*w
-    float *wrow = wraw + PN_TILE;               // final weight (normalised * clamped conf)
-    float *wnrm = wrow + PN_TILE;               // normalised weight
-    float *rawa = wnrm + PN_TILE;               // (spare)
-    float *w5s = rawa + PN_TILE;                // [256]
-    int *sidx = reinterpret_cast<int *>(w5s + PN_H);   // [<=PN_TILE] sample ids of this tile
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int K = a.K, TS = a.TS;
-    const int Ns = a.counters[0] < a.cap_samples ? a.counters[0] : (int)a.cap_samples;
-    const float *P = a.params;
-    if (tid < PN_H) w5s[tid] = P[PO_W5 + tid];
-    const float b5 = P[PO_B5];
-
-#ifdef PN_PHASE_TRACE
-    int titer = -1;
-#endif
-    for (long long tile = blockIdx.x; tile * TS < Ns; tile += gridDim.x) {
-        const long long grow0 = tile * PN_TILE;
-#ifdef PN_PHASE_TRACE
-        ++titer;
-#endif
-        __syncthreads();
-        PN_TR(pn_trace_fwd, 0); PN_TR_HWID(pn_trace_fwd);
-        if (tid < PN_TILE) {
-            const long long vs = tile * TS + tid;
-            sidx[tid] = (tid < TS && vs < Ns) ? a.valid_list[vs] : -1;
-        }
-        __syncthreads();
-        // ---- P1: gather + feature build -----------------------------------------------------
-        {
-            const int row = tid / TPR, q = tid % TPR;
-            const int ls = row / K, k = row - ls * K;
-            const int si = ls < TS ? sidx[ls] : -1;
-            int p = -1;
-            if (si >= 0) p = a.pidx[(long long)si * K + k];
-            float *xa = bufA + row * LDX;
-            if (p >= 0) {
-                const float lx = a.sample_loc[(long long)si * 3], ly = a.sample_loc[(long long)si * 3 + 1], lz = a.sample_loc[(long long)si * 3 + 2];
-                const float px = a.xyz[3 * p], py = a.xyz[3 * p + 1], pz = a.xyz[3 * p + 2];
-                const float dwx = px - lx, dwy = py - ly, dwz = pz - lz;
-                float ppx, ppy, pcz, spx, spy, scz;
-                if (a.xyz_pers) {                      // PointAggregator.forward(sampled_xyz_pers, sample_loc) inputs
-                    ppx = a.xyz_pers[3 * p]; ppy = a.xyz_pers[3 * p + 1]; pcz = a.xyz_pers[3 * p + 2];
-                    spx = a.loc_pers[(long long)si * 3]; spy = a.loc_pers[(long long)si * 3 + 1]; scz = a.loc_pers[(long long)si * 3 + 2];
-                } else {                               // fused path: project in-kernel (neural_points.py:604-610)
-                    float pcx, pcy, scx, scy;
-                    rot3(a.cam.camrot, px - a.cam.campos[0], py - a.cam.campos[1], pz - a.cam.campos[2], false, pcx, pcy, pcz);
-                    rot3(a.cam.camrot, lx - a.cam.campos[0], ly - a.cam.campos[1], lz - a.cam.campos[2], false, scx, scy, scz);
-                    ppx = pcx / pcz; ppy = pcy / pcz; spx = scx / scz; spy = scy / scz;
-                }
-                float d[6];
-                rot3(a.cam.rw2c, dwx, dwy, dwz, true, d[0], d[1], d[2]);            // dists[:3] @ Rw2c^T (point_aggregators.py:526)
-                d[3] = ppx * pcz - spx * scz; d[4] = ppy * pcz - spy * scz; d[5] = pcz - scz;   // :775-777
-                if (q == 0) {
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) dst[row * 8 + j] = d[j];
-                }
-                // embedding + PE3(embedding): EPT dims per thread
-                const float *ep = a.emb + (long long)p * PN_F + EPT * q;
-#pragma unroll
-                for (int i = 0; i < EPT; i += 4) *reinterpret_cast<float4 *>(xa + EPT * q + i) = *reinterpret_cast<const float4 *>(ep + i);
-                // sin/cos(e 2^f): one accurate sincosf at the base frequency, then exact double-angle steps
-                // (sin 2x = 2 s c, cos 2x = 1 - 2 s^2): 38 instead of 126 sincosf per row; |error| grows ~2x per octave
-                // from <= 1 ulp, i.e. <= 2e-6 at the 16x band, far inside the 1e-4 bar.
-#pragma unroll 2
-                for (int i = 0; i < EPT; ++i) {
-                    const int dd = EPT * q + i;
-                    float s, c;
-                    sincosf(xa[dd], &s, &c);
-#pragma unroll
-                    for (int f = 0; f < 3; ++f) {
-                        *reinterpret_cast<float2 *>(xa + PN_F + (dd * 3 + f) * 2) = make_float2(s, c);
-                        const float s2 = 2.f * s * c;
-                        c = 1.f - 2.f * s * s; s = s2;
-                    }
-                }
-                // PE5(dists6): 6 components x 5 octaves = 30 (sin,cos) pairs; thread q takes components q, q+TPR, ...
-                __builtin_amdgcn_wave_barrier();
-                for (int comp = q; comp < 6; comp += TPR) {
-                    float s, c;
-                    sincosf(dst[row * 8 + comp], &s, &c);
-#pragma unroll
-                    for (int f = 0; f < 5; ++f) {
-                        *reinterpret_cast<float2 *>(xa + PN_F * 7 + (comp * 5 + f) * 2) = make_float2(s, c);
-                        const float s2 = 2.f * s * c;
-                        c = 1.f - 2.f * s * s; s = s2;
-                    }
-                }
-                if (q == TPR - 1) {
-#pragma unroll
-                    for (int j = PN_IN1; j < LDX; ++j) xa[j] = 0.f;
-                }
-                if (q == 0) {
-                    float vx, vy, vz, qx, qy, qz;
-                    const int r = si / a.SR;
-                    rot3(a.cam.rw2c, a.raydir[3 * r], a.raydir[3 * r + 1], a.raydir[3 * r + 2], true, vx, vy, vz);      // :506
-                    rot3(a.cam.rw2c, a.dir[3 * p], a.dir[3 * p + 1], a.dir[3 * p + 2], true, qx, qy, qz);               // :566
-                    float *ex = exb + row * 8;
-                    ex[0] = a.color[3 * p]; ex[1] = a.color[3 * p + 1]; ex[2] = a.color[3 * p + 2];
-                    ex[3] = qx - vx; ex[4] = qy - vy; ex[5] = qz - vz;
-                    ex[6] = qx * vx + qy * vy + qz * vz; ex[7] = 0.f;
-                    wraw[row] = 1.0f / fmaxf(sqrtf(dwx * dwx + dwy * dwy + dwz * dwz), 1e-6f);                            // linear :425-428
-                }
-            } else {
-                for (int j = q; j < LDX; j += TPR) xa[j] = 0.f;
-                if (q == 0) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) exb[row * 8 + j] = 0.f;
-                    wraw[row] = 0.f;
-                }
-            }
-        }
-        __syncthreads();
-        PN_TR(pn_trace_fwd, 1);
-        // ---- P2: normalise weights over the K slots, multiply by the clamped confidence -------
-        if (tid < PN_TILE) {
-            const int row = tid, ls = row / K, k = row - ls * K;
-            const int si = ls < TS ? sidx[ls] : -1;
-            float wn = 0.f, w = 0.f;
-            int p = -1;
-            if (si >= 0) {
-                float sum = 0.f;
-                for (int kk = 0; kk < K; ++kk) sum += wraw[ls * K + kk];
-                wn = wraw[row] / fmaxf(sum, 1e-8f);                                                                   // :801-802
-                p = a.pidx[(long long)si * K + k];
-                const float cf = a.conf[p >= 0 ? p : 0];
-                w = wn * fminf(fmaxf(cf, 1e-4f), 1.0f);                                                               // :807-811
-                a.weight[(long long)si * K + k] = wn;
-            }
-            wnrm[row] = wn; wrow[row] = w;
-            if (TRAIN) a.sv.rmeta[grow0 + row] = make_int4(si, p, __float_as_int(wn), __float_as_int(w));
-        }
-        if (TRAIN) {
-            for (int e = tid; e < PN_TILE * (PN_IN1P / 4); e += PN_NTHR) {
-                const int row = e / (PN_IN1P / 4), c4 = e - row * (PN_IN1P / 4);
-                *reinterpret_cast<float4 *>(a.sv.x0 + (grow0 + row) * PN_IN1P + c4 * 4) = *reinterpret_cast<const float4 *>(bufA + row * LDX + c4 * 4);
-            }
-            if (tid < PN_TILE * 2) {
-                const int row = tid >> 1, h = tid & 1;
-                *reinterpret_cast<float4 *>(a.sv.ex + (grow0 + row) * 8 + h * 4) = *reinterpret_cast<const float4 *>(exb + row * 8 + h * 4);
-            }
-        }
-        // ---- layers (in place: all waves finish reading A before anyone overwrites it) ---------------
-        f32x16 acc[PN_MT][PN_NT];
-        PN_TR(pn_trace_fwd, 2);
-        pn_acc_init_bias<PN_MT, PN_NT>(acc, P + PO_B1, wave, lane);
-        pn_tile_gemm<PN_MT, PN_NT, PN_NW>(bufA, LDX, PN_IN1P / 8, a.packed + PK_F1 / 4, wave, lane, acc);
-        PN_TR(pn_trace_fwd, 3);
-        __syncthreads();
-        {
-            const unsigned long long mbits = pn_acc_to_lds_bits<true>(acc, bufA, LDH, wave, lane);
-            if (TRAIN) a.sv.lmask[(tile * 3 + 0) * PN_NTHR + tid] = mbits;
-        }
-        __syncthreads();
-        PN_TR(pn_trace_fwd, 4);
-        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h1, PN_H, grow0, tid);
-        PN_TR(pn_trace_fwd, 5);
-        pn_acc_init_bias<PN_MT, PN_NT>(acc, P + PO_B2, wave, lane);
-        pn_tile_gemm<PN_MT, PN_NT, PN_NW>(bufA, LDH, PN_H / 8, a.packed + PK_F2 / 4, wave, lane, acc);
-        PN_TR(pn_trace_fwd, 6);
-        __syncthreads();
-        {
-            const unsigned long long mbits = pn_acc_to_lds_bits<true>(acc, bufA, LDH, wave, lane);
-            if (TRAIN) a.sv.lmask[(tile * 3 + 1) * PN_NTHR + tid] = mbits;
-        }
-        __syncthreads();
-        PN_TR(pn_trace_fwd, 7);
-        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h2, PN_H, grow0, tid);
-        PN_TR(pn_trace_fwd, 8);
-        pn_acc_init_bias<PN_MT, PN_NT>(acc, P + PO_B3, wave, lane);
-        pn_tile_gemm<PN_MT, PN_NT, PN_NW>(bufA, LDH, PN_H / 8, a.packed + PK_F3 / 4, wave, lane, acc);
-        pn_tile_gemm<PN_MT, PN_NT, PN_NW>(exb, 8, 1, a.packed + PK_F3 / 4 + (PN_H / 8) * (PN_H / 32) * 64, wave, lane, acc);
-        PN_TR(pn_trace_fwd, 9);
-        __syncthreads();
-        {
-            const unsigned long long mbits = pn_acc_to_lds_bits<true>(acc, bufA, LDH, wave, lane);
-            if (TRAIN) a.sv.lmask[(tile * 3 + 2) * PN_NTHR + tid] = mbits;
-        }
-        __syncthreads();
-        PN_TR(pn_trace_fwd, 10);
-        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h3, PN_H, grow0, tid);
-        PN_TR(pn_trace_fwd, 11);
-        pn_acc_init_bias<PN_MT, PN_NT>(acc, P + PO_B4, wave, lane);
-        pn_tile_gemm<PN_MT, PN_NT, PN_NW>(bufA, LDH, PN_H / 8, a.packed + PK_F4 / 4, wave, lane, acc);
-        PN_TR(pn_trace_fwd, 12);
-        __syncthreads();
-        pn_acc_to_lds<PN_MT, PN_NT, true>(acc, bufA, LDH, wave, lane);
-        __syncthreads();
-        PN_TR(pn_trace_fwd, 13);
-        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H, PN_NTHR>(bufA, LDH, a.sv.h4, PN_H, grow0, tid);
-        PN_TR(pn_trace_fwd, 14);
-        // ---- P5: alpha head (256 -> 1, softplus(x - 1)) -----------------------------------------
-        {
-            const int row = tid / TPR, q = tid % TPR;
-            const float *h = bufA + row * LDH + q * CPT;
-            float s = 0.f;
-#pragma unroll
-            for (int c = 0; c < CPT; c += 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(h + c);
-                s += v.x * w5s[q * CPT + c] + v.y * w5s[q * CPT + c + 1] + v.z * w5s[q * CPT + c + 2] + v.w * w5s[q * CPT + c + 3];
-            }
-            s = group_sum<TPR>(s);
-            if (q == 0) {
-                const float x = s + b5 - 1.0f;
-                const float alpha = x > 20.f ? x : log1pf(expf(x));                                                   // raw2out_density :262-265
-                wraw[row] = alpha * wrow[row];
-            }
-        }
-        __syncthreads();
-        PN_TR(pn_trace_fwd, 15);
-        // ---- P6: K-weighted sums -> sigma, f[256] -------------------------------------------------
-        for (int e = tid; e < TS * 64; e += PN_NTHR) {
-            const int ls = e >> 6, c4 = e & 63;
-            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int k = 0; k < K; ++k) {
-                const float w = wrow[ls * K + k];
-                const float4 v = *reinterpret_cast<const float4 *>(bufA + (ls * K + k) * LDH + c4 * 4);
-                f.x += w * v.x; f.y += w * v.y; f.z += w * v.z; f.w += w * v.w;
-            }
-            const long long vs = tile * TS + ls;
-            if (vs < a.cap_samples) *reinterpret_cast<float4 *>(a.sv.fs + vs * PN_H + c4 * 4) = f;
-        }
-        if (tid < TS) {
-            const int si = sidx[tid];
-            if (si >= 0) {
-                float sg = 0.f;
-                for (int k = 0; k < K; ++k) sg += wraw[tid * K + k];
-                a.decoded[(long long)si * 4] = sg;
-            }
-        }
-        PN_TR(pn_trace_fwd, 16);
-    }
-}
-
 // ------------------------------------------------------------------------------ two-tile forward
-#ifndef F2_DBG_COPY
-#define F2_DBG_COPY 1
-#endif
-#ifndef F2_DBG_H4
-#define F2_DBG_H4 1
-#endif
-#ifndef F2_DBG_X0
-#define F2_DBG_X0 1
-#endif
-#ifndef F2_DBG_LMASK
-#define F2_DBG_LMASK 1
-#endif
 // Same organisation as the backward (backward.hip): one workgroup (4 waves, one per SIMD) per CU, two tiles A / B in flight,
 // their layer GEMMs alternating  G1(A) G1(B) G2(A) G2(B) G3(A) G3(B) G4(A) G4(B).  Everything element-wise is issued by the
 // GEMM waves themselves in the shadow of their own MFMAs (pn_tile_gemm_side): the other tile's epilogue (bias, LeakyReLU,
@@ -581,7 +319,7 @@ __device__ __forceinline__ void f2_epi_piece(const f32x16 (&acc)[2][2], const fl
 }
 
 #ifdef PN_PHASE_TRACE
-PN_TR_DECL(pn_trace_fwd2);
+PN_TR_DECL(pn_trace_fwd);
 #endif
 // ---- the boundary program of one buffer, slot by slot (see backward.hip for the rules: no value is consumed in the slot that
 // requested it, pieces stay under ~a dozen instructions, one burst of requests).  Slot map:
@@ -605,7 +343,7 @@ __device__ __forceinline__ void f2_boundary_slot(const FwdArgs &a, const F2Tile 
     if constexpr (SLOT == 1 || SLOT == 3 || SLOT == 67 || SLOT == 141 || SLOT == 215 || SLOT == 223 || SLOT == 271 || SLOT == 295 || SLOT == 299 || SLOT == 375) {
         constexpr int k = SLOT == 1 ? 0 : SLOT == 3 ? 1 : SLOT == 67 ? 2 : SLOT == 141 ? 3 : SLOT == 215 ? 4 : SLOT == 223 ? 5 : SLOT == 271 ? 6 : SLOT == 295 ? 7 : SLOT == 299 ? 8 : 9;
         const int tid = threadIdx.x, titer = C.titer;
-        if (C.trbase >= 0) PN_TR(pn_trace_fwd2, C.trbase + k);
+        if (C.trbase >= 0) PN_TR(pn_trace_fwd, C.trbase + k);
     }
 #endif
     // ---- alpha head of the finished tile (256 -> 1, softplus(x - 1), raw2out_density :262-265)
@@ -647,11 +385,11 @@ __device__ __forceinline__ void f2_boundary_slot(const FwdArgs &a, const F2Tile 
         if (C.k == K) { C.k = 0; C.m += 1; }
         asm volatile("" : "+v"(C.f.x), "+v"(C.f.y), "+v"(C.f.z), "+v"(C.f.w));
     }
-    if constexpr (TRAIN && F2_DBG_H4 && SLOT >= 145 && SLOT < 209 && (SLOT - 145) % 4 == 0) {
+    if constexpr (TRAIN && SLOT >= 145 && SLOT < 209 && (SLOT - 145) % 4 == 0) {
         constexpr int i = (SLOT - 145) / 4;
         C.cpv = *reinterpret_cast<const float4 *>(T.buf + ((tl >> 6) + 4 * i) * LDX + (tl & 63) * 4);
     }
-    if constexpr (TRAIN && F2_DBG_H4 && SLOT >= 145 && SLOT < 209 && (SLOT - 145) % 4 == 2) {
+    if constexpr (TRAIN && SLOT >= 145 && SLOT < 209 && (SLOT - 145) % 4 == 2) {
         constexpr int i = (SLOT - 145) / 4;
         *reinterpret_cast<float4 *>(a.sv.h4 + ((long long)S.tile * PN_TILE + (tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4) = C.cpv;
     }
@@ -746,7 +484,7 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_forward2(FwdArgs a) {
         asm volatile("" : "+v"(tl));
         const int lane = tl & 63, wave = tl >> 6;
         __syncthreads();
-        PN_TR(pn_trace_fwd2, 0);
+        PN_TR(pn_trace_fwd, 0);
         float *wyA = TA.buf + (4 * (lane >> 5)) * LDX + wave * 64 + (lane & 31);     // accumulator-layout write base
         float *wyB = TB.buf + (4 * (lane >> 5)) * LDX + wave * 64 + (lane & 31);
         const float *rxA = TA.buf + wave * LDX + lane * 4, *rxB = TB.buf + wave * LDX + lane * 4;   // copy-out read base (+ 4*i rows)
@@ -776,7 +514,7 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_forward2(FwdArgs a) {
                 if constexpr (EPI && EXTRAS && s == 509) {                                                                          \
                     if (tl < PN_TILE * 2) *reinterpret_cast<float4 *>((YT).buf + (tl >> 1) * LDX + PN_H + (tl & 1) * 4) = *reinterpret_cast<const float4 *>((YT).exb + (tl >> 1) * 8 + (tl & 1) * 4); \
                 }                                                                                                                   \
-                if constexpr (EPI && TRAIN && F2_DBG_LMASK && s == 510) a.sv.lmask[((long long)(YTILE) * 3 + (ML)) * PN_NTHR + tl] = ((unsigned long long)mhi << 32) | mlo; \
+                if constexpr (EPI && TRAIN && s == 510) a.sv.lmask[((long long)(YTILE) * 3 + (ML)) * PN_NTHR + tl] = ((unsigned long long)mhi << 32) | mlo; \
                 if constexpr (COPY0 && TRAIN && s % 32 == 8) {             /* X0 [64][288]: float4 number tl + 256 i, i < 18 */            \
                     const int e_ = tl + (s / 32) * PN_NTHR, row_ = e_ / (PN_IN1P / 4), c4_ = e_ - row_ * (PN_IN1P / 4);                 \
                     cpv = *reinterpret_cast<const float4 *>((XT).buf + row_ * LDX + c4_ * 4);                                          \
@@ -788,32 +526,32 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_forward2(FwdArgs a) {
                 if constexpr (COPY0 && TRAIN && s == 30) {                                                                          \
                     if (tl < PN_TILE * 2) *reinterpret_cast<float4 *>(a.sv.ex + ((long long)(XTILE) * PN_TILE + (tl >> 1)) * 8 + (tl & 1) * 4) = *reinterpret_cast<const float4 *>((XT).exb + (tl >> 1) * 8 + (tl & 1) * 4); \
                 }                                                                                                                   \
-                if constexpr (COPY && TRAIN && F2_DBG_COPY && s % 32 == 4 && s < 512) cpv = *reinterpret_cast<const float4 *>((RX) + 4 * (s / 32) * LDX); \
-                if constexpr (COPY && TRAIN && F2_DBG_COPY && s % 32 == 20 && s < 512) *reinterpret_cast<float4 *>((DST) + ((long long)(XTILE) * PN_TILE + wave + 4 * (s / 32)) * PN_H + lane * 4) = cpv; \
+                if constexpr (COPY && TRAIN && s % 32 == 4 && s < 512) cpv = *reinterpret_cast<const float4 *>((RX) + 4 * (s / 32) * LDX); \
+                if constexpr (COPY && TRAIN && s % 32 == 20 && s < 512) *reinterpret_cast<float4 *>((DST) + ((long long)(XTILE) * PN_TILE + wave + 4 * (s / 32)) * PN_H + lane * 4) = cpv; \
                 BND(s);                                                                                                             \
             });                                                                                                                     \
             __syncthreads();                                                                                                        \
         }
         //      chunks       X-tile  accX  image  next   accY  bias   writeY Y  Y-tile   mask EPI    EXTRAS COPY   COPY0 X   readX dst       X-tile   boundary
         F2_STEP(PN_IN1P / 8, TA.buf, accA, PK_F1, PK_F1, accB, PO_B4, wyB, TB, SB.tile, 0, false, false, false, true, TA, rxA, a.sv.h1, SA.tile, F2_BND_B)
-        PN_TR(pn_trace_fwd2, 1);
+        PN_TR(pn_trace_fwd, 1);
         F2_STEP(PN_IN1P / 8, TB.buf, accB, PK_F1, PK_F2, accA, PO_B1, wyA, TA, SA.tile, 0, true, false, false, true, TB, rxB, a.sv.h1, SB.tile, F2_NOBND)
-        PN_TR(pn_trace_fwd2, 2);
+        PN_TR(pn_trace_fwd, 2);
         F2_STEP(PN_H / 8, TA.buf, accA, PK_F2, PK_F2, accB, PO_B1, wyB, TB, SB.tile, 0, true, false, true, false, TA, rxA, a.sv.h1, SA.tile, F2_NOBND)
-        PN_TR(pn_trace_fwd2, 3);
+        PN_TR(pn_trace_fwd, 3);
         F2_STEP(PN_H / 8, TB.buf, accB, PK_F2, PK_F3, accA, PO_B2, wyA, TA, SA.tile, 1, true, true, true, false, TB, rxB, a.sv.h1, SB.tile, F2_NOBND)
-        PN_TR(pn_trace_fwd2, 4);
+        PN_TR(pn_trace_fwd, 4);
         F2_STEP(PN_H / 8 + 1, TA.buf, accA, PK_F3, PK_F3, accB, PO_B2, wyB, TB, SB.tile, 1, true, true, true, false, TA, rxA, a.sv.h2, SA.tile, F2_NOBND)
-        PN_TR(pn_trace_fwd2, 5);
+        PN_TR(pn_trace_fwd, 5);
         F2_STEP(PN_H / 8 + 1, TB.buf, accB, PK_F3, PK_F4, accA, PO_B3, wyA, TA, SA.tile, 2, true, false, true, false, TB, rxB, a.sv.h2, SB.tile, F2_NOBND)
-        PN_TR(pn_trace_fwd2, 6);
+        PN_TR(pn_trace_fwd, 6);
         F2_STEP(PN_H / 8, TA.buf, accA, PK_F4, PK_F4, accB, PO_B3, wyB, TB, SB.tile, 2, true, false, true, false, TA, rxA, a.sv.h3, SA.tile, F2_NOBND)
-        PN_TR(pn_trace_fwd2, 7);
+        PN_TR(pn_trace_fwd, 7);
 #ifdef PN_PHASE_TRACE
         CB.trbase = -1;
 #endif
         F2_STEP(PN_H / 8, TB.buf, accB, PK_F4, PK_F1, accA, PO_B4, wyA, TA, SA.tile, 0, false, false, true, false, TB, rxB, a.sv.h3, SB.tile, F2_BND_A)
-        PN_TR(pn_trace_fwd2, 8);
+        PN_TR(pn_trace_fwd, 8);
 #undef F2_STEP
 #undef F2_BND_A
 #undef F2_BND_B
@@ -1008,6 +746,6 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
 
 #ifdef PN_PHASE_TRACE
 extern "C" int pnerf_debug_trace_fwd(void *host, size_t bytes) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(pn_trace_fwd2), bytes < sizeof(pn_trace_fwd2) ? bytes : sizeof(pn_trace_fwd2)) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(pn_trace_fwd), bytes < sizeof(pn_trace_fwd) ? bytes : sizeof(pn_trace_fwd)) == hipSuccess ? 0 : -1;
 }
 #endif

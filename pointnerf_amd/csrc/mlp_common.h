@@ -14,14 +14,9 @@
 #define PN_IN3    263                // 256 + colour 3 + (dir - view) 3 + dir.view 1
 #define PN_INC    280                // 256 + view PE 24
 #define PN_HC     128
-#ifndef PN_TILE
-#define PN_TILE   64                 // neighbor rows per aggregator tile (MT = PN_TILE/32 MFMA row tiles): 64 -> 2 WGs/CU. Measured: 32 (3 WGs/CU) is 10 % slower (twice the weight-fragment traffic per MFMA)
-#endif
+#define PN_TILE   64                 // neighbor rows per aggregator tile (2 MFMA row tiles).  Measured: 32-row tiles are 10 % slower (twice the weight-fragment traffic per MFMA)
 #define PN_MT     (PN_TILE / 32)
-#ifndef PN_NTHR
-#define PN_NTHR   256                // threads per aggregator workgroup.  256 = 4 waves x (64 rows x 64 cols).  Measured: 512
-                                     // (8 waves x 32 cols, 128-VGPR cap, 16 waves/CU) is 8-12 % slower (spills, 2x LDS A-reads)
-#endif
+#define PN_NTHR   256                // threads per aggregator workgroup: 4 waves (one per SIMD) x (64 rows x 64 cols), up to 512 registers each
 #define PN_NW     (PN_NTHR / 64)     // waves per aggregator workgroup
 #define PN_NT     (PN_H / (PN_NW * 32))   // MFMA column tiles per wave (1 with 8 waves, 2 with 4)
 #define PN_TPR    (PN_NTHR / PN_TILE)     // threads per tile row in the element-wise phases
@@ -170,26 +165,8 @@ __device__ __forceinline__ void pn_tile_mask_pass(float *__restrict__ H, int ldh
 // ---- 1-bit LeakyReLU masks, in the accumulator layout.  A lane owns the same 64 (row, col) elements of a layer's output in
 // the forward (where it applies bias + LeakyReLU to its accumulators) and in the backward (where it multiplies its dgrad
 // accumulators by LeakyReLU'), so the sign bits travel as ONE 8-byte word per thread per layer: bit r = mt*32 + ct*16 + reg.
-// Written and read fully coalesced ([tile][layer][thread]); the backward fetches its words at the top of the tile.  The 64 KB
-// fp32 read this replaces sat on the critical path after every GEMM (latency-, not bandwidth-bound).
-template <bool LRELU>
-__device__ __forceinline__ unsigned long long pn_acc_to_lds_bits(f32x16 (&acc)[2][2], float *__restrict__ H, int ldh, int wave, int lane) {
-    unsigned lo = 0u, hi = 0u;
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const int col = pn_acc_col<2>(wave, ct, lane);
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float v = acc[rt][ct][reg];
-                if (rt == 0) lo |= (v > 0.f ? 1u : 0u) << (ct * 16 + reg);
-                else hi |= (v > 0.f ? 1u : 0u) << (ct * 16 + reg);
-                H[pn_acc_row(rt, reg, lane) * ldh + col] = LRELU ? pn_lrelu(v) : v;
-            }
-        }
-    return ((unsigned long long)hi << 32) | lo;
-}
+// Written and read fully coalesced ([tile][layer][thread]); the backward fetches its words when it loads the tile.  (The 64 KB
+// fp32 read of the saved activation this replaces sat on the critical path after every GEMM: latency-, not bandwidth-bound.)
 
 // ---- side-job GEMM --------------------------------------------------------------------------------------------------
 // Measured on MI355X (tools/mfma_probe.hip): while one wave streams v_mfma_f32_32x32x2_f32 back to back, ANOTHER wave on the
@@ -250,7 +227,7 @@ struct PnSaved {
     // per neighbor row (rows = row tiles * 64)
     float *x0, *h1, *h2, *h3, *h4, *ex, *dy1, *dy2, *dy3, *dy4;
     int4 *rmeta;                        // per row: {sample id or -1, point id or -1, bits(normalised weight), bits(final weight)}
-    unsigned long long *lmask;          // [row tiles][3 layers h1..h3][PN_NTHR]: LeakyReLU sign bits (pn_acc_to_lds_bits)
+    unsigned long long *lmask;          // [row tiles][3 layers h1..h3][PN_NTHR]: LeakyReLU sign bits in the accumulator layout
     // per valid sample (padded to colour tiles * 64)
     float *fs, *pe, *c1, *c2, *c3, *dfs, *dc1, *dc2, *dc3;
     long long rows, samples;

@@ -194,7 +194,6 @@ class Arena:
 
     def __init__(self):
         self.free, self.headroom = [], 1.15
-        self.align, self.offset = 0, 0      # dev knobs (tools/gpu_arena_align.py): base address = k * align + offset
 
     def take(self, nbytes, device):
         best = None
@@ -205,12 +204,7 @@ class Arena:
             self.free.remove(best)
             return best
         self.free = [t for t in self.free if t.device != device]      # drop too-small blocks before growing
-        want = int(nbytes * self.headroom) + 256
-        if not self.align:
-            return torch.empty(want, dtype=torch.uint8, device=device)
-        raw = torch.empty(want + self.align + self.offset, dtype=torch.uint8, device=device)
-        skip = (-raw.data_ptr()) % self.align + self.offset
-        return raw[skip:skip + want]
+        return torch.empty(int(nbytes * self.headroom) + 256, dtype=torch.uint8, device=device)
 
     def give(self, t):
         if t is not None:
@@ -218,8 +212,6 @@ class Arena:
 
 
 ARENA = Arena()
-WS_PAD = 0            # dev knobs (tools/gpu_arena_align.py)
-DEBUG_PTRS = None
 
 
 def render_forward(cam, pts, packed, flat, raydir, dense, R, SR, K, n_valid, train):
@@ -255,9 +247,7 @@ def render_backward(cam, pts, packed, flat, raydir, dense, R, SR, K, n_valid, fw
     pg.embedding, pg.conf = grads["points_embeding"].data_ptr(), grads["points_conf"].data_ptr()
     pg.dir, pg.color = grads["points_dir"].data_ptr(), grads["points_color"].data_ptr()
     nws = lib.pnerf_render_backward_workspace_bytes(R, SR)
-    ws = torch.empty(nws + WS_PAD, dtype=torch.uint8, device=raydir.device)
-    if DEBUG_PTRS is not None:
-        DEBUG_PTRS.update(ws=ws.data_ptr(), **{k: v.data_ptr() for k, v in grads.items()}, gflat=grad_flat.data_ptr(), saved=fwd["saved"].data_ptr())
+    ws = torch.empty(nws, dtype=torch.uint8, device=raydir.device)
     g = grad_ray_color.contiguous().float()
     L.check(lib.pnerf_render_backward(ctypes.byref(cam), ctypes.byref(pts), _ptr(packed), _ptr(flat), _ptr(raydir),
                                       _ptr(dense["sample_loc"]), _ptr(dense["sample_pidx"]), _ptr(dense["sample_nn"]),
