@@ -157,6 +157,7 @@ struct B2State {           // registers of one in-flight tile
     int rsi, rp;
     long long tile;
     bool valid;
+    float4 exv;            // this thread's float4 of the tile's layer-3 extras [64][8] (threads < 128): into the d f region once d f is dead
 };
 
 __device__ __forceinline__ B2Tile b2_carve(float *base) {
@@ -172,6 +173,8 @@ template <bool DFS_LDS>
 __device__ __forceinline__ void b2_load(const BwdArgs &a, const B2Tile &T, B2State &S, long long tile, long long ntiles, int tl, int TS) {
     S.tile = tile; S.valid = tile < ntiles;
     S.rdx = S.rdy = S.rdz = 0.f;
+    S.exv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (S.valid && tl < 2 * PN_TILE) S.exv = *reinterpret_cast<const float4 *>(a.sv.ex + tile * PN_TILE * 8 + tl * 4);
     const long long grow0 = tile * PN_TILE;
     if (S.valid) {
         S.m1 = a.sv.lmask[(tile * 3 + 0) * PN_NTHR + tl];
@@ -278,31 +281,61 @@ __device__ __forceinline__ void b2_dy4(const BwdArgs &a, const B2Tile &T, const 
     if (tl < PN_TILE) gb5t += T.draw[tl];
 }
 
-// P4: extras of block3's first layer: d colour, d dir from dY3 (row-wise, interleaved columns)
-__device__ __forceinline__ void b2_extras(const BwdArgs &a, const B2Tile &T, const B2State &S, const float *w3ex, int tl) {
+// P4: extras of block3's first layer: d colour, d dir from dY3 (row-wise, interleaved columns: conflict-free LDS reads).
+// P4 in the MFMA shadows of the tile's own layer-3 GEMM (which only reads the same dY3 rows): float4 column group j of the row,
+// sub-piece k, at slot 7 (4 j + k) + 3; reduction at 452 / 456, atomics at 460 / 464
+struct B2Ext { float dex[7]; float4 v, w0, w1, w2; };
+template <int SLOT>
+__device__ __forceinline__ void b2_extras_slot(const BwdArgs &a, const B2Tile &T, const B2State &S, const float *w3ex, B2Ext &E, int tl) {
     const int rrow = tl / TPR, rq = tl % TPR;
-    float dex[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (S.rp >= 0) {
-        const float *dy = T.buf + rrow * LDH + rq * 4;
-        _Pragma("unroll 2") for (int j = 0; j < 16; ++j) {
-            const float4 v = *reinterpret_cast<const float4 *>(dy + 16 * j);
+    if constexpr (SLOT == 0) {
 #pragma unroll
-            for (int jj = 0; jj < 7; ++jj) {
-                const float4 w = *reinterpret_cast<const float4 *>(w3ex + jj * PN_H + rq * 4 + 16 * j);
-                dex[jj] += v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
-            }
+        for (int jj = 0; jj < 7; ++jj) E.dex[jj] = 0.f;
+    }
+    if constexpr (SLOT >= 3 && SLOT < 3 + 7 * 64 && (SLOT - 3) % 7 == 0) {
+        constexpr int q = (SLOT - 3) / 7, j = q / 4, k = q % 4;
+        const float *wj = w3ex + rq * 4 + 16 * j;
+        auto dot = [](const float4 &x, const float4 &y) { return x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w; };
+        if constexpr (k == 0) {
+            E.v = *reinterpret_cast<const float4 *>(T.buf + rrow * LDH + rq * 4 + 16 * j);
+            E.w0 = *reinterpret_cast<const float4 *>(wj); E.w1 = *reinterpret_cast<const float4 *>(wj + PN_H);
+        }
+        if constexpr (k == 1) {
+            E.dex[0] += dot(E.v, E.w0); E.dex[1] += dot(E.v, E.w1);
+            E.w0 = *reinterpret_cast<const float4 *>(wj + 2 * PN_H); E.w1 = *reinterpret_cast<const float4 *>(wj + 3 * PN_H); E.w2 = *reinterpret_cast<const float4 *>(wj + 4 * PN_H);
+            asm volatile("" : "+v"(E.dex[0]), "+v"(E.dex[1]));
+        }
+        if constexpr (k == 2) {
+            E.dex[2] += dot(E.v, E.w0); E.dex[3] += dot(E.v, E.w1); E.dex[4] += dot(E.v, E.w2);
+            E.w0 = *reinterpret_cast<const float4 *>(wj + 5 * PN_H); E.w1 = *reinterpret_cast<const float4 *>(wj + 6 * PN_H);
+            asm volatile("" : "+v"(E.dex[2]), "+v"(E.dex[3]), "+v"(E.dex[4]));
+        }
+        if constexpr (k == 3) {
+            E.dex[5] += dot(E.v, E.w0); E.dex[6] += dot(E.v, E.w1);
+            asm volatile("" : "+v"(E.dex[5]), "+v"(E.dex[6]));
         }
     }
+    if constexpr (SLOT == 452) {
 #pragma unroll
-    for (int jj = 0; jj < 7; ++jj) dex[jj] = group_sum_b<TPR>(dex[jj]);
-    if (rq == 0 && S.rp >= 0) {
-        const int rp = S.rp;
-        atomicAdd(&a.g_color[3 * rp], dex[0]); atomicAdd(&a.g_color[3 * rp + 1], dex[1]); atomicAdd(&a.g_color[3 * rp + 2], dex[2]);
-        float vx, vy, vz, gx, gy, gz;
-        rot3b(a.cam.rw2c, S.rdx, S.rdy, S.rdz, true, vx, vy, vz);
-        // features (q - v, q . v) with q = dir @ Rw2c^T  ->  d q = dex[3:6] + dex[6] * v ; d dir = d q @ Rw2c
-        rot3b(a.cam.rw2c, dex[3] + dex[6] * vx, dex[4] + dex[6] * vy, dex[5] + dex[6] * vz, false, gx, gy, gz);
-        atomicAdd(&a.g_dir[3 * rp], gx); atomicAdd(&a.g_dir[3 * rp + 1], gy); atomicAdd(&a.g_dir[3 * rp + 2], gz);
+        for (int jj = 0; jj < 4; ++jj) E.dex[jj] = group_sum_b<TPR>(E.dex[jj]);
+    }
+    if constexpr (SLOT == 456) {
+#pragma unroll
+        for (int jj = 4; jj < 7; ++jj) E.dex[jj] = group_sum_b<TPR>(E.dex[jj]);
+    }
+    if constexpr (SLOT == 460) {
+        if (rq == 0 && S.rp >= 0) {
+            atomicAdd(&a.g_color[3 * S.rp], E.dex[0]); atomicAdd(&a.g_color[3 * S.rp + 1], E.dex[1]); atomicAdd(&a.g_color[3 * S.rp + 2], E.dex[2]);
+        }
+    }
+    if constexpr (SLOT == 464) {
+        if (rq == 0 && S.rp >= 0) {
+            float vx, vy, vz, gx, gy, gz;
+            rot3b(a.cam.rw2c, S.rdx, S.rdy, S.rdz, true, vx, vy, vz);
+            // features (q - v, q . v) with q = dir @ Rw2c^T  ->  d q = dex[3:6] + dex[6] * v ; d dir = d q @ Rw2c
+            rot3b(a.cam.rw2c, E.dex[3] + E.dex[6] * vx, E.dex[4] + E.dex[6] * vy, E.dex[5] + E.dex[6] * vz, false, gx, gy, gz);
+            atomicAdd(&a.g_dir[3 * S.rp], gx); atomicAdd(&a.g_dir[3 * S.rp + 1], gy); atomicAdd(&a.g_dir[3 * S.rp + 2], gz);
+        }
     }
 }
 
@@ -370,6 +403,7 @@ struct B2Bnd {
     int4 rm;
     float dsgv, s, dotf;
     float4 hv, g4, o;            // dY4 pass registers
+    float4 exn;                  // next tile's extras
     float wv, drv; int siv;
     float dxv[7];
     long long ntile; bool nvalid;
@@ -397,6 +431,8 @@ __device__ __forceinline__ void b2_boundary_slot(const BwdArgs &a, const B2Tile 
         C.nm2 = a.sv.lmask[(te * 3 + 1) * PN_NTHR + tl];
         C.nm3 = a.sv.lmask[(te * 3 + 2) * PN_NTHR + tl];
         C.rm = a.sv.rmeta[te * PN_TILE + (tl & 63)];
+        C.exn = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (C.nvalid && tl < 2 * PN_TILE) C.exn = *reinterpret_cast<const float4 *>(a.sv.ex + te * PN_TILE * 8 + tl * 4);
     }
     if constexpr (SLOT >= 4 && SLOT < 8) {
         const long long te = C.nvalid ? C.ntile : ntiles;
@@ -456,6 +492,7 @@ __device__ __forceinline__ void b2_boundary_slot(const BwdArgs &a, const B2Tile 
         S.tile = C.nvalid ? C.ntile : ntiles; S.valid = C.nvalid;      // an invalid tile lives on the padding tile's storage
         S.m1 = C.nvalid ? C.nm1 : 0ull; S.m2 = C.nvalid ? C.nm2 : 0ull; S.m3 = C.nvalid ? C.nm3 : 0ull;
         S.rdx = S.rdy = S.rdz = 0.f;
+        S.exv = C.exn;
         const int si = C.nvalid ? C.rm.x : -1;
         C.dsgv = 0.f;
         if (si >= 0) C.dsgv = a.grad_decoded[(long long)si * 4];
@@ -616,6 +653,7 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_backward(BwdArgs a) {
         const long long gA = SA.tile * PN_TILE + wave;                                  // copy-out row base (+ 4*i)
         const long long nextB = 2 * pair + 1, nextA = 2 * (pair + gridDim.x);
         float4 cpv = make_float4(0.f, 0.f, 0.f, 0.f), exa = cpv, exb2 = cpv;
+        B2Ext EX;
         float gnone[2] = {0.f, 0.f};
         if (pair == (long long)blockIdx.x) pn_gemm_prefetch_b0(a.packed + PK_D4 / 4, wave, lane, bpre);
 #ifdef PN_PHASE_TRACE
@@ -629,17 +667,19 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_backward(BwdArgs a) {
 #define B2_NOBND(s_) (void)0
 #define B2_BND_B(s_) b2_boundary_slot<s_, DFS_LDS>(a, TB, SB, accB, wyB, CB, nextB, ntiles, w5s, b5, tl, TS, K, gb4v, gw5v, gb5t)
 #define B2_BND_A(s_) b2_boundary_slot<s_, DFS_LDS>(a, TA, SA, accA, wyA, CB, nextA, ntiles, w5s, b5, tl, TS, K, gb4v, gw5v, gb5t)
-#define B2_STEP(XB, ACCX, PK, PKNEXT, ACCY, MY, WY, GBY, EPI, MASKED, COPY, EXTRAS, RX, DST, GROW, XVALID, BND)                      \
+#define B2_STEP(XB, ACCX, PK, PKNEXT, ACCY, MY, WY, GBY, EPI, MASKED, COPY, EXTRAS, EXW, XT, XS, RX, DST, GROW, BND)                  \
         {                                                                                                                           \
             const unsigned mlo_ = (unsigned)(MY), mhi_ = (unsigned)((MY) >> 32);                                                    \
             pn_acc_zero(ACCX);                                                                                                      \
             pn_tile_gemm_side<PN_H / 8>(XB, LDH, a.packed + (PK) / 4, wave, lane, ACCX, bpre, a.packed + (PKNEXT) / 4, [&](auto ss) { \
                 constexpr int s = decltype(ss)::value;                                                                              \
                 if constexpr (EPI && s % 8 == 0) b2_epi_piece<s / 8, MASKED>(ACCY, mlo_, mhi_, WY, GBY);                            \
+                if constexpr (EXW && s == 1) {        /* the tile's extras take over its d f region (dead since the dY4 pass) */          \
+                    if (tl < 2 * PN_TILE) *reinterpret_cast<float4 *>((XT).dfs + tl * 4) = (XS).exv;                                   \
+                }                                                                                                                   \
                 if constexpr (COPY && EXTRAS && s % 32 == 2) {                                                                      \
-                    const float *exr = a.sv.ex + ((GROW) + 4 * (s / 32)) * 8;                                                       \
-                    exa = exb2 = make_float4(0.f, 0.f, 0.f, 0.f);                                                                   \
-                    if (XVALID) { exa = *reinterpret_cast<const float4 *>(exr); exb2 = *reinterpret_cast<const float4 *>(exr + 4); } \
+                    const float *exr = (XT).dfs + (wave + 4 * (s / 32)) * 8;                                                         \
+                    exa = *reinterpret_cast<const float4 *>(exr); exb2 = *reinterpret_cast<const float4 *>(exr + 4);                \
                 }                                                                                                                   \
                 if constexpr (COPY && s % 32 == 4) cpv = *reinterpret_cast<const float4 *>((RX) + 4 * (s / 32) * LDH);              \
                 if constexpr (COPY && s % 32 == 20) *reinterpret_cast<float4 *>((DST) + ((GROW) + 4 * (s / 32)) * PN_H + lane * 4) = cpv; \
@@ -649,34 +689,33 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_backward(BwdArgs a) {
                     gw3e[j_][0] += cpv.x * e_; gw3e[j_][1] += cpv.y * e_; gw3e[j_][2] += cpv.z * e_; gw3e[j_][3] += cpv.w * e_;      \
                     asm volatile("" : "+v"(gw3e[j_][0]), "+v"(gw3e[j_][1]), "+v"(gw3e[j_][2]), "+v"(gw3e[j_][3]));                    \
                 }                                                                                                                   \
+                if constexpr (COPY && EXTRAS) b2_extras_slot<s>(a, XT, XS, w3ex, EX, tl);                                          \
                 BND(s);                                                                                                             \
             });                                                                                                                     \
             __syncthreads();                                                                                                        \
         }
-        //      X-tile   accX  image  accY  maskY  writeY gbY    EPI    MASK   COPY   EXTRAS readX dst        rowbase boundary
-        B2_STEP(TA.buf, accA, PK_D4, PK_D4, accB, 0ull, wyB, gnone, false, false, false, false, rxA, a.sv.dy3, gA, SA.valid, B2_BND_B)
+        //      X-tile   accX  image  next   accY  maskY  writeY gbY    EPI    MASK   COPY   EXTRAS EXW   X   state readX dst       rowbase boundary
+        B2_STEP(TA.buf, accA, PK_D4, PK_D4, accB, 0ull, wyB, gnone, false, false, false, false, true, TA, SA, rxA, a.sv.dy3, gA, B2_BND_B)
         PN_TR(pn_trace_bwd, 1);
         const long long gB = SB.tile * PN_TILE + wave;
-        B2_STEP(TB.buf, accB, PK_D4, PK_D3, accA, SA.m3, wyA, gb[2], true, true, false, false, rxB, a.sv.dy3, gB, SB.valid, B2_NOBND)
+        B2_STEP(TB.buf, accB, PK_D4, PK_D3, accA, SA.m3, wyA, gb[2], true, true, false, false, true, TB, SB, rxB, a.sv.dy3, gB, B2_NOBND)
         PN_TR(pn_trace_bwd, 2);
-        b2_extras(a, TA, SA, w3ex, tl);
         PN_TR(pn_trace_bwd, 3);
-        B2_STEP(TA.buf, accA, PK_D3, PK_D3, accB, SB.m3, wyB, gb[2], true, true, true, true, rxA, a.sv.dy3, gA, SA.valid, B2_NOBND)
+        B2_STEP(TA.buf, accA, PK_D3, PK_D3, accB, SB.m3, wyB, gb[2], true, true, true, true, false, TA, SA, rxA, a.sv.dy3, gA, B2_NOBND)
         PN_TR(pn_trace_bwd, 4);
-        b2_extras(a, TB, SB, w3ex, tl);
         PN_TR(pn_trace_bwd, 5);
-        B2_STEP(TB.buf, accB, PK_D3, PK_D2, accA, SA.m2, wyA, gb[1], true, true, true, true, rxB, a.sv.dy3, gB, SB.valid, B2_NOBND)
+        B2_STEP(TB.buf, accB, PK_D3, PK_D2, accA, SA.m2, wyA, gb[1], true, true, true, true, false, TB, SB, rxB, a.sv.dy3, gB, B2_NOBND)
         PN_TR(pn_trace_bwd, 6);
-        B2_STEP(TA.buf, accA, PK_D2, PK_D2, accB, SB.m2, wyB, gb[1], true, true, true, false, rxA, a.sv.dy2, gA, SA.valid, B2_NOBND)
+        B2_STEP(TA.buf, accA, PK_D2, PK_D2, accB, SB.m2, wyB, gb[1], true, true, true, false, false, TA, SA, rxA, a.sv.dy2, gA, B2_NOBND)
         PN_TR(pn_trace_bwd, 7);
-        B2_STEP(TB.buf, accB, PK_D2, PK_D1, accA, SA.m1, wyA, gb[0], true, true, true, false, rxB, a.sv.dy2, gB, SB.valid, B2_NOBND)
+        B2_STEP(TB.buf, accB, PK_D2, PK_D1, accA, SA.m1, wyA, gb[0], true, true, true, false, false, TB, SB, rxB, a.sv.dy2, gB, B2_NOBND)
         PN_TR(pn_trace_bwd, 8);
-        B2_STEP(TA.buf, accA, PK_D1, PK_D1, accB, SB.m1, wyB, gb[0], true, true, true, false, rxA, a.sv.dy1, gA, SA.valid, B2_NOBND)
+        B2_STEP(TA.buf, accA, PK_D1, PK_D1, accB, SB.m1, wyB, gb[0], true, true, true, false, false, TA, SA, rxA, a.sv.dy1, gA, B2_NOBND)
         PN_TR(pn_trace_bwd, 9);
 #ifdef PN_PHASE_TRACE
         CB.trbase = -1;
 #endif
-        B2_STEP(TB.buf, accB, PK_D1, PK_D4, accA, 0ull, wyA, gnone, false, false, true, false, rxB, a.sv.dy1, gB, SB.valid, B2_BND_A)
+        B2_STEP(TB.buf, accB, PK_D1, PK_D4, accA, 0ull, wyA, gnone, false, false, true, false, false, TB, SB, rxB, a.sv.dy1, gB, B2_BND_A)
         PN_TR(pn_trace_bwd, 10);
 #undef B2_STEP
 #undef B2_BND_A
