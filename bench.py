@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=12288, help="rays of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--render-only", action="store_true", help="supplementary: inference (render, no backward) rays/s")
+    ap.add_argument("--zero1", action="store_true", help="N > 1: shard the point-parameter Adam (reduce-scatter + all-gather) instead of all-reducing the gradients")
     return ap.parse_args()
 
 
@@ -124,8 +125,12 @@ def main():
     agg, npnt = model.aggregator, model.neural_points
     mlp_params = [p for p in agg.parameters() if p.requires_grad]
     pt_params = [p for p in (npnt.points_embeding, npnt.points_conf, npnt.points_dir, npnt.points_color) if p.requires_grad]
-    opt_mlp = torch.optim.Adam(mlp_params, lr=opt.lr, betas=(0.9, 0.999))       # neural_points_volumetric_model.py:196-201
-    opt_pts = torch.optim.Adam(pt_params, lr=opt.plr, betas=(0.9, 0.999))
+    # the reference's two Adam instances (mvs_points_volumetric_model.py:80-91) as one-pass HIP updates; --zero1 shards the
+    # update and its state over the ranks (reduce-scatter / all-gather instead of all-reduce)
+    from pointnerf_amd.optim import FusedAdam, ShardedAdam
+    zero1 = args.zero1 and world > 1
+    opt_mlp = FusedAdam(mlp_params, lr=opt.lr, betas=(0.9, 0.999))
+    opt_pts = ShardedAdam(pt_params, lr=opt.plr, betas=(0.9, 0.999)) if zero1 else FusedAdam(pt_params, lr=opt.plr, betas=(0.9, 0.999))
 
     total = args.warmup + args.steps
     inputs = [step_inputs(i, rank, world, args.rays, dev) for i in range(total)]   # resident in HBM before timing
@@ -139,7 +144,7 @@ def main():
         out = model(**inp)
         loss = loss_fn(opt, out, inp, world)
         loss.backward()
-        pdist.allreduce_grads(mlp_params, pt_params)    # no-op at N=1; RCCL over xGMI otherwise
+        pdist.allreduce_grads(mlp_params, [] if zero1 else pt_params)    # no-op at N=1; RCCL over xGMI otherwise
         opt_mlp.step(); opt_pts.step()
         return loss, model.last_stats
 

@@ -202,6 +202,12 @@ int pnerf_raymarch_forward(const float *d_ray_dist, const uint8_t *d_ray_valid, 
 int pnerf_raymarch_backward(const float *d_ray_dist, const uint8_t *d_ray_valid, const float *d_features, const float *bg3_host,
                             int R, int SR, const float *d_grad_ray_color, float *d_grad_features, void *stream);
 
+/* ---- parameter update: one Adam step of one tensor in one pass (the reference steps two torch.optim.Adam instances,
+ * models/mvs_points_volumetric_model.py:80-91 and :98-118; lr / plr, betas (0.9, 0.999), eps 1e-8, no weight decay).
+ * All four arrays hold n floats (16-byte aligned arrays take the float4 path); step counts from 1 (the value torch keeps in state['step']). */
+int pnerf_adam_step(float *d_param, const float *d_grad, float *d_exp_avg, float *d_exp_avg_sq, int64_t n,
+                    double lr, double beta1, double beta2, double eps, int64_t step, void *stream);
+
 /* ---- per-kernel timing (HIP events recorded on the launch stream; off by default) --------------- */
 int pnerf_prof_enable(int on);
 int pnerf_prof_kernel_count(void);

@@ -29,7 +29,7 @@ struct PnCarver {
 
 // ---- optional per-kernel timing with HIP events on the launch stream (prof.hip) ----------------
 enum PnKernelId { PNK_GRID = 0, PNK_PROBE, PNK_NEIGHBORS, PNK_COMPACT, PNK_PACK, PNK_AGG_FWD, PNK_COLOR_FWD, PNK_RAYMARCH_FWD,
-                  PNK_RAYMARCH_BWD, PNK_COLOR_BWD, PNK_AGG_BWD, PNK_WGRAD, PNK_WGRAD_REDUCE, PNK_GATHER, PNK_COUNT };
+                  PNK_RAYMARCH_BWD, PNK_COLOR_BWD, PNK_AGG_BWD, PNK_WGRAD, PNK_WGRAD_REDUCE, PNK_GATHER, PNK_ADAM, PNK_COUNT };
 extern int pn_prof_enabled;
 void pn_prof_mark(int id, bool begin, hipStream_t s);
 struct PnProfScope {       // RAII: records an event pair around the launches issued while it lives

@@ -18,7 +18,7 @@ hipEvent_t get_event() {
 }
 const char *kNames[PNK_COUNT] = {"grid_build", "probe", "neighbors", "compact", "mlp_pack", "agg_forward", "color_forward",
                                  "raymarch_forward", "raymarch_backward", "color_backward", "agg_backward", "wgrad",
-                                 "wgrad_reduce", "gather"};
+                                 "wgrad_reduce", "gather", "adam"};
 }  // namespace
 
 void pn_prof_mark(int id, bool begin, hipStream_t s) {

@@ -1,0 +1,112 @@
+"""Parameter update of the hot path's caller: the reference steps two ``torch.optim.Adam`` instances per iteration
+(models/mvs_points_volumetric_model.py:80-91 build them, :98-118 step them: MLP parameters with ``opt.lr``, the
+``neural_points.*`` parameters with ``opt.plr``, betas (0.9, 0.999)).  ``FusedAdam`` is that optimizer on
+libpnerf_hip.so (pnerf_adam_step: one pass over p, g, m, v per tensor) with torch's state layout
+(``state[p] = {step, exp_avg, exp_avg_sq}``), so ``state_dict()`` / ``load_state_dict()`` interchange with
+``torch.optim.Adam`` checkpoints.  SURVEY.md 8(f2).
+
+``ShardedAdam`` is the ZeRO-1 form for ray-sharded data parallelism: gradients are reduce-scattered (RCCL over xGMI), every
+rank updates 1/G of each flattened parameter and the updated shards are all-gathered -- the same bytes on the wire as
+all-reducing the gradients, 1/G of the Adam work and state per GPU."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+def _adam_hip(p, g, m, v, lr, b1, b2, eps, step):
+    lib = L.lib()
+    n = p.numel()
+    for t in (p, g, m, v):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.numel() == n):
+            raise ValueError("FusedAdam: parameters, gradients and state must be contiguous fp32 device tensors of one size")
+    L.check(lib.pnerf_adam_step(ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(m.data_ptr()),
+                                ctypes.c_void_p(v.data_ptr()), n, lr, b1, b2, eps, step,
+                                ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)), "pnerf_adam_step")
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr, betas, eps) semantics (no weight decay, no amsgrad) in one HIP pass per tensor."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, update=None):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._update = update or _adam_hip          # tests on CPU inject a torch restatement; the product path is the HIP kernel
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.zeros((), dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                self._update(p.data, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                             int(st["step"].item()))
+        return loss
+
+
+class ShardedAdam:
+    """ZeRO-1 Adam over a process group: state and update are sharded by rank, parameters stay replicated."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None, update=None):
+        self.params = [p for p in params]
+        self.lr, self.betas, self.eps, self.group = lr, betas, eps, group
+        self._update = update or _adam_hip
+        self.step_count = 0
+        dist = torch.distributed
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.state = []
+        for p in self.params:
+            shard = (p.numel() + self.world - 1) // self.world
+            shard = (shard + 3) // 4 * 4                     # float4 alignment of every shard
+            self.state.append(dict(shard=shard, exp_avg=torch.zeros(shard, dtype=torch.float32, device=p.device),
+                                   exp_avg_sq=torch.zeros(shard, dtype=torch.float32, device=p.device)))
+
+    @torch.no_grad()
+    def step(self):
+        dist = torch.distributed
+        self.step_count += 1
+        for p, st in zip(self.params, self.state):
+            if p.grad is None:
+                continue
+            n, shard, W = p.numel(), st["shard"], self.world
+            gpad = torch.zeros(shard * W, dtype=torch.float32, device=p.device)
+            gpad[:n] = p.grad.reshape(-1)
+            gs = torch.empty(shard, dtype=torch.float32, device=p.device)
+            if W > 1:
+                if dist.get_backend(self.group) == "gloo":       # gloo has no reduce_scatter: all-reduce and slice (CPU tests only)
+                    dist.all_reduce(gpad, group=self.group)
+                    gs.copy_(gpad[self.rank * shard:(self.rank + 1) * shard])
+                else:
+                    dist.reduce_scatter_tensor(gs, gpad, group=self.group)
+            else:
+                gs.copy_(gpad)
+            ppad = torch.zeros(shard * W, dtype=torch.float32, device=p.device)
+            ppad[:n] = p.data.reshape(-1)
+            ps = ppad[self.rank * shard:(self.rank + 1) * shard].clone()
+            self._update(ps, gs, st["exp_avg"], st["exp_avg_sq"], float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                         self.step_count)
+            if W > 1:
+                if dist.get_backend(self.group) == "gloo":
+                    dist.all_gather(list(ppad.view(W, shard).unbind(0)), ps, group=self.group)
+                else:
+                    dist.all_gather_into_tensor(ppad, ps, group=self.group)
+            else:
+                ppad.copy_(ps)
+            p.data.copy_(ppad[:n].view_as(p))
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()

@@ -34,12 +34,18 @@ def test_bench_json_contract_single_gpu():
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
 
 
-def test_bench_two_ranks_on_one_gpu():
+def _two_ranks(extra, port_off):
     env = dict(os.environ, PNERF_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--rays", "4096", "--points", "300000", "--cpu-rays", "0"]
-    out = subprocess.check_output(cmd, cwd=ROOT, env=env, timeout=900, stderr=subprocess.STDOUT)
-    d = _last_json(out)
+           "--master-port", str(29600 + (os.getpid() + port_off) % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--rays", "4096", "--points", "300000", "--cpu-rays", "0"] + extra
+    return _last_json(subprocess.check_output(cmd, cwd=ROOT, env=env, timeout=900, stderr=subprocess.STDOUT))
+
+
+def test_bench_two_ranks_on_one_gpu():
+    d = _two_ranks([], 0)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert "cpu_baseline" not in d                      # rank 0 at N=1 only
+    # ZeRO-1 sharding of the point-parameter Adam is the same update: the loss after 3 steps agrees to summation order
+    z = _two_ranks(["--zero1"], 7)
+    assert abs(z["config"]["final_loss"] - d["config"]["final_loss"]) <= 1e-5 * max(1.0, abs(d["config"]["final_loss"]))
