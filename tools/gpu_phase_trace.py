@@ -43,9 +43,9 @@ FWD_NAMES = {(0, 1): "G1(A) | boundary B", (1, 2): "G1(B) | E1(A)", (2, 3): "G2(
              (4, 5): "G3(A) | E2(B), copy A", (5, 6): "G3(B) | E3(A), copy B", (6, 7): "G4(A) | E3(B), copy A", (7, 8): "G4(B) | copy B, boundary A",
              (0, 9): "  S1: start -> slot 1 (requests)", (9, 10): "  S1: slots 1-3", (10, 11): "  S1: E4 (4-67)", (11, 12): "  S1: alpha head (68-141)", (12, 13): "  S1: K-sums + h4 copy (142-215)",
              (13, 14): "  S1: barrier + geometry (216-223)", (14, 15): "  S1: embedding PE (224-271)", (15, 16): "  S1: distance PE + pad (272-295)", (16, 17): "  S1: barrier + weights (296-299)",
-             (17, 18): "  S1: x0 copy-out (300-375)", (18, 1): "  S1: tail (375-575) + barrier"}
-BWD_NAMES = {(0, 1): "G(A,4) | boundary B", (1, 2): "G(B,4) | E(A)", (2, 3): "extras A", (3, 4): "G(A,3) | E(B), copy A", (4, 5): "extras B",
-             (5, 6): "G(B,3) | E(A), copy B", (6, 7): "G(A,2) | E(B), copy A", (7, 8): "G(B,2) | E(A), copy B", (8, 9): "G(A,1) | E(B), copy A",
+             (17, 18): "  S1: slots 300-375 (index shift only)", (18, 1): "  S1: tail (375-575) + barrier"}
+BWD_NAMES = {(0, 1): "G(A,4) | boundary B", (1, 2): "G(B,4) | E(A)", (2, 3): "(between steps)", (3, 4): "G(A,3) | E(B), copy A, extras A", (4, 5): "(between steps)",
+             (5, 6): "G(B,3) | E(A), copy B, extras B", (6, 7): "G(A,2) | E(B), copy A", (7, 8): "G(B,2) | E(A), copy B", (8, 9): "G(A,1) | E(B), copy A",
              (9, 10): "G(B,1) | copy B, boundary A",
              (0, 11): "  S1: start -> slot 0", (11, 12): "  S1: slots 0-3", (12, 13): "  S1: slots 3-9", (13, 14): "  S1: slots 9-17", (14, 15): "  S1: slots 17-34",
              (15, 16): "  S1: slots 34-50", (16, 17): "  S1: slots 50-74", (17, 18): "  S1: slots 74-140", (18, 19): "  S1: slots 140-243",
