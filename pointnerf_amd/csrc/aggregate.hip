@@ -74,7 +74,8 @@ extern "C" int pnerf_mlp_pack(const float *d_params, void *d_packed, void *strea
 // ------------------------------------------------------------------------------ saved activations
 size_t pn_saved_bytes(long long n_valid, int K, long long *rows_out, long long *samples_out) {
     const int TS = pn_tile_samples(K);
-    const long long tiles = (n_valid + TS - 1) / TS + 1;
+    // + PN_NCLS tiles of rounding (each class ends in a partial tile) + PN_NCLS gap tiles (every class owns a padding tile) + 1
+    const long long tiles = (n_valid + TS - 1) / TS + 2 * PN_NCLS + 1;
     const long long rows = tiles * PN_TILE;
     const long long samples = ((tiles * TS + PN_CTILE - 1) / PN_CTILE + 1) * PN_CTILE;
     if (rows_out) *rows_out = rows;
@@ -82,6 +83,7 @@ size_t pn_saved_bytes(long long n_valid, int K, long long *rows_out, long long *
     size_t b = 0;
     b += pn_align((size_t)rows * PN_IN1P * 4) + 8 * pn_align((size_t)rows * PN_H * 4) + pn_align((size_t)rows * 8 * 4) + pn_align((size_t)rows * 16);
     b += pn_align((size_t)tiles * 3 * PN_NTHR * 8);
+    b += pn_cls_bytes(samples);
     b += 2 * pn_align((size_t)samples * PN_H * 4) + pn_align((size_t)samples * 32 * 4) + 6 * pn_align((size_t)samples * PN_HC * 4);
     return b;
 }
@@ -102,7 +104,18 @@ PnSaved pn_saved_carve(void *base, long long n_valid, int K) {
     s.c1 = cv.take<float>((size_t)s.samples * PN_HC); s.c2 = cv.take<float>((size_t)s.samples * PN_HC);
     s.c3 = cv.take<float>((size_t)s.samples * PN_HC); s.dc1 = cv.take<float>((size_t)s.samples * PN_HC);
     s.dc2 = cv.take<float>((size_t)s.samples * PN_HC); s.dc3 = cv.take<float>((size_t)s.samples * PN_HC);
+    pn_cls_carve(cv.take<char>(pn_cls_bytes(s.samples)), s.samples, s);
     return s;
+}
+
+size_t pn_cls_bytes(long long samples) {
+    return pn_align((size_t)samples * 4) + pn_align(PN_CI_WORDS * 4) + pn_align(((size_t)2 * samples + pn_scan_scratch_ints(samples) + 8) * 4);
+}
+void pn_cls_carve(void *base, long long samples, PnSaved &s) {
+    PnCarver cv(base, pn_cls_bytes(samples));
+    s.cls_list = cv.take<int>((size_t)samples);
+    s.cls_info = cv.take<int>(PN_CI_WORDS);
+    s.cls_tmp = cv.take<int>((size_t)2 * samples + pn_scan_scratch_ints(samples) + 8);
 }
 
 extern "C" size_t pnerf_agg_saved_bytes(int64_t n_valid_samples, int K) {
@@ -125,6 +138,8 @@ struct FwdArgs {
     const float *raydir, *sample_loc;
     const float *xyz_pers, *loc_pers;   // optional: perspective coords supplied by the caller (stand-alone aggregator)
     const int *pidx, *valid_list, *counters;
+    const int *cls_list, *cls_info;     // sample classes (pn_classify); cls = the class this launch processes
+    int cls, Kstride;                   // K = neighbor slots PROCESSED per sample of this class, Kstride = slots per sample in pidx / weight
     int R, SR, K, TS;
     long long cap_samples;      // capacity (in valid samples) of fs / saved buffers
     float *decoded, *weight;
@@ -142,6 +157,94 @@ template <int N> __device__ __forceinline__ float group_sum(float v) {      // s
     for (int off = 1; off < N; off <<= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+
+// ------------------------------------------------------------------------------ sample classes
+// 6 % of the neighbor rows of valid samples are empty slots (a sample near the surface's edge has 1..K-1 neighbors); the
+// reference drops them by boolean masking (point_aggregators.py:523-538).  Tiles need whole samples of equal row count, so the
+// valid samples are partitioned by the position of their LAST occupied slot into up to three classes that are processed with
+// K, K/2 and K/4 rows per sample (K % 4 == 0; the query fills slots front to back, and for a caller-supplied mask the last
+// occupied slot is what counts).  The partition is stable (ascending sample id inside a class): results are identical to the
+// one-class launch, rows processed drop from 7.49 M to 7.1 M at the bench configuration.  Every class owns a run of tiles
+// followed by one padding tile (the partner slot of an odd tile count works on it).
+namespace {
+struct ClsArgs { const int *valid_list, *counters, *pidx; int K, n, ncls; int kc[PN_NCLS], ts[PN_NCLS]; };
+
+__global__ void k_cls_flags(ClsArgs c, int which, int *__restrict__ flags) {
+    const int vs = blockIdx.x * blockDim.x + threadIdx.x;
+    if (vs >= c.n) return;
+    const int Ns = c.counters[0] < c.n ? c.counters[0] : c.n;
+    int f = 0;
+    if (vs < Ns) {
+        const long long si = c.valid_list[vs];
+        int hv = 0;
+        for (int k = 0; k < c.K; ++k)
+            if (c.pidx[si * c.K + k] >= 0) hv = k + 1;
+        int cl = 0;
+        for (int j = 1; j < c.ncls; ++j)
+            if (hv <= c.kc[j]) cl = j;
+        f = cl == which;
+    }
+    flags[vs] = f;
+}
+
+__global__ void k_cls_gather(ClsArgs c, int which, const int *__restrict__ pos, const int *__restrict__ count, int *__restrict__ cls_list,
+                             int *__restrict__ info) {
+    const int n = *count, base = info[PN_CI_VBASE + which];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) cls_list[base + i] = c.valid_list[pos[i]];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int tiles = (n + c.ts[which] - 1) / c.ts[which], tb = info[PN_CI_TBASE + which];
+        info[PN_CI_COUNT + which] = n;
+        if (which + 1 < PN_NCLS) { info[PN_CI_VBASE + which + 1] = base + n; info[PN_CI_TBASE + which + 1] = tb + tiles + 1; }
+        info[PN_CI_TILES] = tb + tiles + 1;
+    }
+}
+
+// the padding tile of every class: finite (zero) rows in everything the weight-gradient GEMMs read
+__global__ void k_cls_zero_gaps(PnSaved sv, int ncls) {
+    const int c = blockIdx.y;
+    if (c >= ncls) return;
+    const int n = sv.cls_info[PN_CI_COUNT + c];
+    (void)n;
+    const long long gap = (c + 1 < PN_NCLS ? sv.cls_info[PN_CI_TBASE + c + 1] : sv.cls_info[PN_CI_TILES]) - 1;
+    float *arrs[9] = {sv.x0, sv.h1, sv.h2, sv.h3, sv.h4, sv.dy1, sv.dy2, sv.dy3, sv.dy4};
+    const int which = blockIdx.x;                      // 9 arrays
+    const int w = which == 0 ? PN_IN1P : PN_H;
+    float *p = arrs[which] + gap * PN_TILE * w;
+    for (int i = threadIdx.x; i < PN_TILE * w; i += blockDim.x) p[i] = 0.f;
+}
+}  // namespace
+
+}  // namespace
+
+// class c processes kc[c] slots per sample
+int pn_class_slots(int K, int kc[PN_NCLS]) {
+    if (K % 4 == 0) { kc[0] = K; kc[1] = K / 2; kc[2] = K / 4; return 3; }
+    kc[0] = K; kc[1] = kc[2] = 0;
+    return 1;
+}
+
+int pn_classify(const PnSaved &sv, const int32_t *d_valid_list, const int32_t *d_counters, const int32_t *d_pidx, int K, long long n_valid,
+                bool train, hipStream_t s) {
+    ClsArgs c;
+    c.valid_list = d_valid_list; c.counters = d_counters; c.pidx = d_pidx; c.K = K; c.n = (int)n_valid;
+    c.ncls = pn_class_slots(K, c.kc);
+    for (int j = 0; j < PN_NCLS; ++j) c.ts[j] = c.kc[j] > 0 ? pn_tile_samples(c.kc[j]) : 1;
+    if (hipMemsetAsync(sv.cls_info, 0, PN_CI_WORDS * sizeof(int), s) != hipSuccess) return PNERF_E_LAUNCH;
+    if (n_valid <= 0) return 0;
+    int *flags = sv.cls_tmp, *pos = flags + n_valid, *cnt = pos + n_valid, *scratch = cnt + 8;
+    PnProfScope prof(PNK_COMPACT, s);
+    for (int j = 0; j < c.ncls; ++j) {
+        hipLaunchKernelGGL(k_cls_flags, dim3(pn_cdiv(n_valid, 256)), dim3(256), 0, s, c, j, flags);
+        int rc = pn_compact_gt0_i32(flags, n_valid, pos, cnt, scratch, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_cls_gather, dim3(256), dim3(256), 0, s, c, j, pos, cnt, sv.cls_list, sv.cls_info);
+    }
+    if (train) hipLaunchKernelGGL(k_cls_zero_gaps, dim3(9, c.ncls), dim3(256), 0, s, sv, c.ncls);
+    PN_CHECK_LAUNCH();
+    return 0;
+}
+
+namespace {
 
 // ------------------------------------------------------------------------------ two-tile forward
 // Same organisation as the backward (backward.hip): one workgroup (4 waves, one per SIMD) per CU, two tiles A / B in flight,
@@ -218,7 +321,7 @@ __device__ __forceinline__ void f2_request(const FwdArgs &a, F2State &S, F2Bnd &
         C.cx = a.color[3 * p]; C.cy = a.color[3 * p + 1]; C.cz = a.color[3 * p + 2];
         C.rx = a.raydir[3 * r]; C.ry = a.raydir[3 * r + 1]; C.rz = a.raydir[3 * r + 2];
     }
-    S.p2 = S.si2 >= 0 ? a.pidx[(long long)S.si2 * a.K + k] : -1;
+    S.p2 = S.si2 >= 0 ? a.pidx[(long long)S.si2 * a.Kstride + k] : -1;
     S.t3 = S.t2 + stride;
     S.si3 = f2_sample_of(a, S.t3, row, Ns);
 }
@@ -299,7 +402,7 @@ __device__ __forceinline__ void f2_weights(const FwdArgs &a, const F2Tile &T, co
             for (int kk = 0; kk < a.K; ++kk) sum += T.wraw[ls * a.K + kk];
             wn = T.wraw[row] / fmaxf(sum, 1e-8f);
             w = wn * fminf(fmaxf(C.cf, 1e-4f), 1.0f);
-            a.weight[(long long)C.sicur * a.K + k] = wn;
+            a.weight[(long long)C.sicur * a.Kstride + k] = wn;
         }
         T.wnrm[row] = wn; T.wrow[row] = w;
         if (TRAIN) a.sv.rmeta[(long long)tile * PN_TILE + row] = make_int4(C.sicur, C.sicur >= 0 ? C.pcur : -1, __float_as_int(wn), __float_as_int(w));
@@ -434,7 +537,17 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_forward2(FwdArgs a) {
     float *w5s = smem + 2 * F2_TILE_FLOATS;
     const int tid = threadIdx.x;
     const int K = a.K, TS = a.TS;
-    const int Ns = a.counters[0] < a.cap_samples ? a.counters[0] : (int)a.cap_samples;
+    // this launch processes one sample class: its list, its run of tiles, its range of per-sample rows
+    const int Ns = a.cls_info[PN_CI_COUNT + a.cls];
+    {
+        const long long vb = a.cls_info[PN_CI_VBASE + a.cls], tb = a.cls_info[PN_CI_TBASE + a.cls];
+        a.valid_list = a.cls_list + vb; a.cap_samples = Ns;
+        a.sv.fs += vb * PN_H;
+        if (TRAIN) {
+            a.sv.x0 += tb * PN_TILE * PN_IN1P; a.sv.ex += tb * PN_TILE * 8; a.sv.rmeta += tb * PN_TILE; a.sv.lmask += tb * 3 * PN_NTHR;
+            a.sv.h1 += tb * PN_TILE * PN_H; a.sv.h2 += tb * PN_TILE * PN_H; a.sv.h3 += tb * PN_TILE * PN_H; a.sv.h4 += tb * PN_TILE * PN_H;
+        }
+    }
     const int ntiles = (Ns + TS - 1) / TS;
     const float *P = a.params;
     if (tid < PN_H) w5s[tid] = P[PO_W5 + tid];
@@ -453,8 +566,8 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_forward2(FwdArgs a) {
         SB.t1 = SA.t1 + 1; SB.t2 = SB.t1 + stride;
         SA.si1 = f2_sample_of(a, SA.t1, row, Ns); SA.si2 = f2_sample_of(a, SA.t2, row, Ns);
         SB.si1 = f2_sample_of(a, SB.t1, row, Ns); SB.si2 = f2_sample_of(a, SB.t2, row, Ns);
-        SA.p1 = SA.si1 >= 0 ? a.pidx[(long long)SA.si1 * K + k] : -1;
-        SB.p1 = SB.si1 >= 0 ? a.pidx[(long long)SB.si1 * K + k] : -1;
+        SA.p1 = SA.si1 >= 0 ? a.pidx[(long long)SA.si1 * a.Kstride + k] : -1;
+        SB.p1 = SB.si1 >= 0 ? a.pidx[(long long)SB.si1 * a.Kstride + k] : -1;
         SA.tile = SA.t1; SB.tile = ntiles;              // buffer B starts as an empty finished tile on the padding tile's storage
         f2_request<PERS>(a, SA, CB, tid, Ns, stride);
         SA.tile = SA.t1;
@@ -716,9 +829,6 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
-    const long long tiles = (cap_samples + a.TS - 1) / a.TS;
-    const long long pairs = (tiles + 1) / 2;          // one workgroup per CU, two tiles in flight each
-    const int grid_a = (int)(pairs < (long long)ncu ? (pairs > 0 ? pairs : 1) : ncu);
     const long long ctiles = (cap_samples + PN_CTILE - 1) / PN_CTILE;
     const int grid_c = (int)(ctiles < ncu ? (ctiles > 0 ? ctiles : 1) : ncu);
     const size_t lds_a = F2_LDS_FLOATS * sizeof(float), lds_c = COL_LDS_FLOATS * sizeof(float);
@@ -728,13 +838,24 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     const void *cfn = train ? (const void *)k_color_forward<true> : (const void *)k_color_forward<false>;
     if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipFuncSetAttribute(cfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
+    int rc = pn_classify(sv, d_valid_list, d_counters, d_sample_pidx, K, cap_samples, train, s);
+    if (rc) return rc;
+    a.cls_list = sv.cls_list; a.cls_info = sv.cls_info; a.Kstride = K;
+    int kc[PN_NCLS];
+    const int ncls = pn_class_slots(K, kc);
     {
         PnProfScope prof(PNK_AGG_FWD, s);
-        if (train && pers) hipLaunchKernelGGL((k_agg_forward2<true, true>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
-        else if (train) hipLaunchKernelGGL((k_agg_forward2<true, false>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
-        else if (pers) hipLaunchKernelGGL((k_agg_forward2<false, true>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
-        else hipLaunchKernelGGL((k_agg_forward2<false, false>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+        for (int j = 0; j < ncls; ++j) {            // class sizes are only known on the device: the grid covers the worst case, surplus workgroups return at once
+            a.cls = j; a.K = kc[j]; a.TS = pn_tile_samples(kc[j]);
+            const long long pairs = ((cap_samples + a.TS - 1) / a.TS + 1) / 2;
+            const int grid_a = (int)(pairs < (long long)ncu ? (pairs > 0 ? pairs : 1) : ncu);
+            if (train && pers) hipLaunchKernelGGL((k_agg_forward2<true, true>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            else if (train) hipLaunchKernelGGL((k_agg_forward2<true, false>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            else if (pers) hipLaunchKernelGGL((k_agg_forward2<false, true>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            else hipLaunchKernelGGL((k_agg_forward2<false, false>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+        }
     }
+    a.K = K; a.TS = pn_tile_samples(K); a.valid_list = sv.cls_list;      // the colour MLP walks the class-ordered list: f rows are in that order
     {
         PnProfScope prof(PNK_COLOR_FWD, s);
         if (train) hipLaunchKernelGGL(k_color_forward<true>, dim3(grid_c), dim3(256), lds_c, s, a);

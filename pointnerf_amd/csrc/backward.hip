@@ -25,6 +25,8 @@ struct BwdArgs {
     const float4 *packed;
     const float *raydir;
     const int *pidx, *valid_list, *counters;
+    const int *cls_list, *cls_info;     // sample classes (aggregate.hip: pn_classify); cls = the class this launch processes
+    int cls;
     int SR, K, TS;
     long long cap_samples;
     const float *decoded, *weight, *grad_decoded;
@@ -603,7 +605,15 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_backward(BwdArgs a) {
     float *w3ex = w5s + PN_H;                  // [7][256]  W3[o][256+j]
     const int tid = threadIdx.x;
     const int K = a.K, TS = a.TS;
-    const int Ns = a.counters[0] < a.cap_samples ? a.counters[0] : (int)a.cap_samples;
+    // this launch processes one sample class: its run of tiles, its range of per-sample rows
+    const int Ns = a.cls_info[PN_CI_COUNT + a.cls];
+    {
+        const long long vb = a.cls_info[PN_CI_VBASE + a.cls], tb = a.cls_info[PN_CI_TBASE + a.cls];
+        a.sv.dfs += vb * PN_H;
+        a.sv.x0 += tb * PN_TILE * PN_IN1P; a.sv.ex += tb * PN_TILE * 8; a.sv.rmeta += tb * PN_TILE; a.sv.lmask += tb * 3 * PN_NTHR;
+        a.sv.h4 += tb * PN_TILE * PN_H;
+        a.sv.dy1 += tb * PN_TILE * PN_H; a.sv.dy2 += tb * PN_TILE * PN_H; a.sv.dy3 += tb * PN_TILE * PN_H; a.sv.dy4 += tb * PN_TILE * PN_H;
+    }
     const long long ntiles = ((long long)Ns + TS - 1) / TS;
     const float *P = a.params;
     if (tid < PN_H) {
@@ -765,8 +775,15 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_backward(BwdArgs a) {
 template <int MT, int NT, int WM, int WN, int KB, bool TAIL>
 __global__ __launch_bounds__(WM *WN * 64) void k_wgrad_lds(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
                                                            const float *__restrict__ Bt, int ldbt,
-                                                           long long rows, int rows_per_chunk, float *__restrict__ partial, int Ntot) {
+                                                           long long rows, const int *__restrict__ d_tiles, int rows_per_chunk, float *__restrict__ partial, int Ntot) {
     constexpr int NTHR = WM * WN * 64, MTOT = WM * MT * 32, NTILE = WN * NT * 32;
+    if (d_tiles) {      // the tiles the aggregator kernels actually used are known on the device only: re-split them over the chunks
+        const long long r = (long long)(*d_tiles) * PN_TILE;
+        rows = r < rows ? r : rows;
+        long long rpc = (rows + gridDim.y - 1) / gridDim.y;
+        rpc = (rpc + 63) / 64 * 64;
+        rows_per_chunk = (int)(rpc < 64 ? 64 : rpc);
+    }
     constexpr int A4 = KB * MTOT / 4 / NTHR, B4 = KB * NTILE / 4 / NTHR;      // float4 per thread per stage
     constexpr int T4 = KB * 32 / 4;                                            // float4 of the tail stage (threads < T4 carry one)
     static_assert(A4 * 4 * NTHR == KB * MTOT && B4 * 4 * NTHR == KB * NTILE, "stage must divide evenly");
@@ -879,7 +896,7 @@ __global__ void k_wgrad_reduce(const float *__restrict__ partial, int chunks, in
 
 // Ntot / Nreal: padded / real number of B columns INCLUDING the 32-column tail when Bt != nullptr
 template <int MT, int NT, int WM, int WN, int KB, bool TAIL>
-int launch_wgrad_lds(const float *A, int lda, const float *B, int ldb, const float *Bt, int ldbt, long long rows, float *partial, int Ntot, int Nreal,
+int launch_wgrad_lds(const float *A, int lda, const float *B, int ldb, const float *Bt, int ldbt, long long rows, const int *d_tiles, float *partial, int Ntot, int Nreal,
                      float *grad, int dst, int ldc, hipStream_t s) {
     constexpr int Mtot = WM * MT * 32, NTILE = WN * NT * 32;
     const int ntiles = TAIL ? 1 : Ntot / NTILE;
@@ -895,7 +912,7 @@ int launch_wgrad_lds(const float *A, int lda, const float *B, int ldb, const flo
     const size_t lds = (size_t)2 * KB * (Mtot + NTILE + (TAIL ? 32 : 0)) * sizeof(float);
     if (hipFuncSetAttribute((const void *)k_wgrad_lds<MT, NT, WM, WN, KB, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PNERF_E_LAUNCH;
     { PnProfScope prof(PNK_WGRAD, s);
-    hipLaunchKernelGGL((k_wgrad_lds<MT, NT, WM, WN, KB, TAIL>), dim3(ntiles, chunks), dim3(WM * WN * 64), lds, s, A, lda, B, ldb, Bt, ldbt, rows, (int)rpc, partial, Ntot); }
+    hipLaunchKernelGGL((k_wgrad_lds<MT, NT, WM, WN, KB, TAIL>), dim3(ntiles, chunks), dim3(WM * WN * 64), lds, s, A, lda, B, ldb, Bt, ldbt, rows, d_tiles, (int)rpc, partial, Ntot); }
     PnProfScope prof(PNK_WGRAD_REDUCE, s);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(pn_cdiv((long long)Mtot * Ntot, 256)), dim3(256), 0, s, partial, chunks, Mtot, Ntot, Nreal, grad, dst, ldc);
     PN_CHECK_LAUNCH();
@@ -923,34 +940,40 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
-    const long long tiles = (n_valid + a.TS - 1) / a.TS;
     const long long ctiles = (n_valid + PN_CTILE - 1) / PN_CTILE;
-    const long long pairs = (tiles + 1) / 2;          // one workgroup per CU, two tiles in flight each
-    const int grid_a = (int)(pairs < (long long)ncu ? (pairs > 0 ? pairs : 1) : ncu);
     const int grid_c = (int)(ctiles < ncu ? (ctiles > 0 ? ctiles : 1) : ncu);
     const size_t lds_c = COLB_LDS_FLOATS * sizeof(float), lds_a = AGGB_LDS_FLOATS * sizeof(float);
     if (hipFuncSetAttribute((const void *)k_color_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
-    const bool dfs_lds = a.TS * PN_H <= B2_DFS_FLOATS;
-    const void *kfn = dfs_lds ? (const void *)k_agg_backward<true> : (const void *)k_agg_backward<false>;
-    if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
+    if (hipFuncSetAttribute((const void *)k_agg_backward<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
+    if (hipFuncSetAttribute((const void *)k_agg_backward<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
+    // the forward left the class partition of the valid samples in the saved area (aggregate.hip: pn_classify)
+    a.cls_list = sv.cls_list; a.cls_info = sv.cls_info; a.valid_list = sv.cls_list;
     { PnProfScope prof(PNK_COLOR_BWD, s); hipLaunchKernelGGL(k_color_backward, dim3(grid_c), dim3(256), lds_c, s, a); }
+    int kc[PN_NCLS];
+    const int ncls = pn_class_slots(K, kc);
     { PnProfScope prof(PNK_AGG_BWD, s);
-      if (dfs_lds) hipLaunchKernelGGL(k_agg_backward<true>, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
-      else hipLaunchKernelGGL(k_agg_backward<false>, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a); }
+      for (int j = 0; j < ncls; ++j) {
+          a.cls = j; a.K = kc[j]; a.TS = pn_tile_samples(kc[j]);
+          const long long pairs = ((n_valid + a.TS - 1) / a.TS + 1) / 2;          // one workgroup per CU, two tiles in flight each; worst-case grid
+          const int grid_a = (int)(pairs < (long long)ncu ? (pairs > 0 ? pairs : 1) : ncu);
+          if (a.TS * PN_H <= B2_DFS_FLOATS) hipLaunchKernelGGL(k_agg_backward<true>, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+          else hipLaunchKernelGGL(k_agg_backward<false>, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+      } }
     PN_CHECK_LAUNCH();
-    // weight gradients over the rows / samples of the tiles that actually ran
-    // rows: every row of a processed tile was written by the forward (invalid rows included); samples: only the first n_valid
-    // rows of fs / pe / c1.. exist -- the GEMM masks the rest of the last colour tile (0 * stale bits could be NaN)
-    const long long rows = tiles * PN_TILE, smp = n_valid;
+    // weight gradients over every tile of every class (+ their zero padding tiles): the tile count lives on the device, the host
+    // bound is the allocation.  samples: only the first n_valid rows of fs / pe / c1.. exist -- the GEMM masks the rest of the
+    // last colour tile (0 * stale bits could be NaN)
+    const long long rows = sv.rows, smp = n_valid;
+    const int *dt = sv.cls_info + PN_CI_TILES;
     int rc;
     float *g = d_grad_params;
-    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16, true>(sv.dy1, PN_H, sv.x0, PN_IN1P, sv.x0 + 256, PN_IN1P, rows, d_partials, PN_IN1P, PN_IN1, g, PO_W1, PN_IN1, s))) return rc;
-    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16, false>(sv.dy2, PN_H, sv.h1, PN_H, nullptr, 0, rows, d_partials, 256, 256, g, PO_W2, PN_H, s))) return rc;
-    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16, false>(sv.dy3, PN_H, sv.h2, PN_H, nullptr, 0, rows, d_partials, 256, 256, g, PO_W3, PN_IN3, s))) return rc;
-    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16, false>(sv.dy4, PN_H, sv.h3, PN_H, nullptr, 0, rows, d_partials, 256, 256, g, PO_W4, PN_H, s))) return rc;
-    if ((rc = launch_wgrad_lds<2, 2, 2, 4, 16, true>(sv.dc1, PN_HC, sv.fs, PN_H, sv.pe, 32, smp, d_partials, 288, PN_INC, g, PO_WC1, PN_INC, s))) return rc;
-    if ((rc = launch_wgrad_lds<2, 1, 2, 4, 16, false>(sv.dc2, PN_HC, sv.c1, PN_HC, nullptr, 0, smp, d_partials, 128, 128, g, PO_WC2, PN_HC, s))) return rc;
-    if ((rc = launch_wgrad_lds<2, 1, 2, 4, 16, false>(sv.dc3, PN_HC, sv.c2, PN_HC, nullptr, 0, smp, d_partials, 128, 128, g, PO_WC3, PN_HC, s))) return rc;
+    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16, true>(sv.dy1, PN_H, sv.x0, PN_IN1P, sv.x0 + 256, PN_IN1P, rows, dt, d_partials, PN_IN1P, PN_IN1, g, PO_W1, PN_IN1, s))) return rc;
+    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16, false>(sv.dy2, PN_H, sv.h1, PN_H, nullptr, 0, rows, dt, d_partials, 256, 256, g, PO_W2, PN_H, s))) return rc;
+    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16, false>(sv.dy3, PN_H, sv.h2, PN_H, nullptr, 0, rows, dt, d_partials, 256, 256, g, PO_W3, PN_IN3, s))) return rc;
+    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16, false>(sv.dy4, PN_H, sv.h3, PN_H, nullptr, 0, rows, dt, d_partials, 256, 256, g, PO_W4, PN_H, s))) return rc;
+    if ((rc = launch_wgrad_lds<2, 2, 2, 4, 16, true>(sv.dc1, PN_HC, sv.fs, PN_H, sv.pe, 32, smp, nullptr, d_partials, 288, PN_INC, g, PO_WC1, PN_INC, s))) return rc;
+    if ((rc = launch_wgrad_lds<2, 1, 2, 4, 16, false>(sv.dc2, PN_HC, sv.c1, PN_HC, nullptr, 0, smp, nullptr, d_partials, 128, 128, g, PO_WC2, PN_HC, s))) return rc;
+    if ((rc = launch_wgrad_lds<2, 1, 2, 4, 16, false>(sv.dc3, PN_HC, sv.c2, PN_HC, nullptr, 0, smp, nullptr, d_partials, 128, 128, g, PO_WC3, PN_HC, s))) return rc;
     return 0;
 }
 

@@ -230,8 +230,18 @@ struct PnSaved {
     unsigned long long *lmask;          // [row tiles][3 layers h1..h3][PN_NTHR]: LeakyReLU sign bits in the accumulator layout
     // per valid sample (padded to colour tiles * 64)
     float *fs, *pe, *c1, *c2, *c3, *dfs, *dc1, *dc2, *dc3;
+    // sample classes (aggregate.hip: pn_classify): the valid samples re-listed class by class, and where each class lives
+    int *cls_list;                      // [samples] sample ids, class 0 first
+    int *cls_info;                      // PN_CI_* words
+    int *cls_tmp;                       // scratch of the partition: flags [samples] + positions [samples] + scan scratch
     long long rows, samples;
 };
+// cls_info words: per class c (< PN_NCLS): number of samples, first position in cls_list, first tile; then totals
+enum : int { PN_NCLS = 3, PN_CI_COUNT = 0, PN_CI_VBASE = 4, PN_CI_TBASE = 8, PN_CI_TILES = 12, PN_CI_WORDS = 16 };
+int pn_class_slots(int K, int kc[3]);
+int pn_classify(const PnSaved &sv, const int32_t *d_valid_list, const int32_t *d_counters, const int32_t *d_pidx, int K, long long n_valid, bool train, hipStream_t s);
+size_t pn_cls_bytes(long long samples);
+void pn_cls_carve(void *base, long long samples, PnSaved &s);
 size_t pn_saved_bytes(long long n_valid, int K, long long *rows_out, long long *samples_out);
 PnSaved pn_saved_carve(void *base, long long n_valid, int K);
 

@@ -256,7 +256,7 @@ extern "C" size_t pnerf_agg_workspace_bytes(int64_t n_valid_max, int K) {
     // inference: only fs lives here; training: the caller passes a pnerf_agg_saved_bytes() area instead.
     long long rows, samples;
     pn_saved_bytes(n_valid_max, K, &rows, &samples);
-    return pn_align((size_t)samples * PN_H * sizeof(float)) + pn_wgrad_partials_bytes();
+    return pn_align((size_t)samples * PN_H * sizeof(float)) + pn_cls_bytes(samples) + pn_wgrad_partials_bytes();
 }
 
 static int check_common(const pnerf_camera *cam, const pnerf_points *pts, int R, int SR, int K) {
@@ -287,6 +287,7 @@ extern "C" int pnerf_render_forward(const pnerf_camera *cam, const pnerf_points 
         sv = PnSaved();
         pn_saved_bytes(n_valid_max, K, &sv.rows, &sv.samples);
         sv.fs = (float *)d_ws;
+        pn_cls_carve((char *)d_ws + pn_align((size_t)sv.samples * PN_H * sizeof(float)), sv.samples, sv);
     }
     if (hipMemsetAsync(d_decoded, 0, (size_t)R * SR * 4 * sizeof(float), s) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipMemsetAsync(d_weight, 0, (size_t)R * SR * K * sizeof(float), s) != hipSuccess) return PNERF_E_LAUNCH;
@@ -371,6 +372,7 @@ extern "C" int pnerf_agg_forward(const pnerf_camera *cam, const pnerf_points *pt
         sv = PnSaved();
         pn_saved_bytes(n_valid_max, K, &sv.rows, &sv.samples);
         sv.fs = (float *)d_ws;
+        pn_cls_carve((char *)d_ws + pn_align((size_t)sv.samples * PN_H * sizeof(float)), sv.samples, sv);
     }
     if (hipMemsetAsync(d_decoded, 0, (size_t)R * SR * 4 * sizeof(float), s) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipMemsetAsync(d_weight, 0, (size_t)R * SR * K * sizeof(float), s) != hipSuccess) return PNERF_E_LAUNCH;
