@@ -494,7 +494,7 @@ __device__ __forceinline__ void f2_boundary_slot(const FwdArgs &a, const F2Tile 
     }
     if constexpr (TRAIN && SLOT >= 145 && SLOT < 209 && (SLOT - 145) % 4 == 2) {
         constexpr int i = (SLOT - 145) / 4;
-        *reinterpret_cast<float4 *>(a.sv.h4 + ((long long)S.tile * PN_TILE + (tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4) = C.cpv;
+        pn_store_stream(a.sv.h4 + ((long long)S.tile * PN_TILE + (tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4, C.cpv);
     }
     if constexpr (SLOT == 214) {
         if (tl < TS) {
@@ -634,13 +634,13 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_forward2(FwdArgs a) {
                 }                                                                                                                   \
                 if constexpr (COPY0 && TRAIN && s % 32 == 24) {                                                                     \
                     const int e_ = tl + (s / 32) * PN_NTHR, row_ = e_ / (PN_IN1P / 4), c4_ = e_ - row_ * (PN_IN1P / 4);                 \
-                    *reinterpret_cast<float4 *>(a.sv.x0 + ((long long)(XTILE) * PN_TILE + row_) * PN_IN1P + c4_ * 4) = cpv;           \
+                    pn_store_stream(a.sv.x0 + ((long long)(XTILE) * PN_TILE + row_) * PN_IN1P + c4_ * 4, cpv);                        \
                 }                                                                                                                   \
                 if constexpr (COPY0 && TRAIN && s == 30) {                                                                          \
                     if (tl < PN_TILE * 2) *reinterpret_cast<float4 *>(a.sv.ex + ((long long)(XTILE) * PN_TILE + (tl >> 1)) * 8 + (tl & 1) * 4) = *reinterpret_cast<const float4 *>((XT).exb + (tl >> 1) * 8 + (tl & 1) * 4); \
                 }                                                                                                                   \
                 if constexpr (COPY && TRAIN && s % 32 == 4 && s < 512) cpv = *reinterpret_cast<const float4 *>((RX) + 4 * (s / 32) * LDX); \
-                if constexpr (COPY && TRAIN && s % 32 == 20 && s < 512) *reinterpret_cast<float4 *>((DST) + ((long long)(XTILE) * PN_TILE + wave + 4 * (s / 32)) * PN_H + lane * 4) = cpv; \
+                if constexpr (COPY && TRAIN && s % 32 == 20 && s < 512) pn_store_stream((DST) + ((long long)(XTILE) * PN_TILE + wave + 4 * (s / 32)) * PN_H + lane * 4, cpv); \
                 BND(s);                                                                                                             \
             });                                                                                                                     \
             __syncthreads();                                                                                                        \

@@ -278,7 +278,7 @@ __device__ __forceinline__ void b2_dy4(const BwdArgs &a, const B2Tile &T, const 
             gb4v.x += o.x; gb4v.y += o.y; gb4v.z += o.z; gb4v.w += o.w;
         }
         *reinterpret_cast<float4 *>(T.buf + row * LDH + c4 * 4) = o;
-        *reinterpret_cast<float4 *>(a.sv.dy4 + (grow0 + row) * PN_H + c4 * 4) = o;     // an invalid partner tile writes zeros into the padding tile
+        pn_store_stream(a.sv.dy4 + (grow0 + row) * PN_H + c4 * 4, o);     // an invalid partner tile writes zeros into the padding tile
     }
     if (tl < PN_TILE) gb5t += T.draw[tl];
 }
@@ -589,7 +589,7 @@ __device__ __forceinline__ void b2_boundary_slot(const BwdArgs &a, const B2Tile 
     }
     if constexpr (SLOT >= S_DY4 && SLOT < S_DY4 + 128 && (SLOT - S_DY4) % 8 == 6) {
         constexpr int i = (SLOT - S_DY4) / 8;
-        *reinterpret_cast<float4 *>(a.sv.dy4 + (S.tile * PN_TILE + (tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4) = C.o;
+        pn_store_stream(a.sv.dy4 + (S.tile * PN_TILE + (tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4, C.o);
     }
     if constexpr (SLOT == 452) {
         if (tl < PN_TILE) gb5t += T.draw[tl];
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_backward(BwdArgs a) {
                     exa = *reinterpret_cast<const float4 *>(exr); exb2 = *reinterpret_cast<const float4 *>(exr + 4);                \
                 }                                                                                                                   \
                 if constexpr (COPY && s % 32 == 4) cpv = *reinterpret_cast<const float4 *>((RX) + 4 * (s / 32) * LDH);              \
-                if constexpr (COPY && s % 32 == 20) *reinterpret_cast<float4 *>((DST) + ((GROW) + 4 * (s / 32)) * PN_H + lane * 4) = cpv; \
+                if constexpr (COPY && s % 32 == 20) pn_store_stream((DST) + ((GROW) + 4 * (s / 32)) * PN_H + lane * 4, cpv);             \
                 if constexpr (COPY && EXTRAS && s % 32 >= 21 && s % 32 < 28) {                                                      \
                     constexpr int j_ = s % 32 - 21;                                                                                 \
                     const float e_ = j_ == 0 ? exa.x : j_ == 1 ? exa.y : j_ == 2 ? exa.z : j_ == 3 ? exa.w : j_ == 4 ? exb2.x : j_ == 5 ? exb2.y : exb2.z; \

@@ -46,6 +46,14 @@ enum : int {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// streaming store of saved activations: ~70 GB per step pass through the L2 that also holds the 2.7 MB of packed weights every
+// wave re-reads continuously; non-temporal keeps them from displacing the weights
+typedef float pn_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pn_store_stream(float *p, const float4 &v) {
+    pn_f4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<pn_f4 *>(p));
+}
+
 __device__ __forceinline__ float pn_lrelu(float v) { return v > 0.f ? v : 0.01f * v; }
 __device__ __forceinline__ float pn_lrelu_grad(float post) { return post > 0.f ? 1.f : 0.01f; }
 
