@@ -717,14 +717,14 @@ __global__ __launch_bounds__(PN_NTHR, 1) void k_agg_forward2(FwdArgs a) {
     }
 }
 
-constexpr int COL_LDS_FLOATS = PN_CTILE * LDX + 2 * PN_CTILE * LDC + 32;
+constexpr int COL_LDS_FLOATS = PN_CTILE * LDX + 32;      // 75 KB: two workgroups per CU (the hidden layers reuse the input tile's space)
 
 template <bool TRAIN>
-__global__ __launch_bounds__(256, 1) void k_color_forward(FwdArgs a) {
+__global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *X = smem;                            // [64][LDX]
-    float *H1 = X + PN_CTILE * LDX;             // [64][LDC]
-    float *H2 = H1 + PN_CTILE * LDC;            // [64][LDC]
+    float *H1 = X;                              // [64][LDC]  (over X once layer 1 has read it)
+    float *H2 = X + PN_CTILE * LDC;             // [64][LDC]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Ns = a.counters[0] < a.cap_samples ? a.counters[0] : (int)a.cap_samples;
     const float *P = a.params;
@@ -773,6 +773,7 @@ __global__ __launch_bounds__(256, 1) void k_color_forward(FwdArgs a) {
         f32x16 acc[2][1];
         pn_acc_init_bias<2, 1>(acc, P + PO_BC1, wave, lane);
         pn_tile_gemm<2, 1>(X, LDX, PN_INC / 8, a.packed + PK_C1 / 4, wave, lane, acc);
+        __syncthreads();                        // every wave is done reading X before H1 takes its place
         pn_acc_to_lds<2, 1, true>(acc, H1, LDC, wave, lane);
         __syncthreads();
         if (TRAIN) pn_tile_copy_out<PN_CTILE, PN_HC>(H1, LDC, a.sv.c1, PN_HC, grow0, tid);
@@ -830,7 +831,7 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     if (hipGetDevice(&dev) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
     const long long ctiles = (cap_samples + PN_CTILE - 1) / PN_CTILE;
-    const int grid_c = (int)(ctiles < ncu ? (ctiles > 0 ? ctiles : 1) : ncu);
+    const int grid_c = (int)(ctiles < 2 * ncu ? (ctiles > 0 ? ctiles : 1) : 2 * ncu);       // two workgroups per CU
     const size_t lds_a = F2_LDS_FLOATS * sizeof(float), lds_c = COL_LDS_FLOATS * sizeof(float);
     const bool pers = d_xyz_pers != nullptr;
     const void *kfn = train ? (pers ? (const void *)k_agg_forward2<true, true> : (const void *)k_agg_forward2<true, false>)

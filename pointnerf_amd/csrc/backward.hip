@@ -43,7 +43,7 @@ __device__ __forceinline__ void rot3b(const float *M, float x, float y, float z,
 // ------------------------------------------------------------------------------ colour backward
 constexpr int COLB_LDS_FLOATS = 2 * PN_CTILE * LDC + PN_CTILE * 4;
 
-__global__ __launch_bounds__(256, 1) void k_color_backward(BwdArgs a) {
+__global__ __launch_bounds__(256, 2) void k_color_backward(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *D1 = smem;                          // [64][LDC]
     float *D2 = D1 + PN_CTILE * LDC;            // [64][LDC]
@@ -941,7 +941,7 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     if (hipGetDevice(&dev) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
     const long long ctiles = (n_valid + PN_CTILE - 1) / PN_CTILE;
-    const int grid_c = (int)(ctiles < ncu ? (ctiles > 0 ? ctiles : 1) : ncu);
+    const int grid_c = (int)(ctiles < 2 * ncu ? (ctiles > 0 ? ctiles : 1) : 2 * ncu);       // 69 KB of LDS: two workgroups per CU
     const size_t lds_c = COLB_LDS_FLOATS * sizeof(float), lds_a = AGGB_LDS_FLOATS * sizeof(float);
     if (hipFuncSetAttribute((const void *)k_color_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipFuncSetAttribute((const void *)k_agg_backward<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
