@@ -173,3 +173,36 @@ def test_full_image_eval_loop_matches_oracle():
     gt = torch.rand(h, w, 3, generator=torch.Generator().manual_seed(0))
     p1 = float(eval_loop.psnr(img, gt)); p2 = float(-10 * torch.log10(torch.mean((full["coarse_raycolor"][0] - gt.reshape(-1, 3)) ** 2)))
     assert abs(p1 - p2) < 1e-3
+
+
+def test_standalone_aggregator_with_holes_in_the_neighbor_mask():
+    """PointAggregator.forward is a public entry of its own: a caller may pass any sample_pnt_mask, not only the
+    front-filled slots the query produces.  The sample classes of the HIP path (rows per sample = K, K/2 or K/4) must then be
+    chosen by the LAST occupied slot: knock random slots out of a real query result and compare forward + gradients with the
+    oracle on the same punched mask."""
+    opt, xyz, attrs, inp, mlp, agg, npnt, d = _build("small_k8")
+    t = npnt({"pixel_idx": d["pixel_idx"], "camrotc2w": d["camrotc2w"], "campos": d["campos"], "near": d["near"], "far": d["far"],
+              "focal": None, "h": d["h"], "w": d["w"], "intrinsic": d["intrinsic"], "gt_image": d["gt_image"], "raydir": d["raydir"]})
+    sampled_color, sampled_Rw2c, sampled_dir, sampled_conf, sampled_embedding, sampled_xyz_pers, sampled_xyz, mask, \
+        sample_loc, sample_loc_w, sample_ray_dirs, ray_mask_tensor, vsize, grid_vox_sz = t
+    gen = torch.Generator().manual_seed(11)
+    keep = (torch.rand(mask.shape, generator=gen) > 0.45).to(mask.device)
+    punched = mask & keep                                        # holes anywhere: e.g. slots {0, 5} of 8 occupied
+    assert bool((punched[..., 0] != punched[..., 1]).any())
+    out, ray_valid, weight, conf_c = agg(sampled_color, sampled_Rw2c, sampled_dir, sampled_conf, sampled_embedding, sampled_xyz_pers,
+                                         sampled_xyz, punched, sample_loc, sample_loc_w, sample_ray_dirs, vsize, grid_vox_sz)
+    # oracle on the same gathered tensors and the same mask
+    om = {k: v.clone().requires_grad_(True) for k, v in mlp.items()}
+    nb = dict(mask=punched.cpu(), xyz=sampled_xyz.detach().cpu(), xyz_pers=sampled_xyz_pers.detach().cpu(), emb=sampled_embedding.detach().cpu(),
+              color=sampled_color.detach().cpu(), dir=sampled_dir.detach().cpu(), conf=sampled_conf.detach().cpu())
+    ro, rv, rw, rc = pyref.aggregate(opt, om, nb, sample_loc.detach().cpu(), sample_loc_w.detach().cpu(), sample_ray_dirs.detach().cpu())
+    assert torch.equal(ray_valid.cpu(), rv)
+    assert float((out.detach().cpu() - ro.detach()).abs().max()) <= 1e-4
+    assert float((weight.detach().cpu() - rw.detach()).abs().max()) <= 1e-5
+    gen2 = torch.Generator().manual_seed(12)
+    probe = torch.randn(ro.shape, generator=gen2)
+    (out * probe.to(out.device)).sum().backward()
+    (ro * probe).sum().backward()
+    for n, p in agg.named_parameters():
+        g, r = p.grad.cpu(), om[n].grad
+        assert float((g - r).abs().max()) <= 2e-3 * max(float(r.abs().max()), 1e-8), n
