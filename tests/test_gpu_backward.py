@@ -72,12 +72,14 @@ def test_backward_matches_oracle(name):
     _run(opt, xyz, attrs, inp, mlp)
 
 
-@pytest.mark.parametrize("K,SR", [(12, 20), (3, 70), (16, 12)])
-def test_backward_other_K(K, SR):
+# K % 4 == 0 runs three sample classes (K, K/2, K/4 rows per sample), other K one; a single ray exercises the odd / empty tile
+# pairs of the two-tile kernels
+@pytest.mark.parametrize("K,SR,size", [(12, 20, 12), (3, 70, 12), (16, 12, 12), (1, 8, 12), (2, 16, 9), (4, 24, 12), (5, 20, 7), (8, 128, 1)])
+def test_backward_other_K(K, SR, size):
     opt = config.lego_opt(K=K, SR=SR, P=24, max_o=50000, ranges=[-0.3, -0.3, -0.3, 0.3, 0.3, 0.3])
     xyz = torch.from_numpy(scenes.chair_points(2500, seed=5, radius=0.06))
     attrs = {k: torch.from_numpy(v) for k, v in scenes.point_attributes(2500, 32, 5).items()}
-    inp = pyref.to_torch_inputs(scenes.block_rays(theta_deg=55.0, x0=394, y0=394, size=12))
+    inp = pyref.to_torch_inputs(scenes.block_rays(theta_deg=55.0, x0=394, y0=394, size=size))
     mlp = pyref.init_mlp_params(opt, seed=3, bias_scale=0.1)
     _run(opt, xyz, attrs, inp, mlp)
 
