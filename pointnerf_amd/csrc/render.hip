@@ -230,8 +230,8 @@ __global__ __launch_bounds__(TPB) void k_scatter_add_rows(const float *__restric
 }  // namespace
 
 extern "C" int pnerf_gather_rows(const float *d_src, int n_src, int width, const int32_t *d_idx, int64_t n_idx, float *d_dst, void *stream) {
+    if (n_idx == 0) return 0;                      // nothing to gather (a chunk of rays that hit nothing): pointers may be null
     if (!d_src || !d_idx || !d_dst || n_src <= 0 || width <= 0 || n_idx < 0) return PNERF_E_INVAL;
-    if (n_idx == 0) return 0;
     long long total = n_idx * width;
     int grid = (int)((total + TPB - 1) / TPB < 16384 ? (total + TPB - 1) / TPB : 16384);
     PnProfScope prof(PNK_GATHER, (hipStream_t)stream);
@@ -241,8 +241,8 @@ extern "C" int pnerf_gather_rows(const float *d_src, int n_src, int width, const
 }
 
 extern "C" int pnerf_scatter_add_rows(const float *d_grad_rows, const int32_t *d_idx, int64_t n_idx, int width, float *d_grad_src, int n_src, void *stream) {
-    if (!d_grad_rows || !d_idx || !d_grad_src || n_src <= 0 || width <= 0 || n_idx < 0) return PNERF_E_INVAL;
     if (n_idx == 0) return 0;
+    if (!d_grad_rows || !d_idx || !d_grad_src || n_src <= 0 || width <= 0 || n_idx < 0) return PNERF_E_INVAL;
     long long total = n_idx * width;
     int grid = (int)((total + TPB - 1) / TPB < 4096 ? (total + TPB - 1) / TPB : 4096);
     PnProfScope prof(PNK_GATHER, (hipStream_t)stream);

@@ -175,6 +175,21 @@ def test_full_image_eval_loop_matches_oracle():
     assert abs(p1 - p2) < 1e-3
 
 
+def test_eval_loop_chunk_that_hits_nothing():
+    """A chunk of an image may see no geometry at all (sky): the model must return the background for it, not fail on the
+    empty gathers (found with a full 800 x 800 view)."""
+    from pointnerf_amd import eval_loop
+    opt, xyz, attrs, inp, mlp, agg, npnt, d = _build("small_k8")
+    opt.prob = 1                                      # the probe outputs gather per-point tensors for the hit rays: empty here
+    model = NeuralPointsRayMarching(aggregator=agg, neural_points=npnt, opt=opt)
+    intr = inp["intrinsic"][0].clone()
+    intr[0, 2] += 5000.0                              # look far off to the side: no ray meets the cloud
+    img, hit = eval_loop.render_image(model, d["campos"], d["camrotc2w"], intr, 8, 8, d["near"], d["far"], d["bg_color"], chunk=32)
+    assert not bool(hit.any())
+    assert float((img.reshape(-1, 3) - d["bg_color"].reshape(1, 3)).abs().max()) <= 1e-6
+    opt.prob = 0
+
+
 def test_standalone_aggregator_with_holes_in_the_neighbor_mask():
     """PointAggregator.forward is a public entry of its own: a caller may pass any sample_pnt_mask, not only the
     front-filled slots the query produces.  The sample classes of the HIP path (rows per sample = K, K/2 or K/4) must then be

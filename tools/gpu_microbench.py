@@ -43,7 +43,20 @@ with torch.no_grad():
     n = pidx.numel()
     valid = int((pidx >= 0).sum())
     res["gather_rows_emb32"] = dict(ms=p2["gather"][0] / p2["gather"][1], bytes=n * (4 + 128 + 128), slots=n, valid_slots=valid)
+# full-image evaluation: one 800 x 800 view through eval_loop.render_image (4 chunks, grid cached, canvas on the device)
+import time
+from pointnerf_amd import eval_loop
+d0 = scenes.random_rays(0, 16)
+cam = {k: torch.from_numpy(__import__("numpy").ascontiguousarray(d0[k])).to(dev) for k in ("campos", "camrotc2w", "near", "far", "bg_color")}
+intr = torch.from_numpy(__import__("numpy").asarray(scenes.synth_camera(0.0)[1], dtype="float32")).to(dev)
+with torch.no_grad():
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        img, hit = eval_loop.render_image(model, cam["campos"], cam["camrotc2w"], intr, 800, 800, cam["near"], cam["far"], cam["bg_color"])
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+full = dict(ms=dt * 1e3, rays=640000, rays_per_s=640000 / dt, rays_hit=int(hit.sum()))
 for k, v in res.items():
     v["GBps"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
     v["frac_of_8TBps"] = v["GBps"] / 8000.0
+res["full_image_800x800"] = full
 print(json.dumps(res, indent=1))
