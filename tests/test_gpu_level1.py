@@ -221,3 +221,36 @@ def test_standalone_aggregator_with_holes_in_the_neighbor_mask():
     for n, p in agg.named_parameters():
         g, r = p.grad.cpu(), om[n].grad
         assert float((g - r).abs().max()) <= 2e-3 * max(float(r.abs().max()), 1e-8), n
+
+
+def test_prune_and_grow_between_steps_keep_parity():
+    """The probe-and-grow / prune step of the training loop (run/train_ft.py:417-530, neural_points.py:347-399) changes the
+    point cloud between two renders: the cached voxel grid must be rebuilt and the render of the new cloud must match the
+    oracle on the new cloud."""
+    opt, xyz, attrs, inp, mlp, agg, npnt, d = _build("small_k8")
+    model = NeuralPointsRayMarching(aggregator=agg, neural_points=npnt, opt=opt)
+    with torch.no_grad():
+        model(**d)                                            # builds and caches the grid of the full cloud
+    thresh = 0.55
+    keep = attrs["points_conf"][0, :, 0] >= thresh
+    npnt.prune(thresh)
+    assert npnt.xyz.shape[0] == int(keep.sum())
+    gen = torch.Generator().manual_seed(5)
+    add = 300
+    new_xyz = xyz[keep][:add] + 0.002 * torch.randn(add, 3, generator=gen)
+    new_emb = torch.rand(add, 32, generator=gen) - 0.5
+    new_col, new_dir, new_conf = torch.rand(add, 3, generator=gen), torch.nn.functional.normalize(torch.randn(add, 3, generator=gen), dim=-1), 0.2 + 0.7 * torch.rand(add, 1, generator=gen)
+    dev = npnt.xyz.device
+    npnt.grow_points(new_xyz.to(dev), new_emb.to(dev), new_col.to(dev), new_dir.to(dev), new_conf.to(dev))
+    with torch.no_grad():
+        out = model(**d)
+    xyz2 = torch.cat([xyz[keep], new_xyz], 0)
+    attrs2 = dict(points_embeding=torch.cat([attrs["points_embeding"][:, keep], new_emb[None]], 1),
+                  points_conf=torch.cat([attrs["points_conf"][:, keep], new_conf[None]], 1),
+                  points_dir=torch.cat([attrs["points_dir"][:, keep], new_dir[None]], 1),
+                  points_color=torch.cat([attrs["points_color"][:, keep], new_col[None]], 1))
+    with torch.no_grad():
+        ref = pyref.render(opt, dict(xyz=xyz2, **attrs2), mlp, inp)
+        full = pyref.fill_invalid(ref, inp)
+    assert torch.equal(out["ray_mask"].cpu(), ref["ray_mask"])
+    assert float((out["coarse_raycolor"].cpu() - full["coarse_raycolor"]).abs().max()) <= 1e-4
