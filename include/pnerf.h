@@ -208,6 +208,16 @@ int pnerf_raymarch_backward(const float *d_ray_dist, const uint8_t *d_ray_valid,
 int pnerf_adam_step(float *d_param, const float *d_grad, float *d_exp_avg, float *d_exp_avg_sq, int64_t n,
                     double lr, double beta1, double beta2, double eps, int64_t step, void *stream);
 
+/* ---- point initialisation: voxel down-sampling of a raw cloud (models/mvs/mvs_utils.py:537-561 construct_vox_points_closest,
+ * called at run/train_ft.py:138-139).  Voxel of a point = floor((p - space_min) / vox_size) per axis (fp32), points outside
+ * [0, r) are dropped and counted.  Outputs for the M occupied voxels in ascending (x, y, z) order (torch.unique(dim=0) order):
+ * d_centroid [M,3] mean of the members (summed in point order), d_grid_idx [M,3], d_min_idx [M] = member closest to the centroid
+ * (ties: lowest index).  All outputs are sized for n_points voxels; d_counts[0] = M, d_counts[1] = points outside. */
+size_t pnerf_voxel_downsample_workspace_bytes(int64_t n_points, int rx, int ry, int rz);
+int pnerf_voxel_downsample(const float *d_xyz, int64_t n_points, const float *space_min3_host, const float *vox_size3_host,
+                           int rx, int ry, int rz, float *d_centroid, int32_t *d_grid_idx, int64_t *d_min_idx, int32_t *d_counts,
+                           void *d_ws, size_t ws_bytes, void *stream);
+
 /* ---- per-kernel timing (HIP events recorded on the launch stream; off by default) --------------- */
 int pnerf_prof_enable(int on);
 int pnerf_prof_kernel_count(void);

@@ -304,3 +304,48 @@ def probe_outputs(out, points):
                 shading_avg_dir=torch.sum(g(points["points_dir"][0]) * w, dim=-2),
                 shading_avg_conf=torch.sum(g(points["points_conf"][0]) * w, dim=-2),
                 shading_avg_embedding=torch.sum(g(points["points_embeding"][0]) * w, dim=-2))
+
+
+# ----------------------------------------------------------------------------- point initialisation
+def vox_points_closest(xyz, vox_res, space_min=None, space_max=None):
+    """models/mvs/mvs_utils.py:537-561 (construct_vox_points_closest) restated on CPU without torch_scatter, in the canonical
+    order of the HIP path: voxels in torch.unique(dim=0) order, centroid = fp32 sum in point order / count, closest member by
+    fp32 sqrt(dx^2 + dy^2 + dz^2), ties to the lowest index.  Points outside a caller-given box are dropped.
+    Parity unpinned by the reference (torch_scatter is absent here); the voxel list is pinned against torch.unique in the tests."""
+    xyz = xyz.float()
+    if space_min is None:
+        xyz_min, xyz_max = torch.min(xyz, dim=-2)[0], torch.max(xyz, dim=-2)[0]
+        space_edge = torch.max(xyz_max - xyz_min) * 1.05
+        space_min = (xyz_max + xyz_min) / 2 - space_edge / 2
+        vox = (space_edge / vox_res).expand(3)
+    else:
+        space_min, space_max = torch.as_tensor(space_min).float(), torch.as_tensor(space_max).float()
+        vox = (space_max - space_min) / vox_res
+    cell = torch.floor((xyz - space_min[None]) / vox[None]).to(torch.int64)
+    inside = ((cell >= 0) & (cell < vox_res)).all(dim=-1)
+    key = (cell[:, 0] * vox_res + cell[:, 1]) * vox_res + cell[:, 2]
+    order = torch.argsort(torch.where(inside, key, torch.full_like(key, -1)), stable=True)
+    order = order[int((~inside).sum()):]
+    ks = key[order]
+    bounds = torch.nonzero(torch.cat([torch.tensor([True]), ks[1:] != ks[:-1]])).reshape(-1).tolist() + [len(order)]
+    cen, gidx, midx = [], [], []
+    x32 = xyz.numpy()
+    import numpy as _np
+    for b0, b1 in zip(bounds[:-1], bounds[1:]):
+        mem = order[b0:b1].tolist()
+        s = _np.zeros(3, dtype=_np.float32)
+        for p in mem:
+            s = (s + x32[p]).astype(_np.float32)
+        c = (s / _np.float32(len(mem))).astype(_np.float32)
+        best, arg = _np.float32(3.402823466e38), -1
+        for p in mem:
+            d = (x32[p] - c).astype(_np.float32)
+            r = _np.sqrt(_np.float32(_np.float32(_np.float32(d[0] * d[0]) + _np.float32(d[1] * d[1])) + _np.float32(d[2] * d[2])))
+            if r < best:
+                best, arg = r, p
+        cen.append(c); midx.append(arg)
+        k = int(ks[b0])
+        gidx.append([k // (vox_res * vox_res), (k // vox_res) % vox_res, k % vox_res])
+    return (torch.from_numpy(_np.stack(cen)), torch.tensor(gidx, dtype=torch.int32), torch.tensor(midx, dtype=torch.int64),
+            int((~inside).sum()))
+

@@ -55,8 +55,18 @@ with torch.no_grad():
         img, hit = eval_loop.render_image(model, cam["campos"], cam["camrotc2w"], intr, 800, 800, cam["near"], cam["far"], cam["bg_color"])
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
 full = dict(ms=dt * 1e3, rays=640000, rays_per_s=640000 / dt, rays_hit=int(hit.sum()))
+# point initialisation: voxel down-sampling of a raw cloud, lego script resolution
+from pointnerf_amd import point_init
+raw = torch.from_numpy(scenes.lego_points(2_000_000)).to(dev)
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    cen, gidx, midx = point_init.construct_vox_points_closest(raw, 320)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+vox = dict(ms=dt * 1e3, points=int(raw.shape[0]), voxels=int(cen.shape[0]), vox_res=320, bytes=raw.shape[0] * (12 * 4 + 8) + 320 ** 3 * 16)
+vox["GBps"] = vox["bytes"] / dt / 1e9
 for k, v in res.items():
     v["GBps"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
     v["frac_of_8TBps"] = v["GBps"] / 8000.0
 res["full_image_800x800"] = full
+res["voxel_downsample_2M_res320"] = vox
 print(json.dumps(res, indent=1))
