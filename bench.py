@@ -176,6 +176,21 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    # supplementary, outside the timed region: one step with the voxel grid rebuilt (what the reference pays every
+    # step: query_worldcoords.cu:308-365), and one step without the optimizer
+    extra = {}
+    if not args.render_only:
+        from pointnerf_amd import point_query
+        def timed(fn):
+            torch.cuda.synchronize(); t = time.perf_counter(); fn(); torch.cuda.synchronize()
+            return (time.perf_counter() - t) * 1e3
+        def cold():
+            point_query.clear_grid_cache()
+            one_step(inputs[-1])
+        def no_adam():
+            opt_mlp.zero_grad(set_to_none=True); opt_pts.zero_grad(set_to_none=True)
+            loss_fn(opt, model(**inputs[-1]), inputs[-1], world).backward()
+        extra = {"ms_step_cold_grid": timed(cold), "ms_step_without_optimizer": timed(no_adam)}
     if not np.isfinite(float(loss.item())):
         raise SystemExit("bench.py: non-finite loss after %d steps -- the timed path produced NaN/Inf, the number would be meaningless" % total)
     if rank == 0:
@@ -188,7 +203,7 @@ def main():
                                       "%d rays/GPU/step, fwd+loss+bwd+Adam, grid cached" % (args.points, opt.K, opt.SR, opt.z_depth_dim, args.rays),
                           "parallelism": "ray-shard dp%d, point cloud + MLP replicated" % world,
                           "valid_samples_per_step": smp, "neighbor_rows_per_step": rows,
-                          "rays_hit_per_step": float(np.mean([s["rays_hit"] for s in stats])), "final_loss": float(loss.item())}}
+                          "rays_hit_per_step": float(np.mean([s["rays_hit"] for s in stats])), "final_loss": float(loss.item()), **extra}}
         if prof is not None:
             per = {k: {"ms_per_launch": ms / max(n, 1), "launches": n, "ms_per_step": ms / args.steps} for k, (ms, n) in prof.items() if n > 0}
             alg = {"agg_forward": rows * FLOP_ROW_FWD, "agg_backward": rows * FLOP_ROW_DGRAD,
