@@ -390,7 +390,7 @@ PN_TR_DECL(pn_trace_bwd);
 // workgroup barriers and ~1300 instructions.  All of it is issued by the waves that run the other tile's 512-MFMA GEMM.
 // Everything from HBM is requested in ONE burst at slot 0 (a second burst would stall the GEMM's own operand loads a second
 // time: vmcnt retires in order).  Slot map:
-//   0..8   burst: saved sin/cos of the finished tile (for the embedding gradient), next tile's masks / row metadata / h4 / d f
+//   0..8   burst: embedding values of the finished tile (for its embedding gradient), next tile's masks / row metadata / h4 / d f
 //   10..73 E1: accumulator element s-10 -> LDS                                  75: barrier
 //   77..140 embedding gradient, one embedding dim per 8 slots                   141: barrier (buffer free)
 //   143..161 next tile: state, metadata and the staged h4 / d f rows -> LDS     240: d sigma -> LDS   244: barrier
@@ -399,7 +399,9 @@ PN_TR_DECL(pn_trace_bwd);
 // A piece never consumes an LDS / HBM value in the slot that requested it (the wave would wait, and the MFMA stream with it),
 // and stays under ~12 instructions (the shadow of one MFMA).
 struct B2Bnd {
-    float4 xs[6 * EPT / 4];      // saved (sin, cos) x 3 octaves x EPT dims of this thread's row of the finished tile
+    float4 ev[EPT / 4];          // this thread's EPT embedding values of its row of the finished tile (columns 0..31 of the saved X0)
+    float sc[6];                 // (sin, cos) x 3 octaves of the embedding dim being processed: recomputed like the forward computes them
+                                 // (one sincosf + double-angle steps) instead of loading 48 floats per thread in the burst
     float4 h4[16], df[2];        // staged rows of the next tile
     unsigned long long nm1, nm2, nm3;
     int4 rm;
@@ -421,11 +423,11 @@ __device__ __forceinline__ void b2_boundary_slot(const BwdArgs &a, const B2Tile 
     const int rrow = tl / TPR, rq = tl % TPR;
     constexpr int S_E1 = 10, S_EMB = 77, S_NEXT = 143, S_ALPHA = 246, S_DY4 = 322;
     // ---- one burst of requests
-    if constexpr (SLOT < 3) {
-        const float *x0 = a.sv.x0 + (S.tile * PN_TILE + rrow) * PN_IN1P + PN_F + 6 * EPT * rq;
+    if constexpr (SLOT == 0) {
+        const float *x0 = a.sv.x0 + (S.tile * PN_TILE + rrow) * PN_IN1P + EPT * rq;
 #pragma unroll
-        for (int i = SLOT * 4; i < SLOT * 4 + 4; ++i) C.xs[i] = *reinterpret_cast<const float4 *>(x0 + 4 * i);
-        if (SLOT == 0) { C.ntile = next_tile; C.nvalid = next_tile < ntiles; }
+        for (int i = 0; i < EPT / 4; ++i) C.ev[i] = *reinterpret_cast<const float4 *>(x0 + 4 * i);
+        C.ntile = next_tile; C.nvalid = next_tile < ntiles;
     }
     if constexpr (SLOT == 3) {
         const long long te = C.nvalid ? C.ntile : ntiles;          // an invalid tile reads the (allocated) padding tile and is masked out below
@@ -477,16 +479,25 @@ __device__ __forceinline__ void b2_boundary_slot(const BwdArgs &a, const B2Tile 
             C.dxv[1 + 2 * f] = t.x; C.dxv[2 + 2 * f] = t.y;
         }
     }
-    if constexpr (SLOT >= S_EMB && SLOT < S_EMB + 64 && (SLOT - S_EMB) % 8 == 3) {
+    if constexpr (SLOT >= S_EMB && SLOT < S_EMB + 64 && (SLOT - S_EMB) % 8 == 1) {
         constexpr int i = (SLOT - S_EMB) / 8;
-        const float *xf = reinterpret_cast<const float *>(C.xs);
-        C.dxv[0] += (C.dxv[1] * xf[(i * 3) * 2 + 1] - C.dxv[2] * xf[(i * 3) * 2]) + 2.f * (C.dxv[3] * xf[(i * 3 + 1) * 2 + 1] - C.dxv[4] * xf[(i * 3 + 1) * 2]);
+        const float e = i % 4 == 0 ? C.ev[i / 4].x : i % 4 == 1 ? C.ev[i / 4].y : i % 4 == 2 ? C.ev[i / 4].z : C.ev[i / 4].w;
+        float sn, cs;
+        sincosf(e, &sn, &cs);
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            C.sc[2 * f] = sn; C.sc[2 * f + 1] = cs;
+            const float s2 = 2.f * sn * cs;
+            cs = 1.f - 2.f * sn * sn; sn = s2;
+        }
+    }
+    if constexpr (SLOT >= S_EMB && SLOT < S_EMB + 64 && (SLOT - S_EMB) % 8 == 3) {
+        C.dxv[0] += (C.dxv[1] * C.sc[1] - C.dxv[2] * C.sc[0]) + 2.f * (C.dxv[3] * C.sc[3] - C.dxv[4] * C.sc[2]);
         asm volatile("" : "+v"(C.dxv[0]));
     }
     if constexpr (SLOT >= S_EMB && SLOT < S_EMB + 64 && (SLOT - S_EMB) % 8 == 5) {
         constexpr int i = (SLOT - S_EMB) / 8;
-        const float *xf = reinterpret_cast<const float *>(C.xs);
-        const float g = C.dxv[0] + 4.f * (C.dxv[5] * xf[(i * 3 + 2) * 2 + 1] - C.dxv[6] * xf[(i * 3 + 2) * 2]);
+        const float g = C.dxv[0] + 4.f * (C.dxv[5] * C.sc[5] - C.dxv[6] * C.sc[4]);
         if (S.rp >= 0) atomicAdd(&a.g_emb[(long long)S.rp * PN_F + EPT * rq + i], g);
     }
     // ---- the next tile takes over the buffer
