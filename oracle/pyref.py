@@ -21,6 +21,9 @@ Reference followed (under /root/reference), function by function:
                            models/rendering/diff_render_func.py:36-62 (radiance / alpha / off)
   fill_invalid             models/neural_points_volumetric_model.py:87-123
   training_loss            models/base_rendering_model.py:543-551,630-641
+  compute_losses           models/base_rendering_model.py:533-662 (colour / zero-one / sparse items)
+  rank_ray_miss            models/mvs_points_volumetric_model.py:147-156
+  probe_hole_mask          run/train_ft.py:489-500,532-540
 
 Parity pin: the reference's own PointAggregator / ray_march / near_far_linear_ray_generation
 import and run on CPU in the authoring container; tests/golden/make_golden.py stores their
@@ -349,3 +352,66 @@ def vox_points_closest(xyz, vox_res, space_min=None, space_max=None):
     return (torch.from_numpy(_np.stack(cen)), torch.tensor(gidx, dtype=torch.int32), torch.tensor(midx, dtype=torch.int64),
             int((~inside).sum()))
 
+
+
+# ----------------------------------------------------------------------------- model shell (loss items, ray-miss ranking, probe)
+def compute_losses(out, gt_image, color_items, color_weights, zero_one_items=(), zero_one_weights=(), zero_epsilon=1e-3,
+                   sparse_loss_weight=0.0):
+    """models/base_rendering_model.py:533-662 on the scattered [1,R,*] outputs, written with the reference's own ops
+    (masked_select + MSELoss mean).  Returns (loss_total, {name: loss})."""
+    l2 = torch.nn.MSELoss()
+    total, parts = 0, {}
+    for i, name in enumerate(color_items):
+        if name.startswith("ray_masked"):
+            key = name[len("ray_masked") + 1:]
+            m = (out["ray_mask"] > 0)[..., None].expand(-1, -1, 3)
+            po, pg = torch.masked_select(out[key], m).reshape(1, -1, 3), torch.masked_select(gt_image, m).reshape(1, -1, 3)
+            loss = l2(po, pg) if po.shape[1] > 0 else torch.tensor(0.0)
+        elif name.startswith("ray_miss"):
+            key = name[len("ray_miss") + 1:]
+            m = (out["ray_mask"] == 0)[..., None].expand(-1, -1, 3)
+            po, pg = torch.masked_select(out[key], m).reshape(1, -1, 3), torch.masked_select(gt_image, m).reshape(1, -1, 3)
+            loss = l2(po, pg) * pg.shape[1] if po.shape[1] > 0 else torch.tensor(0.0)
+        else:
+            loss = l2(out[name], gt_image)
+        total = total + (loss * color_weights[i] + 1e-6)
+        parts[name] = loss
+    for i, name in enumerate(zero_one_items):
+        if name not in out:
+            continue
+        val = torch.clamp(out[name], zero_epsilon, 1 - zero_epsilon)
+        loss = torch.mean(torch.log(val) + torch.log(1 - val))
+        total = total + loss * zero_one_weights[i]
+        parts[name] = loss
+    if sparse_loss_weight > 0:
+        loss = torch.sum(out["weight"] * torch.abs(1 - torch.exp(-2 * out["conf_coefficient"]))) / (torch.sum(out["weight"]) + 1e-6)
+        total = total + loss * sparse_loss_weight
+        parts["sparse"] = loss
+    return total, parts
+
+
+def rank_ray_miss(new_id, newloss, inds, losses):
+    """models/mvs_points_volumetric_model.py:147-156 with python lists (stable descending sort is NOT implied by the
+    reference's torch.sort; tests use distinct losses)."""
+    inds, losses = list(inds), list(losses)
+    if new_id in inds:
+        j = inds.index(new_id)
+        losses[j] = max(newloss, losses[j])
+    else:
+        inds[-1], losses[-1] = new_id, newloss
+    order = sorted(range(len(losses)), key=lambda j: -losses[j])
+    return [losses[j] for j in order], [inds[j] for j in order]
+
+
+def probe_hole_mask(ray_mask, opacity, far_dist, raycolor, gt, bg, edge, opacity_thresh, far_thresh=-1.0):
+    """run/train_ft.py:489-500 + bloat_inds :532-540 as index loops over numpy [H,W,*] maps."""
+    H, W = edge.shape
+    miss = (ray_mask < 1) & (np.linalg.norm(gt - bg, axis=-1) > 0.002) & edge
+    near = np.zeros((H, W), np.float32)
+    for r, c in zip(*np.nonzero(miss)):
+        for dr in (-1, 0, 1):
+            for dc in (-1, 0, 1):
+                near[min(max(r + dr, 0), H - 1), min(max(c + dc, 0), W - 1)] = 1
+    if far_thresh > 0:
+        near = near + ((ray_mask > 0) & (far_dist > far_thresh) & (np.linalg.norm(gt - raycolor, axis=-1) < 0.1))
+    return (ray_mask > 0) & (near > 0) & (opacity > opacity_thresh)

@@ -65,6 +65,40 @@ def lego_opt(**overrides):
     return opt
 
 
+def model_shell_flags(**overrides):
+    """The flags the model shell (``MvsPointsVolumetricModel``: losses, optimizers, schedulers, checkpoints, probe/prune
+    cadence) reads, with ``lego_cuda.sh``'s values (line numbers beside each) or the parser defaults where the script is
+    silent (options/train_options.py, models/base_rendering_model.py:30-205)."""
+    kw = dict(
+        model="mvs_points_volumetric",         # :92
+        mode=2,                                # point-nerf only (the per-scene scripts' value); the MVSNet branch is out of scope
+        gpu_ids=[0], checkpoints_dir="./checkpoints", name="lego", resume_iter="best", resume_dir="",   # :6,:121
+        num_point=8192, feature_init_method="rand", feedforward=0,   # :23
+        no_loss=0, verbose=0, compute_depth=0, fine_sample_num=0,
+        color_loss_items=["ray_masked_coarse_raycolor", "ray_miss_coarse_raycolor", "coarse_raycolor"],   # :153
+        color_loss_weights=[1.0, 0.0, 0.0],    # :152
+        depth_loss_items=[], depth_loss_weights=[1.0], bg_loss_items=[], bg_loss_weights=[1.0],
+        l2_size_loss_items=[], l2_size_loss_weights=[0.0],
+        zero_one_loss_items=["conf_coefficient"], zero_one_loss_weights=[0.0001], zero_epsilon=1e-3,   # :144-149
+        visual_items=None, visual_items_additional=[],
+        lr_policy="iter_exponential_decay", lr_decay_iters=1000000, lr_decay_exp=0.1, niter=10000, niter_decay=10000,   # :114-128
+        alter_step=0, print_freq=40,
+        prune_thresh=0.1, prune_iter=10001, prune_max_iter=130000,        # :19-21
+        prob_freq=10001, prob_num_step=20, prob_thresh=0.7, prob_mul=0.4, prob_kernel_size=[3, 3, 3], prob_tiers=[100000],   # :137-142
+        prob_mode=0, prob_top=1, far_thresh=-1.0,                          # :136
+        default_conf=0.15, bgmodel="no", random_sample_size=60, maximum_step=200000,   # :40,:25,:109,:125
+    )
+    kw.update(overrides)
+    return kw
+
+
+def lego_train_opt(**overrides):
+    """lego_cuda.sh as the training loop sees it: the hot-path flags of ``lego_opt`` + the model-shell flags."""
+    kw = model_shell_flags(is_train=1)
+    kw.update(overrides)
+    return lego_opt(**kw)
+
+
 def chair_opt(**overrides):
     """BASELINE.json configs[0]: chair_cuda.sh values (ranges :57, P :60, max_o :56), K=4, SR=32."""
     kw = dict(ranges=[-0.721, -0.695, -0.995, 0.658, 0.706, 1.050], P=12, max_o=410000, K=4, SR=32)

@@ -120,20 +120,38 @@ class NeuralPointsRayMarching(nn.Module):
             output["shading_avg_embedding"] = torch.sum(g(npnt.points_embeding) * wk, dim=-2)[None]
 
 
-def fill_invalid(output, bg_color, tonemap_func=None):
-    """neural_points_volumetric_model.py:87-123 for the keys the fused path emits."""
+PROBE_KEYS = ("ray_max_sample_loc_w", "ray_max_shading_opacity", "shading_avg_color", "shading_avg_dir", "shading_avg_conf",
+              "shading_avg_embedding", "ray_max_far_dist")
+
+
+def fill_invalid(output, bg_color, tonemap_func=None, bg_ray=None, prob=0):
+    """neural_points_volumetric_model.py:87-123: scatter the hit rays' results back to all R submitted rays (missed rays get
+    the background colour / transmittance 1 / opacity 0; with ``prob == 1`` the probe outputs are zero-filled, :121-122
+    ``unmask``).  ``bg_ray`` [B,R,3] replaces the constant background like :104-106."""
     ray_mask = output["ray_mask"]
     B, OR = ray_mask.shape
     sel = ray_mask[0] > 0
     dev = output["coarse_raycolor"].device
     bgt = torch.ones([B, OR, 1], dtype=torch.float32, device=dev)
     bgt[0, sel] = output["coarse_is_background"][0]
-    col = torch.ones([B, OR, 3], dtype=torch.float32, device=dev) * bg_color[None, ...].to(dev)
-    col[0, sel] = output["coarse_raycolor"][0]
+    if bg_ray is not None:
+        col = bgt * bg_ray.to(dev)
+        col[0, sel] = col[0, sel] + output["coarse_raycolor"][0]
+    else:
+        col = torch.ones([B, OR, 3], dtype=torch.float32, device=dev) * bg_color[None, ...].to(dev)
+        if tonemap_func is not None:
+            col = tonemap_func(col)
+        col[0, sel] = output["coarse_raycolor"][0]
     op = torch.zeros([B, OR, output["coarse_point_opacity"].shape[2]], dtype=torch.float32, device=dev)
     op[0, sel] = output["coarse_point_opacity"][0]
     qs = torch.ones([B, OR, 3], dtype=torch.float32, device=dev)
     qs[0, sel] = output["queried_shading"][0]
     out = dict(output)
     out.update(coarse_is_background=bgt, coarse_mask=1 - bgt, coarse_raycolor=col, coarse_point_opacity=op, queried_shading=qs)
+    if prob == 1 and "ray_max_shading_opacity" in output:
+        for k in PROBE_KEYS:
+            if output.get(k) is not None:
+                t = torch.zeros([B, OR, *output[k].shape[2:]], dtype=output[k].dtype, device=dev)
+                t[0, sel] = output[k][0]
+                out[k] = t
     return out

@@ -130,7 +130,11 @@ class lighting_fast_querier():
             mid, seg = ops.mid_depths(D, near_depth, far_depth)
             self._mid_cache = {mk: (mid.to(ray_dirs_tensor.device), seg.to(ray_dirs_tensor.device))}
         mid, seg = self._mid_cache[mk]
+        # point_query.py:81 of the reference; ``opt.ray_jitter`` (ours, default None = that rule) pins it, e.g. to 0 for
+        # parity runs of a training step: the jittered depths come from a device RNG and are not reproducible across devices
         jitter = 0.3 if opt.is_train > 0 else 0.0
+        if getattr(opt, "ray_jitter", None) is not None:
+            jitter = float(opt.ray_jitter)
         raydir = ray_dirs_tensor.detach().reshape(-1, 3).contiguous().float()
         R = raydir.shape[0]
         campos = cam_pos_tensor.detach().reshape(-1)[:3].cpu().tolist() if isinstance(cam_pos_tensor, torch.Tensor) else list(cam_pos_tensor)
