@@ -24,6 +24,7 @@ Reference followed (under /root/reference), function by function:
   compute_losses           models/base_rendering_model.py:533-662 (colour / zero-one / sparse items)
   rank_ray_miss            models/mvs_points_volumetric_model.py:147-156
   probe_hole_mask          run/train_ft.py:489-500,532-540
+  test_view_losses         run/train_ft.py:330-372 (per-view MSE / PSNR items of test())
 
 Parity pin: the reference's own PointAggregator / ray_march / near_far_linear_ray_generation
 import and run on CPU in the authoring container; tests/golden/make_golden.py stores their
@@ -415,3 +416,17 @@ def probe_hole_mask(ray_mask, opacity, far_dist, raycolor, gt, bg, edge, opacity
     if far_thresh > 0:
         near = near + ((ray_mask > 0) & (far_dist > far_thresh) & (np.linalg.norm(gt - raycolor, axis=-1) < 0.1))
     return (ray_mask > 0) & (near > 0) & (opacity > opacity_thresh)
+
+
+def test_view_losses(canvas, gt_rays, pixel_idx, ray_mask, height, width):
+    """run/train_ft.py:330-372 for one view with numpy: canvas [H,W,3] rendered colours, gt_rays [P,3] and pixel_idx [P,2]
+    (px, py) in row-major pixel order, ray_mask [P] bool.  Returns {item: mse, item_psnr: psnr}."""
+    edge = np.zeros((height, width), bool)
+    edge[pixel_idx[:, 1], pixel_idx[:, 0]] = True
+    gt = np.zeros((height * width, 3), np.float32)
+    gt[edge.reshape(-1)] = gt_rays
+    full = float(np.mean((canvas.reshape(-1, 3).astype(np.float64) - gt) ** 2))
+    pred = canvas.reshape(-1, 3)[edge.reshape(-1)][ray_mask]
+    masked = float(np.mean((pred.astype(np.float64) - gt_rays[ray_mask]) ** 2))
+    ps = lambda x: -10.0 * math.log(x) / math.log(10.0)
+    return dict(coarse_raycolor=full, coarse_raycolor_psnr=ps(full), ray_masked_coarse_raycolor=masked, ray_masked_coarse_raycolor_psnr=ps(masked))

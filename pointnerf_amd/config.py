@@ -77,6 +77,7 @@ def model_shell_flags(**overrides):
         no_loss=0, verbose=0, compute_depth=0, fine_sample_num=0,
         color_loss_items=["ray_masked_coarse_raycolor", "ray_miss_coarse_raycolor", "coarse_raycolor"],   # :153
         color_loss_weights=[1.0, 0.0, 0.0],    # :152
+        test_color_loss_items=["coarse_raycolor", "ray_miss_coarse_raycolor", "ray_masked_coarse_raycolor"], test_num_step=10,   # :154
         depth_loss_items=[], depth_loss_weights=[1.0], bg_loss_items=[], bg_loss_weights=[1.0],
         l2_size_loss_items=[], l2_size_loss_weights=[0.0],
         zero_one_loss_items=["conf_coefficient"], zero_one_loss_weights=[0.0001], zero_epsilon=1e-3,   # :144-149

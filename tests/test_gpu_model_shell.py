@@ -144,3 +144,29 @@ def test_probe_hole_on_the_device_matches_the_oracle(tmp_path):
     m.set_input({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in inp.items()})
     out = m.test()
     assert int((out["ray_mask"] > 0).sum()) >= int(hit.sum()) and bool(torch.isfinite(out["coarse_raycolor"]).all())
+
+
+def test_evaluation_loop_through_the_shell_matches_the_oracle(tmp_path):
+    """eval_loop.test_views (= test() of run/train_ft.py:252-414) on two views of 30x30 rays in row-major order."""
+    from pointnerf_amd import eval_loop
+    H = W = 800
+    opt, m, xyz, attrs, mlp, _, seed = _scene("small_k8", tmp_path, is_train=0)
+    size = 30
+    points = dict(xyz=xyz, **attrs)
+    views, refs = [], []
+    for i, theta in enumerate((30.0, 95.0)):
+        inp = pyref.to_torch_inputs(scenes.block_rays(theta_deg=theta, x0=400 - size // 2, y0=400 - size // 2, size=size))
+        views.append(dict(inp, id=i))
+        with torch.no_grad():
+            ref = pyref.render(opt, points, mlp, inp, nthreads=8)
+        pix = inp["pixel_idx"][0].long().numpy()
+        canvas = np.zeros((H, W, 3), np.float32)
+        canvas[pix[:, 1], pix[:, 0]] = pyref.fill_invalid(ref, inp)["coarse_raycolor"][0].numpy()
+        refs.append(pyref.test_view_losses(canvas, inp["gt_image"][0].numpy(), pix, (ref["ray_mask"][0] > 0).numpy(), H, W))
+    got = []
+    psnr, avg = eval_loop.test_views(m, views, opt, H, W, test_num_step=1, chunk=400, on_view=lambda i, v: got.append(v["coarse_raycolor"].clone()))
+    for k in refs[0]:
+        want = float(np.mean([r[k] for r in refs]))
+        assert abs(avg[k] - want) <= 1e-4 * max(1.0, abs(want)), (k, avg[k], want)
+    assert abs(psnr - avg["coarse_raycolor_psnr"]) < 1e-9 and len(got) == 2 and got[0].shape == (H, W, 3)
+    assert float(got[0].abs().sum()) > 0 and float(got[0][:300].abs().sum()) == 0

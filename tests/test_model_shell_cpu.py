@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import pyref
-from pointnerf_amd import config, probe, scenes
+from pointnerf_amd import config, eval_loop, probe, scenes
 from pointnerf_amd.mvs_points_volumetric_model import create_model, get_scheduler
 from pointnerf_amd.neural_points_volumetric_model import fill_invalid, PROBE_KEYS
 
@@ -294,3 +294,48 @@ def test_frame_selection_and_prune_rebuild(tmp_path):
     assert any(p is m.neural_points.points_conf for p in m.neural_params) and len(m.schedulers) == 2
     assert m.schedulers[0].last_epoch == 100
     assert probe.prune_and_grow_step(m, [], opt, total_steps=101, height=4, width=4) == 0 and m.neural_points.xyz.shape[0] == keep
+
+
+class _FakeShell:
+    """Stands in for the model shell in the evaluation loop: ``test()`` colours the rays of the current chunk from a map."""
+
+    def __init__(self, H, W, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.device, self.img, self.hit = torch.device("cpu"), torch.rand(H, W, 3, generator=g), torch.rand(H, W, generator=g) > 0.3
+        self.chunks = 0
+
+    def eval(self):
+        pass
+
+    def set_input(self, d):
+        self.input = d
+
+    def test(self):
+        self.chunks += 1
+        p = self.input["pixel_idx"][0].long()
+        self.output = dict(coarse_raycolor=self.img[p[:, 1], p[:, 0]][None], ray_mask=self.hit[p[:, 1], p[:, 0]][None].to(torch.int8))
+        return self.output
+
+    def get_current_visuals(self, data=None):
+        return dict(gt_image=self.input["gt_image"], coarse_raycolor=self.output["coarse_raycolor"], queried_shading=None)
+
+
+def test_evaluation_loop_scores_views_like_the_reference():
+    H, W = 20, 24
+    opt = config.lego_train_opt()
+    y0, x0, h, w = 3, 5, 12, 14                                      # the view provides rays for a sub-rectangle only
+    py, px = torch.meshgrid(torch.arange(y0, y0 + h), torch.arange(x0, x0 + w), indexing="ij")
+    pix = torch.stack([px, py], -1)[None].float()
+    g = torch.Generator().manual_seed(3)
+    views = [dict(raydir=torch.zeros(1, h * w, 3), pixel_idx=pix, gt_image=torch.rand(1, h * w, 3, generator=g), id=i) for i in range(5)]
+    shell = _FakeShell(H, W, 1)
+    seen = []
+    psnr, avg = eval_loop.test_views(shell, views, opt, H, W, test_num_step=2, chunk=50, on_view=lambda i, v: seen.append((i, sorted(v))))
+    assert [i for i, _ in seen] == [0, 2, 4] and seen[0][1] == ["coarse_raycolor", "gt_image"] and shell.chunks == 3 * 4
+    canvas = np.zeros((H, W, 3), np.float32)
+    canvas[y0:y0 + h, x0:x0 + w] = shell.img[y0:y0 + h, x0:x0 + w].numpy()
+    p = pix[0].reshape(-1, 2).long().numpy()
+    refs = [pyref.test_view_losses(canvas, views[i]["gt_image"][0].numpy(), p, shell.hit[p[:, 1], p[:, 0]].numpy(), H, W) for i in (0, 2, 4)]
+    for k in ("coarse_raycolor", "ray_masked_coarse_raycolor", "coarse_raycolor_psnr", "ray_masked_coarse_raycolor_psnr"):
+        assert abs(avg[k] - np.mean([r[k] for r in refs])) <= 1e-5 * max(1.0, abs(np.mean([r[k] for r in refs]))), k
+    assert abs(psnr - avg["coarse_raycolor_psnr"]) < 1e-12           # the first item of test_color_loss_items is what test() returns
