@@ -930,6 +930,205 @@ int launch_wgrad_lds(const float *A, int lda, const float *B, int ldb, const flo
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------ weight gradients, split-bf16 form
+// The 256 x 256 weight gradients of the four aggregator layers are 1/3 of the step's flops, and an fp32-input MFMA runs at
+// 1/16 of the bf16 rate.  k_wgrad_b3 computes the SAME fp32 product on the bf16 MFMA: every fp32 operand x is split
+// EXACTLY into three bf16 numbers by truncation,
+//     h = top 16 bits of x,   m = top 16 bits of (x - h),   l = (x - h) - m        (8 + 8 + 8 significand bits: x == h + m + l)
+// and  a*b  is accumulated (fp32, inside the MFMA) as  ah*bl + ah*bm + ah*bh + am*bm + am*bh + al*bh:  the three dropped
+// terms are below 2^-23 of the product, i.e. below the rounding of the fp32 accumulation itself.  Six 32-cycle
+// v_mfma_f32_32x32x16_bf16 (K = 16) replace eight 64-cycle v_mfma_f32_32x32x2_f32: 2.67x on the matrix pipe, which turns the kernel
+// from MFMA-bound into HBM-bound (it reads dY and X once: 2 KB per row and layer).
+//
+// Block tile 256 x 256 (all of dW), 8 waves as 2 (M) x 4 (N), each 4 x 2 tiles of 32 x 32.  The operands are k-major in HBM
+// (row = k) and the MFMA wants 8 consecutive k per lane, so the loader thread owns ONE column and 8 consecutive rows
+// (8 dword loads, each coalesced over the wave), splits them in registers and writes one 16-byte [8 x bf16] fragment slot per
+// plane: the LDS image is [plane][k-half][column][8 k] and a fragment read is one conflict-free ds_read_b128.
+// The split (about 90 VALU operations per thread and k-step) is placed by hand between the step's MFMA groups -- a wave's
+// own VALU issues in the shadow of its MFMAs, another wave's does not -- and the global loads run two
+// k-steps ahead in two register sets (about 70 KB in flight per CU).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct B3Set { float a[8], b[8]; };
+
+__device__ __forceinline__ unsigned b3_hi(float x) { return __float_as_uint(x) & 0xffff0000u; }
+
+// 4 floats (k, k+1, k+2, k+3 of one column) -> two packed dwords of each plane
+__device__ __forceinline__ void b3_split4(const float *x, unsigned *h, unsigned *m, unsigned *l) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float x0 = x[2 * p], x1 = x[2 * p + 1];
+        const unsigned h0 = b3_hi(x0), h1 = b3_hi(x1);
+        const float r0 = x0 - __uint_as_float(h0), r1 = x1 - __uint_as_float(h1);
+        const unsigned m0 = b3_hi(r0), m1 = b3_hi(r1);
+        const float s0 = r0 - __uint_as_float(m0), s1 = r1 - __uint_as_float(m1);
+        h[p] = (h0 >> 16) | h1;
+        m[p] = (m0 >> 16) | m1;
+        l[p] = (__float_as_uint(s0) >> 16) | b3_hi(s1);
+    }
+}
+
+// slot -> split piece (0..27) of a k-step, or -1: slots that carry a fragment read carry no piece
+constexpr bool b3_slot_reads(int s) { return s <= 5 || s == 12 || s == 13 || s == 20 || s == 21 || s == 24 || s == 25 || s == 36 || s == 37; }
+constexpr int b3_slot_work(int s) {
+    if (b3_slot_reads(s)) return -1;
+    int n = 0;
+    for (int i = 0; i < s; ++i) n += b3_slot_reads(i) ? 0 : 1;
+    return n < 28 ? n : -1;
+}
+
+constexpr int B3_PLANE = 2 * 256 + 2 * 256;      // uint4 slots of one plane: A [2][256], B [2][256]
+constexpr int B3_STAGE = 3 * B3_PLANE;           // 3072 slots = 48 KB
+constexpr size_t B3_LDS_BYTES = (size_t)2 * B3_STAGE * 16;
+
+template <int LDB>
+__global__ __launch_bounds__(512) void k_wgrad_b3(const float *__restrict__ A, const float *__restrict__ B, long long rows,
+                                                  const int *__restrict__ d_tiles, int rows_per_chunk, float *__restrict__ partial) {
+    constexpr int MT = 4, NT = 2, WN = 4, KB = 16, LDA = PN_H;
+    if (d_tiles) {
+        const long long r = (long long)(*d_tiles) * PN_TILE;
+        rows = r < rows ? r : rows;
+        long long rpc = (rows + gridDim.y - 1) / gridDim.y;
+        rpc = (rpc + 63) / 64 * 64;
+        rows_per_chunk = (int)(rpc < 64 ? 64 : rpc);
+    }
+    extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int col = tid & 255, kh = tid >> 8;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+    long long r1 = r0 + rows_per_chunk;
+    if (r1 > rows) r1 = rows;                     // rows and chunk bounds are multiples of 64: every 16-row step is full
+    const int nsteps = r1 > r0 ? (int)((r1 - r0) / KB) : 0;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) acc[mt][nt][reg] = 0.f;
+    const float *pa = A + (r0 + kh * 8) * LDA + col, *pb = B + (r0 + kh * 8) * LDB + col;     // this thread's column, rows of the step to load
+    auto gload = [&](B3Set &S, bool advance) {         // !advance: past the end of the chunk, re-read the last step (never used)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { S.a[j] = pa[j * LDA]; S.b[j] = pb[j * LDB]; }
+        pa += advance ? KB * LDA : 0; pb += advance ? KB * LDB : 0;
+    };
+    uint2 *const wbase = reinterpret_cast<uint2 *>(smem4) + 2 * (kh * 256 + col);
+    // split 4 k of one operand's column into the three planes of LDS buffer `buf` (half a fragment slot each)
+    auto half = [&](const float *x, int buf, int operand, int hf) {
+        unsigned h[2], m[2], l[2];
+        b3_split4(x + 4 * hf, h, m, l);
+        uint2 *d = wbase + 2 * (buf * B3_STAGE + operand * 512) + hf;
+        d[0] = make_uint2(h[0], h[1]); d[2 * B3_PLANE] = make_uint2(m[0], m[1]); d[4 * B3_PLANE] = make_uint2(l[0], l[1]);
+    };
+    const uint4 *const fbase = smem4 + (lane >> 5) * 256 + (lane & 31);
+    auto frag = [&](int buf, int plane, int operand, int tile) -> bf16x8 {
+        return __builtin_bit_cast(bf16x8, fbase[buf * B3_STAGE + plane * B3_PLANE + operand * 512 + tile * 32]);
+    };
+    // One k-step = 48 MFMAs on LDS buffer CUR.  The three B planes of the wave's two column tiles stay in registers for the
+    // whole step; the A fragments stream through two 2-tile register buffers X / Y:
+    //     row-tile pair p (slots 24 p ..):  12 x  ah * {bl, bm, bh}   |   8 x  am * {bm, bh}   |   4 x  al * bh
+    // (every accumulator is touched once in four MFMAs).  After every MFMA one small piece of other work is issued
+    // (sched_barrier pins it there): the fragment reads of a later group, and the split of register set Sn into
+    // buffer CUR ^ 1 as 28 pieces (per half fragment slot: element, element, pack, element, element, pack, 3 x ds_write_b64).
+    auto step = [&](auto cur_c, B3Set &Sn) {
+        constexpr int CUR = decltype(cur_c)::value;
+        bf16x8 ax[2], ay[2], bl[NT], bm[NT], bh[NT];
+        ax[0] = frag(CUR, 0, 0, wm * MT); ax[1] = frag(CUR, 0, 0, wm * MT + 1);
+        bl[0] = frag(CUR, 2, 1, wn * NT); bl[1] = frag(CUR, 2, 1, wn * NT + 1);
+        unsigned eh[2], em[2], es[2], ph[2], pm[2], pl[2];
+        pn_static_for<48>([&](auto ss) {
+            constexpr int sl = decltype(ss)::value, pr = sl / 24, q = sl % 24;
+            constexpr int grp = q < 12 ? 0 : (q < 20 ? 1 : 2), qi = q - (grp == 0 ? 0 : grp == 1 ? 12 : 20);
+            constexpr int bp = grp == 0 ? qi / 4 : (grp == 1 ? 1 + qi / 4 : 2);            // 0: bl, 1: bm, 2: bh
+            constexpr int ml = qi % 2, nt = (qi % 4) / 2, mt = 2 * pr + ml;
+            constexpr bool use_x = (grp == 1) == (pr == 1);                                 // p0: X Y X, p1: Y X Y
+            const bf16x8 av = use_x ? ax[ml] : ay[ml];
+            const bf16x8 bv = bp == 0 ? bl[nt] : (bp == 1 ? bm[nt] : bh[nt]);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mt][nt], 0, 0, 0);
+            constexpr int w = b3_slot_work(sl);
+            if constexpr (sl == 0 || sl == 1) bm[sl] = frag(CUR, 1, 1, wn * NT + sl);
+            else if constexpr (sl == 2 || sl == 3) bh[sl - 2] = frag(CUR, 0, 1, wn * NT + sl - 2);
+            else if constexpr (sl == 4 || sl == 5) ay[sl - 4] = frag(CUR, 1, 0, wm * MT + sl - 4);             // am, pair 0
+            else if constexpr (sl == 12 || sl == 13) ax[sl - 12] = frag(CUR, 2, 0, wm * MT + sl - 12);          // al, pair 0
+            else if constexpr (sl == 20 || sl == 21) ay[sl - 20] = frag(CUR, 0, 0, wm * MT + 2 + sl - 20);      // ah, pair 1
+            else if constexpr (sl == 24 || sl == 25) ax[sl - 24] = frag(CUR, 1, 0, wm * MT + 2 + sl - 24);      // am, pair 1
+            else if constexpr (sl == 36 || sl == 37) ay[sl - 36] = frag(CUR, 2, 0, wm * MT + 2 + sl - 36);      // al, pair 1
+            else if constexpr (w >= 0) {
+                constexpr int hfi = w / 7, k = w % 7, operand = hfi / 2, hf = hfi % 2;
+                if constexpr (k == 0 || k == 1 || k == 3 || k == 4) {
+                    constexpr int e = (k == 0 ? 0 : k == 1 ? 1 : k == 3 ? 2 : 3), j = 4 * hf + e;
+                    const float x = operand == 0 ? Sn.a[j] : Sn.b[j];
+                    const unsigned h = b3_hi(x);
+                    const float r = x - __uint_as_float(h);
+                    const unsigned m = b3_hi(r);
+                    eh[e & 1] = h; em[e & 1] = m; es[e & 1] = __float_as_uint(r - __uint_as_float(m));
+                } else if constexpr (k == 2 || k == 5) {
+                    constexpr int pp = k == 2 ? 0 : 1;
+                    ph[pp] = __builtin_amdgcn_perm(eh[1], eh[0], 0x07060302u);
+                    pm[pp] = __builtin_amdgcn_perm(em[1], em[0], 0x07060302u);
+                    pl[pp] = __builtin_amdgcn_perm(es[1], es[0], 0x07060302u);
+                } else {
+                    uint2 *d = wbase + 2 * ((CUR ^ 1) * B3_STAGE + operand * 512) + hf;
+                    d[0] = make_uint2(ph[0], ph[1]); d[2 * B3_PLANE] = make_uint2(pm[0], pm[1]); d[4 * B3_PLANE] = make_uint2(pl[0], pl[1]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    if (nsteps > 0) {                             // nsteps is a multiple of 4 (chunks are multiples of 64 rows)
+        B3Set S0, S1;
+        gload(S0, true);
+        gload(S1, true);
+        half(S0.a, 0, 0, 0); half(S0.a, 0, 0, 1); half(S0.b, 0, 1, 0); half(S0.b, 0, 1, 1);
+        __syncthreads();
+        // step i computes buffer i & 1, splits the set holding step i + 1 into the other buffer and, before that, refills the
+        // set step i was split from with step i + 2 (past the end: a harmless re-read whose split is never consumed)
+        for (int i = 0; i < nsteps; i += 2) {
+            gload(S0, i + 3 < nsteps);
+            step(C0{}, S1);
+            __syncthreads();
+            gload(S1, i + 4 < nsteps);
+            step(C1{}, S0);
+            __syncthreads();
+        }
+    }
+    float *out = partial + (size_t)blockIdx.y * 256 * 256;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = (wm * MT + mt) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                const int n = (wn * NT + nt) * 32 + (lane & 31);
+                out[(size_t)m * 256 + n] = acc[mt][nt][reg];
+            }
+}
+
+// dW[256 x 256] (+)= A^T B over `rows` rows; same partial / reduce scheme as launch_wgrad_lds
+template <int LDB>
+int launch_wgrad_b3(const float *A, const float *B, long long rows, const int *d_tiles, float *partial, float *grad, int dst, int ldc, hipStream_t s) {
+    if (rows % PN_TILE) return PNERF_E_INVAL;
+    int chunks = WG_CHUNKS;
+    long long rpc = (rows + chunks - 1) / chunks;
+    rpc = (rpc + 63) / 64 * 64;
+    if (rpc < 64) rpc = 64;
+    chunks = (int)((rows + rpc - 1) / rpc);
+    if (chunks < 1) chunks = 1;
+    if ((size_t)chunks * 256 * 256 > PARTIAL_FLOATS) return PNERF_E_WS;
+    if (hipFuncSetAttribute((const void *)k_wgrad_b3<LDB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_LDS_BYTES) != hipSuccess) return PNERF_E_LAUNCH;
+    { PnProfScope prof(PNK_WGRAD, s);
+    hipLaunchKernelGGL(k_wgrad_b3<LDB>, dim3(1, chunks), dim3(512), B3_LDS_BYTES, s, A, B, rows, d_tiles, (int)rpc, partial); }
+    PnProfScope prof(PNK_WGRAD_REDUCE, s);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(pn_cdiv(256LL * 256, 256)), dim3(256), 0, s, partial, chunks, 256, 256, 256, grad, dst, ldc);
+    PN_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace
 
 size_t pn_wgrad_partials_bytes() { return pn_align(PARTIAL_FLOATS * sizeof(float)); }
@@ -978,10 +1177,12 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     const int *dt = sv.cls_info + PN_CI_TILES;
     int rc;
     float *g = d_grad_params;
-    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16, true>(sv.dy1, PN_H, sv.x0, PN_IN1P, sv.x0 + 256, PN_IN1P, rows, dt, d_partials, PN_IN1P, PN_IN1, g, PO_W1, PN_IN1, s))) return rc;
-    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16, false>(sv.dy2, PN_H, sv.h1, PN_H, nullptr, 0, rows, dt, d_partials, 256, 256, g, PO_W2, PN_H, s))) return rc;
-    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16, false>(sv.dy3, PN_H, sv.h2, PN_H, nullptr, 0, rows, dt, d_partials, 256, 256, g, PO_W3, PN_IN3, s))) return rc;
-    if ((rc = launch_wgrad_lds<4, 2, 2, 4, 16, false>(sv.dy4, PN_H, sv.h3, PN_H, nullptr, 0, rows, dt, d_partials, 256, 256, g, PO_W4, PN_H, s))) return rc;
+    if ((rc = launch_wgrad_b3<PN_IN1P>(sv.dy1, sv.x0, rows, dt, d_partials, g, PO_W1, PN_IN1, s))) return rc;
+    // columns 256..283 of W1 (the distance encoding): a 256 x 32 tile on the fp32 MFMA
+    if ((rc = launch_wgrad_lds<4, 1, 2, 1, 16, false>(sv.dy1, PN_H, sv.x0 + 256, PN_IN1P, nullptr, 0, rows, dt, d_partials, 32, PN_IN1 - 256, g, PO_W1 + 256, PN_IN1, s))) return rc;
+    if ((rc = launch_wgrad_b3<PN_H>(sv.dy2, sv.h1, rows, dt, d_partials, g, PO_W2, PN_H, s))) return rc;
+    if ((rc = launch_wgrad_b3<PN_H>(sv.dy3, sv.h2, rows, dt, d_partials, g, PO_W3, PN_IN3, s))) return rc;
+    if ((rc = launch_wgrad_b3<PN_H>(sv.dy4, sv.h3, rows, dt, d_partials, g, PO_W4, PN_H, s))) return rc;
     if ((rc = launch_wgrad_lds<2, 2, 2, 4, 16, true>(sv.dc1, PN_HC, sv.fs, PN_H, sv.pe, 32, smp, nullptr, d_partials, 288, PN_INC, g, PO_WC1, PN_INC, s))) return rc;
     if ((rc = launch_wgrad_lds<2, 1, 2, 4, 16, false>(sv.dc2, PN_HC, sv.c1, PN_HC, nullptr, 0, smp, nullptr, d_partials, 128, 128, g, PO_WC2, PN_HC, s))) return rc;
     if ((rc = launch_wgrad_lds<2, 1, 2, 4, 16, false>(sv.dc3, PN_HC, sv.c2, PN_HC, nullptr, 0, smp, nullptr, d_partials, 128, 128, g, PO_WC3, PN_HC, s))) return rc;
