@@ -203,7 +203,10 @@ def main():
                                       "%d rays/GPU/step, fwd+loss+bwd+Adam, grid cached" % (args.points, opt.K, opt.SR, opt.z_depth_dim, args.rays),
                           "parallelism": "ray-shard dp%d, point cloud + MLP replicated" % world,
                           "valid_samples_per_step": smp, "neighbor_rows_per_step": rows,
-                          "rays_hit_per_step": float(np.mean([s["rays_hit"] for s in stats])), "final_loss": float(loss.item()), **extra}}
+                          "rays_hit_per_step": float(np.mean([s["rays_hit"] for s in stats])), "final_loss": float(loss.item()),
+                          "arithmetic": "f32 throughout; aggregator forward / input-gradient and colour GEMMs on v_mfma_f32_32x32x2_f32; the four 256x256 "
+                                        "weight-gradient GEMMs split both f32 operands exactly into 3 bf16 planes and keep 6 of the 9 bf16-MFMA "
+                                        "products with f32 accumulation (dropped terms <= 2^-23 of a product)", **extra}}
         if prof is not None:
             per = {k: {"ms_per_launch": ms / max(n, 1), "launches": n, "ms_per_step": ms / args.steps} for k, (ms, n) in prof.items() if n > 0}
             alg = {"agg_forward": rows * FLOP_ROW_FWD, "agg_backward": rows * FLOP_ROW_DGRAD,

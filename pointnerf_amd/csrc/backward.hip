@@ -933,13 +933,16 @@ int launch_wgrad_lds(const float *A, int lda, const float *B, int ldb, const flo
 
 // ------------------------------------------------------------------------------ weight gradients, split-bf16 form
 // The 256 x 256 weight gradients of the four aggregator layers are 1/3 of the step's flops, and an fp32-input MFMA runs at
-// 1/16 of the bf16 rate.  k_wgrad_b3 computes the SAME fp32 product on the bf16 MFMA: every fp32 operand x is split
-// EXACTLY into three bf16 numbers by truncation,
-//     h = top 16 bits of x,   m = top 16 bits of (x - h),   l = (x - h) - m        (8 + 8 + 8 significand bits: x == h + m + l)
-// and  a*b  is accumulated (fp32, inside the MFMA) as  ah*bl + ah*bm + ah*bh + am*bm + am*bh + al*bh:  the three dropped
-// terms are below 2^-23 of the product, i.e. below the rounding of the fp32 accumulation itself.  Six 32-cycle
-// v_mfma_f32_32x32x16_bf16 (K = 16) replace eight 64-cycle v_mfma_f32_32x32x2_f32: 2.67x on the matrix pipe, which turns the kernel
-// from MFMA-bound into HBM-bound (it reads dY and X once: 2 KB per row and layer).
+// 1/16 of the bf16 rate.  k_wgrad_b3 computes the same fp32 product on the bf16 MFMA: every fp32 operand x is split into
+// three bf16 numbers by round-to-nearest,
+//     h = bf16(x),   m = bf16(x - h),   l = bf16((x - h) - m)      (both subtractions and the last conversion are exact)
+// so that x == h + m + l exactly (8 + 8 + 8 significand bits; for |x| below ~1e-33 the residuals are fp32 denormals and the
+// split loses its low bits -- of numbers that small), |m| <= 2^-8 |h|, |l| <= 2^-16 |h|, and  a*b  is accumulated (fp32, inside the
+// MFMA) as  ah*bl + ah*bm + ah*bh + am*bm + am*bh + al*bh:  the three dropped terms are below 2^-23 of the product, i.e. at
+// the level of the fp32 accumulation's own rounding (tests/test_split_bf16_cpu.py restates and checks this arithmetic).  Six
+// 32-cycle v_mfma_f32_32x32x16_bf16 (K = 16) replace eight 64-cycle v_mfma_f32_32x32x2_f32: 2.67x on the matrix pipe.
+// Measured (profiles/r01_pmc_wgrad_split.json): the MFMA pipe is busy ~65 % of the kernel, at a clock the bf16 MFMA load
+// pulls down to ~1.7 GHz (the fp32-MFMA kernels run at ~2.25 GHz).
 //
 // Block tile 256 x 256 (all of dW), 8 waves as 2 (M) x 4 (N), each 4 x 2 tiles of 32 x 32.  The operands are k-major in HBM
 // (row = k) and the MFMA wants 8 consecutive k per lane, so the loader thread owns ONE column and 8 consecutive rows
@@ -952,30 +955,36 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct B3Set { float a[8], b[8]; };
 
-__device__ __forceinline__ unsigned b3_hi(float x) { return __float_as_uint(x) & 0xffff0000u; }
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pn_f32x2 __attribute__((ext_vector_type(2)));
+
+// (x0, x1) -> one dword holding bf16(x0) | bf16(x1) << 16, round-to-nearest-even: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned b3_pack(float x0, float x1) {
+    const pn_f32x2 v = {x0, x1};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float b3_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float b3_up(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
 
 // 4 floats (k, k+1, k+2, k+3 of one column) -> two packed dwords of each plane
 __device__ __forceinline__ void b3_split4(const float *x, unsigned *h, unsigned *m, unsigned *l) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const float x0 = x[2 * p], x1 = x[2 * p + 1];
-        const unsigned h0 = b3_hi(x0), h1 = b3_hi(x1);
-        const float r0 = x0 - __uint_as_float(h0), r1 = x1 - __uint_as_float(h1);
-        const unsigned m0 = b3_hi(r0), m1 = b3_hi(r1);
-        const float s0 = r0 - __uint_as_float(m0), s1 = r1 - __uint_as_float(m1);
-        h[p] = (h0 >> 16) | h1;
-        m[p] = (m0 >> 16) | m1;
-        l[p] = (__float_as_uint(s0) >> 16) | b3_hi(s1);
+        h[p] = b3_pack(x0, x1);
+        const float r0 = x0 - b3_lo(h[p]), r1 = x1 - b3_up(h[p]);
+        m[p] = b3_pack(r0, r1);
+        l[p] = b3_pack(r0 - b3_lo(m[p]), r1 - b3_up(m[p]));
     }
 }
 
-// slot -> split piece (0..27) of a k-step, or -1: slots that carry a fragment read carry no piece
+// slot -> split piece (0..19) of a k-step, or -1: slots that carry a fragment read carry no piece
 constexpr bool b3_slot_reads(int s) { return s <= 5 || s == 12 || s == 13 || s == 20 || s == 21 || s == 24 || s == 25 || s == 36 || s == 37; }
 constexpr int b3_slot_work(int s) {
     if (b3_slot_reads(s)) return -1;
     int n = 0;
     for (int i = 0; i < s; ++i) n += b3_slot_reads(i) ? 0 : 1;
-    return n < 28 ? n : -1;
+    return n < 20 ? n : -1;
 }
 
 constexpr int B3_PLANE = 2 * 256 + 2 * 256;      // uint4 slots of one plane: A [2][256], B [2][256]
@@ -1031,13 +1040,14 @@ __global__ __launch_bounds__(512) void k_wgrad_b3(const float *__restrict__ A, c
     //     row-tile pair p (slots 24 p ..):  12 x  ah * {bl, bm, bh}   |   8 x  am * {bm, bh}   |   4 x  al * bh
     // (every accumulator is touched once in four MFMAs).  After every MFMA one small piece of other work is issued
     // (sched_barrier pins it there): the fragment reads of a later group, and the split of register set Sn into
-    // buffer CUR ^ 1 as 28 pieces (per half fragment slot: element, element, pack, element, element, pack, 3 x ds_write_b64).
+    // buffer CUR ^ 1 as 20 pieces (per half fragment slot: high plane of pair 0, its middle + low planes, the same for pair 1, 3 x ds_write_b64).
     auto step = [&](auto cur_c, B3Set &Sn) {
         constexpr int CUR = decltype(cur_c)::value;
         bf16x8 ax[2], ay[2], bl[NT], bm[NT], bh[NT];
         ax[0] = frag(CUR, 0, 0, wm * MT); ax[1] = frag(CUR, 0, 0, wm * MT + 1);
         bl[0] = frag(CUR, 2, 1, wn * NT); bl[1] = frag(CUR, 2, 1, wn * NT + 1);
-        unsigned eh[2], em[2], es[2], ph[2], pm[2], pl[2];
+        unsigned ph[2], pm[2], pl[2];
+        float r0 = 0.f, r1 = 0.f;
         pn_static_for<48>([&](auto ss) {
             constexpr int sl = decltype(ss)::value, pr = sl / 24, q = sl % 24;
             constexpr int grp = q < 12 ? 0 : (q < 20 ? 1 : 2), qi = q - (grp == 0 ? 0 : grp == 1 ? 12 : 20);
@@ -1056,19 +1066,16 @@ __global__ __launch_bounds__(512) void k_wgrad_b3(const float *__restrict__ A, c
             else if constexpr (sl == 24 || sl == 25) ax[sl - 24] = frag(CUR, 1, 0, wm * MT + 2 + sl - 24);      // am, pair 1
             else if constexpr (sl == 36 || sl == 37) ay[sl - 36] = frag(CUR, 2, 0, wm * MT + 2 + sl - 36);      // al, pair 1
             else if constexpr (w >= 0) {
-                constexpr int hfi = w / 7, k = w % 7, operand = hfi / 2, hf = hfi % 2;
-                if constexpr (k == 0 || k == 1 || k == 3 || k == 4) {
-                    constexpr int e = (k == 0 ? 0 : k == 1 ? 1 : k == 3 ? 2 : 3), j = 4 * hf + e;
-                    const float x = operand == 0 ? Sn.a[j] : Sn.b[j];
-                    const unsigned h = b3_hi(x);
-                    const float r = x - __uint_as_float(h);
-                    const unsigned m = b3_hi(r);
-                    eh[e & 1] = h; em[e & 1] = m; es[e & 1] = __float_as_uint(r - __uint_as_float(m));
-                } else if constexpr (k == 2 || k == 5) {
-                    constexpr int pp = k == 2 ? 0 : 1;
-                    ph[pp] = __builtin_amdgcn_perm(eh[1], eh[0], 0x07060302u);
-                    pm[pp] = __builtin_amdgcn_perm(em[1], em[0], 0x07060302u);
-                    pl[pp] = __builtin_amdgcn_perm(es[1], es[0], 0x07060302u);
+                constexpr int hfi = w / 5, k = w % 5, operand = hfi / 2, hf = hfi % 2;      // per half slot: A0 B0 A1 B1 W
+                if constexpr (k == 0 || k == 2) {
+                    constexpr int pp = k / 2, j = 4 * hf + 2 * pp;
+                    const float x0 = operand == 0 ? Sn.a[j] : Sn.b[j], x1 = operand == 0 ? Sn.a[j + 1] : Sn.b[j + 1];
+                    ph[pp] = b3_pack(x0, x1);
+                    r0 = x0 - b3_lo(ph[pp]); r1 = x1 - b3_up(ph[pp]);
+                } else if constexpr (k == 1 || k == 3) {
+                    constexpr int pp = k / 2;
+                    pm[pp] = b3_pack(r0, r1);
+                    pl[pp] = b3_pack(r0 - b3_lo(pm[pp]), r1 - b3_up(pm[pp]));
                 } else {
                     uint2 *d = wbase + 2 * ((CUR ^ 1) * B3_STAGE + operand * 512) + hf;
                     d[0] = make_uint2(ph[0], ph[1]); d[2 * B3_PLANE] = make_uint2(pm[0], pm[1]); d[4 * B3_PLANE] = make_uint2(pl[0], pl[1]);
