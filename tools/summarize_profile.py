@@ -5,7 +5,7 @@ src, dst = os.path.join("gpurun_out", tag), "profiles"
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "stats", "run_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
 short = {"k_agg_backward": "agg_backward", "k_agg_forward": "agg_forward", "k_color_forward": "color_forward",
-         "k_color_backward": "color_backward", "k_wgrad_lds": "wgrad", "k_wgrad<": "wgrad", "k_neighbors": "neighbors", "k_probe": "probe"}
+         "k_color_backward": "color_backward", "k_wgrad_lds": "wgrad", "k_wgrad_b3": "wgrad", "k_wgrad<": "wgrad", "k_neighbors": "neighbors", "k_probe": "probe"}
 def agg(path):
     out = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(path)):
@@ -15,7 +15,7 @@ def agg(path):
     return out
 f, w = agg(os.path.join(src, "pmc_fetch", "run_counter_collection.csv")), agg(os.path.join(src, "pmc_write", "run_counter_collection.csv"))
 summary, traffic = {}, {}
-steps = 4   # bench.py --steps 3 --warmup 1
+steps = max(f.get("color_backward", [0, 0])[1], 1)   # one colour-backward launch per step the command ran (timed, warm-up and supplementary steps)
 for k in sorted(set(f) | set(w)):
     fk, wk = f.get(k, [0, 1]), w.get(k, [0, 1])
     # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128 B request of a wide coalesced
