@@ -50,8 +50,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // wave re-reads continuously; non-temporal keeps them from displacing the weights
 typedef float pn_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void pn_store_stream(float *p, const float4 &v) {
+#ifdef PN_PLAIN_STREAM_STORES       // dev: A/B of the store policy (tools/_build only)
+    *reinterpret_cast<float4 *>(p) = v;
+#else
     pn_f4 t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<pn_f4 *>(p));
+#endif
 }
 
 __device__ __forceinline__ float pn_lrelu(float v) { return v > 0.f ? v : 0.01f * v; }

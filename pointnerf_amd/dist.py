@@ -46,8 +46,8 @@ def hot_path_loss(opt, out, gt_image, zero_epsilon=1e-3):
     """The lego script's training loss (models/base_rendering_model.py:543-551 ``ray_masked_coarse_raycolor`` x 1.0
     + 1e-6, and :630-641 ``zero_one`` on ``conf_coefficient`` x opt.zero_one_loss_weights[0]) with both means taken
     over the GLOBAL batch."""
-    mask = out["ray_mask"][0] > 0
-    pred, gt = out["coarse_raycolor"][0], gt_image[0][mask]
+    pred = out["coarse_raycolor"][0]
+    gt = gt_image[0].index_select(0, out["_hit_index"]) if "_hit_index" in out else gt_image[0][out["ray_mask"][0] > 0]
     cc = out.get("conf_coefficient")
     n = global_counts(pred.numel(), cc.numel() if cc is not None else 0, device=pred.device)
     loss = ((pred - gt) ** 2).sum() / n[0].clamp(min=1.0) + 1e-6 / world()

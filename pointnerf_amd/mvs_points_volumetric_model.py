@@ -267,12 +267,13 @@ class MvsPointsVolumetricModel:
         opt, out, W = self.opt, self.output, pdist.world()
         dev = out["coarse_raycolor"].device
         hit = out["ray_mask"][0] > 0
+        hidx = out.get("_hit_index")                      # hit-ray indices from the renderer: indexing without a synchronisation
         self.loss_total = 0
         for i, name in enumerate(opt.color_loss_items):
             if name.startswith("ray_masked"):
                 key = name[len("ray_masked") + 1:]
                 pred = self._raw[key][0] if (self._raw is not None and key == "coarse_raycolor") else out[key][0][hit]
-                gt = self.gt_image[0][hit]
+                gt = self.gt_image[0].index_select(0, hidx) if hidx is not None else self.gt_image[0][hit]
                 n = pdist.global_counts(pred.numel(), device=dev)[0]
                 loss = ((pred - gt) ** 2).sum() / n.clamp(min=1.0)
             elif name.startswith("ray_miss"):

@@ -79,19 +79,26 @@ class NeuralPointsRayMarching(nn.Module):
         ray_color, opacity, bg_trans, blend_w, decoded, weight, dense = self.render_dense(campos, raydir, camrotc2w, near, far, bg_color)
         hit = dense["ray_hit"] > 0
         SR, K = int(opt.SR), int(opt.K)
-        output = {}
-        nn_hit = dense["sample_nn"][hit]
+        # Indices of the hit rays WITHOUT a host round trip: their number is already on the host (the counters the arena was
+        # sized from), so a stable sort of the 0/1 flags yields them in ascending order.  Boolean-mask indexing would
+        # synchronise once per tensor (nonzero), and the device would idle between forward, loss and backward while the
+        # host catches up; with this the whole step is enqueued behind one synchronisation.
+        n_hit = self.last_stats["rays_hit"]
+        idx = torch.argsort(dense["ray_hit"], descending=True, stable=True)[:n_hit]
+        take = lambda t: t.index_select(0, idx)
+        output = {"_hit_index": idx}
+        nn_hit = take(dense["sample_nn"])
         output["queried_shading"] = torch.logical_not(torch.any(nn_hit > 0, dim=-1, keepdim=True)).repeat(1, 3).to(torch.float32)[None]
-        output["coarse_raycolor"] = ray_color[hit][None]
-        output["coarse_point_opacity"] = opacity[hit][None]
-        output["coarse_is_background"] = bg_trans[hit][None, :, None]
+        output["coarse_raycolor"] = take(ray_color)[None]
+        output["coarse_point_opacity"] = take(opacity)[None]
+        output["coarse_is_background"] = take(bg_trans)[None, :, None]
         output["ray_mask"] = hit.to(torch.int8)[None]
         want_w = (opt.sparse_loss_weight > 0) or ("conf_coefficient" in opt.zero_one_loss_items) or getattr(opt, "prob", 0) != 0
         if want_w:
-            output["weight"] = weight[hit][None].detach()
-            output["blend_weight"] = blend_w[hit][None, ..., None].detach()
+            output["weight"] = take(weight)[None].detach()
+            output["blend_weight"] = take(blend_w)[None, ..., None].detach()
             conf = self.neural_points.points_conf
-            pidx_hit = dense["sample_pidx"][hit]
+            pidx_hit = take(dense["sample_pidx"])
             output["conf_coefficient"] = gradient_clamp(ops.gather_rows(conf.reshape(-1, 1), pidx_hit)[..., 0])[None]
         if getattr(opt, "prob", 0) == 1 and output["coarse_point_opacity"].shape[1] > 0:
             self._probe_outputs(output, dense, hit)
@@ -130,7 +137,7 @@ def fill_invalid(output, bg_color, tonemap_func=None, bg_ray=None, prob=0):
     ``unmask``).  ``bg_ray`` [B,R,3] replaces the constant background like :104-106."""
     ray_mask = output["ray_mask"]
     B, OR = ray_mask.shape
-    sel = ray_mask[0] > 0
+    sel = output["_hit_index"] if "_hit_index" in output else ray_mask[0] > 0      # index tensor: no nonzero() synchronisation
     dev = output["coarse_raycolor"].device
     bgt = torch.ones([B, OR, 1], dtype=torch.float32, device=dev)
     bgt[0, sel] = output["coarse_is_background"][0]

@@ -82,6 +82,8 @@ def test_optimize_parameters_matches_the_oracle_loop(tmp_path):
     m.set_input({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in inp.items()})
     out = m.test()
     assert not out["coarse_raycolor"].requires_grad and set(m.get_current_visuals()) == {"gt_image", "coarse_raycolor", "queried_shading"}
+    # the renderer's sync-free hit-ray index (stable sort of the flags, count from the counters) is what nonzero() would give
+    assert torch.equal(out["_hit_index"], torch.nonzero(out["ray_mask"][0] > 0).squeeze(1))
     m.save_networks(3, {"total_steps": 3})
     opt2 = config.lego_train_opt(**CASES["small_k8"][0], gpu_ids=[0], checkpoints_dir=str(tmp_path), num_point=xyz.shape[0], is_train=0,
                                  resume_iter=3, resume_dir=str(tmp_path / "lego"), load_points=1)
