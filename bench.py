@@ -158,6 +158,7 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         loss, st = one_step(inputs[i])
@@ -167,6 +168,7 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    extra_allocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0      # hipMalloc calls inside the timed region
     prof = None
     if not args.no_prof:
         prof = ops.prof_collect()
@@ -204,6 +206,7 @@ def main():
                           "parallelism": "ray-shard dp%d, point cloud + MLP replicated" % world,
                           "valid_samples_per_step": smp, "neighbor_rows_per_step": rows,
                           "rays_hit_per_step": float(np.mean([s["rays_hit"] for s in stats])), "final_loss": float(loss.item()),
+                          "device_allocs_in_timed_region": int(extra_allocs),
                           "arithmetic": "f32 throughout; aggregator forward / input-gradient and colour GEMMs on v_mfma_f32_32x32x2_f32; the four 256x256 "
                                         "weight-gradient GEMMs split both f32 operands exactly into 3 bf16 planes and keep 6 of the 9 bf16-MFMA "
                                         "products with f32 accumulation (dropped terms <= 2^-23 of a product)", **extra}}

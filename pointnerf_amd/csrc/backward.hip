@@ -1186,7 +1186,7 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     float *g = d_grad_params;
     if ((rc = launch_wgrad_b3<PN_IN1P>(sv.dy1, sv.x0, rows, dt, d_partials, g, PO_W1, PN_IN1, s))) return rc;
     // columns 256..283 of W1 (the distance encoding): a 256 x 32 tile on the fp32 MFMA
-    if ((rc = launch_wgrad_lds<4, 1, 2, 1, 16, false>(sv.dy1, PN_H, sv.x0 + 256, PN_IN1P, nullptr, 0, rows, dt, d_partials, 32, PN_IN1 - 256, g, PO_W1 + 256, PN_IN1, s))) return rc;
+    if ((rc = launch_wgrad_lds<1, 1, 8, 1, 64, false>(sv.dy1, PN_H, sv.x0 + 256, PN_IN1P, nullptr, 0, rows, dt, d_partials, 32, PN_IN1 - 256, g, PO_W1 + 256, PN_IN1, s))) return rc;
     if ((rc = launch_wgrad_b3<PN_H>(sv.dy2, sv.h1, rows, dt, d_partials, g, PO_W2, PN_H, s))) return rc;
     if ((rc = launch_wgrad_b3<PN_H>(sv.dy3, sv.h2, rows, dt, d_partials, g, PO_W3, PN_IN3, s))) return rc;
     if ((rc = launch_wgrad_b3<PN_H>(sv.dy4, sv.h3, rows, dt, d_partials, g, PO_W4, PN_H, s))) return rc;

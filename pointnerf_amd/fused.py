@@ -64,6 +64,9 @@ class FusedRender(torch.autograd.Function):
         fwd["saved"] = None
         gm = tuple(gflat[o:o + n].view(shp) for (o, n, shp) in env["layout"])
         assert len(gm) == ctx.n_mlp
+        # the graph node outlives this call for as long as the caller keeps the loss: release the step's big tensors (query
+        # outputs, dense weights, packed points) now, so that the next step's allocations find them in the allocator's cache
+        ctx.env = ctx.fwd = ctx.pts = None
         return (None, grads["points_embeding"], grads["points_conf"], grads["points_dir"], grads["points_color"]) + gm
 
 

@@ -45,6 +45,7 @@ class NeuralPointsRayMarching(nn.Module):
                     or getattr(opt, "which_tonemap_func", "off") != "off":
                 raise NotImplementedError("only radiance / alpha / off (every script's setting) is implemented")
         self.last_stats = None
+        self._pool_rays = 0
 
     def render_dense(self, campos, raydir, camrotc2w, near, far, bg_color=None, train=None):
         """The fused step on all R rays.  Returns (ray_color [R,3], opacity, bg_trans, blend_w, decoded, weight, dense)."""
@@ -53,8 +54,11 @@ class NeuralPointsRayMarching(nn.Module):
         if train and getattr(opt, "xyz_grad", 0) > 0:
             raise NotImplementedError("xyz_grad > 0 (optimising point positions) is not on any reference script's path and the "
                                       "fused backward produces no d/d xyz")
-        dense = npnt.query_dense(dict(campos=campos, raydir=raydir, near=near, far=far))
         R = raydir.reshape(-1, 3).shape[0]
+        if train and self._pool_rays < R:              # worst case (every ray hits): ~16 live [R,SR,K] fp32 tensors around the loss
+            ops.reserve_pool(16 * R * int(opt.SR) * int(opt.K) * 4, raydir.device)
+            self._pool_rays = R
+        dense = npnt.query_dense(dict(campos=campos, raydir=raydir, near=near, far=far))
         counters = dense["counters"].cpu()                    # the one sync: sizes the activation arena
         n_valid = int(counters[0])
         self.last_stats = dict(n_valid_samples=n_valid, rays_hit=int(counters[1]), n_selected=int(counters[2]),

@@ -214,6 +214,17 @@ class Arena:
 ARENA = Arena()
 
 
+def reserve_pool(nbytes, device):
+    """Pre-size torch's caching allocator for the step's variable-size tensors (everything indexed by the number of rays
+    that hit the cloud: compacted weights / indices / confidences, the loss temporaries and their gradients).  Their sizes
+    change with every batch, so without a pool the allocator keeps meeting requests no cached block fits and calls
+    hipMalloc in the middle of training steps (measured: 3 per step, each a device-wide stall, 15 ms per step on a
+    freshly booted box).  One block of the worst-case size, allocated and released once, is split and re-merged by the
+    allocator from then on."""
+    t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    del t
+
+
 def render_forward(cam, pts, packed, flat, raydir, dense, R, SR, K, n_valid, train):
     """pnerf_render_forward.  n_valid = host copy of dense['counters'][0] (capacity of the scratch).
     Returns dict(decoded, weight, ray_color, opacity, bg_trans, blend_w, saved)."""
