@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=12288, help="rays of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--render-only", action="store_true", help="supplementary: inference (render, no backward) rays/s")
+    ap.add_argument("--no-overlap-comm", action="store_true", help="N > 1: all-reduce the point gradients after the whole backward instead of behind the weight-gradient GEMMs")
     ap.add_argument("--zero1", action="store_true", help="N > 1: shard the point-parameter Adam (reduce-scatter + all-gather) instead of all-reducing the gradients")
     return ap.parse_args()
 
@@ -117,6 +118,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from pointnerf_amd import config, ops, dist as pdist
+    from pointnerf_amd.fused import FusedRender
 
     # is_train=1: the reference trains with 30 % segment jitter (point_query.py:81); the in-kernel RNG path is what a
     # training step runs, so it is what is timed (parity runs -- tests/ -- use jitter off, where results are bit-defined)
@@ -144,7 +146,10 @@ def main():
         out = model(**inp)
         loss = loss_fn(opt, out, inp, world)
         loss.backward()
-        pdist.allreduce_grads(mlp_params, [] if zero1 else pt_params)    # no-op at N=1; RCCL over xGMI otherwise
+        # no-op at N=1; RCCL over xGMI otherwise.  The three point tensors only the renderer writes (88 % of the bytes) start
+        # their all-reduce as soon as the input-gradient kernels are done, under the weight-gradient GEMMs
+        early = [] if (zero1 or args.no_overlap_comm) else [npnt.points_embeding, npnt.points_dir, npnt.points_color]
+        pdist.allreduce_grads(mlp_params, [] if zero1 else pt_params, ready_event=FusedRender.point_grads_ready if early else None, early_params=early)
         opt_mlp.step(); opt_pts.step()
         return loss, model.last_stats
 

@@ -136,6 +136,10 @@ typedef struct pnerf_points {        /* the neural point cloud, all [N,*] row-ma
 
 typedef struct pnerf_point_grads {   /* gradient accumulators (added to, never zeroed) */
     float *embedding, *conf, *dir, *color;
+    void *ready_event;               /* optional hipEvent_t (NULL: none): recorded on the call's stream as soon as the four point
+                                      * gradients are complete, i.e. BEFORE the weight-gradient GEMMs of the same call are
+                                      * enqueued -- a data-parallel caller starts the all-reduce of the (large) point
+                                      * gradients on another stream behind this event and overlaps it with those GEMMs */
 } pnerf_point_grads;
 
 /* bytes of saved activations per valid neighbor row / per valid sample (training forward) */

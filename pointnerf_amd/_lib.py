@@ -40,7 +40,7 @@ class Points(ctypes.Structure):
 
 
 class PointGrads(ctypes.Structure):
-    _fields_ = [("embedding", c_void_p), ("conf", c_void_p), ("dir", c_void_p), ("color", c_void_p)]
+    _fields_ = [("embedding", c_void_p), ("conf", c_void_p), ("dir", c_void_p), ("color", c_void_p), ("ready_event", c_void_p)]
 
 
 # symbol -> (restype, argtypes); kept in lock-step with include/pnerf.h (tests/test_boundary.py checks it)

@@ -1177,6 +1177,9 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
           else hipLaunchKernelGGL(k_agg_backward<false>, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
       } }
     PN_CHECK_LAUNCH();
+    // the point gradients are final here: let a data-parallel caller start their all-reduce behind this event while the
+    // weight-gradient GEMMs below still run
+    if (pg->ready_event && hipEventRecord((hipEvent_t)pg->ready_event, s) != hipSuccess) return PNERF_E_LAUNCH;
     // weight gradients over every tile of every class (+ their zero padding tiles): the tile count lives on the device, the host
     // bound is the allocation.  samples: only the first n_valid rows of fs / pe / c1.. exist -- the GEMM masks the rest of the
     // last colour tile (0 * stale bits could be NaN)

@@ -57,10 +57,31 @@ def hot_path_loss(opt, out, gt_image, zero_epsilon=1e-3):
     return loss
 
 
-def allreduce_grads(mlp_params, point_params):
-    """Sum gradients over ranks, in place.  MLP: one flat bucket; points: one collective per tensor."""
+_COMM_STREAMS = {}
+
+
+def allreduce_grads(mlp_params, point_params, ready_event=None, early_params=()):
+    """Sum gradients over ranks, in place.  MLP: one flat bucket; points: one collective per tensor.
+
+    ``ready_event`` / ``early_params`` (device tensors only): the gradients of ``early_params`` are complete once
+    ``ready_event`` has fired (``FusedRender.point_grads_ready``: recorded by the library between the input-gradient kernels
+    and the weight-gradient GEMMs), so their all-reduce is issued on a side stream behind that event and overlaps the ~20 ms
+    of weight-gradient GEMMs instead of following them; the calling stream waits for the side stream before it returns.
+    Only valid for parameters whose ``.grad`` IS the tensor the renderer's backward wrote (``zero_grad(set_to_none=True)`` and no
+    other contribution in the graph: embedding, dir and colour -- not the confidences, which also receive the zero-one loss)."""
     if world() == 1:
         return
+    early = [p for p in early_params if p.grad is not None and p.grad.is_cuda] if ready_event is not None else []
+    comm = None
+    if early:
+        dev = early[0].grad.device
+        comm = _COMM_STREAMS.setdefault(dev, torch.cuda.Stream(device=dev))
+        with torch.cuda.stream(comm):
+            comm.wait_event(ready_event)
+            for p in early:
+                p.grad.record_stream(comm)
+                dist.all_reduce(p.grad)
+        point_params = [p for p in point_params if all(p is not q for q in early)]
     gs = [p.grad for p in mlp_params if p.grad is not None]
     if gs:
         flat = torch.cat([g.reshape(-1) for g in gs])
@@ -71,3 +92,5 @@ def allreduce_grads(mlp_params, point_params):
     for p in point_params:
         if p.grad is not None:
             dist.all_reduce(p.grad)
+    if comm is not None:
+        torch.cuda.current_stream(comm.device).wait_stream(comm)

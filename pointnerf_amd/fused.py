@@ -35,6 +35,8 @@ class FusedRender(torch.autograd.Function):
     vector ``env['flat']`` the kernels read, and are passed only so that autograd (and DDP-style hooks) see them:
     backward returns one gradient per parameter, each a view into a single flat gradient buffer."""
 
+    point_grads_ready = None          # torch.cuda.Event of the latest backward (only when env["want_grad_event"])
+
     @staticmethod
     def forward(ctx, env, emb, conf, pdir, color, *mlp_params):
         # env: dict(cam, xyz, raydir, dense, R, SR, K, n_valid, flat, packed, train, layout)
@@ -57,9 +59,14 @@ class FusedRender(torch.autograd.Function):
         gflat = torch.zeros_like(env["flat"])
         names = ("points_embeding", "points_conf", "points_dir", "points_color")
         grads = {n: torch.zeros(shp, dtype=torch.float32, device=dev) for n, shp in zip(names, ctx.shapes)}
+        ev = None
+        if env.get("want_grad_event"):            # data-parallel training: see pnerf_point_grads.ready_event
+            ev = torch.cuda.Event()
+            ev.record()                           # creates the hipEvent_t; re-recorded by the library between dgrad and wgrad
         if env["n_valid"] > 0:
             ops.render_backward(env["cam"], ctx.pts, env["packed"], env["flat"], env["raydir"], env["dense"], env["R"],
-                                env["SR"], env["K"], env["n_valid"], fwd, g_color, gflat, grads)
+                                env["SR"], env["K"], env["n_valid"], fwd, g_color, gflat, grads, ready_event=ev)
+        FusedRender.point_grads_ready = ev
         ops.ARENA.give(fwd["saved"])  # hand the activation arena back for the next step
         fwd["saved"] = None
         gm = tuple(gflat[o:o + n].view(shp) for (o, n, shp) in env["layout"])

@@ -15,6 +15,7 @@ one sample per ray, so they are small gathers on top of the dense render (``pner
 import torch
 import torch.nn as nn
 
+from . import dist as pdist
 from . import ops
 from .fused import FusedRender
 
@@ -71,7 +72,7 @@ class NeuralPointsRayMarching(nn.Module):
         mlp_params, layout = agg.ordered_params()
         env = dict(cam=cam, xyz=npnt.xyz.detach().reshape(-1, 3).contiguous(), raydir=raydir.detach().reshape(-1, 3).contiguous().float(),
                    dense=dense, R=R, SR=int(opt.SR), K=int(opt.K), n_valid=n_valid, flat=st.flat, packed=st.packed_image(),
-                   train=bool(train), layout=layout)
+                   train=bool(train), layout=layout, want_grad_event=bool(train) and raydir.is_cuda and pdist.world() > 1)
         out = FusedRender.apply(env, npnt.points_embeding, npnt.points_conf, npnt.points_dir, npnt.points_color, *mlp_params)
         return out + (dense,)
 

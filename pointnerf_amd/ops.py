@@ -250,13 +250,15 @@ def render_forward(cam, pts, packed, flat, raydir, dense, R, SR, K, n_valid, tra
                 blend_w=blend_w, saved=saved)
 
 
-def render_backward(cam, pts, packed, flat, raydir, dense, R, SR, K, n_valid, fwd, grad_ray_color, grad_flat, grads):
+def render_backward(cam, pts, packed, flat, raydir, dense, R, SR, K, n_valid, fwd, grad_ray_color, grad_flat, grads, ready_event=None):
     """pnerf_render_backward: accumulates into grad_flat (MLP) and grads = dict(points_embeding=..., points_conf=...,
     points_dir=..., points_color=...) (device tensors, same shapes as the parameters)."""
     lib = L.lib()
     pg = L.PointGrads()
     pg.embedding, pg.conf = grads["points_embeding"].data_ptr(), grads["points_conf"].data_ptr()
     pg.dir, pg.color = grads["points_dir"].data_ptr(), grads["points_color"].data_ptr()
+    if ready_event is not None:          # a torch.cuda.Event that has been recorded once (so that its hipEvent_t exists)
+        pg.ready_event = ready_event.cuda_event
     nws = lib.pnerf_render_backward_workspace_bytes(R, SR)
     ws = torch.empty(nws, dtype=torch.uint8, device=raydir.device)
     g = grad_ray_color.contiguous().float()

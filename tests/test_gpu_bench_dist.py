@@ -46,6 +46,10 @@ def test_bench_two_ranks_on_one_gpu():
     d = _two_ranks([], 0)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert "cpu_baseline" not in d                      # rank 0 at N=1 only
+    # the point-gradient all-reduce issued on a side stream behind the library's "point gradients ready" event (overlapping the
+    # weight-gradient GEMMs; the default) gives the same training trajectory as the all-reduce after the whole backward
+    n = _two_ranks(["--no-overlap-comm"], 3)
+    assert abs(n["config"]["final_loss"] - d["config"]["final_loss"]) <= 1e-6 * max(1.0, abs(d["config"]["final_loss"]))
     # ZeRO-1 sharding of the point-parameter Adam is the same update: the loss after 3 steps agrees to summation order
     z = _two_ranks(["--zero1"], 7)
     assert abs(z["config"]["final_loss"] - d["config"]["final_loss"]) <= 1e-5 * max(1.0, abs(d["config"]["final_loss"]))
