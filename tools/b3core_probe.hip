@@ -123,6 +123,127 @@ __global__ __launch_bounds__(256) void k_core(const uint4 *__restrict__ W, int i
     if (s == 123.456f) out[blockIdx.x * 256 + tid] = s;
 }
 
+
+// MODE 3 ("lean"): the same GEMM with the register budget a production kernel can afford -- 80 registers for the core instead
+// of the ~190 the compiler takes when left alone: only `ah` and `bh` are double-buffered, the m / l planes and bm / bl are
+// reloaded in place as soon as their last MFMA of the chunk has issued.  Term order per 16 columns of K:
+//   [0-3] am*bm  [4-7] ah*bm  [8-11] am*bh  [12-15] al*bh  [16-19] ah*bh  [20-23] ah*bl
+// next chunk: bh' + raw A at slots 0-3, h-stage (ah', residual) 4-11, bm' 8-9, m-stage (am') 12-19, l-stage (al') 16-23, bl' after 23.
+template <int SIDE>
+__global__ __launch_bounds__(256) void k_lean(const uint4 *__restrict__ W, int iters, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 64 * LDH; i += 256) smem[i] = (float)((i * 7 + blockIdx.x) & 15) * 0.001f + 0.5f;
+    __syncthreads();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const float *ap = smem + (lane & 31) * LDH + 8 * (lane >> 5);
+    const uint4 *wp = W + (size_t)wave * 6 * 64 + lane;      // [chunk][wave][ct*3 + plane(0 h, 1 m, 2 l)][lane]
+    float side = (float)lane;
+    uint4 ah[2][2], bh[2][2];        // [generation][mt or ct]
+    uint4 am[2], al[2], bm[2], bl[2];
+    float4 raw[2][2];                // [mt][half]: raw values, then residuals in place
+    auto get = [](const uint4 &v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; };
+    auto put = [](uint4 &v, int q, unsigned x) { if (q == 0) v.x = x; else if (q == 1) v.y = x; else if (q == 2) v.z = x; else v.w = x; };
+    // prologue: chunk 0 completely
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        raw[mt][0] = *reinterpret_cast<const float4 *>(ap + mt * 32 * LDH);
+        raw[mt][1] = *reinterpret_cast<const float4 *>(ap + mt * 32 * LDH + 4);
+        float x[8] = {raw[mt][0].x, raw[mt][0].y, raw[mt][0].z, raw[mt][0].w, raw[mt][1].x, raw[mt][1].y, raw[mt][1].z, raw[mt][1].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned h = pack(x[2 * q], x[2 * q + 1]);
+            const float r0 = x[2 * q] - lo(h), r1 = x[2 * q + 1] - up(h);
+            const unsigned m = pack(r0, r1);
+            put(ah[0][mt], q, h); put(am[mt], q, m); put(al[mt], q, pack(r0 - lo(m), r1 - up(m)));
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) { bh[0][ct] = wp[(ct * 3 + 0) * 64]; bm[ct] = wp[(ct * 3 + 1) * 64]; bl[ct] = wp[(ct * 3 + 2) * 64]; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll 1
+        for (int c2 = 0; c2 < NCH / 2; ++c2) {
+        sfor<2>([&](auto gg) {
+            constexpr int g = decltype(gg)::value, n = g ^ 1;
+            const int c = 2 * c2 + g, cn = (c + 1) % NCH;
+            const uint4 *wn = wp + (size_t)cn * 4 * 6 * 64;
+            const float *an = ap + 16 * cn;
+            sfor<24>([&](auto ss) {
+                constexpr int s = decltype(ss)::value, t = s / 4, mt = s & 1, ct = (s >> 1) & 1;
+                const uint4 av = (t == 0 || t == 2) ? am[mt] : (t == 3 ? al[mt] : ah[g][mt]);
+                const uint4 bv = (t == 0 || t == 1) ? bm[ct] : (t == 5 ? bl[ct] : bh[g][ct]);
+                acc[mt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[mt][ct], 0, 0, 0);
+                // ---- next chunk's operands
+                if constexpr (s < 2) bh[n][s] = wn[(s * 3 + 0) * 64];
+                if constexpr (s < 4) raw[s >> 1][s & 1] = *reinterpret_cast<const float4 *>(an + (s >> 1) * 32 * LDH + 4 * (s & 1));
+                if constexpr (s == 8 || s == 9) bm[s - 8] = wn[((s - 8) * 3 + 1) * 64];
+                if constexpr (s >= 4 && s < 12) {                      // h-stage: pair p of the 8
+                    constexpr int p = s - 4, m2 = p / 4, q = p % 4;
+                    float4 &v = raw[m2][q >> 1];
+                    float &x0 = (q & 1) ? v.z : v.x, &x1 = (q & 1) ? v.w : v.y;
+                    const unsigned h = pack(x0, x1);
+                    put(ah[n][m2], q, h);
+                    x0 -= lo(h); x1 -= up(h);
+                }
+                if constexpr (s >= 12 && s < 20) {                     // m-stage (am is free: its last MFMA was slot 11)
+                    constexpr int p = s - 12, m2 = p / 4, q = p % 4;
+                    float4 &v = raw[m2][q >> 1];
+                    float &x0 = (q & 1) ? v.z : v.x, &x1 = (q & 1) ? v.w : v.y;
+                    const unsigned m = pack(x0, x1);
+                    put(am[m2], q, m);
+                    x0 -= lo(m); x1 -= up(m);
+                }
+                if constexpr (s >= 20) {                               // l-stage, two pairs per slot (al is free since slot 15)
+                    constexpr int p0 = 2 * (s - 20);
+                    sfor<2>([&](auto pp) {
+                        constexpr int p = p0 + decltype(pp)::value, m2 = p / 4, q = p % 4;
+                        const float4 &v = raw[m2][q >> 1];
+                        put(al[m2], q, (q & 1) ? pack(v.z, v.w) : pack(v.x, v.y));
+                    });
+                }
+                if constexpr (SIDE > 0) {
+#pragma unroll
+                    for (int k = 0; k < SIDE; ++k) side = side * 1.0001f + 0.5f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // bl' after its last use (slot 23): needed at slot 20 of the next chunk
+            bl[0] = wn[2 * 64]; bl[1] = wn[5 * 64];
+        });
+        }
+    }
+    float s = side;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[a][b][r];
+    if (s == 123.456f) out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int SIDE>
+void run_lean(const uint4 *W, float *out, int iters, const char *name) {
+    const size_t lds = 64 * LDH * 4;
+    hipFuncSetAttribute((const void *)k_lean<SIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k_lean<SIDE>), dim3(256), dim3(256), lds, 0, W, iters, out);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    const double flop = 2.0 * 64 * 256 * 256 * (double)iters * 256;
+    printf("{\"probe\": \"b3core\", \"variant\": \"%s\", \"ms\": %.3f, \"fp32_equiv_TFLOPs\": %.1f, \"us_per_tile_layer\": %.2f}\n", name, ms, flop / ms * 1e-9, ms * 1e3 / iters);
+}
+
 template <int MODE, int SIDE>
 void run(const uint4 *W, float *out, int iters, const char *name) {
     const size_t lds = 64 * LDH * 4;
@@ -152,5 +273,8 @@ int main() {
     run<2, 2>(W, out, iters, "core + 2 side VALU per MFMA");
     run<2, 4>(W, out, iters, "core + 4 side VALU per MFMA");
     run<2, 8>(W, out, iters, "core + 8 side VALU per MFMA");
+    run_lean<0>(W, out, iters, "lean core (80 registers: ah / bh double-buffered, the rest reloaded in place)");
+    run_lean<2>(W, out, iters, "lean core + 2 side VALU per MFMA");
+    run_lean<4>(W, out, iters, "lean core + 4 side VALU per MFMA");
     return 0;
 }
