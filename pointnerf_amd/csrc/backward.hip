@@ -895,14 +895,24 @@ __global__ __launch_bounds__(WM *WN * 64) void k_wgrad_lds(const float *__restri
 }
 
 // sum the split-K partials: grad[dst + m*ldc + n] += sum_c partial[c][m][n]   (n < Nreal)
-__global__ void k_wgrad_reduce(const float *__restrict__ partial, int chunks, int Mtot, int Ntot, int Nreal, float *__restrict__ grad, int dst, int ldc) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= Mtot * Ntot) return;
-    const int m = e / Ntot, n = e - m * Ntot;
-    if (n >= Nreal) return;
+// 256 threads: wave w sums chunks w, w + 4, ... of 64 consecutive outputs (eight loads in flight per lane), the four partial sums are
+// combined in a fixed order -- deterministic, and 4 x 8 times the bytes in flight of one thread per output
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial, int chunks, int Mtot, int Ntot, int Nreal, float *__restrict__ grad, int dst, int ldc) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const size_t stride = (size_t)Mtot * Ntot;
     float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += partial[(size_t)c * Mtot * Ntot + e];
-    grad[dst + m * ldc + n] += s;
+    if (e < Mtot * Ntot) {
+#pragma unroll 8
+        for (int c = w; c < chunks; c += 4) s += partial[c * stride + e];
+    }
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && e < Mtot * Ntot) {
+        const int m = e / Ntot, n = e - m * Ntot;
+        if (n < Nreal) grad[dst + m * ldc + n] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    }
 }
 
 // Ntot / Nreal: padded / real number of B columns INCLUDING the 32-column tail when Bt != nullptr
@@ -925,7 +935,7 @@ int launch_wgrad_lds(const float *A, int lda, const float *B, int ldb, const flo
     { PnProfScope prof(PNK_WGRAD, s);
     hipLaunchKernelGGL((k_wgrad_lds<MT, NT, WM, WN, KB, TAIL>), dim3(ntiles, chunks), dim3(WM * WN * 64), lds, s, A, lda, B, ldb, Bt, ldbt, rows, d_tiles, (int)rpc, partial, Ntot); }
     PnProfScope prof(PNK_WGRAD_REDUCE, s);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(pn_cdiv((long long)Mtot * Ntot, 256)), dim3(256), 0, s, partial, chunks, Mtot, Ntot, Nreal, grad, dst, ldc);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(pn_cdiv((long long)Mtot * Ntot, 64)), dim3(256), 0, s, partial, chunks, Mtot, Ntot, Nreal, grad, dst, ldc);
     PN_CHECK_LAUNCH();
     return 0;
 }
@@ -1131,7 +1141,7 @@ int launch_wgrad_b3(const float *A, const float *B, long long rows, const int *d
     { PnProfScope prof(PNK_WGRAD, s);
     hipLaunchKernelGGL(k_wgrad_b3<LDB>, dim3(1, chunks), dim3(512), B3_LDS_BYTES, s, A, B, rows, d_tiles, (int)rpc, partial); }
     PnProfScope prof(PNK_WGRAD_REDUCE, s);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(pn_cdiv(256LL * 256, 256)), dim3(256), 0, s, partial, chunks, 256, 256, 256, grad, dst, ldc);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(pn_cdiv(256LL * 256, 64)), dim3(256), 0, s, partial, chunks, 256, 256, 256, grad, dst, ldc);
     PN_CHECK_LAUNCH();
     return 0;
 }
