@@ -83,3 +83,19 @@ def test_ops_refuse_cpu_tensors():
         PointAggregator(config.lego_opt()).flatten_()
     with pytest.raises(NotImplementedError):
         PointAggregator(config.lego_opt(agg_distance_kernel="quadric"))
+
+
+def test_ctypes_structs_mirror_the_header(tmp_path):
+    """The PODs cross the C ABI by pointer: the ctypes mirrors must have the header's sizes and field offsets (plain C, gcc)."""
+    import ctypes
+    from pointnerf_amd import _lib
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pnerf.h"\nint main(void) {\n'
+                   'printf("%zu %zu %zu %zu\\n", sizeof(pnerf_grid_params), sizeof(pnerf_camera), sizeof(pnerf_points), sizeof(pnerf_point_grads));\n'
+                   'printf("%zu %zu %zu\\n", offsetof(pnerf_point_grads, ready_event), offsetof(pnerf_points, n), offsetof(pnerf_camera, has_bg));\n'
+                   'return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes, offs = [list(map(int, l.split())) for l in subprocess.check_output([str(exe)]).decode().splitlines()]
+    assert sizes == [ctypes.sizeof(_lib.GridParams), ctypes.sizeof(_lib.Camera), ctypes.sizeof(_lib.Points), ctypes.sizeof(_lib.PointGrads)]
+    assert offs == [_lib.PointGrads.ready_event.offset, _lib.Points.n.offset, _lib.Camera.has_bg.offset]
