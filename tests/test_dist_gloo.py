@@ -62,3 +62,57 @@ def test_two_rank_ray_shard_equals_single_process():
         assert np.abs(a.grad.numpy() - b).max() <= 1e-5 * max(np.abs(b).max(), 1e-8) + 1e-9
     for a, b in zip(p1, p2):      # point 0 sums thousands of empty-slot terms: order-of-summation noise
         assert np.abs(a.grad.numpy() - b).max() <= 5e-4 * max(np.abs(b).max(), 1e-8) + 1e-9
+
+
+# ---- the model shell's loss items under ray sharding: every item's per-rank value, summed over the ranks, is the single-process value
+def _shell_losses(tmp, raw, gt, bg, sl, hits_before):
+    from pointnerf_amd import config
+    from pointnerf_amd.mvs_points_volumetric_model import create_model
+    from pointnerf_amd.neural_points_volumetric_model import fill_invalid
+    opt = config.lego_train_opt(gpu_ids=[], checkpoints_dir=tmp, name="run", num_point=0, K=4, SR=8)
+    m = create_model(opt)
+    mask = raw["ray_mask"][:, sl]
+    h0, h1 = int(hits_before(sl.start or 0)), int(hits_before(sl.stop if sl.stop is not None else mask.shape[1] + (sl.start or 0)))
+    sub = {k: (v[:, h0:h1] if k != "ray_mask" else mask) for k, v in raw.items()}
+    m.set_input(dict(gt_image=gt[:, sl], bg_color=bg))
+    m._raw, m.output = sub, fill_invalid(sub, bg)
+    m.compute_losses()
+    return {k: float(v) for k, v in m.get_current_losses().items()}
+
+
+def _fake(R=48, hits=29, SR=8, K=4):
+    g = torch.Generator().manual_seed(5)
+    mask = torch.zeros(1, R, dtype=torch.int8)
+    mask[0, torch.randperm(R, generator=g)[:hits]] = 1
+    raw = dict(ray_mask=mask, coarse_raycolor=torch.rand(1, hits, 3, generator=g), coarse_point_opacity=torch.rand(1, hits, SR, generator=g),
+               coarse_is_background=torch.rand(1, hits, 1, generator=g), queried_shading=torch.zeros(1, hits, 3),
+               weight=torch.rand(1, hits, SR, K, generator=g), conf_coefficient=torch.rand(1, hits, SR, K, generator=g))
+    cum = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(mask[0].long(), 0)])
+    return raw, torch.rand(1, R, 3, generator=g), torch.ones(1, 3), (lambda i: cum[i])
+
+
+def _shell_worker(rank, world, port, q, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    raw, gt, bg, hb = _fake()
+    q.put((rank, _shell_losses(tmp, raw, gt, bg, pdist.shard_slice(raw["ray_mask"].shape[1]), hb)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_model_shell_loss_items_are_globally_normalised(tmp_path):
+    raw, gt, bg, hb = _fake()
+    one = _shell_losses(str(tmp_path), raw, gt, bg, slice(0, raw["ray_mask"].shape[1]), hb)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_shell_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k, v in one.items():
+        s = got[0][k] + got[1][k]
+        assert abs(s - v) <= 1e-6 * max(1.0, abs(v)), (k, s, v)
