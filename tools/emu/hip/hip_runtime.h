@@ -1,0 +1,178 @@
+// hip_runtime.h (HOST EMULATION SHIM) -- test infrastructure, never part of the product.
+//
+// Lets the .hip kernel sources of pointnerf_amd/csrc be compiled as plain C++ for x86 and executed on the host, one
+// workgroup at a time, every GPU thread as a fiber (tools/emu/emu_runtime.cpp): __syncthreads, the wave-level
+// exchanges (__shfl*, __ballot) and the MFMA builtins are rendezvous points of the fibers of a workgroup / wave.
+// Purpose: this container has no GPU and a round has 90 GPU-minutes; the emulator runs the REAL kernel code on tiny
+// inputs against the oracle, so index / layout / synchronisation bugs are found on the CPU (tests/test_emu_*.py).
+// The MFMA fragment layouts emulated here are the ones the round-1 kernels were validated with on hardware
+// (32x32x2 f32 and 32x32x16 bf16; the f16 form shares the bf16 layout).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define PN_EMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(8) uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return {x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+static inline int2 make_int2(int x, int y) { return {x, y}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return {x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return {x, y, z, w}; }
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorUnknown = 999 };
+typedef void *hipStream_t;
+typedef void *hipEvent_t;
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+
+namespace emu {
+struct Idx3 { unsigned x, y, z; };
+struct Fiber;
+extern Fiber *g_cur;
+extern Idx3 g_tid, g_bid, g_bdim, g_gdim;
+char *lds();
+void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body);
+void syncthreads();
+int lane_id();
+// every active lane of the wave deposits n (<= 64) bytes; returns the wave's 64 x 64-byte table (valid until the lane's next rendezvous)
+const char *wave_exchange(const void *mine, size_t n);
+unsigned long long wave_active_mask();
+int ncu();
+}  // namespace emu
+
+#define threadIdx (emu::g_tid)
+#define blockIdx (emu::g_bid)
+#define blockDim (emu::g_bdim)
+#define gridDim (emu::g_gdim)
+#define hipLaunchKernelGGL(kern, grid, block, ldsb, stream, ...) emu::launch((grid), (block), (ldsb), [=]() { kern(__VA_ARGS__); })
+
+static inline void __syncthreads() { emu::syncthreads(); }
+
+// ---- host API used by the launch code
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = emu::ncu(); return hipSuccess; }
+static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (void *)1; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+
+// ---- bit casts / integer intrinsics
+static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }
+static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); return f; }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+static inline int __ffs(int v) { return __builtin_ffs(v); }
+static inline unsigned long long wall_clock64() { return 0ull; }
+
+// ---- HIP's global min / max
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
+static inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
+static inline long long min(long long a, long long b) { return a < b ? a : b; }
+static inline long long max(long long a, long long b) { return a > b ? a : b; }
+static inline float min(float a, float b) { return fminf(a, b); }
+static inline float max(float a, float b) { return fmaxf(a, b); }
+
+// ---- atomics (workgroups and fibers run one at a time: plain read-modify-write)
+template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> static inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> static inline T atomicAnd(T *p, T v) { T o = *p; *p = o & v; return o; }
+template <class T> static inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }
+template <class T> static inline T atomicCAS(T *p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
+
+// ---- wave-level data exchange
+template <class T> static inline T emu_lane_value(const char *tab, int l) { T v; memcpy(&v, tab + 64 * l, sizeof(T)); return v; }
+template <class T> static inline T __shfl(T v, int src, int = 64) { const char *t = emu::wave_exchange(&v, sizeof(T)); return emu_lane_value<T>(t, src & 63); }
+template <class T> static inline T __shfl_xor(T v, int m, int = 64) { const int l = emu::lane_id(); const char *t = emu::wave_exchange(&v, sizeof(T)); return emu_lane_value<T>(t, (l ^ m) & 63); }
+template <class T> static inline T __shfl_up(T v, unsigned d, int = 64) { const int l = emu::lane_id(); const char *t = emu::wave_exchange(&v, sizeof(T)); return l >= (int)d ? emu_lane_value<T>(t, l - (int)d) : v; }
+template <class T> static inline T __shfl_down(T v, unsigned d, int = 64) { const int l = emu::lane_id(); const char *t = emu::wave_exchange(&v, sizeof(T)); return l + (int)d < 64 ? emu_lane_value<T>(t, l + (int)d) : v; }
+static inline unsigned long long __ballot(int pred) {
+    const unsigned long long act = emu::wave_active_mask();
+    const int p = pred ? 1 : 0;
+    const char *t = emu::wave_exchange(&p, 4);
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) if (((act >> l) & 1) && emu_lane_value<int>(t, l)) m |= 1ull << l;
+    return m;
+}
+
+// ---- MFMA
+typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 emu_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 emu_f16x8 __attribute__((ext_vector_type(8)));
+// v_mfma_f32_32x32x2_f32: A[i][k] in lane i + 32 k, B[k][j] in lane j + 32 k; D reg r of lane l = element
+// (i = (r & 3) + 8 (r >> 2) + 4 (l >> 5), j = l & 31); numerically a k-ordered fmaf chain.
+static inline emu_f32x16 emu_mfma_32x32x2f32(float a, float b, emu_f32x16 c) {
+    const int l = emu::lane_id();
+    float ab[2] = {a, b};
+    const char *t = emu::wave_exchange(ab, 8);
+    const int j = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            float A[2], B[2];
+            memcpy(A, t + 64 * (i + 32 * k), 8); memcpy(B, t + 64 * (j + 32 * k), 8);
+            acc = fmaf(A[0], B[1], acc);
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+// v_mfma_f32_32x32x16_{bf16,f16}: lane l holds A[i = l & 31][k = 8 (l >> 5) .. + 7] and B[k = 8 (l >> 5) .. + 7][j = l & 31]
+template <class V, class E> static inline emu_f32x16 emu_mfma_32x32x16(V a, V b, emu_f32x16 c) {
+    const int l = emu::lane_id();
+    struct { V a, b; } ab = {a, b};
+    static_assert(sizeof(ab) == 32, "two 16-byte fragments");
+    const char *t = emu::wave_exchange(&ab, 32);
+    const int j = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        double acc = c[r];
+        for (int kh = 0; kh < 2; ++kh) {
+            E A[8], B[8];
+            memcpy(A, t + 64 * (i + 32 * kh), 16); memcpy(B, t + 64 * (j + 32 * kh) + 16, 16);
+            for (int q = 0; q < 8; ++q) acc += (double)(float)A[q] * (double)(float)B[q];
+        }
+        c[r] = (float)acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_32x32x2f32((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma_32x32x16<emu_bf16x8, __bf16>((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_32x32x16<emu_f16x8, _Float16>((a), (b), (c))
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_getreg(x) 0u
+#define __builtin_amdgcn_s_barrier() emu::syncthreads()
