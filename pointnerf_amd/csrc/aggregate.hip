@@ -5,14 +5,15 @@
 // PointAggregator.forward / viewmlp (models/aggregators/point_aggregators.py:727-814, 488-644) and
 // positional_encoding (models/helpers/networks.py:175-190).  The reference runs this as ~60 ATen kernels
 // that move every [Nv,256] activation through HBM between layers and compact/scatter rows by boolean
-// masks; here one persistent workgroup per CU keeps a 64-row tile (TS samples x K neighbor slots) in LDS
-// across the whole chain:
-//   gather (embedding 128 B + xyz/dir/colour/conf) -> X0[64x284] in LDS (sin/cos PE computed in place)
-//   -> 284->256->256 -> (+7) ->256->256 on v_mfma_f32_32x32x2_f32, weights streamed from an L2-resident
-//   fragment-ordered image -> alpha head + K-weighted sums (sigma, f[256]) -> f to HBM
-//   -> colour kernel: 64 samples per tile, 280->128->128->128->3.
-// In training mode the activations needed by the backward pass are written once (coalesced) to HBM.
-#include "mlp_common.h"
+// masks; here a workgroup keeps a 64-row tile (TS samples x K neighbor slots) in LDS across the whole chain:
+//   gather (embedding 128 B + xyz/dir/colour/conf) -> X0[64x288] in LDS (sin/cos PE computed in place)
+//   -> 284->256->256 -> (+7) ->256->256 on the f16 matrix pipe with two-plane operands (f16x3.h: fp32-accurate, 5.3x the
+//   fp32 MFMA rate), weights streamed from an L2-resident fragment-ordered image -> alpha head + K-weighted sums
+//   (sigma, f[256]) -> f to HBM -> colour kernel: 64 samples per tile, 280->128->128->128->3 (fp32 MFMA).
+// Two workgroups (4 waves each) share a CU: while one is in an element-wise phase (feature build, epilogue, K-sums) the
+// other's GEMM has the matrix pipe.  In training mode the operands of the weight-gradient GEMMs are written once, already
+// split into their f16 planes and transposed to the k-major order that kernel streams.
+#include "f16x3.h"
 
 // ------------------------------------------------------------------------------ layout / packing
 extern "C" int pnerf_mlp_layout(int feat_dim, int64_t *offsets) {
@@ -22,12 +23,13 @@ extern "C" int pnerf_mlp_layout(int feat_dim, int64_t *offsets) {
     for (int i = 0; i <= PNERF_MLP_NTENSORS; ++i) offsets[i] = o[i];
     return 0;
 }
-extern "C" size_t pnerf_mlp_packed_bytes(void) { return (size_t)PK_TOTAL * sizeof(float); }
+extern "C" size_t pnerf_mlp_packed_bytes(void) { return (size_t)PKH_END; }
 
 namespace {
 struct PackDesc { int src, ld, trans, Kreal, Nreal, Kpad, N, NT, dst; };
-struct PackTable { PackDesc d[14]; };
+struct PackTable { PackDesc d[7]; };
 
+// fp32 images of the colour MLP (mlp_common.h)
 __global__ __launch_bounds__(256) void k_pack(PackTable t, const float *__restrict__ params, float *__restrict__ packed) {
     const PackDesc d = t.d[blockIdx.y];
     const int total = d.Kpad * d.N;
@@ -43,30 +45,62 @@ __global__ __launch_bounds__(256) void k_pack(PackTable t, const float *__restri
         packed[d.dst + e] = v;
     }
 }
+
+// two-plane f16 images of the four aggregator layers (f16x3.h): forward W[m][k] (trans = 0: m = output unit, k = input column)
+// and dgrad W^T[m][k] (trans = 1: m = input column, k = output unit)
+struct PackHDesc { int src, ld, trans, Mreal, Kreal, NCH, MB, dst; };
+struct PackHTable { PackHDesc d[8]; };
+__global__ __launch_bounds__(256) void k_pack_h(PackHTable t, const float *__restrict__ params, char *__restrict__ packed) {
+    const PackHDesc d = t.d[blockIdx.y];
+    const int total = d.NCH * d.MB * 64;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int lane = e & 63, mb = (e >> 6) % d.MB, c = (e >> 6) / d.MB;
+        const int m = 32 * mb + (lane & 31), k0 = 16 * c + 8 * (lane >> 5);
+        unsigned h[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int k = k0 + 2 * j + i;
+                v[i] = 0.f;
+                if (m < d.Mreal && k < d.Kreal) v[i] = d.trans ? params[d.src + k * d.ld + m] : params[d.src + m * d.ld + k];
+            }
+            pn_split2(v[0], v[1], h[j], lo[j]);
+        }
+        uint4 *o = reinterpret_cast<uint4 *>(packed + d.dst) + ((size_t)(c * d.MB + mb) * 2) * 64 + lane;
+        o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        o[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+}
 }  // namespace
 
 extern "C" int pnerf_mlp_pack(const float *d_params, void *d_packed, void *stream) {
     if (!d_params || !d_packed) return PNERF_E_INVAL;
     PackTable t = {{
         // forward images: B[k][n] = W[n][k]
-        {PO_W1, PN_IN1, 1, PN_IN1, PN_H, PN_IN1P, PN_H, 2, PK_F1},
-        {PO_W2, PN_H, 1, PN_H, PN_H, PN_H, PN_H, 2, PK_F2},
-        {PO_W3, PN_IN3, 1, PN_IN3, PN_H, PN_H + 8, PN_H, 2, PK_F3},
-        {PO_W4, PN_H, 1, PN_H, PN_H, PN_H, PN_H, 2, PK_F4},
         {PO_WC1, PN_INC, 1, PN_INC, PN_HC, PN_INC, PN_HC, 1, PK_C1},
         {PO_WC2, PN_HC, 1, PN_HC, PN_HC, PN_HC, PN_HC, 1, PK_C2},
         {PO_WC3, PN_HC, 1, PN_HC, PN_HC, PN_HC, PN_HC, 1, PK_C3},
         // dgrad images: B[k][n] = W[k][n] (k = output unit, n = input unit, first N inputs only)
-        {PO_W4, PN_H, 0, PN_H, PN_H, PN_H, PN_H, 2, PK_D4},
-        {PO_W3, PN_IN3, 0, PN_H, PN_H, PN_H, PN_H, 2, PK_D3},
-        {PO_W2, PN_H, 0, PN_H, PN_H, PN_H, PN_H, 2, PK_D2},
-        {PO_W1, PN_IN1, 0, PN_H, PN_H, PN_H, PN_H, 2, PK_D1},
         {PO_WC3, PN_HC, 0, PN_HC, PN_HC, PN_HC, PN_HC, 1, PK_DC3},
         {PO_WC2, PN_HC, 0, PN_HC, PN_HC, PN_HC, PN_HC, 1, PK_DC2},
         {PO_WC1, PN_INC, 0, PN_HC, PN_H, PN_HC, PN_H, 2, PK_DC1},
+        {0, 0, 0, 0, 0, 0, 0, 1, 0},
+    }};
+    PackHTable th = {{
+        {PO_W1, PN_IN1, 0, PN_H, PN_IN1, 18, 8, PKH_F1},
+        {PO_W2, PN_H, 0, PN_H, PN_H, 16, 8, PKH_F2},
+        {PO_W3, PN_IN3, 0, PN_H, PN_IN3, 17, 8, PKH_F3},
+        {PO_W4, PN_H, 0, PN_H, PN_H, 16, 8, PKH_F4},
+        {PO_W4, PN_H, 1, PN_H, PN_H, 16, 8, PKH_D4},
+        {PO_W3, PN_IN3, 1, PN_IN3, PN_H, 16, 9, PKH_D3},
+        {PO_W2, PN_H, 1, PN_H, PN_H, 16, 8, PKH_D2},
+        {PO_W1, PN_IN1, 1, 32 * PN_MB_D1, PN_H, 16, PN_MB_D1, PKH_D1},
     }};
     PnProfScope prof(PNK_PACK, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_pack, dim3(64, 14), dim3(256), 0, (hipStream_t)stream, t, d_params, (float *)d_packed);
+    hipLaunchKernelGGL(k_pack, dim3(64, 6), dim3(256), 0, (hipStream_t)stream, t, d_params, (float *)d_packed);
+    hipLaunchKernelGGL(k_pack_h, dim3(40, 8), dim3(256), 0, (hipStream_t)stream, th, d_params, (char *)d_packed);
     PN_CHECK_LAUNCH();
     return 0;
 }
@@ -81,8 +115,9 @@ size_t pn_saved_bytes(long long n_valid, int K, long long *rows_out, long long *
     if (rows_out) *rows_out = rows;
     if (samples_out) *samples_out = samples;
     size_t b = 0;
-    b += pn_align((size_t)rows * PN_IN1P * 4) + 8 * pn_align((size_t)rows * PN_H * 4) + pn_align((size_t)rows * 8 * 4) + pn_align((size_t)rows * 16);
-    b += pn_align((size_t)tiles * 3 * PN_NTHR * 8);
+    b += 2 * pn_align((size_t)rows / 8 * PN_NF1 * 32) + 2 * pn_align((size_t)rows / 8 * PN_H * 32);      // x0k, h2k | h1k, h3k
+    b += 4 * pn_align((size_t)rows / 8 * PN_H * 32) + pn_align((size_t)rows * 32 * 32);                // dy1k..dy4k | h4r
+    b += pn_align((size_t)rows * 4) + pn_align((size_t)rows * 16) + pn_align((size_t)tiles * 3 * PN_NTHR * 8) + pn_align(16);
     b += pn_cls_bytes(samples);
     b += 2 * pn_align((size_t)samples * PN_H * 4) + pn_align((size_t)samples * 32 * 4) + 6 * pn_align((size_t)samples * PN_HC * 4);
     return b;
@@ -92,13 +127,15 @@ PnSaved pn_saved_carve(void *base, long long n_valid, int K) {
     PnSaved s;
     size_t total = pn_saved_bytes(n_valid, K, &s.rows, &s.samples);
     PnCarver cv(base, total);
-    s.x0 = cv.take<float>((size_t)s.rows * PN_IN1P);
-    s.h1 = cv.take<float>((size_t)s.rows * PN_H); s.h2 = cv.take<float>((size_t)s.rows * PN_H);
-    s.h3 = cv.take<float>((size_t)s.rows * PN_H); s.h4 = cv.take<float>((size_t)s.rows * PN_H);
-    s.dy1 = cv.take<float>((size_t)s.rows * PN_H); s.dy2 = cv.take<float>((size_t)s.rows * PN_H);
-    s.dy3 = cv.take<float>((size_t)s.rows * PN_H); s.dy4 = cv.take<float>((size_t)s.rows * PN_H);
-    s.ex = cv.take<float>((size_t)s.rows * 8); s.rmeta = cv.take<int4>((size_t)s.rows);
+    const size_t rg = (size_t)s.rows / 8;
+    s.x0k = cv.take<uint4>(rg * PN_NF1 * 2); s.h2k = cv.take<uint4>(rg * PN_NF1 * 2);
+    s.h1k = cv.take<uint4>(rg * PN_H * 2); s.h3k = cv.take<uint4>(rg * PN_H * 2);
+    s.dy1k = cv.take<uint4>(rg * PN_H * 2); s.dy2k = cv.take<uint4>(rg * PN_H * 2);
+    s.dy3k = cv.take<uint4>(rg * PN_H * 2); s.dy4k = cv.take<uint4>(rg * PN_H * 2);
+    s.h4r = cv.take<uint4>((size_t)s.rows * 32 * 2);
+    s.arow = cv.take<float>((size_t)s.rows); s.rmeta = cv.take<int4>((size_t)s.rows);
     s.lmask = cv.take<unsigned long long>((size_t)(s.rows / PN_TILE) * 3 * PN_NTHR);
+    s.gscale = cv.take<unsigned>(4);
     s.fs = cv.take<float>((size_t)s.samples * PN_H); s.dfs = cv.take<float>((size_t)s.samples * PN_H);
     s.pe = cv.take<float>((size_t)s.samples * 32);
     s.c1 = cv.take<float>((size_t)s.samples * PN_HC); s.c2 = cv.take<float>((size_t)s.samples * PN_HC);
@@ -199,18 +236,19 @@ __global__ void k_cls_gather(ClsArgs c, int which, const int *__restrict__ pos, 
     }
 }
 
-// the padding tile of every class: finite (zero) rows in everything the weight-gradient GEMMs read
+// the padding tile of every class: zero rows in everything the weight-gradient GEMMs read
 __global__ void k_cls_zero_gaps(PnSaved sv, int ncls) {
     const int c = blockIdx.y;
     if (c >= ncls) return;
-    const int n = sv.cls_info[PN_CI_COUNT + c];
-    (void)n;
     const long long gap = (c + 1 < PN_NCLS ? sv.cls_info[PN_CI_TBASE + c + 1] : sv.cls_info[PN_CI_TILES]) - 1;
-    float *arrs[9] = {sv.x0, sv.h1, sv.h2, sv.h3, sv.h4, sv.dy1, sv.dy2, sv.dy3, sv.dy4};
-    const int which = blockIdx.x;                      // 9 arrays
-    const int w = which == 0 ? PN_IN1P : PN_H;
-    float *p = arrs[which] + gap * PN_TILE * w;
-    for (int i = threadIdx.x; i < PN_TILE * w; i += blockDim.x) p[i] = 0.f;
+    uint4 *arrs[8] = {sv.x0k, sv.h2k, sv.h1k, sv.h3k, sv.dy1k, sv.dy2k, sv.dy3k, sv.dy4k};
+    const int which = blockIdx.x;                      // 8 arrays x 2 planes
+    const int nf = which < 2 ? PN_NF1 : PN_H;
+    const long long rg_total = sv.rows / 8;
+    for (int plane = 0; plane < 2; ++plane) {
+        uint4 *p = arrs[which] + ((long long)plane * rg_total + gap * 8) * nf;
+        for (int i = threadIdx.x; i < 8 * nf; i += blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
 }
 }  // namespace
 
@@ -239,481 +277,313 @@ int pn_classify(const PnSaved &sv, const int32_t *d_valid_list, const int32_t *d
         if (rc) return rc;
         hipLaunchKernelGGL(k_cls_gather, dim3(256), dim3(256), 0, s, c, j, pos, cnt, sv.cls_list, sv.cls_info);
     }
-    if (train) hipLaunchKernelGGL(k_cls_zero_gaps, dim3(9, c.ncls), dim3(256), 0, s, sv, c.ncls);
+    if (train) hipLaunchKernelGGL(k_cls_zero_gaps, dim3(8, c.ncls), dim3(256), 0, s, sv, c.ncls);
     PN_CHECK_LAUNCH();
     return 0;
 }
 
+
 namespace {
 
-// ------------------------------------------------------------------------------ two-tile forward
-// Same organisation as the backward (backward.hip): one workgroup (4 waves, one per SIMD) per CU, two tiles A / B in flight,
-// their layer GEMMs alternating  G1(A) G1(B) G2(A) G2(B) G3(A) G3(B) G4(A) G4(B).  Everything element-wise is issued by the
-// GEMM waves themselves in the shadow of their own MFMAs (pn_tile_gemm_side): the other tile's epilogue (bias, LeakyReLU,
-// sign bits, accumulators -> LDS), the copy-out of the own tile's previous layer (training) and, in G1(A) / G4(B), the whole
-// boundary of the partner buffer: last epilogue, alpha head, K-weighted sums of the finished tile; gather, positional
-// encodings and weights of the tile that replaces it.  All rows of the tile use stride LDX, so that layer 3's input
-// [h2 | colour, dir - view, dir . view] is one row (264 columns) and every layer is a single GEMM call.
-constexpr int F2_TILE_FLOATS = PN_TILE * LDX + PN_TILE * 8 + 4 * PN_TILE;
-constexpr int F2_LDS_FLOATS = 2 * F2_TILE_FLOATS + PN_H;
-static_assert(F2_LDS_FLOATS * 4 <= 160 * 1024, "two forward tiles must fit the 160 KB LDS");
+// ------------------------------------------------------------------------------ aggregator forward
+// LDS of a workgroup (80 896 bytes: two workgroups per CU):
+//   X     [2][64][PN_XRS]   the activation tile, two f16 planes (f16x3.h): X0 -> h1 -> [h2 | extras] -> h3 -> h4
+//   exb   [64][8] f32       layer-3 extras of the tile's rows until they move next to h2
+//   w5s   [256] f32         alpha head weights
+//   rowf  wraw, wrow, wnrm [64] f32, sidx [64] int
+constexpr int FL_EX = PN_XBYTES, FL_W5 = FL_EX + PN_TILE * 8 * 4, FL_ROW = FL_W5 + PN_H * 4, FL_BYTES = FL_ROW + 4 * PN_TILE * 4;
+static_assert(2 * FL_BYTES <= 160 * 1024, "two forward workgroups must fit the 160 KB LDS");
 
-struct F2Tile {            // LDS of one in-flight tile
-    float *buf;            // [64][LDX]  X0 -> h1 -> h2 (+ extras in columns 256..263) -> h3 -> h4
-    float *exb;            // [64][8]    layer-3 extras until they move into buf
-    float *wraw, *wrow, *wnrm;
-    int *sidx;             // [64] sample id of each ROW (or -1)
-};
-struct F2State {           // registers of one buffer: indices of the tile being loaded next and of the one after it
-    int si1, p1;           // sample / point id of this thread's row in the next tile (ready)
-    int si2;               // sample id of this thread's row in the tile after that (ready)
-    int p2, si3;           // requested during the current boundary
-    int tile;              // tile whose activations live in the buffer
-    int t1, t2, t3;        // tile indices behind si1, si2, si3
-};
-struct F2Bnd {             // registers of one hosted boundary program
-    float4 e0, e1;                 // the thread's 8 embedding dims
-    float px, py, pz, lx, ly, lz;  // point / sample position
+struct FGather {               // what a thread holds of one tile row (4 threads per row, q = thread in row)
+    float4 e0, e1;             // its 8 embedding dims
+    float px, py, pz, lx, ly, lz, cf;
     float ppx, ppy, ppz, lpx, lpy, lpz;   // optional caller-supplied perspective coordinates
-    float cf, dxv, dyv, dzv, cx, cy, cz, rx, ry, rz;
-    float da, db;                  // distance components q and q + 4 of this thread (PE5 input)
-    float s, wn, w;
-    float4 hv, wv, f, cpv;
-    int pcur, sicur, m, k;
-#ifdef PN_PHASE_TRACE
-    int titer, trbase;
-#endif
+    float dxv, dyv, dzv, cx, cy, cz, rx, ry, rz;   // q == 0 only
 };
-
-__device__ __forceinline__ F2Tile f2_carve(float *base) {
-    F2Tile t;
-    t.buf = base; t.exb = t.buf + PN_TILE * LDX;
-    t.wraw = t.exb + PN_TILE * 8; t.wrow = t.wraw + PN_TILE; t.wnrm = t.wrow + PN_TILE;
-    t.sidx = reinterpret_cast<int *>(t.wnrm + PN_TILE);
-    return t;
-}
 
 // sample id of row `row` of tile `tile` (or -1)
-__device__ __forceinline__ int f2_sample_of(const FwdArgs &a, int tile, int row, int Ns) {
+__device__ __forceinline__ int f_sample_of(const FwdArgs &a, long long tile, int row, int Ns) {
     const int ls = row / a.K;
-    const long long vs = (long long)tile * a.TS + ls;
+    const long long vs = tile * a.TS + ls;
     return (ls < a.TS && vs < Ns) ? a.valid_list[vs] : -1;
 }
 
-// requests of the boundary program: the point data of the next tile (indices are already in registers) and the indices of the two after it
 template <bool PERS>
-__device__ __forceinline__ void f2_request(const FwdArgs &a, F2State &S, F2Bnd &C, int tl, int Ns, int stride) {
-    const int row = tl / TPR, q = tl % TPR, k = row % a.K;
-    const int p = S.p1 > 0 ? S.p1 : 0, si = S.si1 > 0 ? S.si1 : 0;     // empty slots / rows read point 0 / sample 0 like the reference (neural_points.py:709); their weight is 0
-    C.pcur = S.p1; C.sicur = S.si1;
+__device__ __forceinline__ void f_gather(const FwdArgs &a, FGather &G, int si_, int p_, int q) {
+    const int p = p_ > 0 ? p_ : 0, si = si_ > 0 ? si_ : 0;     // empty slots / rows read point 0 / sample 0 like the reference (neural_points.py:709); their weight is 0
     const float *ep = a.emb + (long long)p * PN_F + EPT * q;
-    C.e0 = *reinterpret_cast<const float4 *>(ep); C.e1 = *reinterpret_cast<const float4 *>(ep + 4);
-    C.px = a.xyz[3 * p]; C.py = a.xyz[3 * p + 1]; C.pz = a.xyz[3 * p + 2];
-    C.lx = a.sample_loc[(long long)si * 3]; C.ly = a.sample_loc[(long long)si * 3 + 1]; C.lz = a.sample_loc[(long long)si * 3 + 2];
+    G.e0 = *reinterpret_cast<const float4 *>(ep); G.e1 = *reinterpret_cast<const float4 *>(ep + 4);
+    G.px = a.xyz[3 * p]; G.py = a.xyz[3 * p + 1]; G.pz = a.xyz[3 * p + 2];
+    G.lx = a.sample_loc[(long long)si * 3]; G.ly = a.sample_loc[(long long)si * 3 + 1]; G.lz = a.sample_loc[(long long)si * 3 + 2];
     if (PERS) {
-        C.ppx = a.xyz_pers[3 * p]; C.ppy = a.xyz_pers[3 * p + 1]; C.ppz = a.xyz_pers[3 * p + 2];
-        C.lpx = a.loc_pers[(long long)si * 3]; C.lpy = a.loc_pers[(long long)si * 3 + 1]; C.lpz = a.loc_pers[(long long)si * 3 + 2];
+        G.ppx = a.xyz_pers[3 * p]; G.ppy = a.xyz_pers[3 * p + 1]; G.ppz = a.xyz_pers[3 * p + 2];
+        G.lpx = a.loc_pers[(long long)si * 3]; G.lpy = a.loc_pers[(long long)si * 3 + 1]; G.lpz = a.loc_pers[(long long)si * 3 + 2];
     }
-    C.cf = a.conf[p];
+    G.cf = a.conf[p];
     if (q == 0) {
         const int r = si / a.SR;
-        C.dxv = a.dir[3 * p]; C.dyv = a.dir[3 * p + 1]; C.dzv = a.dir[3 * p + 2];
-        C.cx = a.color[3 * p]; C.cy = a.color[3 * p + 1]; C.cz = a.color[3 * p + 2];
-        C.rx = a.raydir[3 * r]; C.ry = a.raydir[3 * r + 1]; C.rz = a.raydir[3 * r + 2];
+        G.dxv = a.dir[3 * p]; G.dyv = a.dir[3 * p + 1]; G.dzv = a.dir[3 * p + 2];
+        G.cx = a.color[3 * p]; G.cy = a.color[3 * p + 1]; G.cz = a.color[3 * p + 2];
+        G.rx = a.raydir[3 * r]; G.ry = a.raydir[3 * r + 1]; G.rz = a.raydir[3 * r + 2];
     }
-    S.p2 = S.si2 >= 0 ? a.pidx[(long long)S.si2 * a.Kstride + k] : -1;
-    S.t3 = S.t2 + stride;
-    S.si3 = f2_sample_of(a, S.t3, row, Ns);
 }
 
-// geometry of the row: 6 distance components, raw weight, layer-3 extras (point_aggregators.py:773-784, :425-428, :506, :566)
+// X0 row of the tile: [e(32) | PE3(e) (192) | PE5(dists) (60) | 1 | 0 0 0], the row's raw weight and layer-3 extras
+// (point_aggregators.py:773-784, :425-428, :506, :566; networks.py:175-190)
 template <bool PERS>
-__device__ __forceinline__ void f2_geometry(const FwdArgs &a, const F2Tile &T, F2Bnd &C, int tl) {
-    const int row = tl / TPR, q = tl % TPR;
-    const float dwx = C.px - C.lx, dwy = C.py - C.ly, dwz = C.pz - C.lz;
+__device__ __forceinline__ void f_build(const FwdArgs &a, const FGather &G, char *X, float *exb, float *wraw, int *sidx, int si, int p, int row, int q) {
+    const float dwx = G.px - G.lx, dwy = G.py - G.ly, dwz = G.pz - G.lz;
     float ppx, ppy, pcz, spx, spy, scz;
     if (PERS) {
-        ppx = C.ppx; ppy = C.ppy; pcz = C.ppz; spx = C.lpx; spy = C.lpy; scz = C.lpz;
+        ppx = G.ppx; ppy = G.ppy; pcz = G.ppz; spx = G.lpx; spy = G.lpy; scz = G.lpz;
     } else {
         float pcx, pcy, scx, scy;
-        rot3(a.cam.camrot, C.px - a.cam.campos[0], C.py - a.cam.campos[1], C.pz - a.cam.campos[2], false, pcx, pcy, pcz);
-        rot3(a.cam.camrot, C.lx - a.cam.campos[0], C.ly - a.cam.campos[1], C.lz - a.cam.campos[2], false, scx, scy, scz);
+        rot3(a.cam.camrot, G.px - a.cam.campos[0], G.py - a.cam.campos[1], G.pz - a.cam.campos[2], false, pcx, pcy, pcz);
+        rot3(a.cam.camrot, G.lx - a.cam.campos[0], G.ly - a.cam.campos[1], G.lz - a.cam.campos[2], false, scx, scy, scz);
         ppx = pcx / pcz; ppy = pcy / pcz; spx = scx / scz; spy = scy / scz;
     }
     float d0, d1, d2;
     rot3(a.cam.rw2c, dwx, dwy, dwz, true, d0, d1, d2);
     const float d3 = ppx * pcz - spx * scz, d4 = ppy * pcz - spy * scz, d5 = pcz - scz;
-    C.da = q == 0 ? d0 : q == 1 ? d1 : q == 2 ? d2 : d3;      // (selects of values, not of struct members: a select of addresses would pin the struct in scratch)
-    C.db = q == 0 ? d4 : d5;
-    if (q == 0) {
-        float vx, vy, vz, qx, qy, qz;
-        rot3(a.cam.rw2c, C.rx, C.ry, C.rz, true, vx, vy, vz);
-        rot3(a.cam.rw2c, C.dxv, C.dyv, C.dzv, true, qx, qy, qz);
-        float *ex = T.exb + row * 8;
-        *reinterpret_cast<float4 *>(ex) = make_float4(C.cx, C.cy, C.cz, qx - vx);
-        *reinterpret_cast<float4 *>(ex + 4) = make_float4(qy - vy, qz - vz, qx * vx + qy * vy + qz * vz, 0.f);
-        T.wraw[row] = C.pcur >= 0 ? 1.0f / fmaxf(sqrtf(dwx * dwx + dwy * dwy + dwz * dwz), 1e-6f) : 0.f;
-        T.sidx[row] = C.sicur;
-    }
-}
-
-// [e | PE3(e)] of embedding dim i of this thread (one accurate sincosf, exact double-angle steps for the octaves)
-template <int I>
-__device__ __forceinline__ void f2_pe_emb(const F2Tile &T, const F2Bnd &C, int tl) {
-    const int row = tl / TPR, q = tl % TPR, dd = EPT * q + I;
-    const float e = I == 0 ? C.e0.x : I == 1 ? C.e0.y : I == 2 ? C.e0.z : I == 3 ? C.e0.w : I == 4 ? C.e1.x : I == 5 ? C.e1.y : I == 6 ? C.e1.z : C.e1.w;
-    float *xa = T.buf + row * LDX;
-    float s, c;
-    sincosf(e, &s, &c);
+    const float da = q == 0 ? d0 : q == 1 ? d1 : q == 2 ? d2 : d3;
+    const float db = q == 0 ? d4 : d5;
+    // the thread's 8 embedding dims and their 3 octaves (one sin / cos pair, exact double-angle steps for the octaves)
+    const float e[8] = {G.e0.x, G.e0.y, G.e0.z, G.e0.w, G.e1.x, G.e1.y, G.e1.z, G.e1.w};
+    pn_x_store4<false>(X, row, EPT * q, e[0], e[1], e[2], e[3]);
+    pn_x_store4<false>(X, row, EPT * q + 4, e[4], e[5], e[6], e[7]);
 #pragma unroll
-    for (int f = 0; f < 3; ++f) {
-        *reinterpret_cast<float2 *>(xa + PN_F + (dd * 3 + f) * 2) = make_float2(s, c);
-        const float s2 = 2.f * s * c;
-        c = 1.f - 2.f * s * s; s = s2;
-    }
-}
-
-// PE5 of distance component q + 4*J of this row (thread q takes components q and q + 4)
-template <int J>
-__device__ __forceinline__ void f2_pe_dist(const F2Tile &T, const F2Bnd &C, int tl) {
-    const int row = tl / TPR, q = tl % TPR, comp = q + 4 * J;
-    if (comp < 6) {
-        float *xa = T.buf + row * LDX;
+    for (int i = 0; i < 8; ++i) {
+        const int dd = EPT * q + i;
         float s, c;
-        sincosf(J == 0 ? C.da : C.db, &s, &c);
+        pn_sincos(e[i], s, c);
+        float v[6];
 #pragma unroll
-        for (int f = 0; f < 5; ++f) {
-            *reinterpret_cast<float2 *>(xa + PN_F * 7 + (comp * 5 + f) * 2) = make_float2(s, c);
+        for (int f = 0; f < 3; ++f) {
+            v[2 * f] = s; v[2 * f + 1] = c;
             const float s2 = 2.f * s * c;
             c = 1.f - 2.f * s * s; s = s2;
         }
+        pn_x_store2(X, row, PN_F + dd * 6, v[0], v[1]);
+        pn_x_store2(X, row, PN_F + dd * 6 + 2, v[2], v[3]);
+        pn_x_store2(X, row, PN_F + dd * 6 + 4, v[4], v[5]);
     }
-}
-
-// weights of the row (q == 0 threads): normalise over the K slots, multiply by the clamped confidence (:801-811)
-template <bool TRAIN>
-__device__ __forceinline__ void f2_weights(const FwdArgs &a, const F2Tile &T, const F2Bnd &C, int tile, int tl) {
-    const int row = tl / TPR, q = tl % TPR;
+    // PE5 of distance components q and q + 4
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int comp = q + 4 * j;
+        if (comp < 6) {
+            float s, c;
+            pn_sincos(j == 0 ? da : db, s, c);
+#pragma unroll
+            for (int f = 0; f < 5; ++f) {
+                pn_x_store2(X, row, PN_F * 7 + (comp * 5 + f) * 2, s, c);
+                const float s2 = 2.f * s * c;
+                c = 1.f - 2.f * s * s; s = s2;
+            }
+        }
+    }
+    if (q == 3) pn_x_store4<false>(X, row, PN_ONES1, 1.f, 0.f, 0.f, 0.f);
     if (q == 0) {
-        const int ls = row / a.K, k = row - ls * a.K;
-        float wn = 0.f, w = 0.f;
-        if (C.sicur >= 0) {
-            float sum = 0.f;
-            for (int kk = 0; kk < a.K; ++kk) sum += T.wraw[ls * a.K + kk];
-            wn = T.wraw[row] / fmaxf(sum, 1e-8f);
-            w = wn * fminf(fmaxf(C.cf, 1e-4f), 1.0f);
-            a.weight[(long long)C.sicur * a.Kstride + k] = wn;
-        }
-        T.wnrm[row] = wn; T.wrow[row] = w;
-        if (TRAIN) a.sv.rmeta[(long long)tile * PN_TILE + row] = make_int4(C.sicur, C.sicur >= 0 ? C.pcur : -1, __float_as_int(wn), __float_as_int(w));
+        float vx, vy, vz, qx, qy, qz;
+        rot3(a.cam.rw2c, G.rx, G.ry, G.rz, true, vx, vy, vz);
+        rot3(a.cam.rw2c, G.dxv, G.dyv, G.dzv, true, qx, qy, qz);
+        float *ex = exb + row * 8;
+        *reinterpret_cast<float4 *>(ex) = make_float4(G.cx, G.cy, G.cz, qx - vx);
+        *reinterpret_cast<float4 *>(ex + 4) = make_float4(qy - vy, qz - vz, qx * vx + qy * vy + qz * vz, 1.f);
+        wraw[row] = p >= 0 ? 1.0f / fmaxf(sqrtf(dwx * dwx + dwy * dwy + dwz * dwz), 1e-6f) : 0.f;
+        sidx[row] = si;
     }
 }
 
-// epilogue piece R of a layer: bias + LeakyReLU + sign bit of accumulator element R -> LDS (accumulator layout)
-template <int R, bool BITS>
-__device__ __forceinline__ void f2_epi_piece(const f32x16 (&acc)[2][2], const float (&bias)[2], float *wy, unsigned &mlo, unsigned &mhi) {
-    constexpr int mt = R >> 5, ct = (R >> 4) & 1, reg = R & 15;
-    const float v = acc[mt][ct][reg] + bias[ct];
-    if (BITS) {
-        if (R < 32) { mlo |= (v > 0.f ? 1u : 0u) << (R & 31); asm volatile("" : "+v"(mlo)); }
-        else { mhi |= (v > 0.f ? 1u : 0u) << (R & 31); asm volatile("" : "+v"(mhi)); }
-    }
-    wy[(mt * 32 + (reg & 3) + 8 * (reg >> 2)) * LDX + ct * 32] = fmaxf(v, 0.01f * v);
+// epilogue of a layer: accumulators + bias, LeakyReLU, sign bits, both planes -> the tile (columns 0..255)
+template <bool BITS>
+__device__ __forceinline__ void f_epilogue(const f32x16 (&acc)[2][2], const float *__restrict__ bias, char *X, int wave, int lane, unsigned long long &mask) {
+    mask = 0ull;
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = pn_d_feat(2 * wave + fb, g, lane);
+            const float4 b = *reinterpret_cast<const float4 *>(bias + f0);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                float v[4] = {acc[fb][rb][4 * g] + b.x, acc[fb][rb][4 * g + 1] + b.y, acc[fb][rb][4 * g + 2] + b.z, acc[fb][rb][4 * g + 3] + b.w};
+                if (BITS) {
+                    unsigned long long bits = 0ull;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bits |= (unsigned long long)(v[i] > 0.f ? 1u : 0u) << i;
+                    mask |= bits << (((fb * 2 + rb) * 4 + g) * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.01f * v[i]);
+                pn_x_store4<false>(X, 32 * rb + (lane & 31), f0, v[0], v[1], v[2], v[3]);
+            }
+        }
 }
 
-#ifdef PN_PHASE_TRACE
-PN_TR_DECL(pn_trace_fwd);
-#endif
-// ---- the boundary program of one buffer, slot by slot (see backward.hip for the rules: no value is consumed in the slot that
-// requested it, pieces stay under ~a dozen instructions, one burst of requests).  Slot map:
-//   0..2    requests for the next tile        4..67  E4: accumulator element s-4 (+ bias, LeakyReLU) -> LDS      68: barrier
-//   70..133 alpha head of the finished tile (column group j: read 70+4j, use 72+4j)   136, 138: reduce, softplus   142: barrier
-//   144..190 K-weighted sums (<= 24 (item, term) pieces, item-major, stores inline), h4 copy-out (training) interleaved; 214 sigma   216: barrier
-//   218..   next tile: geometry (218..221), embedding PE (224 + 6 i), distance PE (272, 280), pad (288)           296: barrier
-//   298     weights;  374: index shift          (X0 / extras go to HBM during the tile's own first GEMM, like every other layer's input)
-template <int SLOT, bool TRAIN, bool PERS>
-__device__ __forceinline__ void f2_boundary_slot(const FwdArgs &a, const F2Tile &T, F2State &S, const f32x16 (&acc)[2][2], const float (&bias4)[2],
-                                                 float *wy, F2Bnd &C, const float *w5s, float b5, int tl, int Ns, int stride) {
-    const int rrow = tl / TPR, rq = tl % TPR;
-    const int K = a.K, TS = a.TS;
-    if constexpr (SLOT == 0) f2_request<PERS>(a, S, C, tl, Ns, stride);
-    if constexpr (SLOT >= 4 && SLOT < 68) {
-        unsigned d0 = 0u, d1 = 0u;
-        f2_epi_piece<SLOT - 4, false>(acc, bias4, wy, d0, d1);
-    }
-    if constexpr (SLOT == 68 || SLOT == 142 || SLOT == 216 || SLOT == 296) __syncthreads();
-#ifdef PN_PHASE_TRACE
-    if constexpr (SLOT == 1 || SLOT == 3 || SLOT == 67 || SLOT == 141 || SLOT == 215 || SLOT == 223 || SLOT == 271 || SLOT == 295 || SLOT == 299 || SLOT == 375) {
-        constexpr int k = SLOT == 1 ? 0 : SLOT == 3 ? 1 : SLOT == 67 ? 2 : SLOT == 141 ? 3 : SLOT == 215 ? 4 : SLOT == 223 ? 5 : SLOT == 271 ? 6 : SLOT == 295 ? 7 : SLOT == 299 ? 8 : 9;
-        const int tid = threadIdx.x, titer = C.titer;
-        if (C.trbase >= 0) PN_TR(pn_trace_fwd, C.trbase + k);
-    }
-#endif
-    // ---- alpha head of the finished tile (256 -> 1, softplus(x - 1), raw2out_density :262-265)
-    if constexpr (SLOT == 69) C.s = 0.f;
-    if constexpr (SLOT >= 70 && SLOT < 134 && (SLOT - 70) % 4 == 0) {
-        constexpr int j = (SLOT - 70) / 4;
-        C.hv = *reinterpret_cast<const float4 *>(T.buf + rrow * LDX + rq * 4 + 16 * j);
-        C.wv = *reinterpret_cast<const float4 *>(w5s + rq * 4 + 16 * j);
-    }
-    if constexpr (SLOT >= 70 && SLOT < 136 && (SLOT - 70) % 4 == 2) {
-        C.s += C.hv.x * C.wv.x + C.hv.y * C.wv.y + C.hv.z * C.wv.z + C.hv.w * C.wv.w;
-        asm volatile("" : "+v"(C.s));
-    }
-    if constexpr (SLOT == 136) C.s = group_sum<TPR>(C.s);
-    if constexpr (SLOT == 138) {
-        if (rq == 0) {
-            const float x = C.s + b5 - 1.0f;
-            const float alpha = x > 20.f ? x : log1pf(expf(x));
-            T.wraw[rrow] = alpha * T.wrow[rrow];
-        }
-    }
-    // ---- K-weighted sums of the finished tile -> f[256] per sample (HBM), sigma; h4 copy-out
-    // (items of 64 float4 columns x TS samples are dealt to the 256 threads; item m of a thread is sample (tl >> 6) + 4 m.  For every K
-    //  there are at most 24 (item, term) pieces per thread: they run in item-major order through one accumulator.)
-    if constexpr (SLOT == 143) { C.f = make_float4(0.f, 0.f, 0.f, 0.f); C.m = 0; C.k = 0; }
-    if constexpr (SLOT >= 144 && SLOT < 192 && (SLOT - 144) % 2 == 0) {
-        const int ls = (tl >> 6) + 4 * C.m, c4 = tl & 63;
-        if (ls < TS) {
-            const float w = T.wrow[ls * K + C.k];
-            const float4 v = *reinterpret_cast<const float4 *>(T.buf + (ls * K + C.k) * LDX + c4 * 4);
-            C.f.x += w * v.x; C.f.y += w * v.y; C.f.z += w * v.z; C.f.w += w * v.w;
-            if (C.k == K - 1) {
-                const long long vs = (long long)S.tile * TS + ls;
-                if (vs < a.cap_samples) *reinterpret_cast<float4 *>(a.sv.fs + vs * PN_H + c4 * 4) = C.f;
-                C.f = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-        C.k += 1;
-        if (C.k == K) { C.k = 0; C.m += 1; }
-        asm volatile("" : "+v"(C.f.x), "+v"(C.f.y), "+v"(C.f.z), "+v"(C.f.w));
-    }
-    if constexpr (TRAIN && SLOT >= 145 && SLOT < 209 && (SLOT - 145) % 4 == 0) {
-        constexpr int i = (SLOT - 145) / 4;
-        C.cpv = *reinterpret_cast<const float4 *>(T.buf + ((tl >> 6) + 4 * i) * LDX + (tl & 63) * 4);
-    }
-    if constexpr (TRAIN && SLOT >= 145 && SLOT < 209 && (SLOT - 145) % 4 == 2) {
-        constexpr int i = (SLOT - 145) / 4;
-        pn_store_stream(a.sv.h4 + ((long long)S.tile * PN_TILE + (tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4, C.cpv);
-    }
-    if constexpr (SLOT == 214) {
-        if (tl < TS) {
-            const int si = T.sidx[tl * K];
-            if (si >= 0) {
-                float sg = 0.f;
-                for (int k = 0; k < K; ++k) sg += T.wraw[tl * K + k];
-                a.decoded[(long long)si * 4] = sg;
-            }
-        }
-    }
-    // ---- the next tile takes over the buffer
-    if constexpr (SLOT == 218) {
-        const int ntiles = (Ns + TS - 1) / TS;
-        S.tile = S.t1 < ntiles ? S.t1 : ntiles;              // a tile past the end lives on the padding tile's storage (all rows empty)
-        f2_geometry<PERS>(a, T, C, tl);
-        float *xa = T.buf + rrow * LDX;
-        *reinterpret_cast<float4 *>(xa + EPT * rq) = C.e0; *reinterpret_cast<float4 *>(xa + EPT * rq + 4) = C.e1;
-    }
-    if constexpr (SLOT >= 224 && SLOT < 272 && (SLOT - 224) % 6 == 0) f2_pe_emb<(SLOT - 224) / 6>(T, C, tl);
-    if constexpr (SLOT == 272) f2_pe_dist<0>(T, C, tl);
-    if constexpr (SLOT == 280) f2_pe_dist<1>(T, C, tl);
-    if constexpr (SLOT == 288) {
-        if (rq == TPR - 1) {
-            float *xa = T.buf + rrow * LDX;
-            *reinterpret_cast<float4 *>(xa + PN_IN1) = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(xa + PN_IN1 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    if constexpr (SLOT == 298) f2_weights<TRAIN>(a, T, C, S.tile, tl);
-    if constexpr (SLOT == 374) {
-        S.si1 = S.si2; S.p1 = S.p2; S.t1 = S.t2; S.si2 = S.si3; S.t2 = S.t3;
-    }
+__device__ __forceinline__ void f_acc_zero(f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 
 template <bool TRAIN, bool PERS>
-__global__ __launch_bounds__(PN_NTHR, 1) void k_agg_forward2(FwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const F2Tile TA = f2_carve(smem), TB = f2_carve(smem + F2_TILE_FLOATS);
-    float *w5s = smem + 2 * F2_TILE_FLOATS;
-    const int tid = threadIdx.x;
+__global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_f[];
+    char *X = smem_f;
+    float *exb = reinterpret_cast<float *>(smem_f + FL_EX), *w5s = reinterpret_cast<float *>(smem_f + FL_W5);
+    float *wraw = reinterpret_cast<float *>(smem_f + FL_ROW), *wrow = wraw + PN_TILE, *wnrm = wrow + PN_TILE;
+    int *sidx = reinterpret_cast<int *>(wnrm + PN_TILE);
+    const int tid0 = threadIdx.x;
     const int K = a.K, TS = a.TS;
     // this launch processes one sample class: its list, its run of tiles, its range of per-sample rows
     const int Ns = a.cls_info[PN_CI_COUNT + a.cls];
-    {
-        const long long vb = a.cls_info[PN_CI_VBASE + a.cls], tb = a.cls_info[PN_CI_TBASE + a.cls];
-        a.valid_list = a.cls_list + vb; a.cap_samples = Ns;
-        a.sv.fs += vb * PN_H;
-        if (TRAIN) {
-            a.sv.x0 += tb * PN_TILE * PN_IN1P; a.sv.ex += tb * PN_TILE * 8; a.sv.rmeta += tb * PN_TILE; a.sv.lmask += tb * 3 * PN_NTHR;
-            a.sv.h1 += tb * PN_TILE * PN_H; a.sv.h2 += tb * PN_TILE * PN_H; a.sv.h3 += tb * PN_TILE * PN_H; a.sv.h4 += tb * PN_TILE * PN_H;
-        }
-    }
-    const int ntiles = (Ns + TS - 1) / TS;
+    const long long vb = a.cls_info[PN_CI_VBASE + a.cls], tb = a.cls_info[PN_CI_TBASE + a.cls];
+    a.valid_list = a.cls_list + vb; a.cap_samples = Ns;
+    a.sv.fs += vb * PN_H;
+    const long long ntiles = ((long long)Ns + TS - 1) / TS;
+    const long long rg_total = a.sv.rows / 8;
     const float *P = a.params;
-    if (tid < PN_H) w5s[tid] = P[PO_W5 + tid];
+    const char *img = reinterpret_cast<const char *>(a.packed);
+    if (tid0 < PN_H) w5s[tid0] = P[PO_W5 + tid0];
     const float b5 = P[PO_B5];
-    const int stride = 2 * (int)gridDim.x;
-    if ((int)blockIdx.x * 2 >= ntiles) return;
+    const long long stride = gridDim.x;
+    if ((long long)blockIdx.x >= ntiles) return;
 
-    f32x16 accA[2][2], accB[2][2];
-    pn_acc_zero(accA); pn_acc_zero(accB);
-    F2State SA, SB;
-    F2Bnd CB;
-    float4 bpre[2];
-    {   // prologue: index pipelines of both buffers; the first tile of buffer A is built plainly
-        const int row = tid / TPR, k = row % K;
-        SA.t1 = 2 * (int)blockIdx.x; SA.t2 = SA.t1 + stride;
-        SB.t1 = SA.t1 + 1; SB.t2 = SB.t1 + stride;
-        SA.si1 = f2_sample_of(a, SA.t1, row, Ns); SA.si2 = f2_sample_of(a, SA.t2, row, Ns);
-        SB.si1 = f2_sample_of(a, SB.t1, row, Ns); SB.si2 = f2_sample_of(a, SB.t2, row, Ns);
-        SA.p1 = SA.si1 >= 0 ? a.pidx[(long long)SA.si1 * a.Kstride + k] : -1;
-        SB.p1 = SB.si1 >= 0 ? a.pidx[(long long)SB.si1 * a.Kstride + k] : -1;
-        SA.tile = SA.t1; SB.tile = ntiles;              // buffer B starts as an empty finished tile on the padding tile's storage
-        f2_request<PERS>(a, SA, CB, tid, Ns, stride);
-        SA.tile = SA.t1;
-        f2_geometry<PERS>(a, TA, CB, tid);
-        float *xa = TA.buf + row * LDX;
-        *reinterpret_cast<float4 *>(xa + EPT * (tid % TPR)) = CB.e0; *reinterpret_cast<float4 *>(xa + EPT * (tid % TPR) + 4) = CB.e1;
-        pn_static_for<8>([&](auto ii) { f2_pe_emb<decltype(ii)::value>(TA, CB, tid); });
-        f2_pe_dist<0>(TA, CB, tid); f2_pe_dist<1>(TA, CB, tid);
-        if (tid % TPR == TPR - 1) {
-            *reinterpret_cast<float4 *>(xa + PN_IN1) = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(xa + PN_IN1 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (tid < PN_TILE) { TB.sidx[tid] = -1; TB.wrow[tid] = 0.f; TB.wraw[tid] = 0.f; }
-        __syncthreads();
-        f2_weights<TRAIN>(a, TA, CB, SA.tile, tid);
-        SA.si1 = SA.si2; SA.p1 = SA.p2; SA.t1 = SA.t2; SA.si2 = SA.si3; SA.t2 = SA.t3;
-        pn_gemm_prefetch_b0(a.packed + PK_F1 / 4, tid >> 6, tid & 63, bpre);
+    // index pipeline of this thread's row: (si0, p0) current tile, (si1, p1) next, si2 the one after
+    long long tile = blockIdx.x;
+    int si0, si1, si2, p0, p1;
+    FGather G;
+    {
+        const int row = tid0 / TPR, q = tid0 % TPR, k = row % K;
+        si0 = f_sample_of(a, tile, row, Ns); si1 = f_sample_of(a, tile + stride, row, Ns); si2 = f_sample_of(a, tile + 2 * stride, row, Ns);
+        p0 = si0 >= 0 ? a.pidx[(long long)si0 * a.Kstride + k] : -1;
+        p1 = si1 >= 0 ? a.pidx[(long long)si1 * a.Kstride + k] : -1;
+        f_gather<PERS>(a, G, si0, p0, q);
     }
-#ifdef PN_PHASE_TRACE
-    int titer = -1;
-#endif
-    for (int pair = blockIdx.x; pair * 2 < ntiles; pair += gridDim.x) {
-#ifdef PN_PHASE_TRACE
-        ++titer;
-#endif
-        int tl = threadIdx.x;
-        asm volatile("" : "+v"(tl));
-        const int lane = tl & 63, wave = tl >> 6;
-        __syncthreads();
-        PN_TR(pn_trace_fwd, 0);
-        float *wyA = TA.buf + (4 * (lane >> 5)) * LDX + wave * 64 + (lane & 31);     // accumulator-layout write base
-        float *wyB = TB.buf + (4 * (lane >> 5)) * LDX + wave * 64 + (lane & 31);
-        const float *rxA = TA.buf + wave * LDX + lane * 4, *rxB = TB.buf + wave * LDX + lane * 4;   // copy-out read base (+ 4*i rows)
-        const int bcol = wave * 64 + (lane & 31);
-        float4 cpv = make_float4(0.f, 0.f, 0.f, 0.f);
-        unsigned mlo = 0u, mhi = 0u;
-        float bias[2] = {0.f, 0.f};
-#ifdef PN_PHASE_TRACE
-        CB.titer = titer; CB.trbase = 9;
-#endif
-        const float bias4[2] = {P[PO_B4 + bcol], P[PO_B4 + bcol + 32]};
 
-        // one G step: GEMM of tile X (NCH chunks of LDS XB against weight image PK) with, in the MFMA shadows,
-        //   E (bias PB, LeakyReLU, sign bits -> mask word ML of tile YT) of the other tile's accumulators ACCY -> WY,
-        //   EXTRAS: that tile's layer-3 extras move next to its h2,
-        //   the copy-out of X's own previous layer RX -> DST (training), and optionally a boundary program BND
-#define F2_NOBND(s_) (void)0
-#define F2_BND_B(s_) f2_boundary_slot<s_, TRAIN, PERS>(a, TB, SB, accB, bias4, wyB, CB, w5s, b5, tl, Ns, stride)
-#define F2_BND_A(s_) f2_boundary_slot<s_, TRAIN, PERS>(a, TA, SA, accA, bias4, wyA, CB, w5s, b5, tl, Ns, stride)
-#define F2_STEP(NCH, XB, ACCX, PK, PKNEXT, ACCY, PB, WY, YT, YTILE, ML, EPI, EXTRAS, COPY, COPY0, XT, RX, DST, XTILE, BND)             \
-        {                                                                                                                           \
-            if (EPI) { bias[0] = P[(PB) + bcol]; bias[1] = P[(PB) + bcol + 32]; mlo = 0u; mhi = 0u; }                               \
-            pn_acc_zero(ACCX);                                                                                                      \
-            pn_tile_gemm_side<NCH>(XB, LDX, a.packed + (PK) / 4, wave, lane, ACCX, bpre, a.packed + (PKNEXT) / 4, [&](auto ss) {    \
-                constexpr int s = decltype(ss)::value;                                                                              \
-                if constexpr (EPI && s % 8 == 0 && s < 512) f2_epi_piece<s / 8, TRAIN>(ACCY, bias, WY, mlo, mhi);                   \
-                if constexpr (EPI && EXTRAS && s == 509) {                                                                          \
-                    if (tl < PN_TILE * 2) *reinterpret_cast<float4 *>((YT).buf + (tl >> 1) * LDX + PN_H + (tl & 1) * 4) = *reinterpret_cast<const float4 *>((YT).exb + (tl >> 1) * 8 + (tl & 1) * 4); \
-                }                                                                                                                   \
-                if constexpr (EPI && TRAIN && s == 510) a.sv.lmask[((long long)(YTILE) * 3 + (ML)) * PN_NTHR + tl] = ((unsigned long long)mhi << 32) | mlo; \
-                if constexpr (COPY0 && TRAIN && s % 32 == 8) {             /* X0 [64][288]: float4 number tl + 256 i, i < 18 */            \
-                    const int e_ = tl + (s / 32) * PN_NTHR, row_ = e_ / (PN_IN1P / 4), c4_ = e_ - row_ * (PN_IN1P / 4);                 \
-                    cpv = *reinterpret_cast<const float4 *>((XT).buf + row_ * LDX + c4_ * 4);                                          \
-                }                                                                                                                   \
-                if constexpr (COPY0 && TRAIN && s % 32 == 24) {                                                                     \
-                    const int e_ = tl + (s / 32) * PN_NTHR, row_ = e_ / (PN_IN1P / 4), c4_ = e_ - row_ * (PN_IN1P / 4);                 \
-                    pn_store_stream(a.sv.x0 + ((long long)(XTILE) * PN_TILE + row_) * PN_IN1P + c4_ * 4, cpv);                        \
-                }                                                                                                                   \
-                if constexpr (COPY0 && TRAIN && s == 30) {                                                                          \
-                    if (tl < PN_TILE * 2) *reinterpret_cast<float4 *>(a.sv.ex + ((long long)(XTILE) * PN_TILE + (tl >> 1)) * 8 + (tl & 1) * 4) = *reinterpret_cast<const float4 *>((XT).exb + (tl >> 1) * 8 + (tl & 1) * 4); \
-                }                                                                                                                   \
-                if constexpr (COPY && TRAIN && s % 32 == 4 && s < 512) cpv = *reinterpret_cast<const float4 *>((RX) + 4 * (s / 32) * LDX); \
-                if constexpr (COPY && TRAIN && s % 32 == 20 && s < 512) pn_store_stream((DST) + ((long long)(XTILE) * PN_TILE + wave + 4 * (s / 32)) * PN_H + lane * 4, cpv); \
-                BND(s);                                                                                                             \
-            });                                                                                                                     \
-            __syncthreads();                                                                                                        \
-        }
-        //      chunks       X-tile  accX  image  next   accY  bias   writeY Y  Y-tile   mask EPI    EXTRAS COPY   COPY0 X   readX dst       X-tile   boundary
-        F2_STEP(PN_IN1P / 8, TA.buf, accA, PK_F1, PK_F1, accB, PO_B4, wyB, TB, SB.tile, 0, false, false, false, true, TA, rxA, a.sv.h1, SA.tile, F2_BND_B)
-        PN_TR(pn_trace_fwd, 1);
-        F2_STEP(PN_IN1P / 8, TB.buf, accB, PK_F1, PK_F2, accA, PO_B1, wyA, TA, SA.tile, 0, true, false, false, true, TB, rxB, a.sv.h1, SB.tile, F2_NOBND)
-        PN_TR(pn_trace_fwd, 2);
-        F2_STEP(PN_H / 8, TA.buf, accA, PK_F2, PK_F2, accB, PO_B1, wyB, TB, SB.tile, 0, true, false, true, false, TA, rxA, a.sv.h1, SA.tile, F2_NOBND)
-        PN_TR(pn_trace_fwd, 3);
-        F2_STEP(PN_H / 8, TB.buf, accB, PK_F2, PK_F3, accA, PO_B2, wyA, TA, SA.tile, 1, true, true, true, false, TB, rxB, a.sv.h1, SB.tile, F2_NOBND)
-        PN_TR(pn_trace_fwd, 4);
-        F2_STEP(PN_H / 8 + 1, TA.buf, accA, PK_F3, PK_F3, accB, PO_B2, wyB, TB, SB.tile, 1, true, true, true, false, TA, rxA, a.sv.h2, SA.tile, F2_NOBND)
-        PN_TR(pn_trace_fwd, 5);
-        F2_STEP(PN_H / 8 + 1, TB.buf, accB, PK_F3, PK_F4, accA, PO_B3, wyA, TA, SA.tile, 2, true, false, true, false, TB, rxB, a.sv.h2, SB.tile, F2_NOBND)
-        PN_TR(pn_trace_fwd, 6);
-        F2_STEP(PN_H / 8, TA.buf, accA, PK_F4, PK_F4, accB, PO_B3, wyB, TB, SB.tile, 2, true, false, true, false, TA, rxA, a.sv.h3, SA.tile, F2_NOBND)
-        PN_TR(pn_trace_fwd, 7);
-#ifdef PN_PHASE_TRACE
-        CB.trbase = -1;
-#endif
-        F2_STEP(PN_H / 8, TB.buf, accB, PK_F4, PK_F1, accA, PO_B4, wyA, TA, SA.tile, 0, false, false, true, false, TB, rxB, a.sv.h3, SB.tile, F2_BND_A)
-        PN_TR(pn_trace_fwd, 8);
-#undef F2_STEP
-#undef F2_BND_A
-#undef F2_BND_B
-#undef F2_NOBND
-    }
-    {   // epilogue: the last tile of buffer B: last layer's epilogue, alpha head, K-weighted sums (plain)
-        const int lane = tid & 63, wave = tid >> 6, bcol = wave * 64 + (lane & 31);
-        const float bias4[2] = {P[PO_B4 + bcol], P[PO_B4 + bcol + 32]};
-        float *wyB = TB.buf + (4 * (lane >> 5)) * LDX + wave * 64 + (lane & 31);
-        unsigned d0 = 0u, d1 = 0u;
-        pn_static_for<64>([&](auto rr) { f2_epi_piece<decltype(rr)::value, false>(accB, bias4, wyB, d0, d1); });
+    f32x16 acc[2][2];
+    for (; tile < ntiles; tile += stride) {
+        // thread-index-derived offsets are recomputed per tile: hoisted out of the loop they become hundreds of loop-carried
+        // registers (every LDS / bias / image address of every unrolled store) and spill
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), row = tid / TPR, q = tid % TPR, k = row % K;
+        const long long gtile = tb + tile;               // tile index inside the saved area
+        __syncthreads();                                 // the previous tile's readers are done with X and the row arrays
+        f_build<PERS>(a, G, X, exb, wraw, sidx, si0, p0, row, q);
         __syncthreads();
-        if (TRAIN) pn_tile_copy_out<PN_TILE, PN_H, PN_NTHR>(TB.buf, LDX, a.sv.h4, PN_H, (long long)SB.tile * PN_TILE, tid);
+        if (q == 0) {      // weights of the row: normalise over the K slots, multiply by the clamped confidence (:801-811)
+            const int ls = row / K;
+            float wn = 0.f, w = 0.f;
+            if (si0 >= 0) {
+                float sum = 0.f;
+                for (int kk = 0; kk < K; ++kk) sum += wraw[ls * K + kk];
+                wn = wraw[row] / fmaxf(sum, 1e-8f);
+                w = wn * fminf(fmaxf(G.cf, 1e-4f), 1.0f);
+                a.weight[(long long)si0 * a.Kstride + k] = wn;
+            }
+            wnrm[row] = wn; wrow[row] = w;
+            if (TRAIN) a.sv.rmeta[gtile * PN_TILE + row] = make_int4(si0, si0 >= 0 ? p0 : -1, __float_as_int(wn), __float_as_int(w));
+        }
+        unsigned long long mask;
+        // ---- layer 1: 288 -> 256
+        if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.x0k, rg_total, gtile * 8, tid);
+        f_acc_zero(acc);
+        pn_gemm_f16x3<18, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_F1), 2 * wave, lane, acc);
+        __syncthreads();
+        f_epilogue<TRAIN>(acc, P + PO_B1, X, wave, lane, mask);
+        if (TRAIN) a.sv.lmask[(gtile * 3 + 0) * PN_NTHR + tid] = mask;
+        __syncthreads();
+        // ---- layer 2: 256 -> 256
+        if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h1k, rg_total, gtile * 8, tid);
+        f_acc_zero(acc);
+        pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_F2), 2 * wave, lane, acc);
+        __syncthreads();
+        f_epilogue<TRAIN>(acc, P + PO_B2, X, wave, lane, mask);
+        if (TRAIN) a.sv.lmask[(gtile * 3 + 1) * PN_NTHR + tid] = mask;
+        if (tid < PN_TILE) {     // the row's extras next to h2: columns 256..262, the ones column, zeros up to 271
+            const float4 u = *reinterpret_cast<const float4 *>(exb + tid * 8), v = *reinterpret_cast<const float4 *>(exb + tid * 8 + 4);
+            pn_x_store4<false>(X, tid, PN_H, u.x, u.y, u.z, u.w);
+            pn_x_store4<false>(X, tid, PN_H + 4, v.x, v.y, v.z, v.w);
+            pn_x_store4<false>(X, tid, PN_H + 8, 0.f, 0.f, 0.f, 0.f);
+            pn_x_store4<false>(X, tid, PN_H + 12, 0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        // ---- layer 3: 256 + 7 -> 256
+        if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.h2k, rg_total, gtile * 8, tid);
+        f_acc_zero(acc);
+        pn_gemm_f16x3<17, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_F3), 2 * wave, lane, acc);
+        __syncthreads();
+        f_epilogue<TRAIN>(acc, P + PO_B3, X, wave, lane, mask);
+        if (TRAIN) a.sv.lmask[(gtile * 3 + 2) * PN_NTHR + tid] = mask;
+        __syncthreads();
+        // ---- layer 4: 256 -> 256
+        if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h3k, rg_total, gtile * 8, tid);
+        f_acc_zero(acc);
+        pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_F4), 2 * wave, lane, acc);
+        // the next tile's point data and the indices of the two after it: requested here, consumed at the top of the next
+        // iteration -- their HBM latency passes under the element-wise tail of this tile
+        const float cf_cur = G.cf;
+        (void)cf_cur;
+        const int si_next = si1, p_next = p1;
+        if (tile + stride < ntiles) f_gather<PERS>(a, G, si1, p1, q);
+        const int p2 = si2 >= 0 ? a.pidx[(long long)si2 * a.Kstride + k] : -1;
+        const int si3 = f_sample_of(a, tile + 3 * stride, row, Ns);
+        __syncthreads();
+        f_epilogue<false>(acc, P + PO_B4, X, wave, lane, mask);
+        __syncthreads();
+        // ---- alpha head (256 -> 1, softplus(x - 1), raw2out_density :262-265): 4 threads per row, 8-column groups interleaved
         {
-            const int row = tid / TPR, q = tid % TPR;
-            const float *h = TB.buf + row * LDX + q * 4;
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float4 v = *reinterpret_cast<const float4 *>(h + 16 * j);
-                const float4 w = *reinterpret_cast<const float4 *>(w5s + q * 4 + 16 * j);
-                s += v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
+            for (int j = 0; j < 8; ++j) {
+                const int c0 = 8 * (q + 4 * j);
+                const float4 v0 = pn_x_load4(X, row, c0), v1 = pn_x_load4(X, row, c0 + 4);
+                const float4 w0 = *reinterpret_cast<const float4 *>(w5s + c0), w1 = *reinterpret_cast<const float4 *>(w5s + c0 + 4);
+                s += v0.x * w0.x + v0.y * w0.y + v0.z * w0.z + v0.w * w0.w + v1.x * w1.x + v1.y * w1.y + v1.z * w1.z + v1.w * w1.w;
             }
             s = group_sum<TPR>(s);
             if (q == 0) {
                 const float x = s + b5 - 1.0f;
-                TB.wraw[row] = (x > 20.f ? x : log1pf(expf(x))) * TB.wrow[row];
+                wraw[row] = (x > 20.f ? x : log1pf(expf(x))) * wrow[row];
+                if (TRAIN) a.sv.arow[gtile * PN_TILE + row] = x;
+            }
+        }
+        if (TRAIN) {     // h4 planes, row-major, for the backward's alpha head
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int e = tid + PN_NTHR * i, plane = e >> 11, r = (e >> 5) & 63, u = e & 31;
+                const uint4 v = *reinterpret_cast<const uint4 *>(X + plane * PN_XPLANE + r * PN_XRS + u * 16);
+                pn_f4 t = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+                __builtin_nontemporal_store(t, reinterpret_cast<pn_f4 *>(a.sv.h4r + ((long long)plane * a.sv.rows + gtile * PN_TILE + r) * 32 + u));
             }
         }
         __syncthreads();
+        // ---- K-weighted sums -> f[256] per sample (HBM), sigma
         for (int e = tid; e < TS * 64; e += PN_NTHR) {
             const int ls = e >> 6, c4 = e & 63;
             float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int k = 0; k < K; ++k) {
-                const float w = TB.wrow[ls * K + k];
-                const float4 v = *reinterpret_cast<const float4 *>(TB.buf + (ls * K + k) * LDX + c4 * 4);
+            for (int kk = 0; kk < K; ++kk) {
+                const float w = wrow[ls * K + kk];
+                const float4 v = pn_x_load4(X, ls * K + kk, c4 * 4);
                 f.x += w * v.x; f.y += w * v.y; f.z += w * v.z; f.w += w * v.w;
             }
-            const long long vs = (long long)SB.tile * TS + ls;
+            const long long vs = tile * TS + ls;
             if (vs < a.cap_samples) *reinterpret_cast<float4 *>(a.sv.fs + vs * PN_H + c4 * 4) = f;
         }
         if (tid < TS) {
-            const int si = TB.sidx[tid * K];
+            const int si = sidx[tid * K];
             if (si >= 0) {
                 float sg = 0.f;
-                for (int k = 0; k < K; ++k) sg += TB.wraw[tid * K + k];
+                for (int kk = 0; kk < K; ++kk) sg += wraw[tid * K + kk];
                 a.decoded[(long long)si * 4] = sg;
             }
         }
+        si0 = si_next; p0 = p_next; si1 = si2; p1 = p2; si2 = si3;
     }
 }
 
@@ -832,10 +702,10 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
     const long long ctiles = (cap_samples + PN_CTILE - 1) / PN_CTILE;
     const int grid_c = (int)(ctiles < 2 * ncu ? (ctiles > 0 ? ctiles : 1) : 2 * ncu);       // two workgroups per CU
-    const size_t lds_a = F2_LDS_FLOATS * sizeof(float), lds_c = COL_LDS_FLOATS * sizeof(float);
+    const size_t lds_a = FL_BYTES, lds_c = COL_LDS_FLOATS * sizeof(float);
     const bool pers = d_xyz_pers != nullptr;
-    const void *kfn = train ? (pers ? (const void *)k_agg_forward2<true, true> : (const void *)k_agg_forward2<true, false>)
-                            : (pers ? (const void *)k_agg_forward2<false, true> : (const void *)k_agg_forward2<false, false>);
+    const void *kfn = train ? (pers ? (const void *)k_agg_forward<true, true> : (const void *)k_agg_forward<true, false>)
+                            : (pers ? (const void *)k_agg_forward<false, true> : (const void *)k_agg_forward<false, false>);
     const void *cfn = train ? (const void *)k_color_forward<true> : (const void *)k_color_forward<false>;
     if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipFuncSetAttribute(cfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
@@ -848,12 +718,12 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
         PnProfScope prof(PNK_AGG_FWD, s);
         for (int j = 0; j < ncls; ++j) {            // class sizes are only known on the device: the grid covers the worst case, surplus workgroups return at once
             a.cls = j; a.K = kc[j]; a.TS = pn_tile_samples(kc[j]);
-            const long long pairs = ((cap_samples + a.TS - 1) / a.TS + 1) / 2;
-            const int grid_a = (int)(pairs < (long long)ncu ? (pairs > 0 ? pairs : 1) : ncu);
-            if (train && pers) hipLaunchKernelGGL((k_agg_forward2<true, true>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
-            else if (train) hipLaunchKernelGGL((k_agg_forward2<true, false>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
-            else if (pers) hipLaunchKernelGGL((k_agg_forward2<false, true>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
-            else hipLaunchKernelGGL((k_agg_forward2<false, false>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            const long long tiles = (cap_samples + a.TS - 1) / a.TS;
+            const int grid_a = (int)(tiles < 2LL * ncu ? (tiles > 0 ? tiles : 1) : 2LL * ncu);     // two workgroups per CU
+            if (train && pers) hipLaunchKernelGGL((k_agg_forward<true, true>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            else if (train) hipLaunchKernelGGL((k_agg_forward<true, false>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            else if (pers) hipLaunchKernelGGL((k_agg_forward<false, true>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            else hipLaunchKernelGGL((k_agg_forward<false, false>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
         }
     }
     a.K = K; a.TS = pn_tile_samples(K); a.valid_list = sv.cls_list;      // the colour MLP walks the class-ordered list: f rows are in that order
@@ -865,9 +735,3 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     PN_CHECK_LAUNCH();
     return 0;
 }
-
-#ifdef PN_PHASE_TRACE
-extern "C" int pnerf_debug_trace_fwd(void *host, size_t bytes) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(pn_trace_fwd), bytes < sizeof(pn_trace_fwd) ? bytes : sizeof(pn_trace_fwd)) == hipSuccess ? 0 : -1;
-}
-#endif

@@ -1,5 +1,7 @@
 // backward.hip -- backward of the aggregator: colour MLP dgrad, per-neighbor MLP dgrad + gather
-// scatter-add, and the weight-gradient GEMMs.
+// scatter-add, and the weight-gradient GEMMs.  The four 256-wide layers run on the f16 matrix pipe with two-plane operands
+// (f16x3.h); all gradients inside the aggregator backward carry a per-call power-of-two scale (k_grad_max) so that they sit
+// in the f16 range, and leave it (atomics, weight-gradient reduction) multiplied by its exact inverse.
 //
 // The reference gets all of this from torch.autograd over ~60 ATen ops (loss.backward() in
 // models/mvs_points_volumetric_model.py:98-118): cuBLAS dgrad/wgrad per nn.Linear, dense
@@ -10,11 +12,10 @@
 //                      embedding / colour / dir / conf gradients of the touched points only
 //   k_wgrad_lds      : dW = dY^T X as split-K MFMA GEMMs over the saved activations, full dW tile
 //                      resident in accumulators, deterministic partial-sum reduction
-// LeakyReLU masks come from the saved post-activations (sign(post) == sign(pre)).
-#include "mlp_common.h"
+// LeakyReLU masks: 1 bit per element, written by the forward in the accumulator layout (layers 1-3), sign of the saved h4 (layer 4).
+#include "f16x3.h"
 
 namespace {
-constexpr int LDH = 260;
 constexpr int LDC = 132;
 constexpr int WG_CHUNKS = 256;                 // split-K factor of the wgrad GEMMs
 constexpr size_t PARTIAL_FLOATS = (size_t)WG_CHUNKS * PN_H * PN_IN1P;
@@ -31,6 +32,7 @@ struct BwdArgs {
     long long cap_samples;
     const float *decoded, *weight, *grad_decoded;
     PnSaved sv;
+    const float *emb;
     float *gparams;
     float *g_emb, *g_conf, *g_dir, *g_color;
 };
@@ -122,655 +124,272 @@ __global__ __launch_bounds__(256, 2) void k_color_backward(BwdArgs a) {
     if (tid < 3) atomicAdd(&a.gparams[PO_BC4 + tid], gb4);
 }
 
+// ------------------------------------------------------------------------------ gradient scale
+// bits of max |d decoded| over the valid samples -> sv.gscale[0] (zeroed by the launcher); every consumer derives the same
+// power of two from it: S = 2^(4 - floor(log2 max)), so that the largest scaled gradient lies in [16, 32)
+__global__ __launch_bounds__(256) void k_grad_max(const int *__restrict__ list, const int *__restrict__ counters, long long cap, const float *__restrict__ gd,
+                                                  unsigned *__restrict__ gscale) {
+    __shared__ unsigned red[4];
+    const long long Ns = counters[0] < cap ? counters[0] : cap;
+    float m = 0.f;
+    for (long long vs = (long long)blockIdx.x * 256 + threadIdx.x; vs < Ns; vs += (long long)gridDim.x * 256) {
+        const float4 g = *reinterpret_cast<const float4 *>(gd + (long long)list[vs] * 4);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = __float_as_uint(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned r = red[0];
+        for (int i = 1; i < 4; ++i) r = red[i] > r ? red[i] : r;
+        if (r != 0u && r < 0x7f800000u) atomicMax(gscale, r);            // (NaN / inf gradients do not pick the scale)
+    }
+}
+__device__ __forceinline__ void pn_scale_from_bits(unsigned mb, float &S, float &invS) {
+    const int e = (int)((mb >> 23) & 0xffu);
+    int se = (e == 0 || e == 255) ? 127 : 127 + 4 - (e - 127);
+    se = se < 2 ? 2 : (se > 252 ? 252 : se);
+    S = __uint_as_float((unsigned)se << 23);
+    invS = __uint_as_float((unsigned)(254 - se) << 23);
+}
+
 // ------------------------------------------------------------------------------ aggregator backward
-// One workgroup (4 waves, one per SIMD) per CU keeps TWO tiles (A, B) in flight and alternates their layer GEMMs:
-//   G(A,4) G(B,4) G(A,3) G(B,3) G(A,2) G(B,2) G(A,1) G(B,1)
-// While tile X's GEMM streams through the MFMA pipe, the same wave issues, in the shadow of its own MFMAs
-// (pn_tile_gemm_side), the other tile's epilogue (accumulators x LeakyReLU' -> LDS, bias column sums) and the copy-out of
-// X's finished dY rows to HBM (plus the W3-extras gradient, which needs exactly those rows).  The phase timeline of the
-// previous design (two single-tile workgroups per CU, tools/gpu_phase_trace.py) showed why: a workgroup spent 80-100 us per
-// tile outside its 64 us of GEMM, because VALU work of one wave crawls (1 instruction / ~84 cycles) while another wave of
-// the same SIMD streams MFMAs -- a second workgroup cannot hide element-wise phases on this hardware, the GEMM wave itself can.
-// Everything a tile needs from HBM/L2 is requested at its start (row metadata and 1-bit LeakyReLU masks written by the
-// forward, the d f tile, the ray direction).
+// One 64-row tile per workgroup at a time, two workgroups per CU (the forward's organisation).  Per tile:
+//   load h4 planes + row metadata + sign words -> alpha head backward (d conf, d alpha pre-activation) -> dY4 in place
+//   -> four dgrad GEMMs on the f16 pipe, each followed by the LeakyReLU' epilogue that writes the next dY tile; the dY tile of
+//   every layer is copied (transposed to k-major planes) to HBM for the weight-gradient GEMM while its own GEMM runs
+//   -> layer-3 extras (d colour, d dir) as a ninth feature block, K split over the four waves
+//   -> d X0 (224 columns: the embedding and its encoding) as fp32 in LDS -> PE chain rule -> atomics into the touched points.
+// Bias gradients are not formed here: they are the ones-column of the weight-gradient GEMMs.
 constexpr int TPR = PN_TPR;                    // threads per tile row in the row-wise phases
 constexpr int EPT = PN_F / TPR;                // embedding dims per thread
-constexpr int B2_DFS_FLOATS = 8 * PN_H;        // d f tile [TS <= 8][256]
-constexpr int B2_TILE_FLOATS = PN_TILE * LDH + B2_DFS_FLOATS + 6 * PN_TILE;
-constexpr int AGGB_LDS_FLOATS = 2 * B2_TILE_FLOATS + PN_H + 7 * PN_H;
-static_assert(AGGB_LDS_FLOATS * 4 <= 160 * 1024, "two tiles must fit the 160 KB LDS");
-static_assert(PN_TILE == 64 && PN_NTHR == 256, "the two-tile backward is written for 64-row tiles and 4 waves");
+constexpr int BL_ROW = PN_XBYTES, BL_W5 = BL_ROW + 7 * PN_TILE * 4, BL_RED = BL_W5 + PN_H * 4, BL_BYTES = BL_RED + PN_TILE * 8 * 4;
+constexpr int LDDX = 228;                      // fp32 row stride of the d X0 tile (over the activation tile's space)
+static_assert(2 * BL_BYTES <= 160 * 1024, "two backward workgroups must fit the 160 KB LDS");
+static_assert(PN_TILE * LDDX * 4 <= PN_XBYTES, "d X0 tile");
 
 template <int N> __device__ __forceinline__ float group_sum_b(float v) {
 #pragma unroll
     for (int off = 1; off < N; off <<= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
-
-struct B2Tile {            // LDS of one in-flight tile
-    float *buf;            // [64][LDH]  h4 -> dY4 -> dY3 -> dY2 -> dY1 -> dX0
-    float *dfs;            // [8][256]   d f rows of the tile's samples
-    float *wrow, *wnrm, *draw, *dsg;
-    int *sidx, *prow;
-};
-struct B2State {           // registers of one in-flight tile
-    unsigned long long m1, m2, m3;
-    float rdx, rdy, rdz;
-    int rsi, rp;
-    long long tile;
-    bool valid;
-    float4 exv;            // this thread's float4 of the tile's layer-3 extras [64][8] (threads < 128): into the d f region once d f is dead
-};
-
-__device__ __forceinline__ B2Tile b2_carve(float *base) {
-    B2Tile t;
-    t.buf = base; t.dfs = t.buf + PN_TILE * LDH;
-    t.wrow = t.dfs + B2_DFS_FLOATS; t.wnrm = t.wrow + PN_TILE; t.draw = t.wnrm + PN_TILE; t.dsg = t.draw + PN_TILE;
-    t.sidx = reinterpret_cast<int *>(t.dsg + PN_TILE); t.prow = t.sidx + PN_TILE;
-    return t;
+__device__ __forceinline__ void b_acc_zero(f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+// dgrad epilogue: accumulators x LeakyReLU' (bit of the forward's sign word) -> both planes of the next dY tile
+__device__ __forceinline__ void b_epilogue(const f32x16 (&acc)[2][2], unsigned long long mask, char *X, int wave, int lane) {
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const unsigned bits = (unsigned)(mask >> (((fb * 2 + rb) * 4 + g) * 4)) & 15u;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = acc[fb][rb][4 * g + i] * (((bits >> i) & 1u) ? 1.f : 0.01f);
+                pn_x_store4<true>(X, 32 * rb + (lane & 31), pn_d_feat(2 * wave + fb, g, lane), v[0], v[1], v[2], v[3]);
+            }
 }
 
-// P0: request everything the tile needs from memory; h4 / d f / row metadata land in LDS
-template <bool DFS_LDS>
-__device__ __forceinline__ void b2_load(const BwdArgs &a, const B2Tile &T, B2State &S, long long tile, long long ntiles, int tl, int TS) {
-    S.tile = tile; S.valid = tile < ntiles;
-    S.rdx = S.rdy = S.rdz = 0.f;
-    S.exv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (S.valid && tl < 2 * PN_TILE) S.exv = *reinterpret_cast<const float4 *>(a.sv.ex + tile * PN_TILE * 8 + tl * 4);
-    const long long grow0 = tile * PN_TILE;
-    if (S.valid) {
-        S.m1 = a.sv.lmask[(tile * 3 + 0) * PN_NTHR + tl];
-        S.m2 = a.sv.lmask[(tile * 3 + 1) * PN_NTHR + tl];
-        S.m3 = a.sv.lmask[(tile * 3 + 2) * PN_NTHR + tl];
-        if (tl < PN_TILE) {
-            const int4 rm = a.sv.rmeta[grow0 + tl];
-            T.sidx[tl] = rm.x; T.prow[tl] = rm.y;
-            T.wnrm[tl] = __int_as_float(rm.z); T.wrow[tl] = __int_as_float(rm.w);
-            T.dsg[tl] = rm.x >= 0 ? a.grad_decoded[(long long)rm.x * 4] : 0.f;
+__global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    char *X = smem_b;
+    float *wrow = reinterpret_cast<float *>(smem_b + BL_ROW), *wnrm = wrow + PN_TILE, *draw = wnrm + PN_TILE, *dsg = draw + PN_TILE, *xrow = dsg + PN_TILE;
+    int *sidx = reinterpret_cast<int *>(xrow + PN_TILE), *prow = sidx + PN_TILE;
+    float *w5s = reinterpret_cast<float *>(smem_b + BL_W5), *red = reinterpret_cast<float *>(smem_b + BL_RED);
+    float *dx = reinterpret_cast<float *>(smem_b);
+    const int tid0 = threadIdx.x;
+    const int K = a.K, TS = a.TS;
+    const int Ns = a.cls_info[PN_CI_COUNT + a.cls];
+    const long long vb = a.cls_info[PN_CI_VBASE + a.cls], tb = a.cls_info[PN_CI_TBASE + a.cls];
+    a.sv.dfs += vb * PN_H;
+    const long long ntiles = ((long long)Ns + TS - 1) / TS, rg_total = a.sv.rows / 8;
+    const float *P = a.params;
+    const char *img = reinterpret_cast<const char *>(a.packed);
+    float S, invS;
+    pn_scale_from_bits(a.sv.gscale[0], S, invS);
+    if (tid0 < PN_H) w5s[tid0] = P[PO_W5 + tid0];
+    red[tid0] = 0.f; red[tid0 + PN_NTHR] = 0.f;
+    float4 gw5v = make_float4(0.f, 0.f, 0.f, 0.f);      // d W5 of columns 4 (tid & 63) .. + 3 (scaled)
+    float gb5t = 0.f;
+    f32x16 acc[2][2];
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int tid = threadIdx.x;                          // (recomputed per tile: see the forward)
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), row = tid / TPR, q = tid % TPR;
+        const long long gtile = tb + tile;
+        __syncthreads();
+        // ---- load: sign words, row metadata, h4 planes
+        const unsigned long long m1 = a.sv.lmask[(gtile * 3 + 0) * PN_NTHR + tid], m2 = a.sv.lmask[(gtile * 3 + 1) * PN_NTHR + tid],
+                                 m3 = a.sv.lmask[(gtile * 3 + 2) * PN_NTHR + tid];
+        if (tid < PN_TILE) {
+            const int4 rm = a.sv.rmeta[gtile * PN_TILE + tid];
+            sidx[tid] = rm.x; prow[tid] = rm.y;
+            wnrm[tid] = __int_as_float(rm.z); wrow[tid] = __int_as_float(rm.w);
+            xrow[tid] = a.sv.arow[gtile * PN_TILE + tid];
+            dsg[tid] = rm.x >= 0 ? a.grad_decoded[(long long)rm.x * 4] * S : 0.f;
         }
-        // (no staging arrays: hipcc hoists the 16 + 2 loads of the unrolled bodies above the first LDS store by itself)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float4 v = *reinterpret_cast<const float4 *>(a.sv.h4 + (grow0 + (tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4);
-            *reinterpret_cast<float4 *>(T.buf + ((tl >> 6) + 4 * i) * LDH + (tl & 63) * 4) = v;
+            const int e = tid + PN_NTHR * i, plane = e >> 11, r = (e >> 5) & 63, u = e & 31;
+            *reinterpret_cast<uint4 *>(X + plane * PN_XPLANE + r * PN_XRS + u * 16) = a.sv.h4r[((long long)plane * a.sv.rows + gtile * PN_TILE + r) * 32 + u];
         }
-        if (DFS_LDS) {
+        __syncthreads();
+        // ---- alpha head backward (4 threads per row): d w_k = d sigma alpha_k + d f . h4_k ; d x = d sigma w sigmoid(x)
+        const int rsi = sidx[row], rp = prow[row];
+        float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;       // the row's embedding values (for its gradient at the end of the tile)
+        if (rp >= 0) {
+            const float *ep = a.emb + (long long)rp * PN_F + EPT * q;
+            e0 = *reinterpret_cast<const float4 *>(ep); e1 = *reinterpret_cast<const float4 *>(ep + 4);
+        }
+        {
+            float dotf = 0.f;
+            if (rsi >= 0) {
+                const float *df = a.sv.dfs + (tile * TS + row / K) * PN_H;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = (tl >> 6) + 4 * i;            // row of the [TS x 256] block
-                const float4 g = r < TS ? *reinterpret_cast<const float4 *>(a.sv.dfs + (tile * TS + r) * PN_H + (tl & 63) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4 *>(T.dfs + r * PN_H + (tl & 63) * 4) = g;
+                for (int j = 0; j < 8; ++j) {
+                    const int c0 = 8 * (q + 4 * j);
+                    const float4 v0 = pn_x_load4(X, row, c0), v1 = pn_x_load4(X, row, c0 + 4);
+                    const float4 g0 = *reinterpret_cast<const float4 *>(df + c0), g1 = *reinterpret_cast<const float4 *>(df + c0 + 4);
+                    dotf += v0.x * g0.x + v0.y * g0.y + v0.z * g0.z + v0.w * g0.w + v1.x * g1.x + v1.y * g1.y + v1.z * g1.z + v1.w * g1.w;
+                }
+            }
+            dotf = group_sum_b<TPR>(dotf) * S;
+            if (q == 0) {
+                float dr = 0.f;
+                if (rsi >= 0) {
+                    const float x = xrow[row];
+                    const float alpha = x > 20.f ? x : log1pf(expf(x));
+                    const float sg = x > 20.f ? 1.f : 1.0f / (1.0f + expf(-x));
+                    // w = wn * clamp(conf) with a straight-through clamp (gradiant_clamp, point_aggregators.py:722-724)
+                    if (rp >= 0) atomicAdd(&a.g_conf[rp], (dsg[row] * alpha + dotf) * wnrm[row] * invS);
+                    dr = dsg[row] * wrow[row] * sg;
+                }
+                draw[row] = dr;
             }
         }
-    } else {                                               // the partner slot of the last odd tile: an all-invalid tile of zeros
-        S.m1 = S.m2 = S.m3 = 0ull;
-        if (tl < PN_TILE) { T.sidx[tl] = -1; T.prow[tl] = -1; T.wnrm[tl] = 0.f; T.wrow[tl] = 0.f; T.dsg[tl] = 0.f; }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) *reinterpret_cast<float4 *>(T.buf + ((tl >> 6) + 4 * i) * LDH + (tl & 63) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
-
-// P1: alpha head (softplus'), d conf, d(alpha pre-activation) per row.  Row-wise: 4 threads per row, float4 columns interleaved
-// (thread q takes float4 q, q+4, ...: conflict-free LDS reads; contiguous 64-column quarters were 8-way bank conflicts)
-template <bool DFS_LDS>
-__device__ __forceinline__ void b2_alpha(const BwdArgs &a, const B2Tile &T, B2State &S, const float *w5s, float b5, int tl, int TS, int K) {
-    const int rrow = tl / TPR, rq = tl % TPR, rls = rrow / K;
-    S.rsi = T.sidx[rrow]; S.rp = T.prow[rrow];
-    if (rq == 0 && S.rp >= 0) {
-        const int r = S.rsi / a.SR;
-        S.rdx = a.raydir[3 * r]; S.rdy = a.raydir[3 * r + 1]; S.rdz = a.raydir[3 * r + 2];
-    }
-    float s = 0.f, dotf = 0.f;
-    if (S.rsi >= 0) {
-        const float *h = T.buf + rrow * LDH + rq * 4;
-        const float *df = DFS_LDS ? T.dfs + rls * PN_H + rq * 4 : a.sv.dfs + (S.tile * TS + rls) * PN_H + rq * 4;
+        __syncthreads();
+        // ---- dY4 = (w d f + d x W5) * LeakyReLU'(h4), in place; d W5 / d b5 partial sums ride along
+        {
+            const int c4 = tid & 63;
+            const float4 w5 = *reinterpret_cast<const float4 *>(w5s + c4 * 4);
 #pragma unroll 4
-        for (int j = 0; j < 16; ++j) {
-            const float4 v = *reinterpret_cast<const float4 *>(h + 16 * j);
-            const float4 g = *reinterpret_cast<const float4 *>(df + 16 * j);
-            const float4 w = *reinterpret_cast<const float4 *>(w5s + rq * 4 + 16 * j);
-            s += v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
-            dotf += v.x * g.x + v.y * g.y + v.z * g.z + v.w * g.w;
-        }
-    }
-    s = group_sum_b<TPR>(s);
-    dotf = group_sum_b<TPR>(dotf);
-    if (rq == 0) {
-        float dr = 0.f;
-        if (S.rsi >= 0) {
-            const float x = s + b5 - 1.0f;
-            const float alpha = x > 20.f ? x : log1pf(expf(x));
-            const float sg = x > 20.f ? 1.f : 1.0f / (1.0f + expf(-x));
-            if (S.rp >= 0) {
-                // w = wn * clamp(conf) with a straight-through clamp (gradiant_clamp, point_aggregators.py:722-724)
-                const float dw = T.dsg[rrow] * alpha + dotf;
-                atomicAdd(&a.g_conf[S.rp], dw * T.wnrm[rrow]);
+            for (int i = 0; i < 16; ++i) {
+                const int r = (tid >> 6) + 4 * i;
+                const int si = sidx[r];
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (si >= 0) {
+                    const float4 hv = pn_x_load4(X, r, c4 * 4);
+                    const float4 g = *reinterpret_cast<const float4 *>(a.sv.dfs + (tile * TS + r / K) * PN_H + c4 * 4);
+                    const float w = wrow[r] * S, dr = draw[r];
+                    o.x = (w * g.x + dr * w5.x) * pn_lrelu_grad(hv.x);
+                    o.y = (w * g.y + dr * w5.y) * pn_lrelu_grad(hv.y);
+                    o.z = (w * g.z + dr * w5.z) * pn_lrelu_grad(hv.z);
+                    o.w = (w * g.w + dr * w5.w) * pn_lrelu_grad(hv.w);
+                    gw5v.x += dr * hv.x; gw5v.y += dr * hv.y; gw5v.z += dr * hv.z; gw5v.w += dr * hv.w;
+                }
+                pn_x_store4<true>(X, r, c4 * 4, o.x, o.y, o.z, o.w);
             }
-            dr = T.dsg[rrow] * T.wrow[rrow] * sg;
+            if (tid < PN_TILE) gb5t += draw[tid];
         }
-        T.draw[rrow] = dr;
-    }
-}
-
-// P2: dY4 = (w * d f + d raw * w5) * lrelu'(h4) in place + HBM; d W5 / d b4 / d b5 partial sums ride along
-template <bool DFS_LDS>
-__device__ __forceinline__ void b2_dy4(const BwdArgs &a, const B2Tile &T, const B2State &S, const float *w5s, int tl, int TS, int K,
-                                       float4 &gb4v, float4 &gw5v, float &gb5t) {
-    const int c4 = tl & 63;
-    const float4 w5 = *reinterpret_cast<const float4 *>(w5s + c4 * 4);
-    const long long grow0 = S.tile * PN_TILE;
-#pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-        const int row = (tl >> 6) + 4 * i;
-        const int si = T.sidx[row];
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (si >= 0) {
-            const int ls = row / K;
-            const float4 hv = *reinterpret_cast<const float4 *>(T.buf + row * LDH + c4 * 4);
-            const float4 g = DFS_LDS ? *reinterpret_cast<const float4 *>(T.dfs + ls * PN_H + c4 * 4)
-                                     : *reinterpret_cast<const float4 *>(a.sv.dfs + (S.tile * TS + ls) * PN_H + c4 * 4);
-            const float w = T.wrow[row], dr = T.draw[row];
-            o.x = (w * g.x + dr * w5.x) * pn_lrelu_grad(hv.x);
-            o.y = (w * g.y + dr * w5.y) * pn_lrelu_grad(hv.y);
-            o.z = (w * g.z + dr * w5.z) * pn_lrelu_grad(hv.z);
-            o.w = (w * g.w + dr * w5.w) * pn_lrelu_grad(hv.w);
-            gw5v.x += dr * hv.x; gw5v.y += dr * hv.y; gw5v.z += dr * hv.z; gw5v.w += dr * hv.w;
-            gb4v.x += o.x; gb4v.y += o.y; gb4v.z += o.z; gb4v.w += o.w;
-        }
-        *reinterpret_cast<float4 *>(T.buf + row * LDH + c4 * 4) = o;
-        pn_store_stream(a.sv.dy4 + (grow0 + row) * PN_H + c4 * 4, o);     // an invalid partner tile writes zeros into the padding tile
-    }
-    if (tl < PN_TILE) gb5t += T.draw[tl];
-}
-
-// P4: extras of block3's first layer: d colour, d dir from dY3 (row-wise, interleaved columns: conflict-free LDS reads).
-// P4 in the MFMA shadows of the tile's own layer-3 GEMM (which only reads the same dY3 rows): float4 column group j of the row,
-// sub-piece k, at slot 7 (4 j + k) + 3; reduction at 452 / 456, atomics at 460 / 464
-struct B2Ext { float dex[7]; float4 v, w0, w1, w2; };
-template <int SLOT>
-__device__ __forceinline__ void b2_extras_slot(const BwdArgs &a, const B2Tile &T, const B2State &S, const float *w3ex, B2Ext &E, int tl) {
-    const int rrow = tl / TPR, rq = tl % TPR;
-    if constexpr (SLOT == 0) {
+        __syncthreads();
+        // ---- layer 4: dY4 -> d h3
+        pn_copy_out_kmajor<PN_H>(X, a.sv.dy4k, rg_total, gtile * 8, tid);
+        b_acc_zero(acc);
+        pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D4), 2 * wave, lane, acc);
+        __syncthreads();
+        b_epilogue(acc, m3, X, wave, lane);
+        __syncthreads();
+        // ---- layer 3: dY3 -> d h2, and the extras block (input columns 256..262 of W3), K split over the waves
+        pn_copy_out_kmajor<PN_H>(X, a.sv.dy3k, rg_total, gtile * 8, tid);
+        b_acc_zero(acc);
+        pn_gemm_f16x3<16, 9, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D3), 2 * wave, lane, acc);
+        {
+            f32x16 acce[2][2];
+            b_acc_zero(acce);
+            pn_gemm_f16x3<16, 9, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D3), 8, lane, acce, 4 * wave, 4 * wave + 4);
 #pragma unroll
-        for (int jj = 0; jj < 7; ++jj) E.dex[jj] = 0.f;
-    }
-    if constexpr (SLOT >= 3 && SLOT < 3 + 7 * 64 && (SLOT - 3) % 7 == 0) {
-        constexpr int q = (SLOT - 3) / 7, j = q / 4, k = q % 4;
-        const float *wj = w3ex + rq * 4 + 16 * j;
-        auto dot = [](const float4 &x, const float4 &y) { return x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w; };
-        if constexpr (k == 0) {
-            E.v = *reinterpret_cast<const float4 *>(T.buf + rrow * LDH + rq * 4 + 16 * j);
-            E.w0 = *reinterpret_cast<const float4 *>(wj); E.w1 = *reinterpret_cast<const float4 *>(wj + PN_H);
-        }
-        if constexpr (k == 1) {
-            E.dex[0] += dot(E.v, E.w0); E.dex[1] += dot(E.v, E.w1);
-            E.w0 = *reinterpret_cast<const float4 *>(wj + 2 * PN_H); E.w1 = *reinterpret_cast<const float4 *>(wj + 3 * PN_H); E.w2 = *reinterpret_cast<const float4 *>(wj + 4 * PN_H);
-            asm volatile("" : "+v"(E.dex[0]), "+v"(E.dex[1]));
-        }
-        if constexpr (k == 2) {
-            E.dex[2] += dot(E.v, E.w0); E.dex[3] += dot(E.v, E.w1); E.dex[4] += dot(E.v, E.w2);
-            E.w0 = *reinterpret_cast<const float4 *>(wj + 5 * PN_H); E.w1 = *reinterpret_cast<const float4 *>(wj + 6 * PN_H);
-            asm volatile("" : "+v"(E.dex[2]), "+v"(E.dex[3]), "+v"(E.dex[4]));
-        }
-        if constexpr (k == 3) {
-            E.dex[5] += dot(E.v, E.w0); E.dex[6] += dot(E.v, E.w1);
-            asm volatile("" : "+v"(E.dex[5]), "+v"(E.dex[6]));
-        }
-    }
-    if constexpr (SLOT == 452) {
+            for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) E.dex[jj] = group_sum_b<TPR>(E.dex[jj]);
-    }
-    if constexpr (SLOT == 456) {
-#pragma unroll
-        for (int jj = 4; jj < 7; ++jj) E.dex[jj] = group_sum_b<TPR>(E.dex[jj]);
-    }
-    if constexpr (SLOT == 460) {
-        if (rq == 0 && S.rp >= 0) {
-            atomicAdd(&a.g_color[3 * S.rp], E.dex[0]); atomicAdd(&a.g_color[3 * S.rp + 1], E.dex[1]); atomicAdd(&a.g_color[3 * S.rp + 2], E.dex[2]);
+                for (int r = 0; r < 4; ++r) atomicAdd(&red[(32 * rb + (lane & 31)) * 8 + 4 * (lane >> 5) + r], acce[0][rb][r]);
         }
-    }
-    if constexpr (SLOT == 464) {
-        if (rq == 0 && S.rp >= 0) {
-            float vx, vy, vz, gx, gy, gz;
-            rot3b(a.cam.rw2c, S.rdx, S.rdy, S.rdz, true, vx, vy, vz);
-            // features (q - v, q . v) with q = dir @ Rw2c^T  ->  d q = dex[3:6] + dex[6] * v ; d dir = d q @ Rw2c
-            rot3b(a.cam.rw2c, E.dex[3] + E.dex[6] * vx, E.dex[4] + E.dex[6] * vy, E.dex[5] + E.dex[6] * vz, false, gx, gy, gz);
-            atomicAdd(&a.g_dir[3 * S.rp], gx); atomicAdd(&a.g_dir[3 * S.rp + 1], gy); atomicAdd(&a.g_dir[3 * S.rp + 2], gz);
-        }
-    }
-}
-
-// P8: embedding gradient through [e | PE3(e)]: d e = dX[e] + sum_f 2^f (dX[sin] cos - dX[cos] sin)
-__device__ __forceinline__ void b2_emb(const BwdArgs &a, const B2Tile &T, const B2State &S, int tl) {
-    const int rrow = tl / TPR, rq = tl % TPR;
-    if (S.rp >= 0) {
-        const float *dx = T.buf + rrow * LDH;
-        const float *x0 = a.sv.x0 + (S.tile * PN_TILE + rrow) * PN_IN1P + PN_F + 6 * EPT * rq;          // EPT dims * 3 freqs * 2
-        float4 xs[6 * EPT / 4];
-#pragma unroll
-        for (int i = 0; i < 6 * EPT / 4; ++i) xs[i] = *reinterpret_cast<const float4 *>(x0 + 4 * i);
-        const float *xf = reinterpret_cast<const float *>(xs);
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-            const int dd = EPT * rq + i;
-            float g = dx[dd], fr = 1.f;
-#pragma unroll
-            for (int f = 0; f < 3; ++f) {
-                const int o = PN_F + (dd * 3 + f) * 2, l = (i * 3 + f) * 2;
-                g += fr * (dx[o] * xf[l + 1] - dx[o + 1] * xf[l]);
-                fr *= 2.f;
+        __syncthreads();
+        b_epilogue(acc, m2, X, wave, lane);
+        if (tid < PN_TILE) {        // d colour, d dir of the row's point from the extras' gradient
+            const int p = prow[tid];
+            const float4 u = *reinterpret_cast<const float4 *>(red + tid * 8), v = *reinterpret_cast<const float4 *>(red + tid * 8 + 4);
+            *reinterpret_cast<float4 *>(red + tid * 8) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(red + tid * 8 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p >= 0) {
+                const int r = sidx[tid] / a.SR;
+                float vx, vy, vz, gx, gy, gz;
+                rot3b(a.cam.rw2c, a.raydir[3 * r], a.raydir[3 * r + 1], a.raydir[3 * r + 2], true, vx, vy, vz);
+                // features (q - v, q . v) with q = dir @ Rw2c^T  ->  d q = dex[3:6] + dex[6] * v ; d dir = d q @ Rw2c
+                rot3b(a.cam.rw2c, u.w + v.z * vx, v.x + v.z * vy, v.y + v.z * vz, false, gx, gy, gz);
+                atomicAdd(&a.g_color[3 * p], u.x * invS); atomicAdd(&a.g_color[3 * p + 1], u.y * invS); atomicAdd(&a.g_color[3 * p + 2], u.z * invS);
+                atomicAdd(&a.g_dir[3 * p], gx * invS); atomicAdd(&a.g_dir[3 * p + 1], gy * invS); atomicAdd(&a.g_dir[3 * p + 2], gz * invS);
             }
-            atomicAdd(&a.g_emb[(long long)S.rp * PN_F + dd], g);
         }
-    }
-}
-
-// Epilogue pieces that run in the MFMA shadow.
-// E: element r of the finished accumulators of tile Y, times LeakyReLU' (bit r of m), into Y's LDS tile; bias column sums
-template <int R, bool MASK>
-__device__ __forceinline__ void b2_epi_piece(const f32x16 (&acc)[2][2], unsigned mlo, unsigned mhi, float *wy, float (&gb)[2]) {
-    constexpr int mt = R >> 5, ct = (R >> 4) & 1, reg = R & 15;
-    float v = acc[mt][ct][reg];
-    if (MASK) {
-        const unsigned bit = ((R < 32 ? mlo : mhi) >> (R & 31)) & 1u;
-        v *= bit ? 1.f : 0.01f;
-        gb[ct] += v;
-        asm volatile("" : "+v"(gb[ct]));       // pin the accumulation to this MFMA shadow (pure arithmetic is otherwise sunk to its use)
-    }
-    wy[(mt * 32 + (reg & 3) + 8 * (reg >> 2)) * LDH + ct * 32] = v;
-}
-
-#ifdef PN_PHASE_TRACE
-PN_TR_DECL(pn_trace_bwd);
-#endif
-// ---- the tile-boundary program, one slot at a time in the MFMA shadows of the OTHER tile's GEMM --------------------------
-// Between a tile's last GEMM (layer 1) and the first GEMM of the tile that replaces it in the same LDS buffer lie: E1
-// (d X0 accumulators -> LDS), the embedding gradient, the next tile's loads, its alpha head and its dY4 pass -- four
-// workgroup barriers and ~1300 instructions.  All of it is issued by the waves that run the other tile's 512-MFMA GEMM.
-// Everything from HBM is requested in ONE burst at slot 0 (a second burst would stall the GEMM's own operand loads a second
-// time: vmcnt retires in order).  Slot map:
-//   0..8   burst: embedding values of the finished tile (for its embedding gradient), next tile's masks / row metadata / h4 / d f
-//   10..73 E1: accumulator element s-10 -> LDS                                  75: barrier
-//   77..140 embedding gradient, one embedding dim per 8 slots                   141: barrier (buffer free)
-//   143..161 next tile: state, metadata and the staged h4 / d f rows -> LDS     240: d sigma -> LDS   244: barrier
-//   246..312 alpha head (one float4 column group per 4 slots, loads two slots ahead of use)  314, 316: reduce, softplus', d conf   320: barrier
-//   322..449 dY4 pass (one tile row group per 8 slots)         452: d b5
-// A piece never consumes an LDS / HBM value in the slot that requested it (the wave would wait, and the MFMA stream with it),
-// and stays under ~12 instructions (the shadow of one MFMA).
-struct B2Bnd {
-    float4 ev[EPT / 4];          // this thread's EPT embedding values of its row of the finished tile (columns 0..31 of the saved X0)
-    float sc[6];                 // (sin, cos) x 3 octaves of the embedding dim being processed: recomputed like the forward computes them
-                                 // (one sincosf + double-angle steps) instead of loading 48 floats per thread in the burst
-    float4 h4[16], df[2];        // staged rows of the next tile
-    unsigned long long nm1, nm2, nm3;
-    int4 rm;
-    float dsgv, s, dotf;
-    float4 hv, g4, o;            // dY4 pass registers
-    float4 exn;                  // next tile's extras
-    float wv, drv; int siv;
-    float dxv[7];
-    long long ntile; bool nvalid;
-#ifdef PN_PHASE_TRACE
-    int titer, trbase;
-#endif
-};
-
-template <int SLOT, bool DFS_LDS>
-__device__ __forceinline__ void b2_boundary_slot(const BwdArgs &a, const B2Tile &T, B2State &S, const f32x16 (&acc)[2][2], float *wy, B2Bnd &C,
-                                                 long long next_tile, long long ntiles, const float *w5s, float b5, int tl, int TS, int K,
-                                                 float4 &gb4v, float4 &gw5v, float &gb5t) {
-    const int rrow = tl / TPR, rq = tl % TPR;
-    constexpr int S_E1 = 10, S_EMB = 77, S_NEXT = 143, S_ALPHA = 246, S_DY4 = 322;
-    // ---- one burst of requests
-    if constexpr (SLOT == 0) {
-        const float *x0 = a.sv.x0 + (S.tile * PN_TILE + rrow) * PN_IN1P + EPT * rq;
+        __syncthreads();
+        // ---- layer 2: dY2 -> d h1
+        pn_copy_out_kmajor<PN_H>(X, a.sv.dy2k, rg_total, gtile * 8, tid);
+        b_acc_zero(acc);
+        pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D2), 2 * wave, lane, acc);
+        __syncthreads();
+        b_epilogue(acc, m1, X, wave, lane);
+        __syncthreads();
+        // ---- layer 1: dY1 -> d X0 (columns 0..223), fp32 into LDS
+        pn_copy_out_kmajor<PN_H>(X, a.sv.dy1k, rg_total, gtile * 8, tid);
+        b_acc_zero(acc);
+        if (wave < 3) pn_gemm_f16x3<16, PN_MB_D1, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D1), 2 * wave, lane, acc);
+        else pn_gemm_f16x3<16, PN_MB_D1, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D1), 6, lane, acc);
+        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < EPT / 4; ++i) C.ev[i] = *reinterpret_cast<const float4 *>(x0 + 4 * i);
-        C.ntile = next_tile; C.nvalid = next_tile < ntiles;
-    }
-    if constexpr (SLOT == 3) {
-        const long long te = C.nvalid ? C.ntile : ntiles;          // an invalid tile reads the (allocated) padding tile and is masked out below
-        C.nm1 = a.sv.lmask[(te * 3 + 0) * PN_NTHR + tl];
-        C.nm2 = a.sv.lmask[(te * 3 + 1) * PN_NTHR + tl];
-        C.nm3 = a.sv.lmask[(te * 3 + 2) * PN_NTHR + tl];
-        C.rm = a.sv.rmeta[te * PN_TILE + (tl & 63)];
-        C.exn = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (C.nvalid && tl < 2 * PN_TILE) C.exn = *reinterpret_cast<const float4 *>(a.sv.ex + te * PN_TILE * 8 + tl * 4);
-    }
-    if constexpr (SLOT >= 4 && SLOT < 8) {
-        const long long te = C.nvalid ? C.ntile : ntiles;
+        for (int fb = 0; fb < 2; ++fb)
+            if (2 * wave + fb < PN_MB_D1) {
 #pragma unroll
-        for (int i = (SLOT - 4) * 4; i < (SLOT - 4) * 4 + 4; ++i) {
-            C.h4[i] = make_float4(0.f, 0.f, 0.f, 0.f);     // (an invalid tile must not bring the padding tile's garbage in: 0 * NaN)
-            if (C.nvalid) C.h4[i] = *reinterpret_cast<const float4 *>(a.sv.h4 + (te * PN_TILE + (tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4);
-        }
-    }
-    if constexpr (DFS_LDS && SLOT == 8) {
-        const long long te = C.nvalid ? C.ntile : ntiles;
+                for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            C.df[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (C.nvalid) C.df[i] = *reinterpret_cast<const float4 *>(a.sv.dfs + (te * TS + (tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4);
-        }
-    }
-    // ---- E1 of the finished tile
-    if constexpr (SLOT >= S_E1 && SLOT < S_E1 + 64) {
-        float gd[2] = {0.f, 0.f};
-        b2_epi_piece<SLOT - S_E1, false>(acc, 0u, 0u, wy, gd);
-    }
-    if constexpr (SLOT == 75 || SLOT == 141 || SLOT == 244 || SLOT == 320) __syncthreads();
-#ifdef PN_PHASE_TRACE
-    if constexpr (SLOT == 0 || SLOT == 3 || SLOT == 9 || SLOT == 17 || SLOT == 34 || SLOT == 50 || SLOT == 74 || SLOT == 140 || SLOT == 243 || SLOT == 319) {
-        constexpr int k = SLOT == 0 ? 0 : SLOT == 3 ? 1 : SLOT == 9 ? 2 : SLOT == 17 ? 3 : SLOT == 34 ? 4 : SLOT == 50 ? 5 : SLOT == 74 ? 6 : SLOT == 140 ? 7 : SLOT == 243 ? 8 : 9;
-        const int tid = threadIdx.x, titer = C.titer;
-        if (C.trbase >= 0) PN_TR(pn_trace_bwd, C.trbase + k);
-    }
-#endif
-    // ---- embedding gradient of the finished tile: dim i of this thread at slots S_EMB + 8 i (+0 LDS reads, +3 / +5 math, +6 atomic)
-    if constexpr (SLOT >= S_EMB && SLOT < S_EMB + 64 && (SLOT - S_EMB) % 8 == 0) {
-        constexpr int i = (SLOT - S_EMB) / 8;
-        const float *dx = T.buf + rrow * LDH;
-        const int dd = EPT * rq + i;
-        C.dxv[0] = dx[dd];
-#pragma unroll
-        for (int f = 0; f < 3; ++f) {
-            const float2 t = *reinterpret_cast<const float2 *>(dx + PN_F + dd * 6 + 2 * f);
-            C.dxv[1 + 2 * f] = t.x; C.dxv[2 + 2 * f] = t.y;
-        }
-    }
-    if constexpr (SLOT >= S_EMB && SLOT < S_EMB + 64 && (SLOT - S_EMB) % 8 == 1) {
-        constexpr int i = (SLOT - S_EMB) / 8;
-        const float e = i % 4 == 0 ? C.ev[i / 4].x : i % 4 == 1 ? C.ev[i / 4].y : i % 4 == 2 ? C.ev[i / 4].z : C.ev[i / 4].w;
-        float sn, cs;
-        sincosf(e, &sn, &cs);
-#pragma unroll
-        for (int f = 0; f < 3; ++f) {
-            C.sc[2 * f] = sn; C.sc[2 * f + 1] = cs;
-            const float s2 = 2.f * sn * cs;
-            cs = 1.f - 2.f * sn * sn; sn = s2;
-        }
-    }
-    if constexpr (SLOT >= S_EMB && SLOT < S_EMB + 64 && (SLOT - S_EMB) % 8 == 3) {
-        C.dxv[0] += (C.dxv[1] * C.sc[1] - C.dxv[2] * C.sc[0]) + 2.f * (C.dxv[3] * C.sc[3] - C.dxv[4] * C.sc[2]);
-        asm volatile("" : "+v"(C.dxv[0]));
-    }
-    if constexpr (SLOT >= S_EMB && SLOT < S_EMB + 64 && (SLOT - S_EMB) % 8 == 5) {
-        constexpr int i = (SLOT - S_EMB) / 8;
-        const float g = C.dxv[0] + 4.f * (C.dxv[5] * C.sc[5] - C.dxv[6] * C.sc[4]);
-        if (S.rp >= 0) atomicAdd(&a.g_emb[(long long)S.rp * PN_F + EPT * rq + i], g);
-    }
-    // ---- the next tile takes over the buffer
-    if constexpr (SLOT == S_NEXT) {
-        S.tile = C.nvalid ? C.ntile : ntiles; S.valid = C.nvalid;      // an invalid tile lives on the padding tile's storage
-        S.m1 = C.nvalid ? C.nm1 : 0ull; S.m2 = C.nvalid ? C.nm2 : 0ull; S.m3 = C.nvalid ? C.nm3 : 0ull;
-        S.rdx = S.rdy = S.rdz = 0.f;
-        S.exv = C.exn;
-        const int si = C.nvalid ? C.rm.x : -1;
-        C.dsgv = 0.f;
-        if (si >= 0) C.dsgv = a.grad_decoded[(long long)si * 4];
-        if (tl < PN_TILE) {
-            T.sidx[tl] = si; T.prow[tl] = C.nvalid ? C.rm.y : -1;
-            T.wnrm[tl] = C.nvalid ? __int_as_float(C.rm.z) : 0.f; T.wrow[tl] = C.nvalid ? __int_as_float(C.rm.w) : 0.f;
-        }
-    }
-    if constexpr (SLOT > S_NEXT && SLOT <= S_NEXT + 16) {
-        constexpr int i = SLOT - S_NEXT - 1;
-        *reinterpret_cast<float4 *>(T.buf + ((tl >> 6) + 4 * i) * LDH + (tl & 63) * 4) = C.h4[i];
-    }
-    if constexpr (DFS_LDS && (SLOT == S_NEXT + 17 || SLOT == S_NEXT + 18)) {
-        constexpr int i = SLOT - S_NEXT - 17;
-        *reinterpret_cast<float4 *>(T.dfs + ((tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4) = C.df[i];
-    }
-    if constexpr (SLOT == 240) {
-        if (tl < PN_TILE) T.dsg[tl] = C.dsgv;
-    }
-    // ---- alpha head of the next tile: float4 column group j loaded at S_ALPHA + 1 + 4 j, consumed two slots later
-    if constexpr (SLOT == S_ALPHA) {
-        S.rsi = T.sidx[rrow]; S.rp = T.prow[rrow];
-        C.s = 0.f; C.dotf = 0.f;
-        if (rq == 0 && S.rp >= 0) {
-            const int r = S.rsi / a.SR;
-            S.rdx = a.raydir[3 * r]; S.rdy = a.raydir[3 * r + 1]; S.rdz = a.raydir[3 * r + 2];
-        }
-    }
-    if constexpr (SLOT > S_ALPHA && SLOT <= S_ALPHA + 64 && (SLOT - S_ALPHA - 1) % 4 == 0) {
-        constexpr int j = (SLOT - S_ALPHA - 1) / 4;
-        const int rls = rrow / K;
-        C.hv = *reinterpret_cast<const float4 *>(T.buf + rrow * LDH + rq * 4 + 16 * j);
-        C.g4 = DFS_LDS ? *reinterpret_cast<const float4 *>(T.dfs + rls * PN_H + rq * 4 + 16 * j)
-                       : *reinterpret_cast<const float4 *>(a.sv.dfs + (S.tile * TS + rls) * PN_H + rq * 4 + 16 * j);
-        C.o = *reinterpret_cast<const float4 *>(w5s + rq * 4 + 16 * j);
-    }
-    if constexpr (SLOT > S_ALPHA && SLOT <= S_ALPHA + 66 && (SLOT - S_ALPHA - 1) % 4 == 2) {
-        C.s += C.hv.x * C.o.x + C.hv.y * C.o.y + C.hv.z * C.o.z + C.hv.w * C.o.w;
-        C.dotf += C.hv.x * C.g4.x + C.hv.y * C.g4.y + C.hv.z * C.g4.z + C.hv.w * C.g4.w;
-        asm volatile("" : "+v"(C.s), "+v"(C.dotf));
-    }
-    if constexpr (SLOT == 314) {
-        C.s = group_sum_b<TPR>(C.s);
-        C.dotf = group_sum_b<TPR>(C.dotf);
-    }
-    if constexpr (SLOT == 316) {
-        if (rq == 0) {
-            float dr = 0.f;
-            if (S.rsi >= 0) {
-                const float x = C.s + b5 - 1.0f;
-                const float alpha = x > 20.f ? x : log1pf(expf(x));
-                const float sg = x > 20.f ? 1.f : 1.0f / (1.0f + expf(-x));
-                if (S.rp >= 0) atomicAdd(&a.g_conf[S.rp], (T.dsg[rrow] * alpha + C.dotf) * T.wnrm[rrow]);
-                dr = T.dsg[rrow] * T.wrow[rrow] * sg;
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4 *>(dx + (32 * rb + (lane & 31)) * LDDX + pn_d_feat(2 * wave + fb, g, lane)) =
+                            make_float4(acc[fb][rb][4 * g], acc[fb][rb][4 * g + 1], acc[fb][rb][4 * g + 2], acc[fb][rb][4 * g + 3]);
             }
-            T.draw[rrow] = dr;
-        }
-    }
-    // ---- dY4 pass of the next tile: row group i at slots S_DY4 + 8 i: +0 LDS reads, +2 / +3 math, +4 partial sums, +5 LDS write, +6 HBM store
-    if constexpr (SLOT >= S_DY4 && SLOT < S_DY4 + 128 && (SLOT - S_DY4) % 8 == 0) {
-        constexpr int i = (SLOT - S_DY4) / 8;
-        const int row = (tl >> 6) + 4 * i, c4 = tl & 63;
-        C.siv = T.sidx[row];
-        C.hv = *reinterpret_cast<const float4 *>(T.buf + row * LDH + c4 * 4);
-        C.g4 = DFS_LDS ? *reinterpret_cast<const float4 *>(T.dfs + (row / K) * PN_H + c4 * 4)
-                       : *reinterpret_cast<const float4 *>(a.sv.dfs + (S.tile * TS + row / K) * PN_H + c4 * 4);
-        C.wv = T.wrow[row]; C.drv = T.draw[row];
-    }
-    if constexpr (SLOT >= S_DY4 && SLOT < S_DY4 + 128 && ((SLOT - S_DY4) % 8 == 2 || (SLOT - S_DY4) % 8 == 3)) {
-        const float4 w5 = *reinterpret_cast<const float4 *>(w5s + (tl & 63) * 4);
-        const float m = C.siv >= 0 ? 1.f : 0.f;                     // invalid rows: kills garbage d f / h4 of the padding tile too
-        const float w = C.wv * m, dr = C.drv * m;
-        if ((SLOT - S_DY4) % 8 == 2) {
-            C.o.x = C.siv >= 0 ? (w * C.g4.x + dr * w5.x) * pn_lrelu_grad(C.hv.x) : 0.f;
-            C.o.y = C.siv >= 0 ? (w * C.g4.y + dr * w5.y) * pn_lrelu_grad(C.hv.y) : 0.f;
-            asm volatile("" : "+v"(C.o.x), "+v"(C.o.y));
-        } else {
-            C.o.z = C.siv >= 0 ? (w * C.g4.z + dr * w5.z) * pn_lrelu_grad(C.hv.z) : 0.f;
-            C.o.w = C.siv >= 0 ? (w * C.g4.w + dr * w5.w) * pn_lrelu_grad(C.hv.w) : 0.f;
-            asm volatile("" : "+v"(C.o.z), "+v"(C.o.w));
-        }
-    }
-    if constexpr (SLOT >= S_DY4 && SLOT < S_DY4 + 128 && (SLOT - S_DY4) % 8 == 4) {
-        const float dr = C.siv >= 0 ? C.drv : 0.f;
-        gw5v.x += dr * C.hv.x; gw5v.y += dr * C.hv.y; gw5v.z += dr * C.hv.z; gw5v.w += dr * C.hv.w;
-        gb4v.x += C.o.x; gb4v.y += C.o.y; gb4v.z += C.o.z; gb4v.w += C.o.w;
-        asm volatile("" : "+v"(gw5v.x), "+v"(gw5v.y), "+v"(gw5v.z), "+v"(gw5v.w), "+v"(gb4v.x), "+v"(gb4v.y), "+v"(gb4v.z), "+v"(gb4v.w));
-    }
-    if constexpr (SLOT >= S_DY4 && SLOT < S_DY4 + 128 && (SLOT - S_DY4) % 8 == 5) {
-        constexpr int i = (SLOT - S_DY4) / 8;
-        *reinterpret_cast<float4 *>(T.buf + ((tl >> 6) + 4 * i) * LDH + (tl & 63) * 4) = C.o;
-    }
-    if constexpr (SLOT >= S_DY4 && SLOT < S_DY4 + 128 && (SLOT - S_DY4) % 8 == 6) {
-        constexpr int i = (SLOT - S_DY4) / 8;
-        pn_store_stream(a.sv.dy4 + (S.tile * PN_TILE + (tl >> 6) + 4 * i) * PN_H + (tl & 63) * 4, C.o);
-    }
-    if constexpr (SLOT == 452) {
-        if (tl < PN_TILE) gb5t += T.draw[tl];
-    }
-}
-
-// DFS_LDS: the tile's d f rows (TS x 256 floats) fit the 8 KB LDS region (K >= 8); otherwise they are read from HBM/L2.
-template <bool DFS_LDS>
-__global__ __launch_bounds__(PN_NTHR, 1) void k_agg_backward(BwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const B2Tile TA = b2_carve(smem), TB = b2_carve(smem + B2_TILE_FLOATS);
-    float *w5s = smem + 2 * B2_TILE_FLOATS;    // [256]
-    float *w3ex = w5s + PN_H;                  // [7][256]  W3[o][256+j]
-    const int tid = threadIdx.x;
-    const int K = a.K, TS = a.TS;
-    // this launch processes one sample class: its run of tiles, its range of per-sample rows
-    const int Ns = a.cls_info[PN_CI_COUNT + a.cls];
-    {
-        const long long vb = a.cls_info[PN_CI_VBASE + a.cls], tb = a.cls_info[PN_CI_TBASE + a.cls];
-        a.sv.dfs += vb * PN_H;
-        a.sv.x0 += tb * PN_TILE * PN_IN1P; a.sv.ex += tb * PN_TILE * 8; a.sv.rmeta += tb * PN_TILE; a.sv.lmask += tb * 3 * PN_NTHR;
-        a.sv.h4 += tb * PN_TILE * PN_H;
-        a.sv.dy1 += tb * PN_TILE * PN_H; a.sv.dy2 += tb * PN_TILE * PN_H; a.sv.dy3 += tb * PN_TILE * PN_H; a.sv.dy4 += tb * PN_TILE * PN_H;
-    }
-    const long long ntiles = ((long long)Ns + TS - 1) / TS;
-    const float *P = a.params;
-    if (tid < PN_H) {
-        w5s[tid] = P[PO_W5 + tid];
-        for (int j = 0; j < 7; ++j) w3ex[j * PN_H + tid] = P[PO_W3 + tid * PN_IN3 + PN_H + j];
-    }
-    const float b5 = P[PO_B5];
-    // gradient partial sums that live in registers for the whole kernel
-    float gb[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};      // d b1..b3: accumulator layout, columns wave*64 + ct*32 + (lane&31)
-    float4 gb4v = make_float4(0.f, 0.f, 0.f, 0.f), gw5v = gb4v;  // d b4, d W5: columns 4*lane .. 4*lane+3
-    float gw3e[7][4];                                            // d W3[col][256 + j], columns 4*lane .. +3
+        __syncthreads();
+        // ---- embedding gradient through [e | PE3(e)]: d e = dX[e] + sum_f 2^f (dX[sin_f] cos_f - dX[cos_f] sin_f)
+        if (rp >= 0) {
+            const float *dr_ = dx + row * LDDX;
+            const float e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
 #pragma unroll
-    for (int j = 0; j < 7; ++j)
+            for (int i = 0; i < EPT; ++i) {
+                const int dd = EPT * q + i;
+                float s, c;
+                pn_sincos(e[i], s, c);
+                float g = dr_[dd], fr = 1.f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) gw3e[j][c] = 0.f;
-    float gb5t = 0.f;
-    f32x16 accA[2][2], accB[2][2];
-    pn_acc_zero(accA); pn_acc_zero(accB);
-    B2State SA, SB;
-    B2Bnd CB;
-    float4 bpre[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};   // chunk-0 weight fragments of the next GEMM
-    if ((long long)blockIdx.x * 2 < ntiles) {
-        // prologue: the first tile of buffer A, plain; buffer B starts as an empty finished tile (zero accumulators, no rows)
-        b2_load<DFS_LDS>(a, TA, SA, 2 * (long long)blockIdx.x, ntiles, tid, TS);
-        SB.tile = ntiles; SB.valid = false; SB.m1 = SB.m2 = SB.m3 = 0ull; SB.rdx = SB.rdy = SB.rdz = 0.f; SB.rsi = -1; SB.rp = -1;
-        __syncthreads();
-        b2_alpha<DFS_LDS>(a, TA, SA, w5s, b5, tid, TS, K);
-        __syncthreads();
-        b2_dy4<DFS_LDS>(a, TA, SA, w5s, tid, TS, K, gb4v, gw5v, gb5t);
-    }
-#ifdef PN_PHASE_TRACE
-    int titer = -1;
-#endif
-    for (long long pair = blockIdx.x; pair * 2 < ntiles; pair += gridDim.x) {
-#ifdef PN_PHASE_TRACE
-        ++titer;
-#endif
-        // thread-index-derived offsets are recomputed per pair (a few VALU ops) instead of living in registers across the loop
-        int tl = threadIdx.x;
-        asm volatile("" : "+v"(tl));
-        const int lane = tl & 63, wave = tl >> 6;
-        __syncthreads();
-        PN_TR(pn_trace_bwd, 0); PN_TR_HWID(pn_trace_bwd);
-        float *wyA = TA.buf + (4 * (lane >> 5)) * LDH + wave * 64 + (lane & 31);     // accumulator-layout write base
-        float *wyB = TB.buf + (4 * (lane >> 5)) * LDH + wave * 64 + (lane & 31);
-        const float *rxA = TA.buf + wave * LDH + lane * 4, *rxB = TB.buf + wave * LDH + lane * 4;   // copy-out read base (+ 4*i rows)
-        const long long gA = SA.tile * PN_TILE + wave;                                  // copy-out row base (+ 4*i)
-        const long long nextB = 2 * pair + 1, nextA = 2 * (pair + gridDim.x);
-        float4 cpv = make_float4(0.f, 0.f, 0.f, 0.f), exa = cpv, exb2 = cpv;
-        B2Ext EX;
-        float gnone[2] = {0.f, 0.f};
-        if (pair == (long long)blockIdx.x) pn_gemm_prefetch_b0(a.packed + PK_D4 / 4, wave, lane, bpre);
-#ifdef PN_PHASE_TRACE
-        CB.titer = titer; CB.trbase = 11;
-#endif
-
-        // one G step: GEMM of tile X (LDS XB, accumulators ACCX, weight image PK) with, in the MFMA shadows,
-        //   E (MASKED: x LeakyReLU' of mask word MY, column sums into GBY) of the other tile's accumulators ACCY -> WY,
-        //   the copy-out of X's own finished rows RX -> DST (COPY), plus the W3-extras gradient (EXTRAS), and
-        //   optionally the whole boundary program of the other tile (BND)
-#define B2_NOBND(s_) (void)0
-#define B2_BND_B(s_) b2_boundary_slot<s_, DFS_LDS>(a, TB, SB, accB, wyB, CB, nextB, ntiles, w5s, b5, tl, TS, K, gb4v, gw5v, gb5t)
-#define B2_BND_A(s_) b2_boundary_slot<s_, DFS_LDS>(a, TA, SA, accA, wyA, CB, nextA, ntiles, w5s, b5, tl, TS, K, gb4v, gw5v, gb5t)
-#define B2_STEP(XB, ACCX, PK, PKNEXT, ACCY, MY, WY, GBY, EPI, MASKED, COPY, EXTRAS, EXW, XT, XS, RX, DST, GROW, BND)                  \
-        {                                                                                                                           \
-            const unsigned mlo_ = (unsigned)(MY), mhi_ = (unsigned)((MY) >> 32);                                                    \
-            pn_acc_zero(ACCX);                                                                                                      \
-            pn_tile_gemm_side<PN_H / 8>(XB, LDH, a.packed + (PK) / 4, wave, lane, ACCX, bpre, a.packed + (PKNEXT) / 4, [&](auto ss) { \
-                constexpr int s = decltype(ss)::value;                                                                              \
-                if constexpr (EPI && s % 8 == 0) b2_epi_piece<s / 8, MASKED>(ACCY, mlo_, mhi_, WY, GBY);                            \
-                if constexpr (EXW && s == 1) {        /* the tile's extras take over its d f region (dead since the dY4 pass) */          \
-                    if (tl < 2 * PN_TILE) *reinterpret_cast<float4 *>((XT).dfs + tl * 4) = (XS).exv;                                   \
-                }                                                                                                                   \
-                if constexpr (COPY && EXTRAS && s % 32 == 2) {                                                                      \
-                    const float *exr = (XT).dfs + (wave + 4 * (s / 32)) * 8;                                                         \
-                    exa = *reinterpret_cast<const float4 *>(exr); exb2 = *reinterpret_cast<const float4 *>(exr + 4);                \
-                }                                                                                                                   \
-                if constexpr (COPY && s % 32 == 4) cpv = *reinterpret_cast<const float4 *>((RX) + 4 * (s / 32) * LDH);              \
-                if constexpr (COPY && s % 32 == 20) pn_store_stream((DST) + ((GROW) + 4 * (s / 32)) * PN_H + lane * 4, cpv);             \
-                if constexpr (COPY && EXTRAS && s % 32 >= 21 && s % 32 < 28) {                                                      \
-                    constexpr int j_ = s % 32 - 21;                                                                                 \
-                    const float e_ = j_ == 0 ? exa.x : j_ == 1 ? exa.y : j_ == 2 ? exa.z : j_ == 3 ? exa.w : j_ == 4 ? exb2.x : j_ == 5 ? exb2.y : exb2.z; \
-                    gw3e[j_][0] += cpv.x * e_; gw3e[j_][1] += cpv.y * e_; gw3e[j_][2] += cpv.z * e_; gw3e[j_][3] += cpv.w * e_;      \
-                    asm volatile("" : "+v"(gw3e[j_][0]), "+v"(gw3e[j_][1]), "+v"(gw3e[j_][2]), "+v"(gw3e[j_][3]));                    \
-                }                                                                                                                   \
-                if constexpr (COPY && EXTRAS) b2_extras_slot<s>(a, XT, XS, w3ex, EX, tl);                                          \
-                BND(s);                                                                                                             \
-            });                                                                                                                     \
-            __syncthreads();                                                                                                        \
+                for (int f = 0; f < 3; ++f) {
+                    const float2 t = *reinterpret_cast<const float2 *>(dr_ + PN_F + dd * 6 + 2 * f);
+                    g += fr * (t.x * c - t.y * s);
+                    const float s2 = 2.f * s * c;
+                    c = 1.f - 2.f * s * s; s = s2;
+                    fr *= 2.f;
+                }
+                atomicAdd(&a.g_emb[(long long)rp * PN_F + dd], g * invS);
+            }
         }
-        //      X-tile   accX  image  next   accY  maskY  writeY gbY    EPI    MASK   COPY   EXTRAS EXW   X   state readX dst       rowbase boundary
-        B2_STEP(TA.buf, accA, PK_D4, PK_D4, accB, 0ull, wyB, gnone, false, false, false, false, true, TA, SA, rxA, a.sv.dy3, gA, B2_BND_B)
-        PN_TR(pn_trace_bwd, 1);
-        const long long gB = SB.tile * PN_TILE + wave;
-        B2_STEP(TB.buf, accB, PK_D4, PK_D3, accA, SA.m3, wyA, gb[2], true, true, false, false, true, TB, SB, rxB, a.sv.dy3, gB, B2_NOBND)
-        PN_TR(pn_trace_bwd, 2);
-        PN_TR(pn_trace_bwd, 3);
-        B2_STEP(TA.buf, accA, PK_D3, PK_D3, accB, SB.m3, wyB, gb[2], true, true, true, true, false, TA, SA, rxA, a.sv.dy3, gA, B2_NOBND)
-        PN_TR(pn_trace_bwd, 4);
-        PN_TR(pn_trace_bwd, 5);
-        B2_STEP(TB.buf, accB, PK_D3, PK_D2, accA, SA.m2, wyA, gb[1], true, true, true, true, false, TB, SB, rxB, a.sv.dy3, gB, B2_NOBND)
-        PN_TR(pn_trace_bwd, 6);
-        B2_STEP(TA.buf, accA, PK_D2, PK_D2, accB, SB.m2, wyB, gb[1], true, true, true, false, false, TA, SA, rxA, a.sv.dy2, gA, B2_NOBND)
-        PN_TR(pn_trace_bwd, 7);
-        B2_STEP(TB.buf, accB, PK_D2, PK_D1, accA, SA.m1, wyA, gb[0], true, true, true, false, false, TB, SB, rxB, a.sv.dy2, gB, B2_NOBND)
-        PN_TR(pn_trace_bwd, 8);
-        B2_STEP(TA.buf, accA, PK_D1, PK_D1, accB, SB.m1, wyB, gb[0], true, true, true, false, false, TA, SA, rxA, a.sv.dy1, gA, B2_NOBND)
-        PN_TR(pn_trace_bwd, 9);
-#ifdef PN_PHASE_TRACE
-        CB.trbase = -1;
-#endif
-        B2_STEP(TB.buf, accB, PK_D1, PK_D4, accA, 0ull, wyA, gnone, false, false, true, false, false, TB, SB, rxB, a.sv.dy1, gB, B2_BND_A)
-        PN_TR(pn_trace_bwd, 10);
-#undef B2_STEP
-#undef B2_BND_A
-#undef B2_BND_B
-#undef B2_NOBND
-    }
-    if ((long long)blockIdx.x * 2 < ntiles) {
-        // epilogue: d X0 of the last B tile and its embedding gradient (A's were done inside the last step)
-        const int lane = tid & 63, wave = tid >> 6;
-        float *wyB = TB.buf + (4 * (lane >> 5)) * LDH + wave * 64 + (lane & 31);
-        float gnone[2] = {0.f, 0.f};
-        pn_static_for<64>([&](auto rr) { b2_epi_piece<decltype(rr)::value, false>(accB, 0u, 0u, wyB, gnone); });
-        __syncthreads();
-        b2_emb(a, TB, SB, tid);
     }
     // flush the register-resident partial sums
     {
-        const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const int col = wave * 64 + ct * 32 + (lane & 31);
-            atomicAdd(&a.gparams[PO_B1 + col], gb[0][ct]);
-            atomicAdd(&a.gparams[PO_B2 + col], gb[1][ct]);
-            atomicAdd(&a.gparams[PO_B3 + col], gb[2][ct]);
-        }
-        const float g4[4] = {gb4v.x, gb4v.y, gb4v.z, gb4v.w}, g5[4] = {gw5v.x, gw5v.y, gw5v.z, gw5v.w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            atomicAdd(&a.gparams[PO_B4 + lane * 4 + c], g4[c]);
-            atomicAdd(&a.gparams[PO_W5 + lane * 4 + c], g5[c]);
-#pragma unroll
-            for (int j = 0; j < 7; ++j) atomicAdd(&a.gparams[PO_W3 + (lane * 4 + c) * PN_IN3 + PN_H + j], gw3e[j][c]);
-        }
-        if (tid < PN_TILE) atomicAdd(&a.gparams[PO_B5], gb5t);
+        const int c4 = tid0 & 63;
+        atomicAdd(&a.gparams[PO_W5 + c4 * 4], gw5v.x * invS); atomicAdd(&a.gparams[PO_W5 + c4 * 4 + 1], gw5v.y * invS);
+        atomicAdd(&a.gparams[PO_W5 + c4 * 4 + 2], gw5v.z * invS); atomicAdd(&a.gparams[PO_W5 + c4 * 4 + 3], gw5v.w * invS);
+        if (tid0 < PN_TILE) atomicAdd(&a.gparams[PO_B5], gb5t * invS);
     }
 }
 
@@ -941,207 +560,145 @@ int launch_wgrad_lds(const float *A, int lda, const float *B, int ldb, const flo
 }
 
 
-// ------------------------------------------------------------------------------ weight gradients, split-bf16 form
-// The 256 x 256 weight gradients of the four aggregator layers are 1/3 of the step's flops, and an fp32-input MFMA runs at
-// 1/16 of the bf16 rate.  k_wgrad_b3 computes the same fp32 product on the bf16 MFMA: every fp32 operand x is split into
-// three bf16 numbers by round-to-nearest,
-//     h = bf16(x),   m = bf16(x - h),   l = bf16((x - h) - m)      (both subtractions and the last conversion are exact)
-// so that x == h + m + l exactly (8 + 8 + 8 significand bits; for |x| below ~1e-33 the residuals are fp32 denormals and the
-// split loses its low bits -- of numbers that small), |m| <= 2^-8 |h|, |l| <= 2^-16 |h|, and  a*b  is accumulated (fp32, inside the
-// MFMA) as  ah*bl + ah*bm + ah*bh + am*bm + am*bh + al*bh:  the three dropped terms are below 2^-23 of the product, i.e. at
-// the level of the fp32 accumulation's own rounding (tests/test_split_bf16_cpu.py restates and checks this arithmetic).  Six
-// 32-cycle v_mfma_f32_32x32x16_bf16 (K = 16) replace eight 64-cycle v_mfma_f32_32x32x2_f32: 2.67x on the matrix pipe.
-// Measured (profiles/r01_pmc_wgrad_split.json): the MFMA pipe is busy ~65 % of the kernel, at a clock the bf16 MFMA load
-// pulls down to ~1.7 GHz (the fp32-MFMA kernels run at ~2.25 GHz).
-//
-// Block tile 256 x 256 (all of dW), 8 waves as 2 (M) x 4 (N), each 4 x 2 tiles of 32 x 32.  The operands are k-major in HBM
-// (row = k) and the MFMA wants 8 consecutive k per lane, so the loader thread owns ONE column and 8 consecutive rows
-// (8 dword loads, each coalesced over the wave), splits them in registers and writes one 16-byte [8 x bf16] fragment slot per
-// plane: the LDS image is [plane][k-half][column][8 k] and a fragment read is one conflict-free ds_read_b128.
-// The split (about 90 VALU operations per thread and k-step) is placed by hand between the step's MFMA groups -- a wave's
-// own VALU issues in the shadow of its MFMAs, another wave's does not -- and the global loads run two
-// k-steps ahead in two register sets (about 70 KB in flight per CU).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-struct B3Set { float a[8], b[8]; };
-
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float pn_f32x2 __attribute__((ext_vector_type(2)));
-
-// (x0, x1) -> one dword holding bf16(x0) | bf16(x1) << 16, round-to-nearest-even: one v_cvt_pk_bf16_f32
-__device__ __forceinline__ unsigned b3_pack(float x0, float x1) {
-    const pn_f32x2 v = {x0, x1};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ float b3_lo(unsigned p) { return __uint_as_float(p << 16); }
-__device__ __forceinline__ float b3_up(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
-
-// 4 floats (k, k+1, k+2, k+3 of one column) -> two packed dwords of each plane
-__device__ __forceinline__ void b3_split4(const float *x, unsigned *h, unsigned *m, unsigned *l) {
+// ------------------------------------------------------------------------------ weight gradients of the four 256-wide layers
+// dW[m][n] = sum_rows dY[row][m] X[row][n] on the f16 pipe: both operands arrive as ready-made two-plane fragments (the
+// producers wrote them k-major: f16x3.h), so the kernel is glds -> LDS -> ds_read_b128 -> MFMA with no conversion work:
+//   256 x (256 + 32) block (all of dW plus a 32-column tail) in the accumulators of 8 waves (2 (M) x 4 (N), 4 x 2 tiles each +
+//   one tail tile), split-K over the rows (one workgroup per CU), 32 rows per stage, two LDS stages filled by
+//   global_load_lds_dwordx4 (every (operand, plane) of a stage is one contiguous run in HBM and in LDS).
+// Tail: NFB == 288: the operand's own columns 256..287 (distance encoding of X0 / layer-3 extras, and the ONES column whose
+// "weight gradient" is the bias gradient); NFB == 256: a constant ones fragment (bias gradient of layers 2 and 4).
+// It is HBM-bound by design: 2 KB per row and layer at ~5 TB/s against ~0.4 us of MFMA work per 32 rows.
+template <int NFB>
+__global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, const uint4 *__restrict__ B, long long rg_total,
+                                                   const int *__restrict__ d_tiles, float *__restrict__ partial) {
+    constexpr int AU = 4 * 256, BU = 4 * NFB;                 // units (16 B) of one plane of a stage: 4 row groups
+    constexpr int STAGE = 2 * AU + 2 * BU;                    // [A h | A m | B h | B m]
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_w[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    // rows of this chunk: the tiles actually used are known on the device only
+    const long long rows = (long long)(*d_tiles) * PN_TILE;
+    long long rpc = (rows + gridDim.x - 1) / gridDim.x;
+    rpc = (rpc + 63) / 64 * 64;
+    const long long r0 = (long long)blockIdx.x * rpc;
+    long long r1 = r0 + rpc;
+    if (r1 > rows) r1 = rows;
+    const int nst = r1 > r0 ? (int)((r1 - r0) / 32) : 0;
+    f32x16 acc[4][2], acct;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const float x0 = x[2 * p], x1 = x[2 * p + 1];
-        h[p] = b3_pack(x0, x1);
-        const float r0 = x0 - b3_lo(h[p]), r1 = x1 - b3_up(h[p]);
-        m[p] = b3_pack(r0, r1);
-        l[p] = b3_pack(r0 - b3_lo(m[p]), r1 - b3_up(m[p]));
+    for (int r = 0; r < 16; ++r) {
+        acct[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; }
     }
-}
-
-// slot -> split piece (0..19) of a k-step, or -1: slots that carry a fragment read carry no piece
-constexpr bool b3_slot_reads(int s) { return s <= 5 || s == 12 || s == 13 || s == 20 || s == 21 || s == 24 || s == 25 || s == 36 || s == 37; }
-constexpr int b3_slot_work(int s) {
-    if (b3_slot_reads(s)) return -1;
-    int n = 0;
-    for (int i = 0; i < s; ++i) n += b3_slot_reads(i) ? 0 : 1;
-    return n < 20 ? n : -1;
-}
-
-constexpr int B3_PLANE = 2 * 256 + 2 * 256;      // uint4 slots of one plane: A [2][256], B [2][256]
-constexpr int B3_STAGE = 3 * B3_PLANE;           // 3072 slots = 48 KB
-constexpr size_t B3_LDS_BYTES = (size_t)2 * B3_STAGE * 16;
-
-template <int LDB>
-__global__ __launch_bounds__(512) void k_wgrad_b3(const float *__restrict__ A, const float *__restrict__ B, long long rows,
-                                                  const int *__restrict__ d_tiles, int rows_per_chunk, float *__restrict__ partial) {
-    constexpr int MT = 4, NT = 2, WN = 4, KB = 16, LDA = PN_H;
-    if (d_tiles) {
-        const long long r = (long long)(*d_tiles) * PN_TILE;
-        rows = r < rows ? r : rows;
-        long long rpc = (rows + gridDim.y - 1) / gridDim.y;
-        rpc = (rpc + 63) / 64 * 64;
-        rows_per_chunk = (int)(rpc < 64 ? 64 : rpc);
-    }
-    extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int col = tid & 255, kh = tid >> 8;
-    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
-    long long r1 = r0 + rows_per_chunk;
-    if (r1 > rows) r1 = rows;                     // rows and chunk bounds are multiples of 64: every 16-row step is full
-    const int nsteps = r1 > r0 ? (int)((r1 - r0) / KB) : 0;
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) acc[mt][nt][reg] = 0.f;
-    const float *pa = A + (r0 + kh * 8) * LDA + col, *pb = B + (r0 + kh * 8) * LDB + col;     // this thread's column, rows of the step to load
-    auto gload = [&](B3Set &S, bool advance) {         // !advance: past the end of the chunk, re-read the last step (never used)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { S.a[j] = pa[j * LDA]; S.b[j] = pb[j * LDB]; }
-        pa += advance ? KB * LDA : 0; pb += advance ? KB * LDB : 0;
+    // stage s -> buffer: wave-instruction j copies units [64 j, 64 j + 64) of the stage's concatenated runs
+    auto issue = [&](int s, int buf) {
+        const long long rg = r0 / 8 + 4LL * s;
+        constexpr int NI = STAGE / 64;
+        for (int j = wave; j < NI; j += 8) {
+            const int u0 = 64 * j;
+            const uint4 *src;
+            if (u0 < 2 * AU) { const int p = u0 / AU, u = u0 - p * AU; src = A + ((long long)p * rg_total + rg) * 256 + u; }
+            else { const int v = u0 - 2 * AU, p = v / BU, u = v - p * BU; src = B + ((long long)p * rg_total + rg) * NFB + u; }
+            __builtin_amdgcn_global_load_lds(src + lane, (__attribute__((address_space(3))) void *)(smem_w + buf * STAGE + u0), 16, 0, 0);
+        }
     };
-    uint2 *const wbase = reinterpret_cast<uint2 *>(smem4) + 2 * (kh * 256 + col);
-    // split 4 k of one operand's column into the three planes of LDS buffer `buf` (half a fragment slot each)
-    auto half = [&](const float *x, int buf, int operand, int hf) {
-        unsigned h[2], m[2], l[2];
-        b3_split4(x + 4 * hf, h, m, l);
-        uint2 *d = wbase + 2 * (buf * B3_STAGE + operand * 512) + hf;
-        d[0] = make_uint2(h[0], h[1]); d[2 * B3_PLANE] = make_uint2(m[0], m[1]); d[4 * B3_PLANE] = make_uint2(l[0], l[1]);
-    };
-    const uint4 *const fbase = smem4 + (lane >> 5) * 256 + (lane & 31);
-    auto frag = [&](int buf, int plane, int operand, int tile) -> bf16x8 {
-        return __builtin_bit_cast(bf16x8, fbase[buf * B3_STAGE + plane * B3_PLANE + operand * 512 + tile * 32]);
-    };
-    // One k-step = 48 MFMAs on LDS buffer CUR.  The three B planes of the wave's two column tiles stay in registers for the
-    // whole step; the A fragments stream through two 2-tile register buffers X / Y:
-    //     row-tile pair p (slots 24 p ..):  12 x  ah * {bl, bm, bh}   |   8 x  am * {bm, bh}   |   4 x  al * bh
-    // (every accumulator is touched once in four MFMAs).  After every MFMA one small piece of other work is issued
-    // (sched_barrier pins it there): the fragment reads of a later group, and the split of register set Sn into
-    // buffer CUR ^ 1 as 20 pieces (per half fragment slot: high plane of pair 0, its middle + low planes, the same for pair 1, 3 x ds_write_b64).
-    auto step = [&](auto cur_c, B3Set &Sn) {
-        constexpr int CUR = decltype(cur_c)::value;
-        bf16x8 ax[2], ay[2], bl[NT], bm[NT], bh[NT];
-        ax[0] = frag(CUR, 0, 0, wm * MT); ax[1] = frag(CUR, 0, 0, wm * MT + 1);
-        bl[0] = frag(CUR, 2, 1, wn * NT); bl[1] = frag(CUR, 2, 1, wn * NT + 1);
-        unsigned ph[2], pm[2], pl[2];
-        float r0 = 0.f, r1 = 0.f;
-        pn_static_for<48>([&](auto ss) {
-            constexpr int sl = decltype(ss)::value, pr = sl / 24, q = sl % 24;
-            constexpr int grp = q < 12 ? 0 : (q < 20 ? 1 : 2), qi = q - (grp == 0 ? 0 : grp == 1 ? 12 : 20);
-            constexpr int bp = grp == 0 ? qi / 4 : (grp == 1 ? 1 + qi / 4 : 2);            // 0: bl, 1: bm, 2: bh
-            constexpr int ml = qi % 2, nt = (qi % 4) / 2, mt = 2 * pr + ml;
-            constexpr bool use_x = (grp == 1) == (pr == 1);                                 // p0: X Y X, p1: Y X Y
-            const bf16x8 av = use_x ? ax[ml] : ay[ml];
-            const bf16x8 bv = bp == 0 ? bl[nt] : (bp == 1 ? bm[nt] : bh[nt]);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mt][nt], 0, 0, 0);
-            constexpr int w = b3_slot_work(sl);
-            if constexpr (sl == 0 || sl == 1) bm[sl] = frag(CUR, 1, 1, wn * NT + sl);
-            else if constexpr (sl == 2 || sl == 3) bh[sl - 2] = frag(CUR, 0, 1, wn * NT + sl - 2);
-            else if constexpr (sl == 4 || sl == 5) ay[sl - 4] = frag(CUR, 1, 0, wm * MT + sl - 4);             // am, pair 0
-            else if constexpr (sl == 12 || sl == 13) ax[sl - 12] = frag(CUR, 2, 0, wm * MT + sl - 12);          // al, pair 0
-            else if constexpr (sl == 20 || sl == 21) ay[sl - 20] = frag(CUR, 0, 0, wm * MT + 2 + sl - 20);      // ah, pair 1
-            else if constexpr (sl == 24 || sl == 25) ax[sl - 24] = frag(CUR, 1, 0, wm * MT + 2 + sl - 24);      // am, pair 1
-            else if constexpr (sl == 36 || sl == 37) ay[sl - 36] = frag(CUR, 2, 0, wm * MT + 2 + sl - 36);      // al, pair 1
-            else if constexpr (w >= 0) {
-                constexpr int hfi = w / 5, k = w % 5, operand = hfi / 2, hf = hfi % 2;      // per half slot: A0 B0 A1 B1 W
-                if constexpr (k == 0 || k == 2) {
-                    constexpr int pp = k / 2, j = 4 * hf + 2 * pp;
-                    const float x0 = operand == 0 ? Sn.a[j] : Sn.b[j], x1 = operand == 0 ? Sn.a[j + 1] : Sn.b[j + 1];
-                    ph[pp] = b3_pack(x0, x1);
-                    r0 = x0 - b3_lo(ph[pp]); r1 = x1 - b3_up(ph[pp]);
-                } else if constexpr (k == 1 || k == 3) {
-                    constexpr int pp = k / 2;
-                    pm[pp] = b3_pack(r0, r1);
-                    pl[pp] = b3_pack(r0 - b3_lo(pm[pp]), r1 - b3_up(pm[pp]));
+    pn_h8 ones = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((lane & 31) == 0) ones = pn_h8{1, 1, 1, 1, 1, 1, 1, 1};
+    if (nst > 0) {
+        issue(0, 0);
+        __syncthreads();
+        for (int s = 0; s < nst; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < nst) issue(s + 1, buf ^ 1);
+            const uint4 *st = smem_w + buf * STAGE;
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {                  // two 16-row k-steps per stage
+                const uint4 *fa = st + (2 * ss + (lane >> 5)) * 256 + (lane & 31);
+                const uint4 *fb = st + 2 * AU + (2 * ss + (lane >> 5)) * NFB + (lane & 31);
+                pn_h8 ah[4], am[4], bh[2], bm[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { ah[i] = __builtin_bit_cast(pn_h8, fa[(4 * wm + i) * 32]); am[i] = __builtin_bit_cast(pn_h8, fa[AU + (4 * wm + i) * 32]); }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { bh[i] = __builtin_bit_cast(pn_h8, fb[(2 * wn + i) * 32]); bm[i] = __builtin_bit_cast(pn_h8, fb[BU + (2 * wn + i) * 32]); }
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p == 2 ? am[i] : ah[i], p == 1 ? bm[j] : bh[j], acc[i][j], 0, 0, 0);
+                // tail tile: row tile 4 wm + wn of dW x columns 256..287
+                const pn_h8 tah = wn == 0 ? ah[0] : wn == 1 ? ah[1] : wn == 2 ? ah[2] : ah[3];
+                const pn_h8 tam = wn == 0 ? am[0] : wn == 1 ? am[1] : wn == 2 ? am[2] : am[3];
+                if (NFB > 256) {
+                    const pn_h8 tbh = __builtin_bit_cast(pn_h8, fb[256]), tbm = __builtin_bit_cast(pn_h8, fb[BU + 256]);
+                    acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbh, acct, 0, 0, 0);
+                    acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbm, acct, 0, 0, 0);
+                    acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tam, tbh, acct, 0, 0, 0);
                 } else {
-                    uint2 *d = wbase + 2 * ((CUR ^ 1) * B3_STAGE + operand * 512) + hf;
-                    d[0] = make_uint2(ph[0], ph[1]); d[2 * B3_PLANE] = make_uint2(pm[0], pm[1]); d[4 * B3_PLANE] = make_uint2(pl[0], pl[1]);
+                    acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, ones, acct, 0, 0, 0);
+                    acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tam, ones, acct, 0, 0, 0);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    };
-    using C0 = std::integral_constant<int, 0>;
-    using C1 = std::integral_constant<int, 1>;
-    if (nsteps > 0) {                             // nsteps is a multiple of 4 (chunks are multiples of 64 rows)
-        B3Set S0, S1;
-        gload(S0, true);
-        gload(S1, true);
-        half(S0.a, 0, 0, 0); half(S0.a, 0, 0, 1); half(S0.b, 0, 1, 0); half(S0.b, 0, 1, 1);
-        __syncthreads();
-        // step i computes buffer i & 1, splits the set holding step i + 1 into the other buffer and, before that, refills the
-        // set step i was split from with step i + 2 (past the end: a harmless re-read whose split is never consumed)
-        for (int i = 0; i < nsteps; i += 2) {
-            gload(S0, i + 3 < nsteps);
-            step(C0{}, S1);
-            __syncthreads();
-            gload(S1, i + 4 < nsteps);
-            step(C1{}, S0);
-            __syncthreads();
+            __syncthreads();                                  // (waits for the glds of stage s + 1 as well: its fence drains vmcnt)
         }
     }
-    float *out = partial + (size_t)blockIdx.y * 256 * 256;
+    float *out = partial + (size_t)blockIdx.x * 256 * 288;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int m = (wm * MT + mt) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                const int n = (wn * NT + nt) * 32 + (lane & 31);
-                out[(size_t)m * 256 + n] = acc[mt][nt][reg];
+            for (int r = 0; r < 16; ++r) {
+                const int m = (4 * wm + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                out[(size_t)m * 288 + (2 * wn + j) * 32 + (lane & 31)] = acc[i][j][r];
             }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = (4 * wm + wn) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        out[(size_t)m * 288 + 256 + (lane & 31)] = acct[r];
+    }
 }
 
-// dW[256 x 256] (+)= A^T B over `rows` rows; same partial / reduce scheme as launch_wgrad_lds
-template <int LDB>
-int launch_wgrad_b3(const float *A, const float *B, long long rows, const int *d_tiles, float *partial, float *grad, int dst, int ldc, hipStream_t s) {
-    if (rows % PN_TILE) return PNERF_E_INVAL;
+// grad_w[m * ldc + n] += invS * sum_c partial[c][m][n]  (n < Nreal);  grad_b[m] += invS * sum_c partial[c][m][bias_col]
+__global__ __launch_bounds__(256) void k_wgrad_reduce_f16(const float *__restrict__ partial, int chunks, int Nreal, int bias_col, const unsigned *__restrict__ gscale,
+                                                          float *__restrict__ grad, int dst_w, int ldc, int dst_b) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const size_t stride = (size_t)256 * 288;
+    float s = 0.f;
+    if (e < 256 * 288) {
+#pragma unroll 8
+        for (int c = w; c < chunks; c += 4) s += partial[c * stride + e];
+    }
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && e < 256 * 288) {
+        float S, invS;
+        pn_scale_from_bits(gscale[0], S, invS);
+        const int m = e / 288, n = e - m * 288;
+        const float v = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) * invS;
+        if (n < Nreal) grad[dst_w + m * ldc + n] += v;
+        else if (n == bias_col) grad[dst_b + m] += v;
+    }
+}
+
+template <int NFB>
+int launch_wgrad_f16(const uint4 *A, const uint4 *B, long long rg_total, const int *d_tiles, long long rows_max, float *partial, const unsigned *gscale,
+                     float *grad, int dst_w, int ldc, int Nreal, int bias_col, int dst_b, hipStream_t s) {
     int chunks = WG_CHUNKS;
-    long long rpc = (rows + chunks - 1) / chunks;
-    rpc = (rpc + 63) / 64 * 64;
-    if (rpc < 64) rpc = 64;
-    chunks = (int)((rows + rpc - 1) / rpc);
-    if (chunks < 1) chunks = 1;
-    if ((size_t)chunks * 256 * 256 > PARTIAL_FLOATS) return PNERF_E_WS;
-    if (hipFuncSetAttribute((const void *)k_wgrad_b3<LDB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_LDS_BYTES) != hipSuccess) return PNERF_E_LAUNCH;
+    const long long tiles = rows_max / PN_TILE;
+    if (tiles < chunks) chunks = (int)(tiles > 0 ? tiles : 1);
+    if ((size_t)chunks * 256 * 288 > PARTIAL_FLOATS) return PNERF_E_WS;
+    constexpr size_t lds = (size_t)2 * (2 * 4 * 256 + 2 * 4 * NFB) * 16;
+    if (hipFuncSetAttribute((const void *)k_wgrad_f16<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PNERF_E_LAUNCH;
     { PnProfScope prof(PNK_WGRAD, s);
-    hipLaunchKernelGGL(k_wgrad_b3<LDB>, dim3(1, chunks), dim3(512), B3_LDS_BYTES, s, A, B, rows, d_tiles, (int)rpc, partial); }
+    hipLaunchKernelGGL(k_wgrad_f16<NFB>, dim3(chunks), dim3(512), lds, s, A, B, rg_total, d_tiles, partial); }
     PnProfScope prof(PNK_WGRAD_REDUCE, s);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(pn_cdiv(256LL * 256, 64)), dim3(256), 0, s, partial, chunks, 256, 256, 256, grad, dst, ldc);
+    hipLaunchKernelGGL(k_wgrad_reduce_f16, dim3(pn_cdiv(256LL * 288, 64)), dim3(256), 0, s, partial, chunks, Nreal, bias_col, gscale, grad, dst_w, ldc, dst_b);
     PN_CHECK_LAUNCH();
     return 0;
 }
@@ -1162,6 +719,7 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     a.pidx = d_sample_pidx; a.valid_list = d_valid_list; a.counters = d_counters;
     a.SR = SR; a.K = K; a.TS = pn_tile_samples(K); a.cap_samples = n_valid;
     a.decoded = d_decoded; a.weight = d_weight; a.grad_decoded = d_grad_decoded; a.sv = sv;
+    a.emb = pts->embedding;
     a.gparams = d_grad_params; a.g_emb = pg->embedding; a.g_conf = pg->conf; a.g_dir = pg->dir; a.g_color = pg->color;
     if (!a.g_emb || !a.g_conf || !a.g_dir || !a.g_color) return PNERF_E_INVAL;
     int dev = 0, ncu = 256;
@@ -1169,22 +727,26 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
     const long long ctiles = (n_valid + PN_CTILE - 1) / PN_CTILE;
     const int grid_c = (int)(ctiles < 2 * ncu ? (ctiles > 0 ? ctiles : 1) : 2 * ncu);       // 69 KB of LDS: two workgroups per CU
-    const size_t lds_c = COLB_LDS_FLOATS * sizeof(float), lds_a = AGGB_LDS_FLOATS * sizeof(float);
+    const size_t lds_c = COLB_LDS_FLOATS * sizeof(float), lds_a = BL_BYTES;
     if (hipFuncSetAttribute((const void *)k_color_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
-    if (hipFuncSetAttribute((const void *)k_agg_backward<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
-    if (hipFuncSetAttribute((const void *)k_agg_backward<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
+    if (hipFuncSetAttribute((const void *)k_agg_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
     // the forward left the class partition of the valid samples in the saved area (aggregate.hip: pn_classify)
     a.cls_list = sv.cls_list; a.cls_info = sv.cls_info; a.valid_list = sv.cls_list;
+    // the scale of this call's gradients (a power of two derived on the device from max |d decoded| over the valid samples)
+    if (hipMemsetAsync(sv.gscale, 0, 4 * sizeof(unsigned), s) != hipSuccess) return PNERF_E_LAUNCH;
+    {
+        const long long blocks = (n_valid + 255) / 256;
+        hipLaunchKernelGGL(k_grad_max, dim3((unsigned)(blocks < 1024 ? (blocks > 0 ? blocks : 1) : 1024)), dim3(256), 0, s, sv.cls_list, d_counters, (long long)n_valid, d_grad_decoded, sv.gscale);
+    }
     { PnProfScope prof(PNK_COLOR_BWD, s); hipLaunchKernelGGL(k_color_backward, dim3(grid_c), dim3(256), lds_c, s, a); }
     int kc[PN_NCLS];
     const int ncls = pn_class_slots(K, kc);
     { PnProfScope prof(PNK_AGG_BWD, s);
       for (int j = 0; j < ncls; ++j) {
           a.cls = j; a.K = kc[j]; a.TS = pn_tile_samples(kc[j]);
-          const long long pairs = ((n_valid + a.TS - 1) / a.TS + 1) / 2;          // one workgroup per CU, two tiles in flight each; worst-case grid
-          const int grid_a = (int)(pairs < (long long)ncu ? (pairs > 0 ? pairs : 1) : ncu);
-          if (a.TS * PN_H <= B2_DFS_FLOATS) hipLaunchKernelGGL(k_agg_backward<true>, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
-          else hipLaunchKernelGGL(k_agg_backward<false>, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+          const long long tiles = (n_valid + a.TS - 1) / a.TS;                    // worst-case grid, two workgroups per CU
+          const int grid_a = (int)(tiles < 2LL * ncu ? (tiles > 0 ? tiles : 1) : 2LL * ncu);
+          hipLaunchKernelGGL(k_agg_backward, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
       } }
     PN_CHECK_LAUNCH();
     // the point gradients are final here: let a data-parallel caller start their all-reduce behind this event while the
@@ -1193,24 +755,16 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     // weight gradients over every tile of every class (+ their zero padding tiles): the tile count lives on the device, the host
     // bound is the allocation.  samples: only the first n_valid rows of fs / pe / c1.. exist -- the GEMM masks the rest of the
     // last colour tile (0 * stale bits could be NaN)
-    const long long rows = sv.rows, smp = n_valid;
+    const long long rows = sv.rows, smp = n_valid, rgt = sv.rows / 8;
     const int *dt = sv.cls_info + PN_CI_TILES;
     int rc;
     float *g = d_grad_params;
-    if ((rc = launch_wgrad_b3<PN_IN1P>(sv.dy1, sv.x0, rows, dt, d_partials, g, PO_W1, PN_IN1, s))) return rc;
-    // columns 256..283 of W1 (the distance encoding): a 256 x 32 tile on the fp32 MFMA
-    if ((rc = launch_wgrad_lds<1, 1, 8, 1, 64, false>(sv.dy1, PN_H, sv.x0 + 256, PN_IN1P, nullptr, 0, rows, dt, d_partials, 32, PN_IN1 - 256, g, PO_W1 + 256, PN_IN1, s))) return rc;
-    if ((rc = launch_wgrad_b3<PN_H>(sv.dy2, sv.h1, rows, dt, d_partials, g, PO_W2, PN_H, s))) return rc;
-    if ((rc = launch_wgrad_b3<PN_H>(sv.dy3, sv.h2, rows, dt, d_partials, g, PO_W3, PN_IN3, s))) return rc;
-    if ((rc = launch_wgrad_b3<PN_H>(sv.dy4, sv.h3, rows, dt, d_partials, g, PO_W4, PN_H, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_NF1>(sv.dy1k, sv.x0k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W1, PN_IN1, PN_IN1, PN_ONES1, PO_B1, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_H>(sv.dy2k, sv.h1k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W2, PN_H, PN_H, PN_H, PO_B2, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_NF1>(sv.dy3k, sv.h2k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W3, PN_IN3, PN_IN3, PN_ONES3, PO_B3, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_H>(sv.dy4k, sv.h3k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W4, PN_H, PN_H, PN_H, PO_B4, s))) return rc;
     if ((rc = launch_wgrad_lds<2, 2, 2, 4, 16, true>(sv.dc1, PN_HC, sv.fs, PN_H, sv.pe, 32, smp, nullptr, d_partials, 288, PN_INC, g, PO_WC1, PN_INC, s))) return rc;
     if ((rc = launch_wgrad_lds<2, 1, 2, 4, 16, false>(sv.dc2, PN_HC, sv.c1, PN_HC, nullptr, 0, smp, nullptr, d_partials, 128, 128, g, PO_WC2, PN_HC, s))) return rc;
     if ((rc = launch_wgrad_lds<2, 1, 2, 4, 16, false>(sv.dc3, PN_HC, sv.c2, PN_HC, nullptr, 0, smp, nullptr, d_partials, 128, 128, g, PO_WC3, PN_HC, s))) return rc;
     return 0;
 }
-
-#ifdef PN_PHASE_TRACE
-extern "C" int pnerf_debug_trace_bwd(void *host, size_t bytes) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(pn_trace_bwd), bytes < sizeof(pn_trace_bwd) ? bytes : sizeof(pn_trace_bwd)) == hipSuccess ? 0 : -1;
-}
-#endif

@@ -1,0 +1,179 @@
+// f16x3.h -- fp32-accurate GEMMs of the aggregator MLP on the f16 matrix pipe of gfx950 (round 2).
+//
+// gfx950 has no xf32/TF32 path: an fp32-input MFMA runs at 1/16 of the 16-bit rate (157 TFLOP/s against 2.5 PFLOP/s), and
+// the parity bar (1e-4 on sigma / RGB against an fp32 reference) rules out plain f16/bf16 inputs.  Every fp32 operand x
+// is therefore carried as TWO f16 numbers
+//       h = f16_rtz(x)           (v_cvt_pkrtz_f16_f32: never overflows to inf)
+//       m = f16_rne(x - h)       (the subtraction is exact)
+// so that x = h + m up to 2^-22 |x| (11 + 11 significand bits; below |x| ~ 6e-5 the planes are f16 subnormals and the
+// ABSOLUTE error is <= 2^-25), and a product is accumulated in fp32 by three v_mfma_f32_32x32x16_f16:
+//       a*b  ~=  ah*bh + ah*bm + am*bh          (the dropped am*bm is <= 2^-20 |a*b|)
+// i.e. 3 x 32 cycles per 16 columns of K instead of 8 x 64 cycles of v_mfma_f32_32x32x2_f32: 5.3x on the matrix pipe at
+// ~fp32 accuracy (tests/test_split_f16_cpu.py restates the arithmetic in numpy; the GPU parity bars are unchanged).
+// The split is done ONCE by whoever produces a value (epilogues write both planes to LDS, the pack kernel splits the
+// weights, the training forward / backward store the planes the weight-gradient GEMM streams), never by the consumer.
+//
+// Orientation: D[feature][row] = W[feature][k] * X^T[k][row] -- the weights are the MFMA "A" operand, the activation tile
+// the "B" operand.  A lane of the 32x32 accumulator then owns ONE tile row and features {4 (l>>5) + 8 g + i}: four
+// consecutive features = one 8-byte store per plane into the row-major activation tile the next layer reads.
+//
+// Layouts
+//   activation tile in LDS   [plane 2][row 64][k] f16, row stride PN_XRS bytes (37 x 16: odd, so the ds_read_b128 of a
+//                            fragment -- lane -> row (l & 31), 8 consecutive k at 8 (l >> 5) -- is conflict-free)
+//   weight image (L2)        uint4 img[chunk][mblock][plane][lane] : lane l of feature block mb holds
+//                            W[32 mb + (l & 31)][16 chunk + 8 (l >> 5) .. + 7]; wave w owns blocks 2w, 2w + 1
+//   k-major planes in HBM    uint4 u[plane][row / 8][feature] = rows 8 g .. 8 g + 7 of one feature: what the weight-gradient
+//                            GEMM (k = rows) loads as ready-made fragments, written by the producers' transposing copy-out
+#pragma once
+#include "mlp_common.h"
+
+typedef _Float16 pn_h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 pn_h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 pn_h8 __attribute__((ext_vector_type(8)));
+
+#define PN_XRS    592                      // bytes per tile row and plane (up to 288 columns + 16 bytes of padding)
+#define PN_XPLANE (PN_TILE * PN_XRS)       // 37 888
+#define PN_XBYTES (2 * PN_XPLANE)          // 75 776
+#define PN_K1     288                      // layer-1 input columns: 284 + ones column (284) + 3 zeros
+#define PN_K3     272                      // layer-3 input columns: 256 + 7 extras + ones column (263) + 8 zeros
+#define PN_ONES1  284                      // column of X0 that holds 1.0 (its weight-gradient column is the bias gradient)
+#define PN_ONES3  263
+#define PN_NF1    288                      // features of the saved k-major X0 and [h2 | extras] planes
+#define PN_MB_D1  7                        // feature blocks of d X0 that are needed (embedding + its encoding: 224 columns)
+
+// ---- images (byte offsets inside the packed buffer, after the fp32 images of the colour MLP)
+#define PN_IMG(nch, mb) ((nch) * (mb) * 2048)
+enum : int {
+    PKH_BASE = PK_TOTAL * 4,
+    PKH_F1 = PKH_BASE, PKH_F2 = PKH_F1 + PN_IMG(18, 8), PKH_F3 = PKH_F2 + PN_IMG(16, 8), PKH_F4 = PKH_F3 + PN_IMG(17, 8),
+    PKH_D4 = PKH_F4 + PN_IMG(16, 8), PKH_D3 = PKH_D4 + PN_IMG(16, 8), PKH_D2 = PKH_D3 + PN_IMG(16, 9), PKH_D1 = PKH_D2 + PN_IMG(16, 8),
+    PKH_END = PKH_D1 + PN_IMG(16, PN_MB_D1)
+};
+
+// sin / cos of the positional encodings: v_sin_f32 / v_cos_f32 (one multiply + one transcendental each) unless built with
+// -DPN_EXACT_SINCOS; the parity bars of tests/test_gpu_render.py and test_gpu_backward.py hold for both
+__device__ __forceinline__ void pn_sincos(float x, float &s, float &c) {
+#ifdef PN_EXACT_SINCOS
+    sincosf(x, &s, &c);
+#else
+    s = __sinf(x); c = __cosf(x);
+#endif
+}
+
+// (x0, x1) -> packed high plane (round toward zero) and packed residual plane (round to nearest)
+__device__ __forceinline__ void pn_split2(float x0, float x1, unsigned &h, unsigned &m) {
+    const auto hh = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    h = __builtin_bit_cast(unsigned, hh);
+    pn_h2 mm;
+    mm[0] = (_Float16)(x0 - (float)hh[0]);
+    mm[1] = (_Float16)(x1 - (float)hh[1]);
+    m = __builtin_bit_cast(unsigned, mm);
+}
+// the same with the value clamped to the f16 range first (gradients: their scale is chosen per call, an outlier must saturate, not poison)
+__device__ __forceinline__ void pn_split2_sat(float x0, float x1, unsigned &h, unsigned &m) {
+    pn_split2(fminf(fmaxf(x0, -65504.f), 65504.f), fminf(fmaxf(x1, -65504.f), 65504.f), h, m);
+}
+__device__ __forceinline__ float pn_h_lo(unsigned p) { return (float)__builtin_bit_cast(pn_h2, p)[0]; }
+__device__ __forceinline__ float pn_h_hi(unsigned p) { return (float)__builtin_bit_cast(pn_h2, p)[1]; }
+
+// one value at tile position (row, col): both planes
+__device__ __forceinline__ void pn_x_store1(char *X, int row, int col, float v) {
+    unsigned h, m;
+    pn_split2(v, 0.f, h, m);
+    *reinterpret_cast<unsigned short *>(X + row * PN_XRS + col * 2) = (unsigned short)h;
+    *reinterpret_cast<unsigned short *>(X + PN_XPLANE + row * PN_XRS + col * 2) = (unsigned short)m;
+}
+// two values at (row, col), (row, col + 1), col even
+__device__ __forceinline__ void pn_x_store2(char *X, int row, int col, float v0, float v1) {
+    unsigned h, m;
+    pn_split2(v0, v1, h, m);
+    *reinterpret_cast<unsigned *>(X + row * PN_XRS + col * 2) = h;
+    *reinterpret_cast<unsigned *>(X + PN_XPLANE + row * PN_XRS + col * 2) = m;
+}
+// four values at (row, col .. col + 3), col % 4 == 0
+template <bool SAT>
+__device__ __forceinline__ void pn_x_store4(char *X, int row, int col, float v0, float v1, float v2, float v3) {
+    unsigned h0, m0, h1, m1;
+    if (SAT) { pn_split2_sat(v0, v1, h0, m0); pn_split2_sat(v2, v3, h1, m1); }
+    else { pn_split2(v0, v1, h0, m0); pn_split2(v2, v3, h1, m1); }
+    *reinterpret_cast<uint2 *>(X + row * PN_XRS + col * 2) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2 *>(X + PN_XPLANE + row * PN_XRS + col * 2) = make_uint2(m0, m1);
+}
+// four values back: h + m
+__device__ __forceinline__ float4 pn_x_load4(const char *X, int row, int col) {
+    const uint2 h = *reinterpret_cast<const uint2 *>(X + row * PN_XRS + col * 2);
+    const uint2 m = *reinterpret_cast<const uint2 *>(X + PN_XPLANE + row * PN_XRS + col * 2);
+    return make_float4(pn_h_lo(h.x) + pn_h_lo(m.x), pn_h_hi(h.x) + pn_h_hi(m.x), pn_h_lo(h.y) + pn_h_lo(m.y), pn_h_hi(h.y) + pn_h_hi(m.y));
+}
+
+// ---- the tile GEMM: acc[fb][rb] (feature block fb of this wave x row block rb) += W[.., 16 NCH] * X^T
+// Three products per (fb, rb) and chunk, ordered so that an accumulator is touched once in four MFMAs; the next chunk's
+// fragments (weights from the L2-resident image, activations from LDS) are requested before the current chunk's MFMAs.
+// MB = feature blocks of the image; NFB = blocks this wave computes (fb0 = its first block).
+template <int NCH, int MB, int NFB>
+__device__ __forceinline__ void pn_gemm_f16x3(const char *X, const uint4 *__restrict__ img, int fb0, int lane, f32x16 (&acc)[2][2], int c_begin = 0, int c_end = NCH) {
+    const char *xb = X + (lane & 31) * PN_XRS + (lane >> 5) * 16;
+    const uint4 *wp = img + fb0 * 128 + lane;
+    uint4 wh[2][2], wm[2][2], xh[2][2], xm[2][2];
+    auto load = [&](int c, int s) {
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) { wh[s][fb] = wp[(c * MB + fb) * 128]; wm[s][fb] = wp[(c * MB + fb) * 128 + 64]; }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            xh[s][rb] = *reinterpret_cast<const uint4 *>(xb + rb * 32 * PN_XRS + c * 32);
+            xm[s][rb] = *reinterpret_cast<const uint4 *>(xb + PN_XPLANE + rb * 32 * PN_XRS + c * 32);
+        }
+    };
+    auto mma = [&](int s) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    const pn_h8 a = __builtin_bit_cast(pn_h8, p == 2 ? wm[s][fb] : wh[s][fb]);
+                    const pn_h8 b = __builtin_bit_cast(pn_h8, p == 1 ? xm[s][rb] : xh[s][rb]);
+                    acc[fb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[fb][rb], 0, 0, 0);
+                }
+    };
+    if (c_begin >= c_end) return;
+    load(c_begin, 0);
+    for (int c = c_begin; c < c_end; c += 2) {
+        if (c + 1 < c_end) load(c + 1, 1);
+        mma(0);
+        if (c + 2 < c_end) load(c + 2, 0);
+        if (c + 1 < c_end) mma(1);
+    }
+}
+
+// accumulator element (fb, rb, g, i) of a lane: feature = 32 fbg + 8 g + 4 (l >> 5) + i (fbg = global block), row = 32 rb + (l & 31)
+__device__ __forceinline__ int pn_d_feat(int fbg, int g, int lane) { return 32 * fbg + 8 * g + 4 * (lane >> 5); }
+
+// ---- transposing copy-out: the tile's NF columns -> k-major planes (training).  Unit (plane, row group rg, feature f) = rows
+// 8 rg .. 8 rg + 7 of column f: eight 2-byte LDS reads (consecutive lanes -> consecutive columns: conflict-free) and one
+// coalesced 16-byte store.  dst = base of the array ([2][rg_total][NF] units), rg0 = first row group of the tile.
+template <int NF>
+__device__ __forceinline__ void pn_copy_out_kmajor(const char *X, uint4 *__restrict__ dst, long long rg_total, long long rg0, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int combo = wave * 4 + i, plane = combo >> 3, rg = combo & 7;
+        const char *src = X + plane * PN_XPLANE + rg * 8 * PN_XRS;
+        uint4 *d = dst + ((long long)plane * rg_total + rg0 + rg) * NF;
+#pragma unroll
+        for (int j = 0; j < (NF + 63) / 64; ++j) {
+            const int f = lane + 64 * j;
+            if (f < NF) {
+                unsigned w[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned lo = *reinterpret_cast<const unsigned short *>(src + (2 * r) * PN_XRS + f * 2);
+                    const unsigned hi = *reinterpret_cast<const unsigned short *>(src + (2 * r + 1) * PN_XRS + f * 2);
+                    w[r] = lo | (hi << 16);
+                }
+                pn_f4 t = {__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
+                __builtin_nontemporal_store(t, reinterpret_cast<pn_f4 *>(d + f));
+            }
+        }
+    }
+}

@@ -1,6 +1,6 @@
-// mlp_common.h -- layout of the aggregator MLP, its MFMA-fragment weight images, and the 64-row tile
-// GEMM built on v_mfma_f32_32x32x2_f32 (exact fp32: the 1e-4 parity bar on sigma/RGB against an fp32
-// reference rules out plain bf16 inputs; see DESIGN.md "precision").
+// mlp_common.h -- layout of the aggregator MLP, the fp32 MFMA-fragment weight images and the 64-row fp32 tile GEMM
+// (v_mfma_f32_32x32x2_f32) of the COLOUR MLP, and the saved-activation area.  The four 256-wide aggregator layers run on
+// the f16 matrix pipe with two-plane operands: f16x3.h.
 #pragma once
 #include "pn_common.h"
 #include <type_traits>
@@ -174,72 +174,24 @@ __device__ __forceinline__ void pn_tile_mask_pass(float *__restrict__ H, int ldh
     }
 }
 
-// ---- 1-bit LeakyReLU masks, in the accumulator layout.  A lane owns the same 64 (row, col) elements of a layer's output in
+// ---- 1-bit LeakyReLU masks, in the accumulator layout.  A lane owns the same 64 (row, feature) elements of a layer's output in
 // the forward (where it applies bias + LeakyReLU to its accumulators) and in the backward (where it multiplies its dgrad
-// accumulators by LeakyReLU'), so the sign bits travel as ONE 8-byte word per thread per layer: bit r = mt*32 + ct*16 + reg.
-// Written and read fully coalesced ([tile][layer][thread]); the backward fetches its words when it loads the tile.  (The 64 KB
-// fp32 read of the saved activation this replaces sat on the critical path after every GEMM: latency-, not bandwidth-bound.)
+// accumulators by LeakyReLU'), so the sign bits travel as ONE 8-byte word per thread per layer.
+// Written and read fully coalesced ([tile][layer][thread]).
 
-// ---- side-job GEMM --------------------------------------------------------------------------------------------------
-// Measured on MI355X (tools/mfma_probe.hip): while one wave streams v_mfma_f32_32x32x2_f32 back to back, ANOTHER wave on the
-// same SIMD gets one VALU instruction through per ~84 cycles (s_setprio does not change it), but the streaming wave's OWN
-// independent VALU / LDS / VMEM instructions issue for free in the 64-cycle shadow of each MFMA (<= ~15 per MFMA).  So
-// element-wise work is hidden by the wave that runs the GEMM, not by a second workgroup: the chunk loop is fully unrolled
-// and after every MFMA a hook `side(slot)` (slot = compile-time constant 0 .. 16*NCH-1) may issue a few instructions that
-// belong to a DIFFERENT tile (or to finished rows of this one).  sched_barrier keeps hipcc from regrouping them.
 template <int... I, class F> __device__ __forceinline__ void pn_static_for_impl(std::integer_sequence<int, I...>, F &&f) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void pn_static_for(F &&f) { pn_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
-// `bpre` holds this GEMM's chunk-0 weight fragments on entry (requested during the previous GEMM: a step would otherwise
-// start with an exposed L2 round trip) and, on exit, chunk 0 of the NEXT GEMM's image `Wnext` (nullptr: none).
-template <int NCH, class Side>
-__device__ __forceinline__ void pn_tile_gemm_side(const float *__restrict__ A, int lda, const float4 *__restrict__ Wp, int wave, int lane,
-                                                  f32x16 (&acc)[2][2], float4 (&bpre)[2], const float4 *__restrict__ Wnext, Side &&side) {
-    const float *ap = A + (lane & 31) * lda + 4 * (lane >> 5);
-    const float4 *wp = Wp + (wave * 2) * 64 + lane;
-    float4 a[2][2], b[2][2];
-    b[0][0] = bpre[0]; b[0][1] = bpre[1];
-    a[0][0] = *reinterpret_cast<const float4 *>(ap); a[0][1] = *reinterpret_cast<const float4 *>(ap + 32 * lda);
-    pn_static_for<NCH>([&](auto cc) {
-        constexpr int c = decltype(cc)::value, cur = c & 1, nxt = cur ^ 1;
-        if constexpr (c + 1 < NCH) {
-            b[nxt][0] = wp[((c + 1) * 8) * 64]; b[nxt][1] = wp[((c + 1) * 8 + 1) * 64];
-            a[nxt][0] = *reinterpret_cast<const float4 *>(ap + 8 * (c + 1)); a[nxt][1] = *reinterpret_cast<const float4 *>(ap + 32 * lda + 8 * (c + 1));
-        } else if (Wnext) {
-            const float4 *wn = Wnext + (wave * 2) * 64 + lane;
-            bpre[0] = wn[0]; bpre[1] = wn[64];
-        }
-        pn_static_for<16>([&](auto jj) {
-            constexpr int j = decltype(jj)::value, i = j >> 2, ct = (j >> 1) & 1, mt = j & 1;
-            const float av = i == 0 ? a[cur][mt].x : (i == 1 ? a[cur][mt].y : (i == 2 ? a[cur][mt].z : a[cur][mt].w));
-            const float bv = i == 0 ? b[cur][ct].x : (i == 1 ? b[cur][ct].y : (i == 2 ? b[cur][ct].z : b[cur][ct].w));
-            acc[mt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt][ct], 0, 0, 0);
-            side(std::integral_constant<int, c * 16 + j>{});
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    });
-}
-
-__device__ __forceinline__ void pn_gemm_prefetch_b0(const float4 *__restrict__ Wp, int wave, int lane, float4 (&bpre)[2]) {
-    const float4 *wp = Wp + (wave * 2) * 64 + lane;
-    bpre[0] = wp[0]; bpre[1] = wp[64];
-}
-
-__device__ __forceinline__ void pn_acc_zero(f32x16 (&acc)[2][2]) {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) acc[mt][ct][reg] = 0.f;
-}
-
 // ---- saved-activation area (training) -------------------------------------------------------
 struct PnSaved {
-    // per neighbor row (rows = row tiles * 64)
-    float *x0, *h1, *h2, *h3, *h4, *ex, *dy1, *dy2, *dy3, *dy4;
+    // per neighbor row (rows = row tiles * 64), f16 plane pairs (f16x3.h):
+    uint4 *x0k, *h1k, *h2k, *h3k;       // k-major [2][rows / 8][NF] inputs of the four layers (NF = 288, 256, 288, 256): what the weight-gradient GEMM streams
+    uint4 *dy1k, *dy2k, *dy3k, *dy4k;   // k-major [2][rows / 8][256] output gradients of the four layers, SCALED by the backward's power-of-two scale
+    uint4 *h4r;                         // row-major [2][rows][32] last activation (alpha head / K-weighted sums of the backward)
+    float *arow;                        // per row: pre-activation of the alpha head
     int4 *rmeta;                        // per row: {sample id or -1, point id or -1, bits(normalised weight), bits(final weight)}
     unsigned long long *lmask;          // [row tiles][3 layers h1..h3][PN_NTHR]: LeakyReLU sign bits in the accumulator layout
+    unsigned *gscale;                   // [4]: bits of max |d decoded| over the valid samples (the backward derives its scale from it)
     // per valid sample (padded to colour tiles * 64)
     float *fs, *pe, *c1, *c2, *c3, *dfs, *dc1, *dc2, *dc3;
     // sample classes (aggregate.hip: pn_classify): the valid samples re-listed class by class, and where each class lives
@@ -259,26 +211,3 @@ PnSaved pn_saved_carve(void *base, long long n_valid, int K);
 
 __host__ __device__ inline int pn_tile_samples(int K) { return PN_TILE / K; }
 
-// ---- dev-only phase timeline (build with EXTRA_DEFS=-DPN_PHASE_TRACE; tools/gpu_phase_trace.py reads it) ----------
-#ifdef PN_PHASE_TRACE
-#define PN_TR_WGS   512
-#define PN_TR_IT0   20
-#define PN_TR_ITERS 6
-#define PN_TR_SLOTS 24
-#define PN_TR_DECL(name) __device__ unsigned long long name[PN_TR_WGS * PN_TR_ITERS * PN_TR_SLOTS]
-#define PN_TR(buf, ph)                                                                                              \
-    do {                                                                                                            \
-        if (tid == 0 && blockIdx.x < PN_TR_WGS && titer >= PN_TR_IT0 && titer < PN_TR_IT0 + PN_TR_ITERS)           \
-            buf[((size_t)blockIdx.x * PN_TR_ITERS + (titer - PN_TR_IT0)) * PN_TR_SLOTS + (ph)] = wall_clock64();    \
-    } while (0)
-#define PN_TR_HWID(buf)                                                                                             \
-    do {                                                                                                            \
-        if (tid == 0 && blockIdx.x < PN_TR_WGS && titer >= PN_TR_IT0 && titer < PN_TR_IT0 + PN_TR_ITERS)           \
-            buf[((size_t)blockIdx.x * PN_TR_ITERS + (titer - PN_TR_IT0)) * PN_TR_SLOTS + PN_TR_SLOTS - 1] =         \
-                (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |                                    \
-                ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);                             \
-    } while (0)
-#else
-#define PN_TR(buf, ph)
-#define PN_TR_HWID(buf)
-#endif

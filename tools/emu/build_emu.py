@@ -16,13 +16,13 @@ OUT = os.path.join(ROOT, "tools", "_build", "emu")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 FILES = ["scan", "grid", "query", "aggregate", "render", "backward", "optim", "pointinit", "prof"]
 EXACT = {"grid", "query", "pointinit"}
-# the hand-unrolled round-1 tile programs take > 5 minutes at -O1 on the host compiler
-OPT = {"aggregate": os.environ.get("PN_EMU_OPT_AGG", "-O0"), "backward": os.environ.get("PN_EMU_OPT_AGG", "-O0")}
+OPT = {}
 
 
 def preprocess(text):
     text = re.sub(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(\w+)\s+(\w+)\[\];", r"\1 *\2 = (\1 *)emu::lds();", text)
     text = re.sub(r'asm volatile\(""[^;]*\);', ";", text)
+    text = text.replace("(__attribute__((address_space(3))) void *)", "(void *)")
     return text
 
 

@@ -171,6 +171,28 @@ template <class V, class E> static inline emu_f32x16 emu_mfma_32x32x16(V a, V b,
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_32x32x2f32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma_32x32x16<emu_bf16x8, __bf16>((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_32x32x16<emu_f16x8, _Float16>((a), (b), (c))
+// v_cvt_pkrtz_f16_f32: two floats -> two halfs, round toward zero (finite inputs never become inf)
+typedef _Float16 emu_h2 __attribute__((ext_vector_type(2)));
+static inline _Float16 emu_f16_rtz(float x) {
+    _Float16 r = (_Float16)x;                       // round to nearest even
+    unsigned short b; memcpy(&b, &r, 2);
+    if ((b & 0x7fff) == 0x7c00 && !std::isinf(x)) { b = (b & 0x8000) | 0x7bff; memcpy(&r, &b, 2); return r; }
+    if (std::fabs((float)r) > std::fabs(x)) { b -= 1; memcpy(&r, &b, 2); }      // one ulp toward zero
+    return r;
+}
+static inline emu_h2 emu_cvt_pkrtz(float a, float b) { emu_h2 r; r[0] = emu_f16_rtz(a); r[1] = emu_f16_rtz(b); return r; }
+#define __builtin_amdgcn_cvt_pkrtz(a, b) emu_cvt_pkrtz((a), (b))
+#define __sinf(x) sinf(x)
+#define __cosf(x) cosf(x)
+#define __expf(x) expf(x)
+#define __builtin_amdgcn_fmed3f(a, b, c) fmaxf(fminf(fmaxf((a), (b)), (c)), fminf((a), (b)))
+// global_load_lds_dwordx4 & co: LDS destination = wave-uniform base + lane * size (+ offset), global source per lane
+static inline void emu_global_load_lds(const void *g, void *lds_base, unsigned size, unsigned offset) {
+    memcpy((char *)lds_base + offset + (size_t)emu::lane_id() * size, g, size);
+}
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((g), (void *)(l), (size), (off))
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
