@@ -222,6 +222,12 @@ int pnerf_voxel_downsample(const float *d_xyz, int64_t n_points, const float *sp
                            int rx, int ry, int rz, float *d_centroid, int32_t *d_grid_idx, int64_t *d_min_idx, int32_t *d_counts,
                            void *d_ws, size_t ws_bytes, void *stream);
 
+/* ---- diagnostics: ONE v_mfma_f32_32x32x16_f16, D = A B with caller-built fragments: d_a / d_b [64 lanes][8] f16 (lane l holds
+ * A[l & 31][8 (l >> 5) .. + 7] resp. B[8 (l >> 5) .. + 7][l & 31]), d_out [64 lanes][16] f32 (register r of lane l =
+ * D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31]).  The tests pin with it the fragment layout and the un-flushed handling of f16
+ * subnormal inputs that the two-plane GEMMs of the aggregator (csrc/f16x3.h) rely on. */
+int pnerf_debug_mfma_f16(const void *d_a, const void *d_b, float *d_out, void *stream);
+
 /* ---- per-kernel timing (HIP events recorded on the launch stream; off by default) --------------- */
 int pnerf_prof_enable(int on);
 int pnerf_prof_kernel_count(void);

@@ -83,6 +83,7 @@ PROTOTYPES = {
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pnerf_raymarch_backward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_f32), c_int, c_int,
                                         c_void_p, c_void_p, c_void_p]),
+    "pnerf_debug_mfma_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "pnerf_prof_enable": (c_int, [c_int]),
     "pnerf_prof_kernel_count": (c_int, []),
     "pnerf_prof_kernel_name": (ctypes.c_char_p, [c_int]),

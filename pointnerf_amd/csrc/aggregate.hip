@@ -105,6 +105,23 @@ extern "C" int pnerf_mlp_pack(const float *d_params, void *d_packed, void *strea
     return 0;
 }
 
+namespace {
+__global__ __launch_bounds__(64) void k_debug_mfma_f16(const uint4 *__restrict__ a, const uint4 *__restrict__ b, float *__restrict__ d) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pn_h8, a[threadIdx.x]), __builtin_bit_cast(pn_h8, b[threadIdx.x]), acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[threadIdx.x * 16 + r] = acc[r];
+}
+}  // namespace
+extern "C" int pnerf_debug_mfma_f16(const void *d_a, const void *d_b, float *d_out, void *stream) {
+    if (!d_a || !d_b || !d_out) return PNERF_E_INVAL;
+    hipLaunchKernelGGL(k_debug_mfma_f16, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint4 *)d_a, (const uint4 *)d_b, d_out);
+    PN_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------ saved activations
 size_t pn_saved_bytes(long long n_valid, int K, long long *rows_out, long long *samples_out) {
     const int TS = pn_tile_samples(K);

@@ -40,8 +40,10 @@ class FusedRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, env, emb, conf, pdir, color, *mlp_params):
         # env: dict(cam, xyz, raydir, dense, R, SR, K, n_valid, flat, packed, train, layout)
-        pts = ops.make_points(env["xyz"], emb.detach().reshape(-1, emb.shape[-1]), conf.detach().reshape(-1, 1),
-                              pdir.detach().reshape(-1, 3), color.detach().reshape(-1, 3))
+        # (the C structure holds raw pointers: keep the arrays it points to alive until the backward has read them)
+        ctx.point_arrays = (emb.detach().reshape(-1, emb.shape[-1]), conf.detach().reshape(-1, 1), pdir.detach().reshape(-1, 3),
+                            color.detach().reshape(-1, 3))
+        pts = ops.make_points(env["xyz"], *ctx.point_arrays)
         fwd = ops.render_forward(env["cam"], pts, env["packed"], env["flat"], env["raydir"], env["dense"],
                                  env["R"], env["SR"], env["K"], env["n_valid"], env["train"])
         ctx.env, ctx.pts, ctx.fwd = env, pts, fwd
@@ -73,7 +75,7 @@ class FusedRender(torch.autograd.Function):
         assert len(gm) == ctx.n_mlp
         # the graph node outlives this call for as long as the caller keeps the loss: release the step's big tensors (query
         # outputs, dense weights, packed points) now, so that the next step's allocations find them in the allocator's cache
-        ctx.env = ctx.fwd = ctx.pts = None
+        ctx.env = ctx.fwd = ctx.pts = ctx.point_arrays = None
         return (None, grads["points_embeding"], grads["points_conf"], grads["points_dir"], grads["points_color"]) + gm
 
 
@@ -98,8 +100,10 @@ class Aggregate(torch.autograd.Function):
         L.check(lib.pnerf_compact_valid(ops._ptr(nn), R * SR, ops._ptr(vlist), ops._ptr(counters), ops._ptr(cws), nws, ops._stream()),
                 "pnerf_compact_valid")
         n_valid = int(counters[0].item())
-        pts = ops.make_points(env["xyz_slots"], emb.detach().reshape(-1, emb.shape[-1]).contiguous(), conf.detach().reshape(-1, 1).contiguous(),
-                              pdir.detach().reshape(-1, 3).contiguous(), color.detach().reshape(-1, 3).contiguous())
+        # (the C structure holds raw pointers: the per-slot arrays must stay alive until the backward has read them)
+        slot_arrays = (emb.detach().reshape(-1, emb.shape[-1]).contiguous(), conf.detach().reshape(-1, 1).contiguous(),
+                       pdir.detach().reshape(-1, 3).contiguous(), color.detach().reshape(-1, 3).contiguous())
+        pts = ops.make_points(env["xyz_slots"], *slot_arrays)
         f32 = dict(dtype=torch.float32, device=dev)
         decoded, weight = torch.empty(R, SR, 4, **f32), torch.empty(R, SR, K, **f32)
         saved = ws = None
@@ -114,6 +118,7 @@ class Aggregate(torch.autograd.Function):
                                       ops._ptr(env["pidx"]), ops._ptr(vlist), ops._ptr(counters), R, SR, K, ops._ptr(decoded), ops._ptr(weight),
                                       ops._ptr(saved), n_valid, ops._ptr(ws), nw, ops._stream()), "pnerf_agg_forward")
         ctx.env, ctx.pts, ctx.keep = env, pts, (vlist, counters, saved, decoded, weight, n_valid)
+        ctx.slot_arrays = slot_arrays
         ctx.shapes = (tuple(emb.shape), tuple(conf.shape), tuple(pdir.shape), tuple(color.shape))
         ctx.mark_non_differentiable(weight)
         return decoded, weight
@@ -144,6 +149,6 @@ class Aggregate(torch.autograd.Function):
                                            ops._ptr(saved), ops._ptr(gflat), ctypes.byref(pg), ops._ptr(ws), nws, ops._stream()),
                     "pnerf_agg_backward")
         ops.ARENA.give(saved)
-        ctx.keep = None
+        ctx.keep = ctx.slot_arrays = None
         gm = tuple(gflat[o:o + n].view(shp) for (o, n, shp) in env["layout"])
         return (None,) + tuple(grads) + gm

@@ -75,8 +75,7 @@ class PointAggregator(nn.Module):
         """Move every parameter into one flat device vector (idempotent; call after .to(device)/load_state_dict)."""
         params = dict(self.named_parameters())
         dev = next(iter(params.values())).device
-        if dev.type != "cuda":
-            raise RuntimeError("pointnerf_amd.PointAggregator runs on the GPU only: call .to('cuda') before use")
+        ops._need_cuda(next(iter(params.values())), "PointAggregator parameters (call .to('cuda') before use)")
         lay, total = self._named_layout()
         base = self._flat
         already = base is not None and base.device == dev and all(

@@ -22,6 +22,20 @@ def _emu(monkeypatch):
         yield
 
 
+@pytest.fixture(autouse=True)
+def _poison(monkeypatch):
+    """the saved-activation arena starts as NaN bit patterns (as in the -m gpu tests): nothing unwritten may reach a result"""
+    from pointnerf_amd import ops
+    orig = ops.Arena.take
+
+    def take(self, nbytes, device):
+        t = orig(self, nbytes, device)
+        t.fill_(0xFF)
+        return t
+
+    monkeypatch.setattr(ops.Arena, "take", take)
+
+
 def _tiny_case(K, SR, size, n=1200, seed=5):
     opt = config.lego_opt(K=K, SR=SR, P=24, max_o=50000, ranges=[-0.3, -0.3, -0.3, 0.3, 0.3, 0.3])
     xyz = torch.from_numpy(scenes.chair_points(n, seed=seed, radius=0.06))
@@ -35,8 +49,30 @@ def test_emulated_forward_matches_oracle():
     TR._compare(*build_case("small_k4"))
 
 
-@pytest.mark.parametrize("K,SR,size", [(8, 12, 5), (3, 10, 4)])
+def test_emulated_f16_mfma_layout_and_subnormals():
+    import ctypes
+    import mfma_case
+    from emu_util import emu_lib
+    a, b, D, _ = mfma_case.build()
+    out = np.zeros((64, 16), np.float32)
+    rc = emu_lib().pnerf_debug_mfma_f16(a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), None)
+    assert rc == 0
+    assert np.abs(mfma_case.unpack(out) - D).max() <= 1e-6 * np.abs(D).max()
+
+
+# K % 4 == 0 runs three sample classes (K, K/2, K/4 rows per sample), other K one
+@pytest.mark.parametrize("K,SR,size", [(8, 12, 5), (3, 10, 4), (12, 8, 4), (1, 6, 5), (16, 6, 3)])
 def test_emulated_forward_and_backward_match_oracle(K, SR, size):
     case = _tiny_case(K, SR, size)
     TR._compare(*case)
     TB._run(*case)
+
+
+def test_emulated_level1_chain(monkeypatch):
+    """NeuralPoints.forward -> PointAggregator.forward -> ray_march as separate modules (the reference's forward body) with
+    autograd through them, on per-slot gathered arrays (tests/test_gpu_level1.py on a reduced case)"""
+    import cases
+    import test_gpu_level1 as T1
+    monkeypatch.setattr(T1, "DEV", "cpu")
+    monkeypatch.setitem(cases.CASES, "small_k4", (dict(K=4, SR=10, P=12, max_o=50000, ranges=[-0.3, -0.3, -0.3, 0.3, 0.3, 0.3]), 900, 5, 1))
+    T1.test_level1_chain_matches_oracle_and_fused("small_k4")

@@ -163,3 +163,21 @@ def test_grid_cache_never_serves_a_recycled_address():
         hit = dense["ray_hit"].cpu() > 0
         assert torch.equal(dense["sample_pidx"].cpu()[hit][None], q["sample_pidx"]), seed
         del xd, dense
+
+
+def test_f16_mfma_fragment_layout_and_subnormal_inputs():
+    """one v_mfma_f32_32x32x16_f16 through the C ABI: the layout csrc/f16x3.h assumes, and subnormal f16 inputs are NOT flushed"""
+    import ctypes
+    import numpy as np
+    import mfma_case
+    from pointnerf_amd import _lib as L
+    a, b, D, D_flushed = mfma_case.build()
+    da, db = torch.from_numpy(a.view(np.int16)).cuda(), torch.from_numpy(b.view(np.int16)).cuda()
+    out = torch.zeros(64, 16, device="cuda")
+    L.check(L.lib().pnerf_debug_mfma_f16(ctypes.c_void_p(da.data_ptr()), ctypes.c_void_p(db.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "pnerf_debug_mfma_f16")
+    torch.cuda.synchronize()
+    got = mfma_case.unpack(out.cpu().numpy())
+    err, err_if_flushed = np.abs(got - D).max(), np.abs(D_flushed - D).max()
+    print("max |D - exact| = %.3e (a flushing pipe would give %.3e)" % (err, err_if_flushed))
+    assert err <= 1e-6 * np.abs(D).max() and err < 0.01 * err_if_flushed

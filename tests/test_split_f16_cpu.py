@@ -1,0 +1,59 @@
+"""CPU check of the arithmetic behind the f16 two-plane GEMMs (pointnerf_amd/csrc/f16x3.h): an fp32 number x is carried as
+h = f16_rtz(x), m = f16_rne(x - h); x = h + m to 2^-21 |x| (absolute 2^-24 in the f16 subnormal range), and the three
+products the kernels keep (ah*bh + ah*bm + am*bh, fp32 accumulation) reproduce the fp32 product to ~2^-20.
+numpy restatement of pn_split2 (v_cvt_pkrtz_f16_f32 = round toward zero, v_cvt_pk_f16_f32 = round to nearest even)."""
+import numpy as np
+
+
+def f16_rtz(x):
+    x = np.asarray(x, np.float32)
+    with np.errstate(over="ignore"):
+        r = x.astype(np.float16)
+    r = np.where(np.isinf(r) & np.isfinite(x), np.copysign(np.float16(65504.0), x).astype(np.float16), r)
+    too_big = np.abs(r.astype(np.float32)) > np.abs(x)
+    bits = r.view(np.uint16)
+    return np.where(too_big, (bits - 1).astype(np.uint16), bits).view(np.float16)
+
+
+def split2(x):
+    x = np.asarray(x, np.float32)
+    h = f16_rtz(x)
+    m = (x - h.astype(np.float32)).astype(np.float32).astype(np.float16)
+    return h, m
+
+
+def test_two_planes_carry_22_bits():
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(400000) * 10.0 ** rng.uniform(-3, 4, 400000)).astype(np.float32)
+    x = np.clip(x, -65000, 65000)
+    h, m = split2(x)
+    err = np.abs(h.astype(np.float64) + m.astype(np.float64) - x.astype(np.float64))
+    assert np.all(err <= np.maximum(2.0 ** -21 * np.abs(x), 2.0 ** -25)), float((err / np.abs(x)).max())
+    assert np.all(np.abs(h.astype(np.float32)) <= np.abs(x))                       # round toward zero: never overflows
+    assert np.all(np.abs(m.astype(np.float32)) <= 2.0 ** -10 * np.abs(x) + 2.0 ** -24)
+    # tiny values: absolute accuracy of the f16 subnormal grid
+    t = (rng.standard_normal(100000) * 1e-6).astype(np.float32)
+    th, tm = split2(t)
+    assert float(np.abs(th.astype(np.float64) + tm.astype(np.float64) - t).max()) <= 2.0 ** -25
+    # the largest finite values saturate instead of becoming inf
+    hh, mm = split2(np.float32([65504.0, -65504.0, 70000.0]))
+    assert np.all(np.isfinite(hh.astype(np.float32)))
+
+
+def test_three_products_reproduce_a_256_term_dot_product():
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((2000, 256)).astype(np.float32) * rng.uniform(0.01, 4.0, (2000, 1)).astype(np.float32)
+    B = (rng.standard_normal((2000, 256)) * 0.08).astype(np.float32)
+    ah, am = [v.astype(np.float64) for v in split2(A)]
+    bh, bm = [v.astype(np.float64) for v in split2(B)]
+    three = (ah * bh + ah * bm + am * bh).sum(1)
+    exact = (A.astype(np.float64) * B.astype(np.float64)).sum(1)
+    scale = np.abs(A.astype(np.float64) * B.astype(np.float64)).sum(1)
+    plain = np.zeros(2000, np.float32)
+    for k in range(256):
+        plain = (plain + A[:, k] * B[:, k]).astype(np.float32)
+    e3 = float((np.abs(three - exact) / scale).max())
+    ep = float((np.abs(plain - exact) / scale).max())
+    print("three-product error / sum|a b| = %.2e, sequential fp32 = %.2e" % (e3, ep))
+    assert e3 <= 2.0 ** -20                                   # the dropped am*bm term and the planes' own rounding
+    assert e3 <= 40 * ep                                      # the same class as fp32 round-off of the plain sum
