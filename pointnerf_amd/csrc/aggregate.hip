@@ -447,6 +447,9 @@ __device__ __forceinline__ void f_acc_zero(f32x16 (&acc)[2][2]) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 
+#ifdef PN_PHASE_TRACE
+PN_TR_DECL(pn_trace_fwd);
+#endif
 template <bool TRAIN, bool PERS>
 __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_f[];
@@ -483,7 +486,9 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
     }
 
     f32x16 acc[2][2];
+    PN_TR_ITER_DECL;
     for (; tile < ntiles; tile += stride) {
+        PN_TR_ITER_NEXT;
         // thread-index-derived offsets are recomputed per tile: hoisted out of the loop they become hundreds of loop-carried
         // registers (every LDS / bias / image address of every unrolled store) and spill
         int tid = threadIdx.x;
@@ -491,6 +496,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), row = tid / TPR, q = tid % TPR, k = row % K;
         const long long gtile = tb + tile;               // tile index inside the saved area
         __syncthreads();                                 // the previous tile's readers are done with X and the row arrays
+        PN_TR(pn_trace_fwd, 0); PN_TR_HWID(pn_trace_fwd);
         f_build<PERS>(a, G, X, exb, wraw, sidx, si0, p0, row, q);
         __syncthreads();
         if (q == 0) {      // weights of the row: normalise over the K slots, multiply by the clamped confidence (:801-811)
@@ -507,19 +513,25 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
             if (TRAIN) a.sv.rmeta[gtile * PN_TILE + row] = make_int4(si0, si0 >= 0 ? p0 : -1, __float_as_int(wn), __float_as_int(w));
         }
         unsigned long long mask;
+        PN_TR(pn_trace_fwd, 1);
         // ---- layer 1: 288 -> 256
         if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.x0k, rg_total, gtile * 8, tid);
         f_acc_zero(acc);
+        PN_TR(pn_trace_fwd, 2);
         pn_gemm_f16x3<18, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_F1), 2 * wave, lane, acc);
         __syncthreads();
+        PN_TR(pn_trace_fwd, 3);
         f_epilogue<TRAIN>(acc, P + PO_B1, X, wave, lane, mask);
         if (TRAIN) a.sv.lmask[(gtile * 3 + 0) * PN_NTHR + tid] = mask;
         __syncthreads();
+        PN_TR(pn_trace_fwd, 4);
         // ---- layer 2: 256 -> 256
         if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h1k, rg_total, gtile * 8, tid);
         f_acc_zero(acc);
+        PN_TR(pn_trace_fwd, 5);
         pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_F2), 2 * wave, lane, acc);
         __syncthreads();
+        PN_TR(pn_trace_fwd, 6);
         f_epilogue<TRAIN>(acc, P + PO_B2, X, wave, lane, mask);
         if (TRAIN) a.sv.lmask[(gtile * 3 + 1) * PN_NTHR + tid] = mask;
         if (tid < PN_TILE) {     // the row's extras next to h2: columns 256..262, the ones column, zeros up to 271
@@ -530,18 +542,24 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
             pn_x_store4<false>(X, tid, PN_H + 12, 0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
+        PN_TR(pn_trace_fwd, 7);
         // ---- layer 3: 256 + 7 -> 256
         if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.h2k, rg_total, gtile * 8, tid);
         f_acc_zero(acc);
+        PN_TR(pn_trace_fwd, 8);
         pn_gemm_f16x3<17, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_F3), 2 * wave, lane, acc);
         __syncthreads();
+        PN_TR(pn_trace_fwd, 9);
         f_epilogue<TRAIN>(acc, P + PO_B3, X, wave, lane, mask);
         if (TRAIN) a.sv.lmask[(gtile * 3 + 2) * PN_NTHR + tid] = mask;
         __syncthreads();
+        PN_TR(pn_trace_fwd, 10);
         // ---- layer 4: 256 -> 256
         if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h3k, rg_total, gtile * 8, tid);
         f_acc_zero(acc);
+        PN_TR(pn_trace_fwd, 11);
         pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_F4), 2 * wave, lane, acc);
+        PN_TR(pn_trace_fwd, 12);
         // the next tile's point data and the indices of the two after it: requested here, consumed at the top of the next
         // iteration -- their HBM latency passes under the element-wise tail of this tile
         const float cf_cur = G.cf;
@@ -551,8 +569,10 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         const int p2 = si2 >= 0 ? a.pidx[(long long)si2 * a.Kstride + k] : -1;
         const int si3 = f_sample_of(a, tile + 3 * stride, row, Ns);
         __syncthreads();
+        PN_TR(pn_trace_fwd, 13);
         f_epilogue<false>(acc, P + PO_B4, X, wave, lane, mask);
         __syncthreads();
+        PN_TR(pn_trace_fwd, 14);
         // ---- alpha head (256 -> 1, softplus(x - 1), raw2out_density :262-265): 4 threads per row, 8-column groups interleaved
         {
             float s = 0.f;
@@ -580,6 +600,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
             }
         }
         __syncthreads();
+        PN_TR(pn_trace_fwd, 15);
         // ---- K-weighted sums -> f[256] per sample (HBM), sigma
         for (int e = tid; e < TS * 64; e += PN_NTHR) {
             const int ls = e >> 6, c4 = e & 63;
@@ -601,6 +622,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
             }
         }
         si0 = si_next; p0 = p_next; si1 = si2; p1 = p2; si2 = si3;
+        PN_TR(pn_trace_fwd, 16);
     }
 }
 
@@ -752,3 +774,9 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     PN_CHECK_LAUNCH();
     return 0;
 }
+
+#ifdef PN_PHASE_TRACE
+extern "C" int pnerf_debug_trace_fwd(void *host, size_t bytes) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(pn_trace_fwd), bytes < sizeof(pn_trace_fwd) ? bytes : sizeof(pn_trace_fwd)) == hipSuccess ? 0 : -1;
+}
+#endif

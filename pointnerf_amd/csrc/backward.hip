@@ -198,6 +198,9 @@ __device__ __forceinline__ void b_epilogue(const f32x16 (&acc)[2][2], unsigned l
             }
 }
 
+#ifdef PN_PHASE_TRACE
+PN_TR_DECL(pn_trace_bwd);
+#endif
 __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     char *X = smem_b;
@@ -220,12 +223,15 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
     float4 gw5v = make_float4(0.f, 0.f, 0.f, 0.f);      // d W5 of columns 4 (tid & 63) .. + 3 (scaled)
     float gb5t = 0.f;
     f32x16 acc[2][2];
+    PN_TR_ITER_DECL;
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        PN_TR_ITER_NEXT;
         int tid = threadIdx.x;                          // (recomputed per tile: see the forward)
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), row = tid / TPR, q = tid % TPR;
         const long long gtile = tb + tile;
         __syncthreads();
+        PN_TR(pn_trace_bwd, 0); PN_TR_HWID(pn_trace_bwd);
         // ---- load: sign words, row metadata, h4 planes
         const unsigned long long m1 = a.sv.lmask[(gtile * 3 + 0) * PN_NTHR + tid], m2 = a.sv.lmask[(gtile * 3 + 1) * PN_NTHR + tid],
                                  m3 = a.sv.lmask[(gtile * 3 + 2) * PN_NTHR + tid];
@@ -242,6 +248,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
             *reinterpret_cast<uint4 *>(X + plane * PN_XPLANE + r * PN_XRS + u * 16) = a.sv.h4r[((long long)plane * a.sv.rows + gtile * PN_TILE + r) * 32 + u];
         }
         __syncthreads();
+        PN_TR(pn_trace_bwd, 1);
         // ---- alpha head backward (4 threads per row): d w_k = d sigma alpha_k + d f . h4_k ; d x = d sigma w sigmoid(x)
         const int rsi = sidx[row], rp = prow[row];
         float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;       // the row's embedding values (for its gradient at the end of the tile)
@@ -276,6 +283,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
             }
         }
         __syncthreads();
+        PN_TR(pn_trace_bwd, 2);
         // ---- dY4 = (w d f + d x W5) * LeakyReLU'(h4), in place; d W5 / d b5 partial sums ride along
         {
             const int c4 = tid & 63;
@@ -300,27 +308,33 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
             if (tid < PN_TILE) gb5t += draw[tid];
         }
         __syncthreads();
+        PN_TR(pn_trace_bwd, 3);
         // ---- layer 4: dY4 -> d h3
         pn_copy_out_kmajor<PN_H>(X, a.sv.dy4k, rg_total, gtile * 8, tid);
         b_acc_zero(acc);
+        PN_TR(pn_trace_bwd, 4);
         pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D4), 2 * wave, lane, acc);
         __syncthreads();
+        PN_TR(pn_trace_bwd, 5);
         b_epilogue(acc, m3, X, wave, lane);
         __syncthreads();
+        PN_TR(pn_trace_bwd, 6);
         // ---- layer 3: dY3 -> d h2, and the extras block (input columns 256..262 of W3), K split over the waves
         pn_copy_out_kmajor<PN_H>(X, a.sv.dy3k, rg_total, gtile * 8, tid);
         b_acc_zero(acc);
+        PN_TR(pn_trace_bwd, 7);
         pn_gemm_f16x3<16, 9, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D3), 2 * wave, lane, acc);
         {
             f32x16 acce[2][2];
             b_acc_zero(acce);
-            pn_gemm_f16x3<16, 9, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D3), 8, lane, acce, 4 * wave, 4 * wave + 4);
+            pn_gemm_f16x3<4, 9, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D3), 8, lane, acce, 4 * wave);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) atomicAdd(&red[(32 * rb + (lane & 31)) * 8 + 4 * (lane >> 5) + r], acce[0][rb][r]);
         }
         __syncthreads();
+        PN_TR(pn_trace_bwd, 8);
         b_epilogue(acc, m2, X, wave, lane);
         if (tid < PN_TILE) {        // d colour, d dir of the row's point from the extras' gradient
             const int p = prow[tid];
@@ -338,19 +352,25 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
             }
         }
         __syncthreads();
+        PN_TR(pn_trace_bwd, 9);
         // ---- layer 2: dY2 -> d h1
         pn_copy_out_kmajor<PN_H>(X, a.sv.dy2k, rg_total, gtile * 8, tid);
         b_acc_zero(acc);
+        PN_TR(pn_trace_bwd, 10);
         pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D2), 2 * wave, lane, acc);
         __syncthreads();
+        PN_TR(pn_trace_bwd, 11);
         b_epilogue(acc, m1, X, wave, lane);
         __syncthreads();
+        PN_TR(pn_trace_bwd, 12);
         // ---- layer 1: dY1 -> d X0 (columns 0..223), fp32 into LDS
         pn_copy_out_kmajor<PN_H>(X, a.sv.dy1k, rg_total, gtile * 8, tid);
         b_acc_zero(acc);
+        PN_TR(pn_trace_bwd, 13);
         if (wave < 3) pn_gemm_f16x3<16, PN_MB_D1, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D1), 2 * wave, lane, acc);
         else pn_gemm_f16x3<16, PN_MB_D1, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D1), 6, lane, acc);
         __syncthreads();
+        PN_TR(pn_trace_bwd, 14);
 #pragma unroll
         for (int fb = 0; fb < 2; ++fb)
             if (2 * wave + fb < PN_MB_D1) {
@@ -362,6 +382,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
                             make_float4(acc[fb][rb][4 * g], acc[fb][rb][4 * g + 1], acc[fb][rb][4 * g + 2], acc[fb][rb][4 * g + 3]);
             }
         __syncthreads();
+        PN_TR(pn_trace_bwd, 15);
         // ---- embedding gradient through [e | PE3(e)]: d e = dX[e] + sum_f 2^f (dX[sin_f] cos_f - dX[cos_f] sin_f)
         if (rp >= 0) {
             const float *dr_ = dx + row * LDDX;
@@ -383,6 +404,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
                 atomicAdd(&a.g_emb[(long long)rp * PN_F + dd], g * invS);
             }
         }
+        PN_TR(pn_trace_bwd, 16);
     }
     // flush the register-resident partial sums
     {
@@ -564,16 +586,31 @@ int launch_wgrad_lds(const float *A, int lda, const float *B, int ldb, const flo
 // dW[m][n] = sum_rows dY[row][m] X[row][n] on the f16 pipe: both operands arrive as ready-made two-plane fragments (the
 // producers wrote them k-major: f16x3.h), so the kernel is glds -> LDS -> ds_read_b128 -> MFMA with no conversion work:
 //   256 x (256 + 32) block (all of dW plus a 32-column tail) in the accumulators of 8 waves (2 (M) x 4 (N), 4 x 2 tiles each +
-//   one tail tile), split-K over the rows (one workgroup per CU), 32 rows per stage, two LDS stages filled by
-//   global_load_lds_dwordx4 (every (operand, plane) of a stage is one contiguous run in HBM and in LDS).
+//   one tail tile), split-K over the rows (one workgroup per CU), 16 rows per stage, a ring of four LDS stages filled by
+//   global_load_lds_dwordx4 (every (operand, plane) of a stage is one contiguous run in HBM and in LDS) THREE stages ahead:
+//   the kernel is HBM-bound by design (2 KB per row and layer against ~0.35 us of MFMA work per 16 rows), so what matters is
+//   that ~100 KB per CU are in flight at all times -- with two stages the queue drained at every barrier (4.1 TB/s measured).
+//   The LDS-DMA count is tracked by hand (s_waitcnt vmcnt(N) + raw s_barrier: __syncthreads() would drain the queue).
 // Tail: NFB == 288: the operand's own columns 256..287 (distance encoding of X0 / layer-3 extras, and the ONES column whose
 // "weight gradient" is the bias gradient); NFB == 256: a constant ones fragment (bias gradient of layers 2 and 4).
-// It is HBM-bound by design: 2 KB per row and layer at ~5 TB/s against ~0.4 us of MFMA work per 32 rows.
+#ifdef PN_EMU
+#define PN_WAIT_VMCNT(n) ((void)0)
+#else
+#define PN_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#endif
+template <int N> __device__ __forceinline__ void pn_wait_vm_stages(int stages) {       // wait until at most `stages` x N of this wave's loads are outstanding
+    if (stages >= 2) PN_WAIT_VMCNT(2 * N);
+    else if (stages == 1) PN_WAIT_VMCNT(N);
+    else PN_WAIT_VMCNT(0);
+}
 template <int NFB>
 __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, const uint4 *__restrict__ B, long long rg_total,
                                                    const int *__restrict__ d_tiles, float *__restrict__ partial) {
-    constexpr int AU = 4 * 256, BU = 4 * NFB;                 // units (16 B) of one plane of a stage: 4 row groups
+    constexpr int AU = 2 * 256, BU = 2 * NFB;                 // units (16 B) of one plane of a stage: 2 row groups = 16 rows
     constexpr int STAGE = 2 * AU + 2 * BU;                    // [A h | A m | B h | B m]
+    constexpr int NI = STAGE / 64, NIW = (NI + 7) / 8;        // wave-instructions per stage, per wave (the last ones are padded)
+    constexpr int NST = 4;
+    static_assert(STAGE % 64 == 0, "a stage is a whole number of 1 KB wave copies");
     extern __shared__ __attribute__((aligned(16))) uint4 smem_w[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -584,7 +621,7 @@ __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, 
     const long long r0 = (long long)blockIdx.x * rpc;
     long long r1 = r0 + rpc;
     if (r1 > rows) r1 = rows;
-    const int nst = r1 > r0 ? (int)((r1 - r0) / 32) : 0;
+    const int nst = r1 > r0 ? (int)((r1 - r0) / 16) : 0;
     f32x16 acc[4][2], acct;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -592,57 +629,59 @@ __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; }
     }
-    // stage s -> buffer: wave-instruction j copies units [64 j, 64 j + 64) of the stage's concatenated runs
+    // stage s -> buffer: wave-instruction j copies units [64 j, 64 j + 64) of the stage's concatenated runs; every wave issues
+    // exactly NIW instructions (a wave without a piece of its own re-reads the stage's first KB into the pad slot)
     auto issue = [&](int s, int buf) {
-        const long long rg = r0 / 8 + 4LL * s;
-        constexpr int NI = STAGE / 64;
-        for (int j = wave; j < NI; j += 8) {
-            const int u0 = 64 * j;
+        const long long rg = r0 / 8 + 2LL * s;
+#pragma unroll
+        for (int i = 0; i < NIW; ++i) {
+            const bool pad = wave + 8 * i >= NI;
+            const int j = pad ? 0 : wave + 8 * i, u0 = 64 * j;
+            const uint4 *dst = smem_w + (pad ? NST * STAGE : buf * STAGE + u0);
             const uint4 *src;
             if (u0 < 2 * AU) { const int p = u0 / AU, u = u0 - p * AU; src = A + ((long long)p * rg_total + rg) * 256 + u; }
             else { const int v = u0 - 2 * AU, p = v / BU, u = v - p * BU; src = B + ((long long)p * rg_total + rg) * NFB + u; }
-            __builtin_amdgcn_global_load_lds(src + lane, (__attribute__((address_space(3))) void *)(smem_w + buf * STAGE + u0), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(src + lane, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
     };
     pn_h8 ones = {0, 0, 0, 0, 0, 0, 0, 0};
     if ((lane & 31) == 0) ones = pn_h8{1, 1, 1, 1, 1, 1, 1, 1};
     if (nst > 0) {
         issue(0, 0);
-        __syncthreads();
+        if (nst > 1) issue(1, 1);
+        if (nst > 2) issue(2, 2);
         for (int s = 0; s < nst; ++s) {
-            const int buf = s & 1;
-            if (s + 1 < nst) issue(s + 1, buf ^ 1);
-            const uint4 *st = smem_w + buf * STAGE;
+            // stage s has landed for every wave, and every wave is done with stage s - 1 (whose buffer the next issue overwrites)
+            pn_wait_vm_stages<NIW>(nst - 1 - s);
+            __builtin_amdgcn_s_barrier();
+            if (s + 3 < nst) issue(s + 3, (s + 3) & 3);
+            const uint4 *st = smem_w + (s & 3) * STAGE;
+            const uint4 *fa = st + (lane >> 5) * 256 + (lane & 31);
+            const uint4 *fb = st + 2 * AU + (lane >> 5) * NFB + (lane & 31);
+            pn_h8 ah[4], am[4], bh[2], bm[2];
 #pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {                  // two 16-row k-steps per stage
-                const uint4 *fa = st + (2 * ss + (lane >> 5)) * 256 + (lane & 31);
-                const uint4 *fb = st + 2 * AU + (2 * ss + (lane >> 5)) * NFB + (lane & 31);
-                pn_h8 ah[4], am[4], bh[2], bm[2];
+            for (int i = 0; i < 4; ++i) { ah[i] = __builtin_bit_cast(pn_h8, fa[(4 * wm + i) * 32]); am[i] = __builtin_bit_cast(pn_h8, fa[AU + (4 * wm + i) * 32]); }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { ah[i] = __builtin_bit_cast(pn_h8, fa[(4 * wm + i) * 32]); am[i] = __builtin_bit_cast(pn_h8, fa[AU + (4 * wm + i) * 32]); }
+            for (int i = 0; i < 2; ++i) { bh[i] = __builtin_bit_cast(pn_h8, fb[(2 * wn + i) * 32]); bm[i] = __builtin_bit_cast(pn_h8, fb[BU + (2 * wn + i) * 32]); }
 #pragma unroll
-                for (int i = 0; i < 2; ++i) { bh[i] = __builtin_bit_cast(pn_h8, fb[(2 * wn + i) * 32]); bm[i] = __builtin_bit_cast(pn_h8, fb[BU + (2 * wn + i) * 32]); }
+            for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p == 2 ? am[i] : ah[i], p == 1 ? bm[j] : bh[j], acc[i][j], 0, 0, 0);
-                // tail tile: row tile 4 wm + wn of dW x columns 256..287
-                const pn_h8 tah = wn == 0 ? ah[0] : wn == 1 ? ah[1] : wn == 2 ? ah[2] : ah[3];
-                const pn_h8 tam = wn == 0 ? am[0] : wn == 1 ? am[1] : wn == 2 ? am[2] : am[3];
-                if (NFB > 256) {
-                    const pn_h8 tbh = __builtin_bit_cast(pn_h8, fb[256]), tbm = __builtin_bit_cast(pn_h8, fb[BU + 256]);
-                    acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbh, acct, 0, 0, 0);
-                    acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbm, acct, 0, 0, 0);
-                    acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tam, tbh, acct, 0, 0, 0);
-                } else {
-                    acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, ones, acct, 0, 0, 0);
-                    acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tam, ones, acct, 0, 0, 0);
-                }
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p == 2 ? am[i] : ah[i], p == 1 ? bm[j] : bh[j], acc[i][j], 0, 0, 0);
+            // tail tile: row tile 4 wm + wn of dW x columns 256..287
+            const pn_h8 tah = wn == 0 ? ah[0] : wn == 1 ? ah[1] : wn == 2 ? ah[2] : ah[3];
+            const pn_h8 tam = wn == 0 ? am[0] : wn == 1 ? am[1] : wn == 2 ? am[2] : am[3];
+            if (NFB > 256) {
+                const pn_h8 tbh = __builtin_bit_cast(pn_h8, fb[256]), tbm = __builtin_bit_cast(pn_h8, fb[BU + 256]);
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbh, acct, 0, 0, 0);
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbm, acct, 0, 0, 0);
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tam, tbh, acct, 0, 0, 0);
+            } else {
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, ones, acct, 0, 0, 0);
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tam, ones, acct, 0, 0, 0);
             }
-            __syncthreads();                                  // (waits for the glds of stage s + 1 as well: its fence drains vmcnt)
         }
     }
     float *out = partial + (size_t)blockIdx.x * 256 * 288;
@@ -693,7 +732,7 @@ int launch_wgrad_f16(const uint4 *A, const uint4 *B, long long rg_total, const i
     const long long tiles = rows_max / PN_TILE;
     if (tiles < chunks) chunks = (int)(tiles > 0 ? tiles : 1);
     if ((size_t)chunks * 256 * 288 > PARTIAL_FLOATS) return PNERF_E_WS;
-    constexpr size_t lds = (size_t)2 * (2 * 4 * 256 + 2 * 4 * NFB) * 16;
+    constexpr size_t lds = ((size_t)4 * (2 * 2 * 256 + 2 * 2 * NFB) + 64) * 16;       // four stages + the pad slot
     if (hipFuncSetAttribute((const void *)k_wgrad_f16<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PNERF_E_LAUNCH;
     { PnProfScope prof(PNK_WGRAD, s);
     hipLaunchKernelGGL(k_wgrad_f16<NFB>, dim3(chunks), dim3(512), lds, s, A, B, rg_total, d_tiles, partial); }
@@ -768,3 +807,9 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     if ((rc = launch_wgrad_lds<2, 1, 2, 4, 16, false>(sv.dc3, PN_HC, sv.c2, PN_HC, nullptr, 0, smp, nullptr, d_partials, 128, 128, g, PO_WC3, PN_HC, s))) return rc;
     return 0;
 }
+
+#ifdef PN_PHASE_TRACE
+extern "C" int pnerf_debug_trace_bwd(void *host, size_t bytes) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(pn_trace_bwd), bytes < sizeof(pn_trace_bwd) ? bytes : sizeof(pn_trace_bwd)) == hipSuccess ? 0 : -1;
+}
+#endif

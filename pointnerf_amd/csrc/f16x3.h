@@ -106,72 +106,101 @@ __device__ __forceinline__ float4 pn_x_load4(const char *X, int row, int col) {
     return make_float4(pn_h_lo(h.x) + pn_h_lo(m.x), pn_h_hi(h.x) + pn_h_hi(m.x), pn_h_lo(h.y) + pn_h_lo(m.y), pn_h_hi(h.y) + pn_h_hi(m.y));
 }
 
-// ---- the tile GEMM: acc[fb][rb] (feature block fb of this wave x row block rb) += W[.., 16 NCH] * X^T
-// Three products per (fb, rb) and chunk, ordered so that an accumulator is touched once in four MFMAs; the next chunk's
-// fragments (weights from the L2-resident image, activations from LDS) are requested before the current chunk's MFMAs.
-// MB = feature blocks of the image; NFB = blocks this wave computes (fb0 = its first block).
-template <int NCH, int MB, int NFB>
-__device__ __forceinline__ void pn_gemm_f16x3(const char *X, const uint4 *__restrict__ img, int fb0, int lane, f32x16 (&acc)[2][2], int c_begin = 0, int c_end = NCH) {
-    const char *xb = X + (lane & 31) * PN_XRS + (lane >> 5) * 16;
-    const uint4 *wp = img + fb0 * 128 + lane;
-    uint4 wh[2][2], wm[2][2], xh[2][2], xm[2][2];
-    auto load = [&](int c, int s) {
+// ---- the tile GEMM: acc[fb][rb] (feature block fb of this wave x row block rb) += W[.., 16 NC columns from chunk c0] * X^T
+// Three products per (fb, rb) and chunk, ordered so that an accumulator is touched once in four MFMAs.  The weight fragments
+// come from the L2-resident image (500+ cycles under load) and are requested PN_WPF chunks (x 384 cycles of MFMA) ahead in a
+// ring of PN_WPF + 1 register sets; the activation fragments come from LDS one chunk ahead.  The chunk loop is unrolled
+// completely (compile-time register sets).  MB = feature blocks of the image; NFB = blocks this wave computes from fb0 on.
+#ifndef PN_WPF
+#define PN_WPF 2
+#endif
+// dev experiments (tools/_build variants only): issue-slot spacing after every MFMA / wave priority during the GEMM
+#if defined(PN_MFMA_NOPS) && !defined(PN_EMU)
+#define PN_MFMA_GAP() do { asm volatile("s_nop %0\n\ts_nop %0" ::"n"(PN_MFMA_NOPS)); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PN_MFMA_GAP() ((void)0)
+#endif
+#if defined(PN_GEMM_PRIO) && !defined(PN_EMU)
+#define PN_GEMM_PRIO_BEGIN() __builtin_amdgcn_s_setprio(PN_GEMM_PRIO)
+#define PN_GEMM_PRIO_END() __builtin_amdgcn_s_setprio(0)
+#else
+#define PN_GEMM_PRIO_BEGIN() ((void)0)
+#define PN_GEMM_PRIO_END() ((void)0)
+#endif
+template <int NC, int MB, int NFB>
+__device__ __forceinline__ void pn_gemm_f16x3(const char *X, const uint4 *__restrict__ img, int fb0, int lane, f32x16 (&acc)[2][2], int c0 = 0) {
+    constexpr int PF = PN_WPF < NC ? PN_WPF : NC - 1, NS = PF + 1;
+    const char *xb = X + (lane & 31) * PN_XRS + (lane >> 5) * 16 + c0 * 32;
+    const uint4 *wp = img + ((size_t)c0 * MB + fb0) * 128 + lane;
+    uint4 wh[NS][2], wm[NS][2], xh[2][2], xm[2][2];
+    auto load_w = [&](auto cc) {
+        constexpr int c = decltype(cc)::value, s = c % NS;
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) { wh[s][fb] = wp[(c * MB + fb) * 128]; wm[s][fb] = wp[(c * MB + fb) * 128 + 64]; }
+    };
+    auto load_x = [&](auto cc) {
+        constexpr int c = decltype(cc)::value, s = c & 1;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             xh[s][rb] = *reinterpret_cast<const uint4 *>(xb + rb * 32 * PN_XRS + c * 32);
             xm[s][rb] = *reinterpret_cast<const uint4 *>(xb + PN_XPLANE + rb * 32 * PN_XRS + c * 32);
         }
     };
-    auto mma = [&](int s) {
+    pn_static_for<PF>([&](auto cc) { load_w(cc); });
+    load_x(std::integral_constant<int, 0>{});
+    PN_GEMM_PRIO_BEGIN();
+    pn_static_for<NC>([&](auto cc) {
+        constexpr int c = decltype(cc)::value, sw = c % NS, sx = c & 1;
+        if constexpr (c + PF < NC) load_w(std::integral_constant<int, c + PF>{});
+        if constexpr (c + 1 < NC) load_x(std::integral_constant<int, c + 1>{});
+        // (without the fences hipcc sinks every load down to its first use to shorten live ranges: "load; s_waitcnt; mfma" --
+        //  an exposed L2 round trip per chunk, measured 30 % of the MFMA rate)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) {
-                    const pn_h8 a = __builtin_bit_cast(pn_h8, p == 2 ? wm[s][fb] : wh[s][fb]);
-                    const pn_h8 b = __builtin_bit_cast(pn_h8, p == 1 ? xm[s][rb] : xh[s][rb]);
+                    const pn_h8 a = __builtin_bit_cast(pn_h8, p == 2 ? wm[sw][fb] : wh[sw][fb]);
+                    const pn_h8 b = __builtin_bit_cast(pn_h8, p == 1 ? xm[sx][rb] : xh[sx][rb]);
                     acc[fb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[fb][rb], 0, 0, 0);
+                    PN_MFMA_GAP();
                 }
-    };
-    if (c_begin >= c_end) return;
-    load(c_begin, 0);
-    for (int c = c_begin; c < c_end; c += 2) {
-        if (c + 1 < c_end) load(c + 1, 1);
-        mma(0);
-        if (c + 2 < c_end) load(c + 2, 0);
-        if (c + 1 < c_end) mma(1);
-    }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    PN_GEMM_PRIO_END();
 }
 
 // accumulator element (fb, rb, g, i) of a lane: feature = 32 fbg + 8 g + 4 (l >> 5) + i (fbg = global block), row = 32 rb + (l & 31)
 __device__ __forceinline__ int pn_d_feat(int fbg, int g, int lane) { return 32 * fbg + 8 * g + 4 * (lane >> 5); }
 
 // ---- transposing copy-out: the tile's NF columns -> k-major planes (training).  Unit (plane, row group rg, feature f) = rows
-// 8 rg .. 8 rg + 7 of column f: eight 2-byte LDS reads (consecutive lanes -> consecutive columns: conflict-free) and one
-// coalesced 16-byte store.  dst = base of the array ([2][rg_total][NF] units), rg0 = first row group of the tile.
+// 8 rg .. 8 rg + 7 of column f.  gfx950's LDS transpose read does the 16-bit transposition: per 16-lane group,
+//     ds_read_b64_tr_b16:  lane i, element j  <-  element (i & 3) of the 8-byte slot addressed by lane 4 j + (i >> 2)
+// (semantics pinned on the hardware by tools/trb16_probe.hip), so with lane i pointing at row (i >> 2) & 3, columns 4 (i & 3) .. + 3
+// of a [4 rows][16 columns] block every lane receives 4 consecutive ROWS of column i: two reads = one 16-byte unit, stored
+// coalesced (lane -> column).  dst = base of the array ([2][rg_total][NF] units), rg0 = first row group of the tile.
+typedef short pn_s4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 pn_lds_read_tr16(const char *p) {
+    const pn_s4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) pn_s4 *)p);
+    return __builtin_bit_cast(uint2, r);
+}
 template <int NF>
 __device__ __forceinline__ void pn_copy_out_kmajor(const char *X, uint4 *__restrict__ dst, long long rg_total, long long rg0, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
+    const int blk = ((lane >> 2) & 3) * PN_XRS + ((lane >> 4) * 16 + (lane & 3) * 4) * 2;      // this lane's slot inside a [4][64-column] block
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int combo = wave * 4 + i, plane = combo >> 3, rg = combo & 7;
-        const char *src = X + plane * PN_XPLANE + rg * 8 * PN_XRS;
+        const char *src = X + plane * PN_XPLANE + rg * 8 * PN_XRS + blk;
         uint4 *d = dst + ((long long)plane * rg_total + rg0 + rg) * NF;
 #pragma unroll
         for (int j = 0; j < (NF + 63) / 64; ++j) {
             const int f = lane + 64 * j;
+            const uint2 lo = pn_lds_read_tr16(src + j * 128), hi = pn_lds_read_tr16(src + 4 * PN_XRS + j * 128);
             if (f < NF) {
-                unsigned w[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const unsigned lo = *reinterpret_cast<const unsigned short *>(src + (2 * r) * PN_XRS + f * 2);
-                    const unsigned hi = *reinterpret_cast<const unsigned short *>(src + (2 * r + 1) * PN_XRS + f * 2);
-                    w[r] = lo | (hi << 16);
-                }
-                pn_f4 t = {__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
+                pn_f4 t = {__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y)};
                 __builtin_nontemporal_store(t, reinterpret_cast<pn_f4 *>(d + f));
             }
         }

@@ -211,3 +211,32 @@ PnSaved pn_saved_carve(void *base, long long n_valid, int K);
 
 __host__ __device__ inline int pn_tile_samples(int K) { return PN_TILE / K; }
 
+
+// ---- dev-only phase timeline (build with EXTRA_DEFS=-DPN_PHASE_TRACE into tools/_build; tools/gpu_phase_trace.py reads it) ----------
+// thread 0 of the first PN_TR_WGS workgroups stamps s_memrealtime (100 MHz) at the phase boundaries of PN_TR_ITERS tile iterations
+#ifdef PN_PHASE_TRACE
+#define PN_TR_WGS   512
+#define PN_TR_IT0   20
+#define PN_TR_ITERS 6
+#define PN_TR_SLOTS 24
+#define PN_TR_DECL(name) __device__ unsigned long long name[PN_TR_WGS * PN_TR_ITERS * PN_TR_SLOTS]
+#define PN_TR(buf, ph)                                                                                              \
+    do {                                                                                                            \
+        if (tid == 0 && blockIdx.x < PN_TR_WGS && titer >= PN_TR_IT0 && titer < PN_TR_IT0 + PN_TR_ITERS)           \
+            buf[((size_t)blockIdx.x * PN_TR_ITERS + (titer - PN_TR_IT0)) * PN_TR_SLOTS + (ph)] = wall_clock64();    \
+    } while (0)
+#define PN_TR_HWID(buf)                                                                                             \
+    do {                                                                                                            \
+        if (tid == 0 && blockIdx.x < PN_TR_WGS && titer >= PN_TR_IT0 && titer < PN_TR_IT0 + PN_TR_ITERS)           \
+            buf[((size_t)blockIdx.x * PN_TR_ITERS + (titer - PN_TR_IT0)) * PN_TR_SLOTS + PN_TR_SLOTS - 1] =         \
+                (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |                                    \
+                ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);                             \
+    } while (0)
+#define PN_TR_ITER_DECL int titer = -1
+#define PN_TR_ITER_NEXT ++titer
+#else
+#define PN_TR(buf, ph)
+#define PN_TR_HWID(buf)
+#define PN_TR_ITER_DECL
+#define PN_TR_ITER_NEXT
+#endif

@@ -23,6 +23,7 @@ def preprocess(text):
     text = re.sub(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(\w+)\s+(\w+)\[\];", r"\1 *\2 = (\1 *)emu::lds();", text)
     text = re.sub(r'asm volatile\(""[^;]*\);', ";", text)
     text = text.replace("(__attribute__((address_space(3))) void *)", "(void *)")
+    text = text.replace("(__attribute__((address_space(3))) pn_s4 *)", "(const pn_s4 *)")
     return text
 
 

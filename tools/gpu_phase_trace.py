@@ -1,7 +1,7 @@
 """dev: per-phase timeline of k_agg_forward / k_agg_backward on the bench workload.
 
 Needs libpnerf_hip.so built with  make -C pointnerf_amd/csrc -B EXTRA_DEFS=-DPN_PHASE_TRACE  (never the shipped build):
-thread 0 of every workgroup stamps s_memrealtime (100 MHz) at each phase boundary of tile iterations 20..25 together
+thread 0 of every workgroup stamps s_memrealtime (100 MHz) at each phase boundary of tile iterations 20..25 (one 64-row tile per iteration, two workgroups per CU) together
 with HW_ID / XCC_ID, so that the two workgroups sharing a CU can be paired and their GEMM phases overlaid.
 Prints a JSON summary; raw stamps go to gpurun_out/phase_trace.npz."""
 import ctypes, json, os, sys
@@ -37,19 +37,16 @@ def read(name):
     return buf.reshape(WGS, ITERS, SLOTS)
 
 
-FWD_GEMM = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8)]
-BWD_GEMM = [(0, 1), (1, 2), (3, 4), (5, 6), (6, 7), (7, 8), (8, 9), (9, 10)]
-FWD_NAMES = {(0, 1): "G1(A) | boundary B", (1, 2): "G1(B) | E1(A)", (2, 3): "G2(A) | E1(B), copy A", (3, 4): "G2(B) | E2(A), copy B",
-             (4, 5): "G3(A) | E2(B), copy A", (5, 6): "G3(B) | E3(A), copy B", (6, 7): "G4(A) | E3(B), copy A", (7, 8): "G4(B) | copy B, boundary A",
-             (0, 9): "  S1: start -> slot 1 (requests)", (9, 10): "  S1: slots 1-3", (10, 11): "  S1: E4 (4-67)", (11, 12): "  S1: alpha head (68-141)", (12, 13): "  S1: K-sums + h4 copy (142-215)",
-             (13, 14): "  S1: barrier + geometry (216-223)", (14, 15): "  S1: embedding PE (224-271)", (15, 16): "  S1: distance PE + pad (272-295)", (16, 17): "  S1: barrier + weights (296-299)",
-             (17, 18): "  S1: slots 300-375 (index shift only)", (18, 1): "  S1: tail (375-575) + barrier"}
-BWD_NAMES = {(0, 1): "G(A,4) | boundary B", (1, 2): "G(B,4) | E(A)", (2, 3): "(between steps)", (3, 4): "G(A,3) | E(B), copy A, extras A", (4, 5): "(between steps)",
-             (5, 6): "G(B,3) | E(A), copy B, extras B", (6, 7): "G(A,2) | E(B), copy A", (7, 8): "G(B,2) | E(A), copy B", (8, 9): "G(A,1) | E(B), copy A",
-             (9, 10): "G(B,1) | copy B, boundary A",
-             (0, 11): "  S1: start -> slot 0", (11, 12): "  S1: slots 0-3", (12, 13): "  S1: slots 3-9", (13, 14): "  S1: slots 9-17", (14, 15): "  S1: slots 17-34",
-             (15, 16): "  S1: slots 34-50", (16, 17): "  S1: slots 50-74", (17, 18): "  S1: slots 74-140", (18, 19): "  S1: slots 140-243",
-             (19, 20): "  S1: slots 243-319", (20, 1): "  S1: slots 319-511 + barrier"}
+FWD_GEMM = [(2, 3), (5, 6), (8, 9), (11, 12)]
+BWD_GEMM = [(4, 5), (7, 8), (10, 11), (13, 14)]
+FWD_NAMES = {(0, 1): "build X0 + weights", (1, 2): "copy-out X0, acc zero", (2, 3): "GEMM1 + barrier", (3, 4): "E1 + barrier", (4, 5): "copy-out h1",
+             (5, 6): "GEMM2 + barrier", (6, 7): "E2 + extras + barrier", (7, 8): "copy-out h2x", (8, 9): "GEMM3 + barrier", (9, 10): "E3 + barrier",
+             (10, 11): "copy-out h3", (11, 12): "GEMM4", (12, 13): "next gather issue + barrier", (13, 14): "E4 + barrier", (14, 15): "alpha + h4 copy + barrier",
+             (15, 16): "K-sums"}
+BWD_NAMES = {(0, 1): "load h4 / meta + barrier", (1, 2): "alpha backward + barrier", (2, 3): "dY4 pass + barrier", (3, 4): "copy-out dY4", (4, 5): "GEMM4 + barrier",
+             (5, 6): "E(m3) + barrier", (6, 7): "copy-out dY3", (7, 8): "GEMM3 + extras + barrier", (8, 9): "E(m2) + extras finish + barrier", (9, 10): "copy-out dY2",
+             (10, 11): "GEMM2 + barrier", (11, 12): "E(m1) + barrier", (12, 13): "copy-out dY1", (13, 14): "GEMM1 + barrier", (14, 15): "dX0 -> LDS + barrier",
+             (15, 16): "embedding gradient"}
 
 def analyse(tr, names, gemm, last):
     t = tr[:, :, :max(last, max(max(k) for k in names)) + 1].astype(np.int64)
@@ -103,4 +100,4 @@ def analyse(tr, names, gemm, last):
 fwd, bwd = read("pnerf_debug_trace_fwd"), read("pnerf_debug_trace_bwd")
 os.makedirs("gpurun_out", exist_ok=True)
 np.savez_compressed("gpurun_out/phase_trace.npz", fwd=fwd, bwd=bwd)
-print(json.dumps({"forward": analyse(fwd, FWD_NAMES, FWD_GEMM, 8), "backward": analyse(bwd, BWD_NAMES, BWD_GEMM, 10)}, indent=1))
+print(json.dumps({"forward": analyse(fwd, FWD_NAMES, FWD_GEMM, 16), "backward": analyse(bwd, BWD_NAMES, BWD_GEMM, 16)}, indent=1))

@@ -1,0 +1,20 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r2d; mkdir -p $O
+./tools/_build/trb16_probe > $O/trb16.txt 2>&1
+timeout 300 python bench.py --cpu-rays 0 --steps 10 > $O/bench_shipped.json 2>$O/bench_shipped.err
+cp pointnerf_amd/libpnerf_hip.so /tmp/shipped.so
+for V in prio3 nop7 nop3 nop7prio; do
+  cp tools/_build/$V.so pointnerf_amd/libpnerf_hip.so
+  timeout 300 python bench.py --cpu-rays 0 --steps 10 > $O/bench_$V.json 2>/dev/null
+done
+cp /tmp/shipped.so pointnerf_amd/libpnerf_hip.so
+for f in shipped prio3 nop7 nop3 nop7prio; do python - <<PY
+import json
+try:
+    d=json.load(open("$O/bench_$f.json")); k=d["kernels"]
+    print("%-12s %.0f rays/s %.2f ms  fwd %.2f bwd %.2f wgrad %.2f" % ("$f", d["value"], d["ms_per_step"], k["agg_forward"]["ms_per_step"], k.get("agg_backward",{}).get("ms_per_step",0), k.get("wgrad",{}).get("ms_per_step",0)))
+except Exception as e: print("$f", "ERR", e)
+PY
+done
+head -40 $O/trb16.txt
