@@ -227,6 +227,9 @@ int pnerf_voxel_downsample(const float *d_xyz, int64_t n_points, const float *sp
  * D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31]).  The tests pin with it the fragment layout and the un-flushed handling of f16
  * subnormal inputs that the two-plane GEMMs of the aggregator (csrc/f16x3.h) rely on. */
 int pnerf_debug_mfma_f16(const void *d_a, const void *d_b, float *d_out, void *stream);
+/* the two-plane split of csrc/f16x3.h on n floats (n even): d_h / d_m [n] f16 (high plane: round toward zero; residual plane: round to
+ * nearest of x - h); sat != 0 clamps to the f16 range first (the gradient form).  Tests compare it bit for bit with the numpy restatement. */
+int pnerf_debug_split(const float *d_x, int64_t n, void *d_h, void *d_m, int sat, void *stream);
 
 /* ---- per-kernel timing (HIP events recorded on the launch stream; off by default) --------------- */
 int pnerf_prof_enable(int on);

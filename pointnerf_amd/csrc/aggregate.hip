@@ -115,6 +115,24 @@ __global__ __launch_bounds__(64) void k_debug_mfma_f16(const uint4 *__restrict__
     for (int r = 0; r < 16; ++r) d[threadIdx.x * 16 + r] = acc[r];
 }
 }  // namespace
+namespace {
+__global__ __launch_bounds__(256) void k_debug_split(const float *__restrict__ x, long long n, unsigned *__restrict__ h, unsigned *__restrict__ m, int sat) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; 2 * i < n; i += (long long)gridDim.x * 256) {
+        unsigned hh, mm;
+        if (sat) pn_split2_sat(x[2 * i], x[2 * i + 1], hh, mm);
+        else pn_split2(x[2 * i], x[2 * i + 1], hh, mm);
+        h[i] = hh; m[i] = mm;
+    }
+}
+}  // namespace
+extern "C" int pnerf_debug_split(const float *d_x, int64_t n, void *d_h, void *d_m, int sat, void *stream) {
+    if (!d_x || !d_h || !d_m || n < 0 || (n & 1)) return PNERF_E_INVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_debug_split, dim3(64), dim3(256), 0, (hipStream_t)stream, d_x, (long long)n, (unsigned *)d_h, (unsigned *)d_m, sat);
+    PN_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pnerf_debug_mfma_f16(const void *d_a, const void *d_b, float *d_out, void *stream) {
     if (!d_a || !d_b || !d_out) return PNERF_E_INVAL;
     hipLaunchKernelGGL(k_debug_mfma_f16, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint4 *)d_a, (const uint4 *)d_b, d_out);
@@ -412,30 +430,36 @@ __device__ __forceinline__ void f_build(const FwdArgs &a, const FGather &G, char
     }
 }
 
-// epilogue of a layer: accumulators + bias, LeakyReLU, sign bits, both planes -> the tile (columns 0..255)
-template <bool BITS>
-__device__ __forceinline__ void f_epilogue(const f32x16 (&acc)[2][2], const float *__restrict__ bias, char *X, int wave, int lane, unsigned long long &mask) {
-    mask = 0ull;
+// epilogue of a layer: accumulators + bias, LeakyReLU, sign bits, both planes -> the tile (columns 0..255).
+// Sign word: one v_alignbit_b32 per element shifts the element's sign bit into a 32-bit accumulator (MSB first), element
+// e = ((fb * 2 + rb) * 4 + g) * 4 + i of a lane -> bit 31 - (e & 31) of half e >> 5; bit set = negative = slope 0.01 in the backward
+__device__ __forceinline__ void f_load_bias(const float *__restrict__ bias, int wave, int lane, float4 (&b)[8]) {
 #pragma unroll
     for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int f0 = pn_d_feat(2 * wave + fb, g, lane);
-            const float4 b = *reinterpret_cast<const float4 *>(bias + f0);
+        for (int g = 0; g < 4; ++g) b[fb * 4 + g] = *reinterpret_cast<const float4 *>(bias + pn_d_feat(2 * wave + fb, g, lane));
+}
+template <bool BITS>
+__device__ __forceinline__ void f_epilogue(const f32x16 (&acc)[2][2], const float4 (&bias)[8], char *X, int wave, int lane, unsigned long long &mask) {
+    unsigned mw[2] = {0u, 0u};
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f0 = pn_d_feat(2 * wave + fb, g, lane);
+                const float4 b = bias[fb * 4 + g];
                 float v[4] = {acc[fb][rb][4 * g] + b.x, acc[fb][rb][4 * g + 1] + b.y, acc[fb][rb][4 * g + 2] + b.z, acc[fb][rb][4 * g + 3] + b.w};
                 if (BITS) {
-                    unsigned long long bits = 0ull;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) bits |= (unsigned long long)(v[i] > 0.f ? 1u : 0u) << i;
-                    mask |= bits << (((fb * 2 + rb) * 4 + g) * 4);
+                    for (int i = 0; i < 4; ++i) mw[fb] = __builtin_amdgcn_alignbit(mw[fb], __float_as_uint(v[i]), 31);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.01f * v[i]);
                 pn_x_store4<false>(X, 32 * rb + (lane & 31), f0, v[0], v[1], v[2], v[3]);
             }
-        }
+    mask = ((unsigned long long)mw[1] << 32) | mw[0];
 }
 
 __device__ __forceinline__ void f_acc_zero(f32x16 (&acc)[2][2]) {
@@ -495,10 +519,10 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), row = tid / TPR, q = tid % TPR, k = row % K;
         const long long gtile = tb + tile;               // tile index inside the saved area
-        __syncthreads();                                 // the previous tile's readers are done with X and the row arrays
+        PN_LDS_BARRIER();                                 // the previous tile's readers are done with X and the row arrays
         PN_TR(pn_trace_fwd, 0); PN_TR_HWID(pn_trace_fwd);
         f_build<PERS>(a, G, X, exb, wraw, sidx, si0, p0, row, q);
-        __syncthreads();
+        PN_LDS_BARRIER();
         if (q == 0) {      // weights of the row: normalise over the K slots, multiply by the clamped confidence (:801-811)
             const int ls = row / K;
             float wn = 0.f, w = 0.f;
@@ -513,26 +537,29 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
             if (TRAIN) a.sv.rmeta[gtile * PN_TILE + row] = make_int4(si0, si0 >= 0 ? p0 : -1, __float_as_int(wn), __float_as_int(w));
         }
         unsigned long long mask;
+        float4 bias[8];
         PN_TR(pn_trace_fwd, 1);
         // ---- layer 1: 288 -> 256
         if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.x0k, rg_total, gtile * 8, tid);
         f_acc_zero(acc);
         PN_TR(pn_trace_fwd, 2);
         pn_gemm_f16x3<18, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_F1), 2 * wave, lane, acc);
-        __syncthreads();
+        f_load_bias(P + PO_B1, wave, lane, bias);           // (requested before the barrier: the wait for the slowest wave covers the L2 round trip)
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 3);
-        f_epilogue<TRAIN>(acc, P + PO_B1, X, wave, lane, mask);
+        f_epilogue<TRAIN>(acc, bias, X, wave, lane, mask);
         if (TRAIN) a.sv.lmask[(gtile * 3 + 0) * PN_NTHR + tid] = mask;
-        __syncthreads();
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 4);
         // ---- layer 2: 256 -> 256
         if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h1k, rg_total, gtile * 8, tid);
         f_acc_zero(acc);
         PN_TR(pn_trace_fwd, 5);
         pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_F2), 2 * wave, lane, acc);
-        __syncthreads();
+        f_load_bias(P + PO_B2, wave, lane, bias);           // (requested before the barrier: the wait for the slowest wave covers the L2 round trip)
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 6);
-        f_epilogue<TRAIN>(acc, P + PO_B2, X, wave, lane, mask);
+        f_epilogue<TRAIN>(acc, bias, X, wave, lane, mask);
         if (TRAIN) a.sv.lmask[(gtile * 3 + 1) * PN_NTHR + tid] = mask;
         if (tid < PN_TILE) {     // the row's extras next to h2: columns 256..262, the ones column, zeros up to 271
             const float4 u = *reinterpret_cast<const float4 *>(exb + tid * 8), v = *reinterpret_cast<const float4 *>(exb + tid * 8 + 4);
@@ -541,18 +568,19 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
             pn_x_store4<false>(X, tid, PN_H + 8, 0.f, 0.f, 0.f, 0.f);
             pn_x_store4<false>(X, tid, PN_H + 12, 0.f, 0.f, 0.f, 0.f);
         }
-        __syncthreads();
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 7);
         // ---- layer 3: 256 + 7 -> 256
         if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.h2k, rg_total, gtile * 8, tid);
         f_acc_zero(acc);
         PN_TR(pn_trace_fwd, 8);
         pn_gemm_f16x3<17, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_F3), 2 * wave, lane, acc);
-        __syncthreads();
+        f_load_bias(P + PO_B3, wave, lane, bias);           // (requested before the barrier: the wait for the slowest wave covers the L2 round trip)
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 9);
-        f_epilogue<TRAIN>(acc, P + PO_B3, X, wave, lane, mask);
+        f_epilogue<TRAIN>(acc, bias, X, wave, lane, mask);
         if (TRAIN) a.sv.lmask[(gtile * 3 + 2) * PN_NTHR + tid] = mask;
-        __syncthreads();
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 10);
         // ---- layer 4: 256 -> 256
         if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h3k, rg_total, gtile * 8, tid);
@@ -568,10 +596,11 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         if (tile + stride < ntiles) f_gather<PERS>(a, G, si1, p1, q);
         const int p2 = si2 >= 0 ? a.pidx[(long long)si2 * a.Kstride + k] : -1;
         const int si3 = f_sample_of(a, tile + 3 * stride, row, Ns);
-        __syncthreads();
+        f_load_bias(P + PO_B4, wave, lane, bias);
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 13);
-        f_epilogue<false>(acc, P + PO_B4, X, wave, lane, mask);
-        __syncthreads();
+        f_epilogue<false>(acc, bias, X, wave, lane, mask);
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 14);
         // ---- alpha head (256 -> 1, softplus(x - 1), raw2out_density :262-265): 4 threads per row, 8-column groups interleaved
         {
@@ -579,9 +608,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int c0 = 8 * (q + 4 * j);
-                const float4 v0 = pn_x_load4(X, row, c0), v1 = pn_x_load4(X, row, c0 + 4);
-                const float4 w0 = *reinterpret_cast<const float4 *>(w5s + c0), w1 = *reinterpret_cast<const float4 *>(w5s + c0 + 4);
-                s += v0.x * w0.x + v0.y * w0.y + v0.z * w0.z + v0.w * w0.w + v1.x * w1.x + v1.y * w1.y + v1.z * w1.z + v1.w * w1.w;
+                s = pn_x_dot8(X, row, c0, *reinterpret_cast<const float4 *>(w5s + c0), *reinterpret_cast<const float4 *>(w5s + c0 + 4), s);
             }
             s = group_sum<TPR>(s);
             if (q == 0) {
@@ -596,20 +623,16 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
                 const int e = tid + PN_NTHR * i, plane = e >> 11, r = (e >> 5) & 63, u = e & 31;
                 const uint4 v = *reinterpret_cast<const uint4 *>(X + plane * PN_XPLANE + r * PN_XRS + u * 16);
                 pn_f4 t = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-                __builtin_nontemporal_store(t, reinterpret_cast<pn_f4 *>(a.sv.h4r + ((long long)plane * a.sv.rows + gtile * PN_TILE + r) * 32 + u));
+                PN_STREAM_STORE(t, reinterpret_cast<pn_f4 *>(a.sv.h4r + ((long long)plane * a.sv.rows + gtile * PN_TILE + r) * 32 + u));
             }
         }
-        __syncthreads();
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 15);
         // ---- K-weighted sums -> f[256] per sample (HBM), sigma
         for (int e = tid; e < TS * 64; e += PN_NTHR) {
             const int ls = e >> 6, c4 = e & 63;
             float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int kk = 0; kk < K; ++kk) {
-                const float w = wrow[ls * K + kk];
-                const float4 v = pn_x_load4(X, ls * K + kk, c4 * 4);
-                f.x += w * v.x; f.y += w * v.y; f.z += w * v.z; f.w += w * v.w;
-            }
+            for (int kk = 0; kk < K; ++kk) pn_x_axpy4(X, ls * K + kk, c4 * 4, wrow[ls * K + kk], f);
             const long long vs = tile * TS + ls;
             if (vs < a.cap_samples) *reinterpret_cast<float4 *>(a.sv.fs + vs * PN_H + c4 * 4) = f;
         }

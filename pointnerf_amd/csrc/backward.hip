@@ -164,7 +164,7 @@ __device__ __forceinline__ void pn_scale_from_bits(unsigned mb, float &S, float 
 // Bias gradients are not formed here: they are the ones-column of the weight-gradient GEMMs.
 constexpr int TPR = PN_TPR;                    // threads per tile row in the row-wise phases
 constexpr int EPT = PN_F / TPR;                // embedding dims per thread
-constexpr int BL_ROW = PN_XBYTES, BL_W5 = BL_ROW + 7 * PN_TILE * 4, BL_RED = BL_W5 + PN_H * 4, BL_BYTES = BL_RED + PN_TILE * 8 * 4;
+constexpr int BL_ROW = PN_XBYTES, BL_W5 = BL_ROW + 7 * PN_TILE * 4, BL_BYTES = BL_W5 + PN_H * 4;
 constexpr int LDDX = 228;                      // fp32 row stride of the d X0 tile (over the activation tile's space)
 static_assert(2 * BL_BYTES <= 160 * 1024, "two backward workgroups must fit the 160 KB LDS");
 static_assert(PN_TILE * LDDX * 4 <= PN_XBYTES, "d X0 tile");
@@ -182,20 +182,25 @@ __device__ __forceinline__ void b_acc_zero(f32x16 (&acc)[2][2]) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
-// dgrad epilogue: accumulators x LeakyReLU' (bit of the forward's sign word) -> both planes of the next dY tile
+// dgrad epilogue: accumulators x LeakyReLU' (sign bit of the forward's word: element e = ((fb * 2 + rb) * 4 + g) * 4 + i at bit
+// 31 - (e & 31) of half fb) -> both planes of the next dY tile
 __device__ __forceinline__ void b_epilogue(const f32x16 (&acc)[2][2], unsigned long long mask, char *X, int wave, int lane) {
 #pragma unroll
-    for (int fb = 0; fb < 2; ++fb)
+    for (int fb = 0; fb < 2; ++fb) {
+        const unsigned mw = (unsigned)(mask >> (32 * fb));
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const unsigned bits = (unsigned)(mask >> (((fb * 2 + rb) * 4 + g) * 4)) & 15u;
                 float v[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = acc[fb][rb][4 * g + i] * (((bits >> i) & 1u) ? 1.f : 0.01f);
+                for (int i = 0; i < 4; ++i) {
+                    const int e = (rb * 4 + g) * 4 + i;
+                    v[i] = acc[fb][rb][4 * g + i] * ((int)(mw << e) < 0 ? 0.01f : 1.f);
+                }
                 pn_x_store4<true>(X, 32 * rb + (lane & 31), pn_d_feat(2 * wave + fb, g, lane), v[0], v[1], v[2], v[3]);
             }
+    }
 }
 
 #ifdef PN_PHASE_TRACE
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
     char *X = smem_b;
     float *wrow = reinterpret_cast<float *>(smem_b + BL_ROW), *wnrm = wrow + PN_TILE, *draw = wnrm + PN_TILE, *dsg = draw + PN_TILE, *xrow = dsg + PN_TILE;
     int *sidx = reinterpret_cast<int *>(xrow + PN_TILE), *prow = sidx + PN_TILE;
-    float *w5s = reinterpret_cast<float *>(smem_b + BL_W5), *red = reinterpret_cast<float *>(smem_b + BL_RED);
+    float *w5s = reinterpret_cast<float *>(smem_b + BL_W5);
     float *dx = reinterpret_cast<float *>(smem_b);
     const int tid0 = threadIdx.x;
     const int K = a.K, TS = a.TS;
@@ -219,7 +224,6 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
     float S, invS;
     pn_scale_from_bits(a.sv.gscale[0], S, invS);
     if (tid0 < PN_H) w5s[tid0] = P[PO_W5 + tid0];
-    red[tid0] = 0.f; red[tid0 + PN_NTHR] = 0.f;
     float4 gw5v = make_float4(0.f, 0.f, 0.f, 0.f);      // d W5 of columns 4 (tid & 63) .. + 3 (scaled)
     float gb5t = 0.f;
     f32x16 acc[2][2];
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), row = tid / TPR, q = tid % TPR;
         const long long gtile = tb + tile;
-        __syncthreads();
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 0); PN_TR_HWID(pn_trace_bwd);
         // ---- load: sign words, row metadata, h4 planes
         const unsigned long long m1 = a.sv.lmask[(gtile * 3 + 0) * PN_NTHR + tid], m2 = a.sv.lmask[(gtile * 3 + 1) * PN_NTHR + tid],
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
             const int e = tid + PN_NTHR * i, plane = e >> 11, r = (e >> 5) & 63, u = e & 31;
             *reinterpret_cast<uint4 *>(X + plane * PN_XPLANE + r * PN_XRS + u * 16) = a.sv.h4r[((long long)plane * a.sv.rows + gtile * PN_TILE + r) * 32 + u];
         }
-        __syncthreads();
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 1);
         // ---- alpha head backward (4 threads per row): d w_k = d sigma alpha_k + d f . h4_k ; d x = d sigma w sigmoid(x)
         const int rsi = sidx[row], rp = prow[row];
@@ -263,9 +267,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int c0 = 8 * (q + 4 * j);
-                    const float4 v0 = pn_x_load4(X, row, c0), v1 = pn_x_load4(X, row, c0 + 4);
-                    const float4 g0 = *reinterpret_cast<const float4 *>(df + c0), g1 = *reinterpret_cast<const float4 *>(df + c0 + 4);
-                    dotf += v0.x * g0.x + v0.y * g0.y + v0.z * g0.z + v0.w * g0.w + v1.x * g1.x + v1.y * g1.y + v1.z * g1.z + v1.w * g1.w;
+                    dotf = pn_x_dot8(X, row, c0, *reinterpret_cast<const float4 *>(df + c0), *reinterpret_cast<const float4 *>(df + c0 + 4), dotf);
                 }
             }
             dotf = group_sum_b<TPR>(dotf) * S;
@@ -282,20 +284,27 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
                 draw[row] = dr;
             }
         }
-        __syncthreads();
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 2);
         // ---- dY4 = (w d f + d x W5) * LeakyReLU'(h4), in place; d W5 / d b5 partial sums ride along
         {
             const int c4 = tid & 63;
             const float4 w5 = *reinterpret_cast<const float4 *>(w5s + c4 * 4);
-#pragma unroll 4
+            float4 gq[16];                                   // the d f values of the 16 rows, requested in one burst (the accumulators are dead here)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = (tid >> 6) + 4 * i;
+                gq[i] = sidx[r] >= 0 ? *reinterpret_cast<const float4 *>(a.sv.dfs + (tile * TS + r / K) * PN_H + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int r = (tid >> 6) + 4 * i;
                 const int si = sidx[r];
                 float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (si >= 0) {
                     const float4 hv = pn_x_load4(X, r, c4 * 4);
-                    const float4 g = *reinterpret_cast<const float4 *>(a.sv.dfs + (tile * TS + r / K) * PN_H + c4 * 4);
+                    const float4 g = gq[i];
                     const float w = wrow[r] * S, dr = draw[r];
                     o.x = (w * g.x + dr * w5.x) * pn_lrelu_grad(hv.x);
                     o.y = (w * g.y + dr * w5.y) * pn_lrelu_grad(hv.y);
@@ -307,40 +316,45 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
             }
             if (tid < PN_TILE) gb5t += draw[tid];
         }
-        __syncthreads();
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 3);
         // ---- layer 4: dY4 -> d h3
         pn_copy_out_kmajor<PN_H>(X, a.sv.dy4k, rg_total, gtile * 8, tid);
         b_acc_zero(acc);
         PN_TR(pn_trace_bwd, 4);
         pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D4), 2 * wave, lane, acc);
-        __syncthreads();
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 5);
         b_epilogue(acc, m3, X, wave, lane);
-        __syncthreads();
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 6);
         // ---- layer 3: dY3 -> d h2, and the extras block (input columns 256..262 of W3), K split over the waves
         pn_copy_out_kmajor<PN_H>(X, a.sv.dy3k, rg_total, gtile * 8, tid);
         b_acc_zero(acc);
         PN_TR(pn_trace_bwd, 7);
         pn_gemm_f16x3<16, 9, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D3), 2 * wave, lane, acc);
-        {
-            f32x16 acce[2][2];
-            b_acc_zero(acce);
-            pn_gemm_f16x3<4, 9, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D3), 8, lane, acce, 4 * wave);
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(&red[(32 * rb + (lane & 31)) * 8 + 4 * (lane >> 5) + r], acce[0][rb][r]);
-        }
-        __syncthreads();
+        f32x16 acce[2][2];
+        b_acc_zero(acce);
+        pn_gemm_f16x3<4, 9, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D3), 8, lane, acce, 4 * wave);
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 8);
         b_epilogue(acc, m2, X, wave, lane);
+        // the waves' partial sums of the extras block go to the tile's free bytes (80 per row and plane behind column 255):
+        // wave w -> plane w >> 1, 32-byte slot w & 1; a lane holds features 4 (l >> 5) .. + 3 of rows (l & 31), (l & 31) + 32
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+            *reinterpret_cast<float4 *>(X + (wave >> 1) * PN_XPLANE + (32 * rb + (lane & 31)) * PN_XRS + 512 + (wave & 1) * 32 + (lane >> 5) * 16) =
+                make_float4(acce[0][rb][0], acce[0][rb][1], acce[0][rb][2], acce[0][rb][3]);
+        PN_LDS_BARRIER();
         if (tid < PN_TILE) {        // d colour, d dir of the row's point from the extras' gradient
             const int p = prow[tid];
-            const float4 u = *reinterpret_cast<const float4 *>(red + tid * 8), v = *reinterpret_cast<const float4 *>(red + tid * 8 + 4);
-            *reinterpret_cast<float4 *>(red + tid * 8) = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(red + tid * 8 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float4 a0 = *reinterpret_cast<const float4 *>(X + (w >> 1) * PN_XPLANE + tid * PN_XRS + 512 + (w & 1) * 32);
+                const float4 a1 = *reinterpret_cast<const float4 *>(X + (w >> 1) * PN_XPLANE + tid * PN_XRS + 512 + (w & 1) * 32 + 16);
+                u.x += a0.x; u.y += a0.y; u.z += a0.z; u.w += a0.w; v.x += a1.x; v.y += a1.y; v.z += a1.z; v.w += a1.w;
+            }
             if (p >= 0) {
                 const int r = sidx[tid] / a.SR;
                 float vx, vy, vz, gx, gy, gz;
@@ -351,17 +365,17 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
                 atomicAdd(&a.g_dir[3 * p], gx * invS); atomicAdd(&a.g_dir[3 * p + 1], gy * invS); atomicAdd(&a.g_dir[3 * p + 2], gz * invS);
             }
         }
-        __syncthreads();
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 9);
         // ---- layer 2: dY2 -> d h1
         pn_copy_out_kmajor<PN_H>(X, a.sv.dy2k, rg_total, gtile * 8, tid);
         b_acc_zero(acc);
         PN_TR(pn_trace_bwd, 10);
         pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D2), 2 * wave, lane, acc);
-        __syncthreads();
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 11);
         b_epilogue(acc, m1, X, wave, lane);
-        __syncthreads();
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 12);
         // ---- layer 1: dY1 -> d X0 (columns 0..223), fp32 into LDS
         pn_copy_out_kmajor<PN_H>(X, a.sv.dy1k, rg_total, gtile * 8, tid);
@@ -369,7 +383,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         PN_TR(pn_trace_bwd, 13);
         if (wave < 3) pn_gemm_f16x3<16, PN_MB_D1, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D1), 2 * wave, lane, acc);
         else pn_gemm_f16x3<16, PN_MB_D1, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D1), 6, lane, acc);
-        __syncthreads();
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 14);
 #pragma unroll
         for (int fb = 0; fb < 2; ++fb)
@@ -381,7 +395,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
                         *reinterpret_cast<float4 *>(dx + (32 * rb + (lane & 31)) * LDDX + pn_d_feat(2 * wave + fb, g, lane)) =
                             make_float4(acc[fb][rb][4 * g], acc[fb][rb][4 * g + 1], acc[fb][rb][4 * g + 2], acc[fb][rb][4 * g + 3]);
             }
-        __syncthreads();
+        PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 15);
         // ---- embedding gradient through [e | PE3(e)]: d e = dX[e] + sum_f 2^f (dX[sin_f] cos_f - dX[cos_f] sin_f)
         if (rp >= 0) {

@@ -50,6 +50,22 @@ enum : int {
     PKH_END = PKH_D1 + PN_IMG(16, PN_MB_D1)
 };
 
+// streaming stores of the saved planes (dev A/B of the store policy: -DPN_PLAIN_STREAM_STORES, tools/_build only)
+#ifdef PN_PLAIN_STREAM_STORES
+#define PN_STREAM_STORE(val, ptr) (*(ptr) = (val))
+#else
+#define PN_STREAM_STORE(val, ptr) __builtin_nontemporal_store((val), (ptr))
+#endif
+
+// Workgroup barrier for LDS hazards only.  __syncthreads() carries a full fence: hipcc emits s_waitcnt vmcnt(0) in front of the
+// s_barrier, i.e. every barrier would also wait for the fire-and-forget stores of the copy-outs (HBM round trips) and for the next
+// tile's prefetched gathers.  The tile kernels only order LDS traffic with their barriers.
+#ifdef PN_EMU
+#define PN_LDS_BARRIER() __syncthreads()
+#else
+#define PN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
 // sin / cos of the positional encodings: v_sin_f32 / v_cos_f32 (one multiply + one transcendental each) unless built with
 // -DPN_EXACT_SINCOS; the parity bars of tests/test_gpu_render.py and test_gpu_backward.py hold for both
 __device__ __forceinline__ void pn_sincos(float x, float &s, float &c) {
@@ -60,18 +76,25 @@ __device__ __forceinline__ void pn_sincos(float x, float &s, float &c) {
 #endif
 }
 
-// (x0, x1) -> packed high plane (round toward zero) and packed residual plane (round to nearest)
+// (x0, x1) -> packed high plane (round toward zero) and packed residual plane (round to nearest): three instructions,
+// v_cvt_pkrtz_f16_f32 and one v_fma_mix{lo,hi}_f16 per element (m = f16(x * 1.0 - h), the fused form of "convert back, subtract,
+// convert"; hipcc does not form it by itself: 5 instructions).  tests: pnerf_debug_split against the numpy restatement, bit for bit
 __device__ __forceinline__ void pn_split2(float x0, float x1, unsigned &h, unsigned &m) {
     const auto hh = __builtin_amdgcn_cvt_pkrtz(x0, x1);
     h = __builtin_bit_cast(unsigned, hh);
+#ifdef PN_EMU
     pn_h2 mm;
     mm[0] = (_Float16)(x0 - (float)hh[0]);
     mm[1] = (_Float16)(x1 - (float)hh[1]);
     m = __builtin_bit_cast(unsigned, mm);
+#else
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(m) : "v"(x0), "v"(x1), "v"(h));
+#endif
 }
 // the same with the value clamped to the f16 range first (gradients: their scale is chosen per call, an outlier must saturate, not poison)
 __device__ __forceinline__ void pn_split2_sat(float x0, float x1, unsigned &h, unsigned &m) {
-    pn_split2(fminf(fmaxf(x0, -65504.f), 65504.f), fminf(fmaxf(x1, -65504.f), 65504.f), h, m);
+    pn_split2(__builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f), h, m);
 }
 __device__ __forceinline__ float pn_h_lo(unsigned p) { return (float)__builtin_bit_cast(pn_h2, p)[0]; }
 __device__ __forceinline__ float pn_h_hi(unsigned p) { return (float)__builtin_bit_cast(pn_h2, p)[1]; }
@@ -106,6 +129,31 @@ __device__ __forceinline__ float4 pn_x_load4(const char *X, int row, int col) {
     return make_float4(pn_h_lo(h.x) + pn_h_lo(m.x), pn_h_hi(h.x) + pn_h_hi(m.x), pn_h_lo(h.y) + pn_h_lo(m.y), pn_h_hi(h.y) + pn_h_hi(m.y));
 }
 
+// acc + (h + m) * w for the two packed values of a plane pair: fmaf of a converted half is ONE v_fma_mix_f32 (no conversion, no add)
+__device__ __forceinline__ float pn_fma2_lo(unsigned h, unsigned m, float w, float acc) {
+    return __builtin_fmaf((float)__builtin_bit_cast(pn_h2, m)[0], w, __builtin_fmaf((float)__builtin_bit_cast(pn_h2, h)[0], w, acc));
+}
+__device__ __forceinline__ float pn_fma2_hi(unsigned h, unsigned m, float w, float acc) {
+    return __builtin_fmaf((float)__builtin_bit_cast(pn_h2, m)[1], w, __builtin_fmaf((float)__builtin_bit_cast(pn_h2, h)[1], w, acc));
+}
+// dot product of 8 tile columns (row, col .. col + 7, col % 8 == 0) with 8 floats
+__device__ __forceinline__ float pn_x_dot8(const char *X, int row, int col, const float4 &w0, const float4 &w1, float acc) {
+    const uint4 h = *reinterpret_cast<const uint4 *>(X + row * PN_XRS + col * 2);
+    const uint4 m = *reinterpret_cast<const uint4 *>(X + PN_XPLANE + row * PN_XRS + col * 2);
+    acc = pn_fma2_lo(h.x, m.x, w0.x, acc); acc = pn_fma2_hi(h.x, m.x, w0.y, acc);
+    acc = pn_fma2_lo(h.y, m.y, w0.z, acc); acc = pn_fma2_hi(h.y, m.y, w0.w, acc);
+    acc = pn_fma2_lo(h.z, m.z, w1.x, acc); acc = pn_fma2_hi(h.z, m.z, w1.y, acc);
+    acc = pn_fma2_lo(h.w, m.w, w1.z, acc); acc = pn_fma2_hi(h.w, m.w, w1.w, acc);
+    return acc;
+}
+// f += w * (4 tile columns at (row, col))
+__device__ __forceinline__ void pn_x_axpy4(const char *X, int row, int col, float w, float4 &f) {
+    const uint2 h = *reinterpret_cast<const uint2 *>(X + row * PN_XRS + col * 2);
+    const uint2 m = *reinterpret_cast<const uint2 *>(X + PN_XPLANE + row * PN_XRS + col * 2);
+    f.x = pn_fma2_lo(h.x, m.x, w, f.x); f.y = pn_fma2_hi(h.x, m.x, w, f.y);
+    f.z = pn_fma2_lo(h.y, m.y, w, f.z); f.w = pn_fma2_hi(h.y, m.y, w, f.w);
+}
+
 // ---- the tile GEMM: acc[fb][rb] (feature block fb of this wave x row block rb) += W[.., 16 NC columns from chunk c0] * X^T
 // Three products per (fb, rb) and chunk, ordered so that an accumulator is touched once in four MFMAs.  The weight fragments
 // come from the L2-resident image (500+ cycles under load) and are requested PN_WPF chunks (x 384 cycles of MFMA) ahead in a
@@ -127,6 +175,8 @@ __device__ __forceinline__ float4 pn_x_load4(const char *X, int row, int col) {
 #define PN_GEMM_PRIO_BEGIN() ((void)0)
 #define PN_GEMM_PRIO_END() ((void)0)
 #endif
+// (Measured and rejected: running the tile's transposing copy-out as a side job between the chunks' MFMA groups -- its stores share the
+//  in-order vmcnt queue with the weight fragments, every chunk then waits for HBM writes: +3 us per GEMM against 2.4 us saved.)
 template <int NC, int MB, int NFB>
 __device__ __forceinline__ void pn_gemm_f16x3(const char *X, const uint4 *__restrict__ img, int fb0, int lane, f32x16 (&acc)[2][2], int c0 = 0) {
     constexpr int PF = PN_WPF < NC ? PN_WPF : NC - 1, NS = PF + 1;
@@ -201,7 +251,7 @@ __device__ __forceinline__ void pn_copy_out_kmajor(const char *X, uint4 *__restr
             const uint2 lo = pn_lds_read_tr16(src + j * 128), hi = pn_lds_read_tr16(src + 4 * PN_XRS + j * 128);
             if (f < NF) {
                 pn_f4 t = {__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y)};
-                __builtin_nontemporal_store(t, reinterpret_cast<pn_f4 *>(d + f));
+                PN_STREAM_STORE(t, reinterpret_cast<pn_f4 *>(d + f));
             }
         }
     }

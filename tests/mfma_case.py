@@ -29,3 +29,22 @@ def unpack(d):
         for r in range(16):
             out[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31] = d[l, r]
     return out
+
+
+def split_inputs():
+    """values for the two-plane split: wide dynamic range, subnormal-range values, the f16 boundary, out-of-range values"""
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(65536) * 10.0 ** rng.uniform(-9, 4.5, 65536)).astype(np.float32)
+    x[:8] = [0.0, -0.0, 65504.0, -65504.0, 65519.9, 1e-8, -3e-8, 6.1e-5]
+    return x
+
+
+def split_expected(x, sat):
+    from test_split_f16_cpu import f16_rtz
+    x = np.asarray(x, np.float32)
+    if sat:
+        x = np.clip(x, -65504.0, 65504.0)
+    h = f16_rtz(x)
+    with np.errstate(over="ignore"):
+        m = (x - h.astype(np.float32)).astype(np.float32).astype(np.float16)
+    return h, m

@@ -60,6 +60,19 @@ def test_emulated_f16_mfma_layout_and_subnormals():
     assert np.abs(mfma_case.unpack(out) - D).max() <= 1e-6 * np.abs(D).max()
 
 
+def test_emulated_split_matches_numpy():
+    import ctypes
+    import mfma_case
+    from emu_util import emu_lib
+    x = mfma_case.split_inputs()
+    for sat in (0, 1):
+        xs = x if sat else np.clip(x, -60000, 60000)
+        h, m = np.zeros(x.size, np.float16), np.zeros(x.size, np.float16)
+        assert emu_lib().pnerf_debug_split(xs.ctypes.data_as(ctypes.c_void_p), x.size, h.ctypes.data_as(ctypes.c_void_p), m.ctypes.data_as(ctypes.c_void_p), sat, None) == 0
+        eh, em = mfma_case.split_expected(xs, sat)
+        assert np.array_equal(h.view(np.uint16), eh.view(np.uint16)) and np.array_equal(m.view(np.uint16), em.view(np.uint16))
+
+
 # K % 4 == 0 runs three sample classes (K, K/2, K/4 rows per sample), other K one
 @pytest.mark.parametrize("K,SR,size", [(8, 12, 5), (3, 10, 4), (12, 8, 4), (1, 6, 5), (16, 6, 3)])
 def test_emulated_forward_and_backward_match_oracle(K, SR, size):

@@ -181,3 +181,22 @@ def test_f16_mfma_fragment_layout_and_subnormal_inputs():
     err, err_if_flushed = np.abs(got - D).max(), np.abs(D_flushed - D).max()
     print("max |D - exact| = %.3e (a flushing pipe would give %.3e)" % (err, err_if_flushed))
     assert err <= 1e-6 * np.abs(D).max() and err < 0.01 * err_if_flushed
+
+
+def test_two_plane_split_is_bit_exact():
+    """pn_split2 (v_cvt_pkrtz_f16_f32 + v_fma_mix{lo,hi}_f16) against the numpy restatement of tests/test_split_f16_cpu.py, bit for bit"""
+    import ctypes
+    import numpy as np
+    import mfma_case
+    from pointnerf_amd import _lib as L
+    x = mfma_case.split_inputs()
+    for sat in (0, 1):
+        xs = x if sat else np.clip(x, -60000, 60000)
+        dx = torch.from_numpy(xs).cuda()
+        h, m = torch.zeros(x.size, dtype=torch.int16, device="cuda"), torch.zeros(x.size, dtype=torch.int16, device="cuda")
+        L.check(L.lib().pnerf_debug_split(ctypes.c_void_p(dx.data_ptr()), x.size, ctypes.c_void_p(h.data_ptr()), ctypes.c_void_p(m.data_ptr()), sat,
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "pnerf_debug_split")
+        torch.cuda.synchronize()
+        eh, em = mfma_case.split_expected(xs, sat)
+        assert np.array_equal(h.cpu().numpy().view(np.uint16), eh.view(np.uint16))
+        assert np.array_equal(m.cpu().numpy().view(np.uint16), em.view(np.uint16))

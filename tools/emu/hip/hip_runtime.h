@@ -206,6 +206,7 @@ static inline emu_s4 emu_ds_read_tr16_b64(const void *p) {
     return r;
 }
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu_ds_read_tr16_b64((const void *)(p))
+#define __builtin_amdgcn_alignbit(hi, lo, sh) ((unsigned)(((((unsigned long long)(hi)) << 32) | (unsigned)(lo)) >> ((sh) & 31)))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)

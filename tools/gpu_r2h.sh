@@ -1,20 +1,14 @@
 #!/bin/bash
-# round-2 dev call: tests, shipped bench, variant benches, phase trace, render-only
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r2g; mkdir -p $O
-(timeout 600 python -m pytest tests -m gpu -q --maxfail=12 -p no:cacheprovider 2>&1 | tail -60 > $O/tests.log); tail -2 $O/tests.log
+O=gpurun_out/r2h; mkdir -p $O
 timeout 300 python bench.py --cpu-rays 0 --steps 10 > $O/bench_shipped.json 2>$O/bench_shipped.err
 cp pointnerf_amd/libpnerf_hip.so /tmp/shipped.so
-for V in ; do
+for V in plain; do
   cp tools/_build/$V.so pointnerf_amd/libpnerf_hip.so
   timeout 300 python bench.py --cpu-rays 0 --steps 10 > $O/bench_$V.json 2>/dev/null
 done
-cp tools/_build/trace.so pointnerf_amd/libpnerf_hip.so
-timeout 300 python tools/gpu_phase_trace.py > $O/phase_trace.json 2>$O/phase_trace.err
 cp /tmp/shipped.so pointnerf_amd/libpnerf_hip.so
-timeout 300 python bench.py --cpu-rays 0 --steps 10 --render-only > $O/bench_render_only.json 2>/dev/null
-timeout 300 python bench.py --cpu-rays 0 --steps 10 > $O/bench_shipped2.json 2>/dev/null
-for f in shipped shipped2 render_only; do python - <<PY
+for f in shipped plain; do python - <<PY
 import json
 try:
     d=json.load(open("$O/bench_$f.json")); k=d["kernels"]
@@ -22,3 +16,4 @@ try:
 except Exception as e: print("$f", "ERR", e)
 PY
 done
+bash tools/gpu_pmc_mfma.sh r2h
