@@ -69,8 +69,9 @@ int pnerf_grid_info(const void *d_grid_ws, int32_t *host_info, void *stream);
  * Ray samples come either from d_raypos [R,D,3] (the native op's own input) or -- fused, never
  * materialised -- from campos + raydir * mid[d] with the D mid-point depths d_mid computed by the
  * host exactly as near_far_linear_ray_generation does (models/rendering/diff_ray_marching.py:369-392).
- * If jitter > 0 (training: point_query.py:81 uses 0.3) segment lengths are perturbed in-kernel by a
- * counter-based RNG keyed on (seed, ray, d); near/far are then required.
+ * If jitter > 0 (training: point_query.py:81 uses 0.3) d_mid holds the D un-jittered segment lengths and every segment is
+ * scaled by 1 + jitter (U - 0.5) in-kernel, U = pnerf_debug_uniform(seed, ray * D + d); the end points are the SEQUENTIAL fp32
+ * running sum (torch.cumsum of the reference's CPU path), so the samples are bit-defined; near/far are then required.
  *
  * Outputs are DENSE OVER ALL R RAYS (no host sync, no compaction):
  *   d_sample_loc  [R,SR,3] f32   world position of the first <=SR occupied samples, 0 elsewhere
@@ -227,6 +228,10 @@ int pnerf_voxel_downsample(const float *d_xyz, int64_t n_points, const float *sp
  * D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31]).  The tests pin with it the fragment layout and the un-flushed handling of f16
  * subnormal inputs that the two-plane GEMMs of the aggregator (csrc/f16x3.h) rely on. */
 int pnerf_debug_mfma_f16(const void *d_a, const void *d_b, float *d_out, void *stream);
+/* the counter-based uniforms of the jittered ray sampling (pnerf_query with jitter > 0 draws U[r * D + d] = uniform(seed, r * D + d)):
+ * d_out[i] = uniform(seed, first + i) in [0, 1).  With these the jittered samples are a deterministic function of the inputs and
+ * equal the reference's near_far_linear_ray_generation (diff_ray_marching.py:369-385, CPU) fed the same numbers, bit for bit. */
+int pnerf_debug_uniform(uint64_t seed, uint64_t first, int64_t n, float *d_out, void *stream);
 /* the two-plane split of csrc/f16x3.h on n floats (n even): d_h / d_m [n] f16 (high plane: round toward zero; residual plane: round to
  * nearest of x - h); sat != 0 clamps to the f16 range first (the gradient form).  Tests compare it bit for bit with the numpy restatement. */
 int pnerf_debug_split(const float *d_x, int64_t n, void *d_h, void *d_m, int sat, void *stream);

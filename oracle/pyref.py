@@ -60,16 +60,19 @@ def grid_hyperparameters(opt, xyz):
                 scaled_vdim=scaled_vdim, radius=float(radius), vsize=np.asarray(opt.vsize))
 
 
-def ray_samples(campos, raydir, D, near, far):
-    """diff_ray_marching.py:369-392 with jitter=0.  campos [1,3], raydir [1,R,3] -> raypos [1,R,D,3], mid [D]."""
+def ray_samples(campos, raydir, D, near, far, jitter=0.0, uniforms=None):
+    """diff_ray_marching.py:369-392.  campos [1,3], raydir [1,R,3] -> raypos [1,R,D,3], mid [D] (jitter = 0) or [1,R,D].
+    jitter > 0: `uniforms` [1,R,D] plays the role of the reference's torch.rand (the HIP path draws them from a counter RNG,
+    pnerf_debug_uniform); torch.cumsum on the CPU is the sequential fp32 running sum."""
     t = torch.linspace(0, 1, D + 1).view(1, -1)
     t = near * (1 - t) + far * t
-    seg = (t[..., 1:] - t[..., :-1]) * (1 + 0.0 * (torch.zeros(1, 1, D) - 0.5))
+    u = torch.zeros(1, 1, D) if uniforms is None else uniforms
+    seg = (t[..., 1:] - t[..., :-1]) * (1 + jitter * (u - 0.5))
     end = torch.cumsum(seg, dim=2)
-    end = near + torch.cat([torch.zeros(1, 1, 1), end], dim=2)
+    end = near + torch.cat([torch.zeros(end.shape[0], end.shape[1], 1), end], dim=2)
     mid = (end[:, :, :-1] + end[:, :, 1:]) / 2
     raypos = campos[:, None, None, :] + raydir[:, :, None, :] * mid[:, :, :, None]
-    return raypos, mid.reshape(-1)
+    return raypos, (mid.reshape(-1) if uniforms is None else mid)
 
 
 def w2pers(p, camrot, campos):
@@ -78,13 +81,13 @@ def w2pers(p, camrot, campos):
     return torch.stack([c[..., 0] / c[..., 2], c[..., 1] / c[..., 2], c[..., 2]], dim=-1)
 
 
-def query(opt, xyz, inp, impl="oracle", nthreads=1):
+def query(opt, xyz, inp, impl="oracle", nthreads=1, jitter=0.0, uniforms=None):
     """lighting_fast_querier.query_points (point_query.py:74-98) on CPU.
     Returns dict(sample_pidx [1,R2,SR,K] i32, sample_loc_w, sample_loc (pers), sample_ray_dirs, ray_mask [1,R] i8, hp)."""
     hp = grid_hyperparameters(opt, xyz)
     campos, raydir = inp["campos"], inp["raydir"]
     near, far = float(inp["near"].min()), float(inp["far"].max())
-    raypos, _ = ray_samples(campos, raydir, opt.z_depth_dim, near, far)
+    raypos, _ = ray_samples(campos, raydir, opt.z_depth_dim, near, far, jitter=jitter, uniforms=uniforms)
     R = raydir.shape[1]
     fn = oq.oracle_query if impl == "oracle" else oq.ref_query
     pidx, loc_w, ray_mask, info = fn(raypos[0].numpy(), xyz.numpy(), opt.kernel_size, opt.query_size,
@@ -162,10 +165,13 @@ def gather_neighbors(points, pidx, camrot, campos):
                 conf=g(points["points_conf"][0]))
 
 
-def aggregate(opt, mlp, nb, loc_p, loc_w, ray_dirs, Rw2c=None):
+def aggregate(opt, mlp, nb, loc_p, loc_w, ray_dirs, Rw2c=None, kink=None):
     """PointAggregator.forward + viewmlp for the lego configuration.
     nb: dict from gather_neighbors with tensors [1,R,SR,K,*]; loc_* / ray_dirs [1,R,SR,3].
-    Returns output [1,R,SR,4], ray_valid [1,R,SR] bool, weight [1,R,SR,K], conf_coefficient [1,R,SR,K]."""
+    Returns output [1,R,SR,4], ray_valid [1,R,SR] bool, weight [1,R,SR,K], conf_coefficient [1,R,SR,K].
+    kink: optional dict that receives, for the tests' LeakyReLU-kink attribution, the smallest |pre-activation| of every
+    neighbor row over the four viewmlp layers (`row_min_pre` [n rows], rows in mask order) and of every valid sample over the
+    three colour layers (`sample_min_pre` [n valid samples])."""
     mask = nb["mask"]
     B, R, SR, K = mask.shape
     Rw2c = torch.eye(3) if Rw2c is None else Rw2c
@@ -193,7 +199,15 @@ def aggregate(opt, mlp, nb, loc_p, loc_w, ray_dirs, Rw2c=None):
     feat = nb["emb"].reshape(-1, nb["emb"].shape[-1])[mf]
     feat = torch.cat([feat, positional_encoding(feat, opt.num_feat_freqs), d], dim=-1)       # 284
     act = lambda x: F.leaky_relu(x, 0.01)
-    lin = lambda x, k: F.linear(x, mlp[k + ".weight"], mlp[k + ".bias"])
+    tracked = {}
+
+    def lin(x, k):
+        y = F.linear(x, mlp[k + ".weight"], mlp[k + ".bias"])
+        if kink is not None and (k.startswith("block") or k in ("color_branch.0", "color_branch.2", "color_branch.4")):
+            grp = "row" if k.startswith("block") else "sample"
+            m = y.detach().abs().min(dim=-1)[0]
+            tracked[grp] = m if grp not in tracked else torch.minimum(tracked[grp], m)
+        return y
     feat = act(lin(act(lin(feat, "block1.0")), "block1.2"))
     view = ray_dirs.reshape(-1, 3) @ Rt                                                      # :506
     view_pe = positional_encoding(view, opt.num_viewdir_freqs, ori=True)[:, 3:]              # 24
@@ -214,6 +228,8 @@ def aggregate(opt, mlp, nb, loc_p, loc_w, ray_dirs, Rw2c=None):
     rgb = torch.sigmoid(lin(c, "color_branch.6")) * (1 + 2 * 0.001) - 0.001                  # :269-273
     res = torch.cat([sigma, rgb], dim=-1)
     out = out.view(-1, 4).index_put((vf.nonzero()[:, 0],), res).view(B, R, SR, 4)
+    if kink is not None:
+        kink["row_min_pre"], kink["sample_min_pre"] = tracked["row"], tracked["sample"]
     return out, ray_valid, w, conf_c
 
 
@@ -246,7 +262,7 @@ def ray_march(rdist, ray_valid, feats, bg_color=None):
     return color, rgb, opacity, acc, bw, bg_t
 
 
-def render(opt, points, mlp, inp, impl="oracle", q=None, nthreads=1, Rw2c=None):
+def render(opt, points, mlp, inp, impl="oracle", q=None, nthreads=1, Rw2c=None, kink=None):
     """NeuralPointsRayMarching.forward (neural_points_volumetric_model.py:252-329) on CPU.
     points: dict xyz [N,3], points_embeding [1,N,F], points_conf [1,N,1], points_dir/color [1,N,3]."""
     if q is None:
@@ -254,7 +270,7 @@ def render(opt, points, mlp, inp, impl="oracle", q=None, nthreads=1, Rw2c=None):
             q = query(opt, points["xyz"].detach(), inp, impl=impl, nthreads=nthreads)
     camrot, campos = inp["camrotc2w"][0], inp["campos"][0]
     nb = gather_neighbors(points, q["sample_pidx"], camrot, campos)
-    feats, ray_valid, w, conf_c = aggregate(opt, mlp, nb, q["sample_loc"], q["sample_loc_w"], q["sample_ray_dirs"], Rw2c=Rw2c)
+    feats, ray_valid, w, conf_c = aggregate(opt, mlp, nb, q["sample_loc"], q["sample_loc_w"], q["sample_ray_dirs"], Rw2c=Rw2c, kink=kink)
     rd = ray_dist(opt, q["sample_loc"], ray_valid)
     color, _, opacity, acc, bw, bg_t = ray_march(rd, ray_valid, feats, inp["bg_color"])
     return dict(coarse_raycolor=color, coarse_point_opacity=opacity, coarse_is_background=bg_t,

@@ -45,6 +45,10 @@ __device__ __forceinline__ bool pn_occupied(const PnGridDev &g, float x, float y
     return (g.occ[lin >> 5] >> (lin & 31)) & 1u;
 }
 
+__global__ void k_debug_uniform(unsigned long long seed, unsigned long long first, long long n, float *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = pn_uniform(seed, first + i);
+}
+
 // one wavefront per ray
 template <bool FROM_RAYPOS, bool JITTER>
 __global__ __launch_bounds__(TPB) void k_probe(PnGridDev g, RayGen rg, int R, int D, int SR,
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(TPB) void k_probe(PnGridDev g, RayGen rg, int R, in
     if (!FROM_RAYPOS) { dx = rg.raydir[3 * r]; dy = rg.raydir[3 * r + 1]; dz = rg.raydir[3 * r + 2]; }
     float *out = sample_loc + (size_t)r * SR * 3;
     int count = 0;
-    float carry = 0.f;   // JITTER: running sum of segment lengths
+    double carry = 0.0;  // JITTER: running sum of segment lengths
     for (int base = 0; base < D && count < SR; base += 64) {
         const int d = base + lane;
         float px = 0.f, py = 0.f, pz = 0.f;
@@ -64,14 +68,21 @@ __global__ __launch_bounds__(TPB) void k_probe(PnGridDev g, RayGen rg, int R, in
         if (JITTER) {
             float seg = 0.f;
             if (d < D) seg = rg.mid[d] * (1.0f + rg.jitter * (pn_uniform(rg.seed, (unsigned long long)r * D + d) - 0.5f));
-            float inc = seg;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                float y = __shfl_up(inc, off, 64);
-                if (lane >= off) inc += y;
+            // end points = near + running sum of the segment lengths IN SEQUENCE, accumulated in double and rounded to fp32 per element:
+            // bit for bit torch.cumsum of the reference's CPU path (diff_ray_marching.py:376-383; ATen's CPU cumsum accumulates
+            // floats in double), so that with the same uniforms the jittered samples are the reference's.  One serial chain per
+            // ray (a shuffle scan would round differently): 64 readlane + add steps per chunk, ~10 us for a whole batch.
+            double run = carry;
+            float inc = 0.f, prev = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < 64; ++j) {
+                const float sj = __shfl(seg, j, 64);
+                const float before = (float)run;
+                run = run + (double)sj;
+                if (lane == j) { inc = (float)run; prev = before; }
             }
-            float e1 = rg.near_d + (carry + inc), e0 = rg.near_d + (carry + (inc - seg));
-            carry += __shfl(inc, 63, 64);
+            carry = run;
+            const float e1 = rg.near_d + inc, e0 = rg.near_d + prev;
             if (d < D) {
                 float t = (e0 + e1) * 0.5f;
                 px = rg.cx + dx * t; py = rg.cy + dy * t; pz = rg.cz + dz * t;
@@ -187,6 +198,14 @@ __global__ __launch_bounds__(TPB) void k_ray_hit(int R, int SR, const int *__res
     if (threadIdx.x < 3 && tally[threadIdx.x]) atomicAdd(&counters[1 + threadIdx.x], tally[threadIdx.x]);
 }
 }  // namespace
+
+extern "C" int pnerf_debug_uniform(uint64_t seed, uint64_t first, int64_t n, float *d_out, void *stream) {
+    if (!d_out || n < 0) return PNERF_E_INVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_debug_uniform, dim3(256), dim3(256), 0, (hipStream_t)stream, (unsigned long long)seed, (unsigned long long)first, (long long)n, d_out);
+    PN_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" size_t pnerf_query_workspace_bytes(int R, int SR) {
     return pn_align((size_t)(R > 0 ? R : 1) * sizeof(int)) + pn_align(pn_scan_scratch_ints((long long)R * SR) * sizeof(int));

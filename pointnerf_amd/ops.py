@@ -127,6 +127,13 @@ def query_dense(grid, R, D, SR, K, raypos=None, campos=None, raydir=None, mid=No
     return dict(sample_loc=loc, sample_pidx=pidx, sample_nn=nn, ray_hit=hit, valid_list=vlist, counters=counters)
 
 
+def jitter_uniforms(seed, R, D, device):
+    """The uniforms U[r, d] the jittered query draws for ``seed`` (pnerf_debug_uniform): [1, R, D] f32 device tensor."""
+    out = torch.empty(1, R, D, dtype=torch.float32, device=device)
+    L.check(L.lib().pnerf_debug_uniform(int(seed) & (2 ** 64 - 1), 0, R * D, _ptr(out), _stream()), "pnerf_debug_uniform")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ MLP + renderer
 def mlp_layout():
     """name -> (offset, shape) of the flat parameter vector, reference state_dict order."""

@@ -139,9 +139,10 @@ class lighting_fast_querier():
         R = raydir.shape[0]
         campos = cam_pos_tensor.detach().reshape(-1)[:3].cpu().tolist() if isinstance(cam_pos_tensor, torch.Tensor) else list(cam_pos_tensor)
         self.count += 1
+        self.last_seed = self.count * 0x9E3779B1       # the jitter uniforms of this call are pnerf_debug_uniform(last_seed, ray * D + d)
         dense = ops.query_dense(grid, R, D, int(opt.SR), int(opt.K), campos=campos, raydir=raydir,
                                 mid=seg if jitter > 0 else mid, near=near_depth, far=far_depth, jitter=jitter,
-                                seed=self.count * 0x9E3779B1)
+                                seed=self.last_seed)
         self.last_grid, self.last_dense = grid, dense
         return dense
 

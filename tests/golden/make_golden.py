@@ -9,6 +9,10 @@ What is pinned (the reference has no tests or golden vectors of it
   * models/helpers/networks.py               positional_encoding
   * gradients of a fixed scalar of the rendered colour w.r.t. the MLP weights and the point
     tensors, through the reference modules (torch.autograd)
+  * refblocks.npz (python tests/golden/make_golden.py --blocks): the JITTERED ray generation (torch.rand replaced by known
+    uniforms for the call), and two pure-torch blocks of models/neural_points_volumetric_model.py that cannot be imported
+    (the module needs absent third-party packages) and are therefore exec'ed FROM THE REFERENCE'S SOURCE TEXT: the ray_dist
+    block (:271-279) and fill_invalid (:87-123)
 Inputs are NOT stored: they are regenerated from seeds by pointnerf_amd/scenes.py,
 oracle/pyref.init_mlp_params and the C oracle query, all deterministic.
 """
@@ -87,5 +91,54 @@ def main():
     print("raygen_pe ok")
 
 
+def jitter_uniforms(R, D, seed=11):
+    """the known uniforms of the jitter fixture (regenerated by the tests from the same seed)"""
+    return torch.from_numpy(np.random.default_rng(seed).random((1, R, D), dtype=np.float32))
+
+
+def ref_blocks():
+    import textwrap
+    import types
+    src = open("/root/reference/models/neural_points_volumetric_model.py").read().split("\n")
+    fix = {}
+    # ---- jittered ray generation: the reference function with torch.rand returning known numbers
+    inp = pyref.to_torch_inputs(scenes.block_rays(size=4))
+    R, D = inp["raydir"].shape[1], 400
+    u = jitter_uniforms(R, D)
+    orig = torch.rand
+    torch.rand = lambda shape, device=None: u.reshape(tuple(shape))
+    try:
+        raypos, seg, _, mid = near_far_linear_ray_generation(inp["campos"], inp["raydir"], D, near=2.0, far=6.0, jitter=0.3)
+    finally:
+        torch.rand = orig
+    fix["jitter_raypos"], fix["jitter_mid"] = raypos.numpy(), mid.numpy()
+    # ---- ray_dist block :271-279, exec'ed from the source text on a seeded case
+    opt, xyz, attrs, inp, mlp = build_case("small_k8")
+    out = pyref.render(opt, dict(xyz=xyz, **attrs), mlp, inp)
+    q = out["query"]
+    block = textwrap.dedent("\n".join(src[270:279]))
+    assert block.lstrip().startswith("ray_dist = torch.cummax") and "ray_dist *= ray_valid.float()" in block, block
+    env = dict(torch=torch, sample_loc=q["sample_loc"].clone(), vsize=q["hp"]["vsize"], ray_valid=out["ray_valid"],
+               self=types.SimpleNamespace(opt=types.SimpleNamespace(raydist_mode_unit=opt.raydist_mode_unit)))
+    exec(block, env)
+    fix["ray_dist"] = env["ray_dist"].numpy()
+    # ---- fill_invalid :87-123 as a function of a stand-in `self`
+    fn_src = textwrap.dedent("\n".join(src[86:123]))
+    assert fn_src.startswith("def fill_invalid(self, output, input):"), fn_src[:80]
+    env = dict(torch=torch)
+    exec(fn_src, env)
+    me = types.SimpleNamespace(input={}, opt=types.SimpleNamespace(prob=0), tonemap_func=lambda x: x)
+    o = {k: out[k].detach().clone() for k in ("ray_mask", "coarse_is_background", "coarse_raycolor", "coarse_point_opacity", "queried_shading")}
+    r = env["fill_invalid"](me, o, {"bg_color": inp["bg_color"]})
+    for k in ("coarse_is_background", "coarse_mask", "coarse_raycolor", "coarse_point_opacity", "queried_shading"):
+        fix["fill_" + k] = r[k].numpy()
+    np.savez_compressed(os.path.join(HERE, "refblocks.npz"), **fix)
+    print("refblocks ok", {k: v.shape for k, v in fix.items()})
+
+
 if __name__ == "__main__":
-    main()
+    if "--blocks" in sys.argv:
+        ref_blocks()
+    else:
+        main()
+        ref_blocks()

@@ -89,3 +89,11 @@ def test_emulated_level1_chain(monkeypatch):
     monkeypatch.setattr(T1, "DEV", "cpu")
     monkeypatch.setitem(cases.CASES, "small_k4", (dict(K=4, SR=10, P=12, max_o=50000, ranges=[-0.3, -0.3, -0.3, 0.3, 0.3, 0.3]), 900, 5, 1))
     T1.test_level1_chain_matches_oracle_and_fused("small_k4")
+
+
+def test_emulated_jitter_is_bit_defined():
+    """the jittered ray sampling (sequential running sum per ray, counter RNG) against the oracle fed the same uniforms"""
+    import test_gpu_query as TQ
+    opt, xyz, attrs, inp, mlp = _tiny_case(8, 12, 5)
+    opt.is_train = 1
+    assert TQ._jitter_parity(opt, xyz, inp, "cpu") > 5
