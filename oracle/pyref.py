@@ -104,7 +104,7 @@ def query(opt, xyz, inp, impl="oracle", nthreads=1, jitter=0.0, uniforms=None):
 def positional_encoding(x, freqs, ori=False):
     """networks.py:175-190: per input dim d, per freq f: (sin, cos) interleaved; ori=True is
     [x | all sins | all coss]."""
-    bands = 2.0 ** torch.arange(freqs, dtype=torch.float32)
+    bands = 2.0 ** torch.arange(freqs, dtype=x.dtype)
     p = (x[..., None] * bands).reshape(x.shape[:-1] + (freqs * x.shape[-1],))
     if ori:
         return torch.cat([x, torch.sin(p), torch.cos(p)], dim=-1)
@@ -174,16 +174,17 @@ def aggregate(opt, mlp, nb, loc_p, loc_w, ray_dirs, Rw2c=None, kink=None):
     three colour layers (`sample_min_pre` [n valid samples])."""
     mask = nb["mask"]
     B, R, SR, K = mask.shape
-    Rw2c = torch.eye(3) if Rw2c is None else Rw2c
+    dt = loc_w.dtype
+    Rw2c = torch.eye(3, dtype=dt) if Rw2c is None else Rw2c.to(dt)
     Rt = Rw2c.transpose(-1, -2)
     ray_valid = mask.any(dim=-1)
-    out = torch.zeros(B, R, SR, 4)
+    out = torch.zeros(B, R, SR, 4, dtype=dt)
     xp, lp = nb["xyz_pers"], loc_p[..., None, :]
     dists = torch.cat([nb["xyz"] - loc_w[..., None, :],
                        torch.stack([xp[..., 0] * xp[..., 2] - lp[..., 0] * lp[..., 2],
                                     xp[..., 1] * xp[..., 2] - lp[..., 1] * lp[..., 2],
                                     xp[..., 2] - lp[..., 2]], dim=-1)], dim=-1)          # :773-781
-    w = mask.float() / torch.clamp(torch.linalg.norm(dists[..., :3], dim=-1), min=1e-6)     # linear :425-428
+    w = mask.to(dt) / torch.clamp(torch.linalg.norm(dists[..., :3], dim=-1), min=1e-6)     # linear :425-428
     w = w / torch.clamp(w.sum(dim=-1, keepdim=True), min=1e-8)                               # :801-802
     conf = nb["conf"][..., 0]
     conf_c = conf - (conf - conf.clamp(1e-4, 1.0)).detach()                                  # gradiant_clamp
@@ -218,8 +219,8 @@ def aggregate(opt, mlp, nb, loc_p, loc_w, ray_dirs, Rw2c=None, kink=None):
     feat = act(lin(act(lin(feat, "block3.0")), "block3.2"))
     alpha = F.softplus(lin(feat, "alpha_branch.0") - 1)                                      # :262-265
     n_all = B * R * SR * K
-    a_full = torch.zeros(n_all, 1).index_put((mf.nonzero()[:, 0],), alpha)
-    f_full = torch.zeros(n_all, feat.shape[-1]).index_put((mf.nonzero()[:, 0],), feat)
+    a_full = torch.zeros(n_all, 1, dtype=dt).index_put((mf.nonzero()[:, 0],), alpha)
+    f_full = torch.zeros(n_all, feat.shape[-1], dtype=dt).index_put((mf.nonzero()[:, 0],), feat)
     wk = wc.reshape(-1, K, 1)
     sigma = (a_full.view(-1, K, 1) * wk).sum(dim=1)[vf]                                      # :608-614
     fs = (f_full.view(-1, K, feat.shape[-1]) * wk).sum(dim=1)[vf]                            # :622-628
@@ -238,19 +239,19 @@ def ray_dist(opt, loc_p, ray_valid):
     """neural_points_volumetric_model.py:271-279."""
     vs2 = float(opt.vsize[2])
     z = torch.cummax(loc_p[..., 2], dim=-1)[0]
-    d = torch.cat([z[..., 1:] - z[..., :-1], torch.full(z.shape[:2] + (1,), vs2)], dim=-1)
+    d = torch.cat([z[..., 1:] - z[..., :-1], torch.full(z.shape[:2] + (1,), vs2, dtype=z.dtype)], dim=-1)
     m = d < 1e-8
     if opt.raydist_mode_unit > 0:
         m = m | (d > 2 * vs2)
-    m = m.float()
+    m = m.to(d.dtype)
     d = d * (1.0 - m) + m * vs2
-    return d * ray_valid.float()
+    return d * ray_valid.to(d.dtype)
 
 
 def ray_march(rdist, ray_valid, feats, bg_color=None):
     """diff_ray_marching.py:508-554 with radiance_render / alpha_blend."""
     rgb = feats[..., 1:4]
-    sigma = feats[..., 0] * ray_valid.float()
+    sigma = feats[..., 0] * ray_valid.to(feats.dtype)
     opacity = 1 - torch.exp(-sigma * rdist)
     acc = torch.cumprod(1.0 - opacity + 1e-10, dim=-1)
     bg_t = acc[:, :, [-1]]
@@ -258,7 +259,7 @@ def ray_march(rdist, ray_valid, feats, bg_color=None):
     bw = (opacity * acc)[..., None]
     color = (rgb * bw).sum(dim=-2)
     if bg_color is not None:
-        color = color + bg_color.float().view(bg_t.shape[0], 1, 3) * bg_t
+        color = color + bg_color.to(color.dtype).view(bg_t.shape[0], 1, 3) * bg_t
     return color, rgb, opacity, acc, bw, bg_t
 
 
@@ -277,6 +278,18 @@ def render(opt, points, mlp, inp, impl="oracle", q=None, nthreads=1, Rw2c=None, 
                 ray_mask=q["ray_mask"], weight=w, blend_weight=bw, conf_coefficient=conf_c,
                 decoded_features=feats, ray_valid=ray_valid, ray_dist=rd, query=q,
                 queried_shading=torch.logical_not(ray_valid.any(dim=-1, keepdim=True)).repeat(1, 1, 3).float())
+
+
+def render_f64(opt, points, mlp, inp, q, Rw2c=None, kink=None):
+    """The same renderer in float64 on the SAME query result q (indices and sample positions stay the fp32 ones): the yardstick
+    against which the fp32 oracle's and the HIP path's own rounding (incl. LeakyReLU-kink flips) are measured by the tests."""
+    d = lambda t: t.detach().double()
+    pts = {k: (d(v).requires_grad_(v.requires_grad) if torch.is_floating_point(v) else v) for k, v in points.items()}
+    m64 = {k: d(v).requires_grad_(v.requires_grad) for k, v in mlp.items()}
+    i64 = {k: (d(v) if isinstance(v, torch.Tensor) and torch.is_floating_point(v) else v) for k, v in inp.items()}
+    q64 = {k: (d(v) if isinstance(v, torch.Tensor) and torch.is_floating_point(v) else v) for k, v in q.items()}
+    out = render(opt, pts, m64, i64, q=q64, Rw2c=Rw2c, kink=kink)
+    return out, pts, m64
 
 
 def fill_invalid(out, inp):
