@@ -71,7 +71,12 @@ def allreduce_grads(mlp_params, point_params, ready_event=None, early_params=())
     other contribution in the graph: embedding, dir and colour -- not the confidences, which also receive the zero-one loss)."""
     if world() == 1:
         return
-    early = [p for p in early_params if p.grad is not None and p.grad.is_cuda] if ready_event is not None else []
+    # the side-stream all-reduce is only sound on the very tensor the renderer's backward wrote: if autograd cloned it (a non-stealable
+    # layout, a pre-existing .grad, a hook) or added another contribution, p.grad is a different tensor that is completed on the main
+    # stream AFTER the event, and the early reduction would race it -- such parameters take the ordinary path below
+    from .fused import FusedRender
+    early = [p for p in early_params if p.grad is not None and p.grad.is_cuda and p.grad.data_ptr() in FusedRender.point_grad_ptrs] \
+        if ready_event is not None else []
     comm = None
     if early:
         dev = early[0].grad.device

@@ -36,6 +36,7 @@ class FusedRender(torch.autograd.Function):
     backward returns one gradient per parameter, each a view into a single flat gradient buffer."""
 
     point_grads_ready = None          # torch.cuda.Event of the latest backward (only when env["want_grad_event"])
+    point_grad_ptrs = frozenset()     # data pointers of the point-gradient tensors the latest backward wrote
 
     @staticmethod
     def forward(ctx, env, emb, conf, pdir, color, *mlp_params):
@@ -44,8 +45,12 @@ class FusedRender(torch.autograd.Function):
         ctx.point_arrays = (emb.detach().reshape(-1, emb.shape[-1]), conf.detach().reshape(-1, 1), pdir.detach().reshape(-1, 3),
                             color.detach().reshape(-1, 3))
         pts = ops.make_points(env["xyz"], *ctx.point_arrays)
+        # a step whose saved activations would exceed the arena budget runs its forward without saving anything; the backward then
+        # re-runs the forward chunk of rays by chunk of rays (ops.arena_budget_bytes)
+        from . import _lib as L
+        ctx.recompute = bool(env["train"]) and L.lib().pnerf_agg_saved_bytes(env["n_valid"], env["K"]) > ops.arena_budget_bytes()
         fwd = ops.render_forward(env["cam"], pts, env["packed"], env["flat"], env["raydir"], env["dense"],
-                                 env["R"], env["SR"], env["K"], env["n_valid"], env["train"])
+                                 env["R"], env["SR"], env["K"], env["n_valid"], env["train"] and not ctx.recompute)
         ctx.env, ctx.pts, ctx.fwd = env, pts, fwd
         ctx.shapes = (tuple(emb.shape), tuple(conf.shape), tuple(pdir.shape), tuple(color.shape))
         ctx.n_mlp = len(mlp_params)
@@ -55,7 +60,7 @@ class FusedRender(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_color, *unused):
         env, fwd = ctx.env, ctx.fwd
-        if not env["train"] or fwd["saved"] is None:
+        if not env["train"] or (fwd["saved"] is None and not ctx.recompute):
             raise RuntimeError("pointnerf_amd: backward through a render that was run with train=False")
         dev = g_color.device
         gflat = torch.zeros_like(env["flat"])
@@ -65,11 +70,16 @@ class FusedRender(torch.autograd.Function):
         if env.get("want_grad_event"):            # data-parallel training: see pnerf_point_grads.ready_event
             ev = torch.cuda.Event()
             ev.record()                           # creates the hipEvent_t; re-recorded by the library between dgrad and wgrad
-        if env["n_valid"] > 0:
+        if env["n_valid"] > 0 and ctx.recompute:
+            FusedRender._backward_in_chunks(env, ctx.pts, g_color.contiguous().float(), gflat, grads, ev)
+        elif env["n_valid"] > 0:
             ops.render_backward(env["cam"], ctx.pts, env["packed"], env["flat"], env["raydir"], env["dense"], env["R"],
                                 env["SR"], env["K"], env["n_valid"], fwd, g_color, gflat, grads, ready_event=ev)
         FusedRender.point_grads_ready = ev
-        ops.ARENA.give(fwd["saved"])  # hand the activation arena back for the next step
+        # what the early all-reduce may touch: exactly the tensors this backward wrote (dist.allreduce_grads checks p.grad against them)
+        FusedRender.point_grad_ptrs = {grads[n].data_ptr() for n in names}
+        if fwd["saved"] is not None:
+            ops.ARENA.give(fwd["saved"])  # hand the activation arena back for the next step
         fwd["saved"] = None
         gm = tuple(gflat[o:o + n].view(shp) for (o, n, shp) in env["layout"])
         assert len(gm) == ctx.n_mlp
@@ -77,6 +87,42 @@ class FusedRender(torch.autograd.Function):
         # outputs, dense weights, packed points) now, so that the next step's allocations find them in the allocator's cache
         ctx.env = ctx.fwd = ctx.pts = ctx.point_arrays = None
         return (None, grads["points_embeding"], grads["points_conf"], grads["points_dir"], grads["points_color"]) + gm
+
+
+def _backward_in_chunks(env, pts, g_color, gflat, grads, ev):
+    """Backward of a render step whose saved activations do not fit the arena budget: for consecutive runs of rays, re-run the
+    training forward (its saved activations within the budget) and the backward; gradients accumulate in the same buffers.
+    One host synchronisation per chunk (its number of valid samples sizes its arena)."""
+    from . import _lib as L
+    lib = L.lib()
+    dense, R, SR, K = env["dense"], env["R"], env["SR"], env["K"]
+    budget = ops.arena_budget_bytes()
+    per_ray = max(lib.pnerf_agg_saved_bytes(env["n_valid"], K) / max(R, 1), 1.0)
+    step = max(int(0.8 * budget / per_ray), 1)
+    todo = [(r0, min(r0 + step, R)) for r0 in range(0, R, step)]
+    last = None
+    while todo:
+        r0, r1 = todo.pop(0)
+        nn = dense["sample_nn"][r0:r1]
+        vlist, counters = ops.compact_valid(nn)
+        n_c = int(counters[0].item())
+        if n_c == 0:
+            continue
+        if lib.pnerf_agg_saved_bytes(n_c, K) > budget and r1 - r0 > 1:      # denser than the average: halve the run
+            mid = (r0 + r1) // 2
+            todo[:0] = [(r0, mid), (mid, r1)]
+            continue
+        sub = dict(sample_loc=dense["sample_loc"][r0:r1], sample_pidx=dense["sample_pidx"][r0:r1], sample_nn=nn, valid_list=vlist, counters=counters)
+        rd = env["raydir"][r0:r1]
+        f = ops.render_forward(env["cam"], pts, env["packed"], env["flat"], rd, sub, r1 - r0, SR, K, n_c, True)
+        last = (r0, r1)
+        ops.render_backward(env["cam"], pts, env["packed"], env["flat"], rd, sub, r1 - r0, SR, K, n_c, f, g_color[r0:r1], gflat, grads,
+                            ready_event=ev if not todo else None)
+        ops.ARENA.give(f["saved"])
+    FusedRender.last_chunks = None if last is None else (step, R)
+
+
+FusedRender._backward_in_chunks = staticmethod(_backward_in_chunks)
 
 
 class Aggregate(torch.autograd.Function):
@@ -93,12 +139,7 @@ class Aggregate(torch.autograd.Function):
         dev = emb.device
         R, SR, K = env["R"], env["SR"], env["K"]
         nn = env["nn"]
-        vlist = torch.empty(max(R * SR, 1), dtype=torch.int32, device=dev)
-        counters = torch.empty(8, dtype=torch.int32, device=dev)
-        nws = lib.pnerf_compact_workspace_bytes(R * SR)
-        cws = torch.empty(nws, dtype=torch.uint8, device=dev)
-        L.check(lib.pnerf_compact_valid(ops._ptr(nn), R * SR, ops._ptr(vlist), ops._ptr(counters), ops._ptr(cws), nws, ops._stream()),
-                "pnerf_compact_valid")
+        vlist, counters = ops.compact_valid(nn)
         n_valid = int(counters[0].item())
         # (the C structure holds raw pointers: the per-slot arrays must stay alive until the backward has read them)
         slot_arrays = (emb.detach().reshape(-1, emb.shape[-1]).contiguous(), conf.detach().reshape(-1, 1).contiguous(),

@@ -346,6 +346,11 @@ class MvsPointsVolumetricModel:
         if miss is None:
             return
         miss = miss.detach()
+        if pdist.world() > 1:
+            # the item is a SUM over this rank's rays: every rank must rank the views by the same (global) number, or the ranks pick
+            # different probe frames, grow different points and the replicated cloud diverges
+            miss = miss.clone()
+            torch.distributed.all_reduce(miss)
         if opt.prob_num_step > 1:
             self.top_ray_miss_loss, self.top_ray_miss_ids = self.rank_ray_miss(self.input["id"][0], miss, self.top_ray_miss_ids,
                                                                                   self.top_ray_miss_loss)
@@ -415,6 +420,7 @@ class MvsPointsVolumetricModel:
     def load_networks(self, epoch):
         """mvs_points_volumetric_model.py:308-326: non-strict load from ``opt.resume_dir``; a "best" checkpoint without stored
         confidences gets ``default_conf``."""
+        replaced = False
         for name, net in zip(self.model_names, self.get_networks()):
             path = os.path.join(self.opt.resume_dir, "{}_net_{}.pth".format(epoch, name))
             if not os.path.isfile(path):
@@ -435,11 +441,17 @@ class MvsPointsVolumetricModel:
                     new = nn.Parameter(v.to(self.device))
                     new.requires_grad = old.requires_grad
                     setattr(self.neural_points, attr, new)
+                    replaced = True
             net.load_state_dict(sd, strict=False)
         if self.device.type == "cuda":
             self.aggregator.flatten_()
-        if self.is_train and self.optimizers:
+        if self.is_train and self.optimizers and replaced:
+            # new parameter objects: the optimizers are rebuilt around them, and the schedulers with them -- a scheduler left on a
+            # discarded optimizer decays a learning rate nobody reads (the reference keeps its optimizers across load_state_dict)
+            steps = [s.last_epoch for s in getattr(self, "schedulers", [])]
             self.setup_optimizer(self.opt)
+            if steps:
+                self.init_scheduler(max(steps), self.opt)
 
     def cleanup(self):
         if getattr(self, "neural_points", None) is not None:

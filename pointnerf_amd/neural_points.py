@@ -58,6 +58,13 @@ class NeuralPoints(nn.Module):
         del self.querier
         self.querier = self.lighting_fast_querier(self.device, self.opt)
 
+    def invalidate_grid(self):
+        """Drop the cached voxel grids.  The cache recognises a changed cloud by (storage address, version counter, shape); writes
+        that bypass the version counter -- ``xyz.data.copy_()`` / ``xyz.data.add_()`` from a caller's script, a raw-pointer kernel
+        -- must be followed by this call, or the query keeps walking the old grid.  prune / grow_points / set_points call it."""
+        from . import point_query
+        point_query.clear_grid_cache()
+
     def _param(self, t, flag):
         p = nn.Parameter(t)
         p.requires_grad = getattr(self.opt, flag) > 0
@@ -71,6 +78,7 @@ class NeuralPoints(nn.Module):
             t = getattr(self, name)
             if t is not None:
                 setattr(self, name, self._param(t[:, mask, :], flag))
+        self.invalidate_grid()
         print("@@@@@@@@@  pruned {}/{}".format(torch.sum(mask == 0), mask.shape[0]))
 
     def grow_points(self, add_xyz, add_embedding, add_color, add_dir, add_conf, add_eulers=None, add_Rw2c=None):
@@ -80,6 +88,7 @@ class NeuralPoints(nn.Module):
             t = getattr(self, name)
             if t is not None:
                 setattr(self, name, self._param(torch.cat([t, add[None, ...]], dim=1), flag))
+        self.invalidate_grid()
 
     def set_points(self, points_xyz, points_embeding, points_color=None, points_dir=None, points_conf=None, parameter=False,
                    Rw2c=None, eulers=None):
@@ -101,6 +110,7 @@ class NeuralPoints(nn.Module):
                 if "1" in list(mode):
                     setattr(self, name, t)
         self.points_embeding = wrap(points_embeding, "feat_grad")
+        self.invalidate_grid()
         if Rw2c is None:
             self.Rw2c = torch.eye(3, device=points_xyz.device, dtype=points_xyz.dtype)
         else:

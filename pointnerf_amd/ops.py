@@ -221,6 +221,28 @@ class Arena:
 ARENA = Arena()
 
 
+def arena_budget_bytes():
+    """Upper bound for the saved-activation arena of ONE render step (9.6 KB per neighbor row: 68 GB at the bench configuration).
+    A training step whose rows would need more (Barn-scale clouds at K = 12, large ray batches) does not fail or swap: its forward runs
+    in inference mode and its backward re-runs the forward chunk of rays by chunk of rays, each chunk within the budget
+    (fused.FusedRender).  PNERF_ARENA_BUDGET_GB overrides the default of 160 GB (of the 288 GB of an MI355X)."""
+    import os
+    return int(float(os.environ.get("PNERF_ARENA_BUDGET_GB", "160")) * (1 << 30))
+
+
+def compact_valid(sample_nn):
+    """work list of the samples with neighbors: (valid_list [n] i32, counters [8] i32) from sample_nn [R,SR] (pnerf_compact_valid)"""
+    lib = L.lib()
+    n = sample_nn.numel()
+    dev = sample_nn.device
+    vlist = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    counters = torch.empty(8, dtype=torch.int32, device=dev)
+    nws = lib.pnerf_compact_workspace_bytes(n)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    L.check(lib.pnerf_compact_valid(_ptr(sample_nn), n, _ptr(vlist), _ptr(counters), _ptr(ws), nws, _stream()), "pnerf_compact_valid")
+    return vlist, counters
+
+
 def reserve_pool(nbytes, device):
     """Pre-size torch's caching allocator for the step's variable-size tensors (everything indexed by the number of rays
     that hit the cloud: compacted weights / indices / confidences, the loss temporaries and their gradients).  Their sizes

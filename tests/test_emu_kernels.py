@@ -97,3 +97,10 @@ def test_emulated_jitter_is_bit_defined():
     opt, xyz, attrs, inp, mlp = _tiny_case(8, 12, 5)
     opt.is_train = 1
     assert TQ._jitter_parity(opt, xyz, inp, "cpu") > 5
+
+
+def test_emulated_backward_by_ray_chunks(monkeypatch):
+    """arena budget exceeded -> inference forward + chunked recompute backward (fused._backward_in_chunks) equals the one-pass step"""
+    opt, xyz, attrs, inp, mlp = _tiny_case(4, 8, 4)
+    step, R = TB._chunked_equals_one_pass(opt, xyz, attrs, inp, mlp, "cpu", 0.0055, monkeypatch)
+    assert step < R

@@ -91,3 +91,48 @@ def test_backward_config1_chair():
     inp = pyref.to_torch_inputs(scenes.block_rays())
     mlp = pyref.init_mlp_params(opt, seed=0, bias_scale=0.05)
     _run(opt, xyz, attrs, inp, mlp)
+
+
+def _model_grads(opt, xyz, attrs, inp, mlp, dev):
+    """loss.backward() through NeuralPointsRayMarching (the fused autograd node): gradients of every parameter"""
+    from pointnerf_amd.neural_points import NeuralPoints
+    from pointnerf_amd.point_aggregators import PointAggregator
+    from pointnerf_amd.neural_points_volumetric_model import NeuralPointsRayMarching
+    agg = PointAggregator(opt).to(dev)
+    agg.load_state_dict(mlp)
+    agg.flatten_()
+    npnt = NeuralPoints(32, xyz.shape[0], opt, torch.device(dev))
+    a = {k: v.to(dev) for k, v in attrs.items()}
+    npnt.set_points(xyz.to(dev), a["points_embeding"], points_color=a["points_color"], points_dir=a["points_dir"], points_conf=a["points_conf"], parameter=True)
+    model = NeuralPointsRayMarching(aggregator=agg, neural_points=npnt, opt=opt)
+    d = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in inp.items()}
+    out = model(**d)
+    pyref.training_loss(opt, out, {"gt_image": d["gt_image"]}).backward()
+    g = {n: p.grad.detach().cpu().clone() for n, p in agg.named_parameters()}
+    g.update({n: getattr(npnt, n).grad.detach().cpu().clone() for n in ("points_embeding", "points_conf", "points_dir", "points_color")})
+    return g
+
+
+def _chunked_equals_one_pass(opt, xyz, attrs, inp, mlp, dev, budget_gb, monkeypatch):
+    from pointnerf_amd.fused import FusedRender
+    one = _model_grads(opt, xyz, attrs, inp, mlp, dev)
+    monkeypatch.setenv("PNERF_ARENA_BUDGET_GB", str(budget_gb))
+    FusedRender.last_chunks = None
+    many = _model_grads(opt, xyz, attrs, inp, mlp, dev)
+    assert FusedRender.last_chunks is not None and FusedRender.last_chunks[0] < FusedRender.last_chunks[1], "the budget did not force chunks"
+    for k in one:
+        scale = max(float(one[k].abs().max()), 1e-12)
+        assert float((one[k] - many[k]).abs().max()) <= 2e-5 * scale, k
+    return FusedRender.last_chunks
+
+
+def test_backward_by_ray_chunks_equals_one_pass(monkeypatch):
+    """a render step whose saved activations exceed the arena budget: forward without saving, backward re-runs the forward per run of
+    rays (fused._backward_in_chunks); same gradients as the one-pass step"""
+    opt = config.lego_opt(K=8, SR=24, P=12, max_o=50000, ranges=[-0.3, -0.3, -0.3, 0.3, 0.3, 0.3])
+    xyz = torch.from_numpy(scenes.chair_points(1500, seed=0, radius=0.06))
+    attrs = {k: torch.from_numpy(v) for k, v in scenes.point_attributes(1500, 32, 0).items()}
+    inp = pyref.to_torch_inputs(scenes.block_rays(theta_deg=30.0, x0=394, y0=394, size=12))
+    mlp = pyref.init_mlp_params(opt, seed=0, bias_scale=0.1)
+    step, R = _chunked_equals_one_pass(opt, xyz, attrs, inp, mlp, DEV, 0.02, monkeypatch)
+    print("chunks of", step, "rays of", R)

@@ -153,6 +153,12 @@ def test_checkpoint_round_trip_and_default_conf(tmp_path):
     m2.setup(opt2)
     for k, v in m.net_ray_marching.state_dict().items():
         assert torch.equal(v, m2.net_ray_marching.state_dict()[k]), k
+    # resume keeps every scheduler attached to the optimizer that is actually stepped (the learning rate must keep decaying)
+    assert len(m2.schedulers) == len(m2.optimizers) == 2 and all(s.optimizer is o for s, o in zip(m2.schedulers, m2.optimizers))
+    lr0 = [o.param_groups[0]["lr"] for o in m2.optimizers]
+    for _ in range(2000):
+        m2.update_learning_rate(verbose=False)
+    assert all(o.param_groups[0]["lr"] < l for o, l in zip(m2.optimizers, lr0))
     # "best" checkpoint without stored confidences: default_conf fills them (mvs_points_volumetric_model.py:318-320); a
     # checkpoint with a different point count replaces the parameters and the optimizer is rebuilt on the new ones
     sd_best = {k: v for k, v in sd.items() if k != "neural_points.points_conf"}
@@ -167,6 +173,10 @@ def test_checkpoint_round_trip_and_default_conf(tmp_path):
     m3.load_networks("best")
     assert torch.equal(m3.neural_points.xyz.data, xyz) and float((m3.neural_points.points_conf - opt3.default_conf).abs().max()) == 0
     assert any(p is m3.neural_points.points_embeding for p in m3.neural_params)
+    # the parameters were replaced: optimizers rebuilt, and schedulers (if any) rebuilt on them
+    m3.init_scheduler(10, opt3)
+    m3.load_networks("best")
+    assert all(s.optimizer is o for s, o in zip(m3.schedulers, m3.optimizers))
 
 
 def test_fill_invalid_scatters_probe_outputs_and_bg_ray():
