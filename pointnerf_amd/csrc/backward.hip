@@ -628,14 +628,11 @@ __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, 
     extern __shared__ __attribute__((aligned(16))) uint4 smem_w[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    // rows of this chunk: the tiles actually used are known on the device only
-    const long long rows = (long long)(*d_tiles) * PN_TILE;
-    long long rpc = (rows + gridDim.x - 1) / gridDim.x;
-    rpc = (rpc + 63) / 64 * 64;
-    const long long r0 = (long long)blockIdx.x * rpc;
-    long long r1 = r0 + rpc;
-    if (r1 > rows) r1 = rows;
-    const int nst = r1 > r0 ? (int)((r1 - r0) / 16) : 0;
+    // 16-row stages are dealt to the workgroups round-robin (stage blockIdx.x + gridDim.x * i): at any moment the chip reads ONE contiguous
+    // run of each plane instead of 256 runs that are a fixed, channel-aliasing distance apart.  The tiles actually used are known on the
+    // device only.
+    const long long stages = (long long)(*d_tiles) * (PN_TILE / 16);
+    const int nst = stages > (long long)blockIdx.x ? (int)((stages - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
     f32x16 acc[4][2], acct;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -646,7 +643,7 @@ __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, 
     // stage s -> buffer: wave-instruction j copies units [64 j, 64 j + 64) of the stage's concatenated runs; every wave issues
     // exactly NIW instructions (a wave without a piece of its own re-reads the stage's first KB into the pad slot)
     auto issue = [&](int s, int buf) {
-        const long long rg = r0 / 8 + 2LL * s;
+        const long long rg = 2LL * ((long long)blockIdx.x + (long long)gridDim.x * s);
 #pragma unroll
         for (int i = 0; i < NIW; ++i) {
             const bool pad = wave + 8 * i >= NI;
@@ -668,7 +665,12 @@ __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, 
             // stage s has landed for every wave, and every wave is done with stage s - 1 (whose buffer the next issue overwrites)
             pn_wait_vm_stages<NIW>(nst - 1 - s);
             __builtin_amdgcn_s_barrier();
+#ifndef PN_WG_NOLOAD          // dev ablations (tools/_build only): timing without the loads / without the MFMAs, results meaningless
             if (s + 3 < nst) issue(s + 3, (s + 3) & 3);
+#endif
+#ifdef PN_WG_NOMFMA
+            continue;
+#endif
             const uint4 *st = smem_w + (s & 3) * STAGE;
             const uint4 *fa = st + (lane >> 5) * 256 + (lane & 31);
             const uint4 *fb = st + 2 * AU + (lane >> 5) * NFB + (lane & 31);
