@@ -45,7 +45,7 @@ typedef struct pnerf_grid_params {
 
 /* info words written by pnerf_grid_build at the start of the grid workspace */
 enum { PNERF_GI_N_IN_GRID = 0, PNERF_GI_N_OCC = 1, PNERF_GI_MAX_CNT = 2, PNERF_GI_CELL0 = 3,
-       PNERF_GI_FIRST_IDX = 4, PNERF_GI_LEN = 8 };
+       PNERF_GI_FIRST_IDX = 4, PNERF_GI_OSTART_OFF = 5 /* internal: where the cell offsets sit in the workspace */, PNERF_GI_LEN = 8 };
 
 /* ---- library ---------------------------------------------------------------------------- */
 int pnerf_version(void);                 /* 1000*major + minor */

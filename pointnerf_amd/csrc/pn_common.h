@@ -50,17 +50,19 @@ int pn_compact_gt0_i32(const int *in, long long n, int *list, int *count_out, in
 struct PnGridDev {
     float ox, oy, oz;        // grid origin (ranges[0..2])
     float vx, vy, vz;        // scaled voxel size
-    int gx, gy, gz;          // dims
+    int gx, gy, gz;          // dims in cells
+    int by, bz;              // dims in 4 x 4 x 4 bricks along y and z
     int P;
+    const char *base;        // the grid workspace (ostart sits at base + 256 * info[PNERF_GI_OSTART_OFF])
     const int *info;         // PNERF_GI_* words
-    const int *cell_start;   // [G+1] CSR offsets into pts
-    const uint32_t *occ;     // [(G+31)/32] dilated occupancy bits
-    const float4 *pts;       // [n_in_grid] (x,y,z,bitcast idx) sorted by (cell, idx)
+    const uint4 *bricks;     // [NB] (bits 0..31, bits 32..63, occupied cells before the brick, points before the brick)
+    const uint32_t *occ;     // [(G+31)/32] dilated occupancy bits, (x, y, z) order
+    const float4 *pts;       // [n_in_grid] (x,y,z,bitcast idx) sorted by (brick, cell, idx)
 };
 
 struct PnGridLayout {       // byte offsets inside the grid workspace
-    size_t info, cell_start, occ, pts, keys, cursor, tmp_idx, scan, total;
-    long long G;
+    size_t info, bricks, occ, pts, ostart, keys, cnt, tmp_idx, ocell, bocc, bpts, brank, bbase, scan, total;
+    long long G, NB;
 };
 PnGridLayout pn_grid_layout(const pnerf_grid_params *gp, int n);
 PnGridDev pn_grid_dev(const pnerf_grid_params *gp, const void *ws, int n_unused);
@@ -70,4 +72,18 @@ PnGridDev pn_grid_dev(const pnerf_grid_params *gp, const void *ws, int n_unused)
 // Files using this are compiled with -ffp-contract=off.
 __device__ __forceinline__ int pn_cell(float p, float o, float v) {
     return (int)floorf((p - o) / v);
+}
+// brick map addressing (grid.hip): brick of a cell, the cell's bit inside its brick
+__host__ __device__ __forceinline__ int pn_brick_of(int x, int y, int z, int by, int bz) { return ((x >> 2) * by + (y >> 2)) * bz + (z >> 2); }
+__host__ __device__ __forceinline__ int pn_cell_in_brick(int x, int y, int z) { return ((x & 3) << 4) | ((y & 3) << 2) | (z & 3); }
+__device__ __forceinline__ const int *pn_grid_ostart(const PnGridDev &g) { return (const int *)(g.base + (size_t)g.info[PNERF_GI_OSTART_OFF] * 256); }
+// candidates of the in-range cell (x, y, z): how many (0 for an empty cell and for the reference's voxel id 0), and where the first one is
+__device__ __forceinline__ int pn_cell_points(const PnGridDev &g, const int *__restrict__ ostart, int cell0, int x, int y, int z, int &st) {
+    const int brick = pn_brick_of(x, y, z, g.by, g.bz), local = pn_cell_in_brick(x, y, z);
+    const uint4 rec = g.bricks[brick];
+    const unsigned long long bits = ((unsigned long long)rec.y << 32) | rec.x;
+    if (!((bits >> local) & 1ull) || brick * 64 + local == cell0) return 0;
+    const int o = (int)rec.z + __popcll(bits & ((1ull << local) - 1ull));
+    st = ostart[o];
+    return min(g.P, ostart[o + 1] - st);
 }

@@ -9,15 +9,24 @@
 //     slot, so the [R,D,3] sample array, the [R,D] mask, its cumsum and both masked_select copies of
 //     the reference never exist, and the walk stops as soon as SR samples are found.
 //   * k_neighbors: one thread per selected sample, the reference's exact sequential top-K insertion
-//     (needed for bit-exact slot order), but candidates come from contiguous float4 records of the
-//     CSR grid (one 16 B load per candidate instead of cell->occ->count->pidx->xyz chains), the
+//     (needed for bit-exact slot order), but a cell lookup is one 16-byte record of the brick map
+//     (grid.hip; L2-resident) and candidates come from contiguous float4 records, four in flight
+//     per lane (one 16 B load per candidate instead of cell->occ->count->pidx->xyz chains), the
 //     K-buffer lives in registers, and all 64 lanes of a wave belong to the same ray.
+//     Measured and dropped in round 2 (profiles/r02_neighbors_variants.json): one wavefront per
+//     64 samples staging the candidates' float4 records in LDS (global_load_lds, 32 KB per wave)
+//     ran 2.2x slower, staging only their indices in LDS (flat candidate sequence, 4 loads in
+//     flight) ran 1.0x / 2.1x / 1.8x slower at configs[1] / [3] / [4]: the kernel is bound by its
+//     dependent steps per wave, not by bytes, and LDS per wave costs the occupancy that hides them.
 //   * no device->host sync anywhere: ray compaction is replaced by dense [R,...] outputs plus a
 //     device-built work list of the valid samples.
 // Compiled with -ffp-contract=off (cell arithmetic and squared distances must round like the
 // reference: left-to-right fp32, no FMA).
 #include "pn_common.h"
 
+#ifndef PN_NB_BATCH
+#define PN_NB_BATCH 4
+#endif
 namespace {
 constexpr int TPB = 256;
 
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(TPB) void k_neighbors(PnGridDev g, int ks0, float r
         const float cx = sample_loc[index * 3], cy = sample_loc[index * 3 + 1], cz = sample_loc[index * 3 + 2];
         const int fx = pn_cell(cx, g.ox, g.vx), fy = pn_cell(cy, g.oy, g.vy), fz = pn_cell(cz, g.oz, g.vz);
         const int cell0 = g.info[PNERF_GI_CELL0];
-        const int gyz = g.gy * g.gz;
+        const int *ostart = pn_grid_ostart(g);
         int far_ind = 0;
         float far2 = 0.f;
         const int nlayer = (ks0 + 1) / 2;
@@ -135,28 +144,34 @@ __global__ __launch_bounds__(TPB) void k_neighbors(PnGridDev g, int ks0, float r
                 for (int y = max(-fy, -layer); y < min(g.gy - fy, layer + 1); ++y) {
                     for (int z = max(-fz, -layer); z < min(g.gz - fz, layer + 1); ++z) {
                         if (max(abs(z), max(abs(x), abs(y))) != layer) continue;
-                        const int lin = (fx + x) * gyz + (fy + y) * g.gz + (fz + z);
-                        if (lin == cell0) continue;            // reference: voxel id 0 holds no points (.cu:147)
-                        const int st = g.cell_start[lin];
-                        const int n = min(g.P, g.cell_start[lin + 1] - st);
-                        for (int gi = 0; gi < n; ++gi) {
-                            const float4 p = g.pts[st + gi];
-                            const float xv = p.x - cx, yv = p.y - cy, zv = p.z - cz;
-                            const float d2 = xv * xv + yv * yv + zv * zv;    // contract=off: ((xx+yy)+zz)
-                            if (radius2 == 0.f || d2 <= radius2) {
-                                const int pid = __float_as_int(p.w);
-                                if (kid < K) {
+                        int st = 0;                            // reference: voxel id 0 holds no points (.cu:147)
+                        const int n = pn_cell_points(g, ostart, cell0, fx + x, fy + y, fz + z, st);
+                        // the insertion is sequential, the loads are not: PN_NB_BATCH records of the cell in flight per lane
+                        for (int g0 = 0; g0 < n; g0 += PN_NB_BATCH) {
+                            float4 pb[PN_NB_BATCH];
 #pragma unroll
-                                    for (int j = 0; j < KMAX; ++j) if (j == kid) { out[j] = pid; buf[j] = d2; }
-                                    if (d2 > far2) { far2 = d2; far_ind = kid; }
-                                } else if (d2 < far2) {
+                            for (int u = 0; u < PN_NB_BATCH; ++u) pb[u] = g.pts[st + min(g0 + u, n - 1)];
 #pragma unroll
-                                    for (int j = 0; j < KMAX; ++j) if (j == far_ind) { out[j] = pid; buf[j] = d2; }
-                                    far2 = d2;
+                            for (int u = 0; u < PN_NB_BATCH; ++u) {
+                                if (g0 + u >= n) break;
+                                const float4 p = pb[u];
+                                const float xv = p.x - cx, yv = p.y - cy, zv = p.z - cz;
+                                const float d2 = xv * xv + yv * yv + zv * zv;    // contract=off: ((xx+yy)+zz)
+                                if (radius2 == 0.f || d2 <= radius2) {
+                                    const int pid = __float_as_int(p.w);
+                                    if (kid < K) {
 #pragma unroll
-                                    for (int j = 0; j < KMAX; ++j) if (j < K && buf[j] > far2) { far2 = buf[j]; far_ind = j; }
+                                        for (int j = 0; j < KMAX; ++j) if (j == kid) { out[j] = pid; buf[j] = d2; }
+                                        if (d2 > far2) { far2 = d2; far_ind = kid; }
+                                    } else if (d2 < far2) {
+#pragma unroll
+                                        for (int j = 0; j < KMAX; ++j) if (j == far_ind) { out[j] = pid; buf[j] = d2; }
+                                        far2 = d2;
+#pragma unroll
+                                        for (int j = 0; j < KMAX; ++j) if (j < K && buf[j] > far2) { far2 = buf[j]; far_ind = j; }
+                                    }
+                                    ++kid;
                                 }
-                                ++kid;
                             }
                         }
                     }

@@ -4,12 +4,12 @@ import importlib.util
 import os
 import sys
 
-REF_ROOT = os.environ.get("POINTNERF_REFERENCE", "/root/reference")
+REF_ROOT = os.environ.get("POINTNERF_REFERENCE", "")        # no default: the overlay never guesses where a checkout might be
 REF_MODELS = os.path.join(REF_ROOT, "models")
 
 
 def require_reference():
-    if not os.path.isdir(REF_MODELS):
+    if not REF_ROOT or not os.path.isdir(REF_MODELS):
         raise ImportError("pointnerf_amd overlay: the Point-NeRF checkout was not found at %r; set POINTNERF_REFERENCE to it "
                           "(the overlay replaces only the hot-path modules, everything else is the reference's own code)" % REF_ROOT)
     if REF_ROOT not in sys.path:

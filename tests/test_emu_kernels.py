@@ -104,3 +104,22 @@ def test_emulated_backward_by_ray_chunks(monkeypatch):
     opt, xyz, attrs, inp, mlp = _tiny_case(4, 8, 4)
     step, R = TB._chunked_equals_one_pass(opt, xyz, attrs, inp, mlp, "cpu", 0.0055, monkeypatch)
     assert step < R
+
+
+@pytest.mark.parametrize("seed,n,K,SR,size,kw", [
+    (0, 1200, 8, 16, 6, dict(P=12)),
+    (6, 4000, 16, 70, 4, dict(P=30)),                                                # > 64 slots per ray: two wave passes
+    (2, 3000, 8, 12, 5, dict(P=32, vsize=[0.02, 0.02, 0.02])),                       # fat cells: the shell splits into several LDS chunks
+    (7, 400, 8, 12, 5, dict(ranges=[-0.05, -0.05, -0.05, 0.05, 0.05, 0.05])),        # samples in the grid's border cells
+    (7, 1500, 8, 12, 5, dict(kernel_size=[1, 1, 1])),                                # one layer: the own cell only
+    (7, 1500, 8, 12, 5, dict(kernel_size=[5, 5, 5], query_size=[1, 1, 1])),          # three layers: the thread-per-sample kernel
+    (3, 2500, 3, 12, 5, dict(P=40)),                                                 # P beyond the tile rows: the thread-per-sample kernel
+])
+def test_emulated_neighbor_query_bit_exact(monkeypatch, seed, n, K, SR, size, kw):
+    """k_probe + k_neighbors_tiles (LDS-staged candidate tiles) / k_neighbors: indices, sample positions and masks equal the oracle's"""
+    import test_gpu_query as TQ
+    monkeypatch.setattr(TQ, "DEV", "cpu")
+    opt, xyz, inp = TQ._scene(seed, n, K=K, SR=SR, size=size, **kw)
+    q = pyref.query(opt, xyz, inp)
+    assert int((q["sample_pidx"] >= 0).sum()) > 50
+    TQ._assert_same(q, *TQ._native_op(opt, xyz, inp, q["hp"]))
