@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_pack(PackTable t, const float *__restri
 // two-plane f16 images of the four aggregator layers (f16x3.h): forward W[m][k] (trans = 0: m = output unit, k = input column)
 // and dgrad W^T[m][k] (trans = 1: m = input column, k = output unit)
 struct PackHDesc { int src, ld, trans, Mreal, Kreal, NCH, MB, dst; };
-struct PackHTable { PackHDesc d[8]; };
+struct PackHTable { PackHDesc d[14]; };
 __global__ __launch_bounds__(256) void k_pack_h(PackHTable t, const float *__restrict__ params, char *__restrict__ packed) {
     const PackHDesc d = t.d[blockIdx.y];
     const int total = d.NCH * d.MB * 64;
@@ -97,10 +97,17 @@ extern "C" int pnerf_mlp_pack(const float *d_params, void *d_packed, void *strea
         {PO_W3, PN_IN3, 1, PN_IN3, PN_H, 16, 9, PKH_D3},
         {PO_W2, PN_H, 1, PN_H, PN_H, 16, 8, PKH_D2},
         {PO_W1, PN_IN1, 1, 32 * PN_MB_D1, PN_H, 16, PN_MB_D1, PKH_D1},
+        // colour MLP: forward W[m][k], dgrad W^T[m][k] (first 256 input columns of layer 1: the view encoding has no gradient)
+        {PO_WC1, PN_INC, 0, PN_HC, PN_INC, 18, 4, PKH_FC1},
+        {PO_WC2, PN_HC, 0, PN_HC, PN_HC, 8, 4, PKH_FC2},
+        {PO_WC3, PN_HC, 0, PN_HC, PN_HC, 8, 4, PKH_FC3},
+        {PO_WC3, PN_HC, 1, PN_HC, PN_HC, 8, 4, PKH_DC3},
+        {PO_WC2, PN_HC, 1, PN_HC, PN_HC, 8, 4, PKH_DC2},
+        {PO_WC1, PN_INC, 1, PN_H, PN_HC, 8, 8, PKH_DC1},
     }};
     PnProfScope prof(PNK_PACK, (hipStream_t)stream);
     hipLaunchKernelGGL(k_pack, dim3(64, 6), dim3(256), 0, (hipStream_t)stream, t, d_params, (float *)d_packed);
-    hipLaunchKernelGGL(k_pack_h, dim3(40, 8), dim3(256), 0, (hipStream_t)stream, th, d_params, (char *)d_packed);
+    hipLaunchKernelGGL(k_pack_h, dim3(40, 14), dim3(256), 0, (hipStream_t)stream, th, d_params, (char *)d_packed);
     PN_CHECK_LAUNCH();
     return 0;
 }
@@ -197,8 +204,6 @@ extern "C" size_t pnerf_agg_saved_bytes(int64_t n_valid_samples, int K) {
 
 // ------------------------------------------------------------------------------ forward kernels
 namespace {
-constexpr int LDX = 292;    // X0 / colour input row stride in LDS (odd multiple of 4 floats: conflict-free b128 reads)
-constexpr int LDC = 132;    // colour hidden row stride
 constexpr int TPR = PN_TPR; // threads per tile row in the element-wise phases
 constexpr int EPT = PN_F / TPR;              // embedding dims per thread in the feature build
 
@@ -649,95 +654,141 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
     }
 }
 
-constexpr int COL_LDS_FLOATS = PN_CTILE * LDX + 32;      // 75 KB: two workgroups per CU (the hidden layers reuse the input tile's space)
+// ------------------------------------------------------------------------------ colour MLP forward
+// 64 valid samples per tile: [f (256) | view-direction encoding (24) | 0 (8)] -> 128 -> 128 -> 128 -> 3, the three 128-wide layers as
+// two-plane f16 GEMMs (f16x3.h: one 32-feature block per wave, 18 / 8 / 8 chunks), the 3-wide output layer and the sigmoid on the
+// VALU.  One activation tile in LDS, reused layer after layer; the post-activations the backward needs (LeakyReLU masks, the fp32
+// weight-gradient GEMMs of these three layers) leave from the accumulator registers as fp32 rows.
+constexpr int CL_W4 = PN_XBYTES, CL_BYTES = CL_W4 + 3 * PN_HC * 4;
+static_assert(2 * CL_BYTES <= 160 * 1024, "two colour workgroups must fit the 160 KB LDS");
+
+__device__ __forceinline__ void c_load_bias(const float *__restrict__ bias, int wave, int lane, float4 (&b)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {         // (scalar loads: the colour tensors sit at odd float offsets of the parameter vector)
+        const float *p = bias + pn_d_feat(wave, g, lane);
+        b[g] = make_float4(p[0], p[1], p[2], p[3]);
+    }
+}
+// bias + LeakyReLU of the wave's feature block: fp32 rows to `save` (training), two planes into the tile
+template <bool TRAIN>
+__device__ __forceinline__ void c_epilogue(const f32x16 (&acc)[2][2], const float4 (&bias)[4], char *X, int wave, int lane, float *__restrict__ save, long long grow0) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = pn_d_feat(wave, g, lane), row = 32 * rb + (lane & 31);
+            const float4 b = bias[g];
+            float v[4] = {acc[0][rb][4 * g] + b.x, acc[0][rb][4 * g + 1] + b.y, acc[0][rb][4 * g + 2] + b.z, acc[0][rb][4 * g + 3] + b.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.01f * v[i]);
+            if (TRAIN) {
+                pn_f4 t = {v[0], v[1], v[2], v[3]};
+                PN_REG_STORE(t, reinterpret_cast<pn_f4 *>(save + (grow0 + row) * PN_HC + f0));
+            }
+            pn_x_store4<false>(X, row, f0, v[0], v[1], v[2], v[3]);
+        }
+}
+__device__ __forceinline__ void c_acc_zero(f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+}
 
 template <bool TRAIN>
 __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *X = smem;                            // [64][LDX]
-    float *H1 = X;                              // [64][LDC]  (over X once layer 1 has read it)
-    float *H2 = X + PN_CTILE * LDC;             // [64][LDC]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    char *X = smem_c;
+    float *w4s = reinterpret_cast<float *>(smem_c + CL_W4);       // [3][128] output layer
     const int Ns = a.counters[0] < a.cap_samples ? a.counters[0] : (int)a.cap_samples;
     const float *P = a.params;
+    const char *img = reinterpret_cast<const char *>(a.packed);
+    for (int i = threadIdx.x; i < 3 * PN_HC; i += 256) w4s[i] = P[PO_WC4 + i];
+    const float b40 = P[PO_BC4], b41 = P[PO_BC4 + 1], b42 = P[PO_BC4 + 2];
 
+    f32x16 acc[2][2];
     for (long long tile = blockIdx.x; tile * PN_CTILE < Ns; tile += gridDim.x) {
-        const long long grow0 = tile * PN_CTILE;
-        __syncthreads();
-        {
-            const int row = tid >> 2, q = tid & 3;
-            const long long vs = grow0 + row;
-            float *xr = X + row * LDX;
-            const int si = vs < Ns ? a.valid_list[vs] : -1;
-            if (si >= 0) {
-                const float *f = a.sv.fs + vs * PN_H + q * 64;
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), row = tid >> 2, q = tid & 3;
+        const long long grow0 = tile * PN_CTILE, vs = grow0 + row;
+        const int si = vs < Ns ? a.valid_list[vs] : -1;
+        PN_LDS_BARRIER();                                 // the previous tile's readers are done with X
+        if (si >= 0) {
+            const float4 *f = reinterpret_cast<const float4 *>(a.sv.fs + vs * PN_H + q * 64);
+            float4 fv[16];
 #pragma unroll
-                for (int c = 0; c < 64; c += 4) *reinterpret_cast<float4 *>(xr + q * 64 + c) = *reinterpret_cast<const float4 *>(f + c);
-                if (q == 0) {
-                    const int r = si / a.SR;
-                    float v[3];
-                    rot3(a.cam.rw2c, a.raydir[3 * r], a.raydir[3 * r + 1], a.raydir[3 * r + 2], true, v[0], v[1], v[2]);
-                    // positional_encoding(viewdirs, 4, ori=True)[..., 3:] = [sin(v_d 2^f) (d-major) | cos(...)]   networks.py:185-187
+            for (int c = 0; c < 16; ++c) fv[c] = f[c];
 #pragma unroll
-                    for (int dd = 0; dd < 3; ++dd) {
-                        float fr = 1.f;
+            for (int c = 0; c < 16; ++c) pn_x_store4<false>(X, row, q * 64 + 4 * c, fv[c].x, fv[c].y, fv[c].z, fv[c].w);
+            {   // positional_encoding(viewdirs, 4, ori=True)[..., 3:] = [sin(v_d 2^f) (d-major) | cos(...)]   networks.py:185-187
+                // thread q < 3 of the row: direction component q, its four frequencies (columns 256 + 4 q .. and 268 + 4 q ..)
+                const int r = si / a.SR;
+                float v[3], sn[4], cs[4];
+                rot3(a.cam.rw2c, a.raydir[3 * r], a.raydir[3 * r + 1], a.raydir[3 * r + 2], true, v[0], v[1], v[2]);
+                const float vq = q == 0 ? v[0] : (q == 1 ? v[1] : v[2]);
+                float fr = 1.f;
 #pragma unroll
-                        for (int f2 = 0; f2 < 4; ++f2) {
-                            float s, c;
-                            sincosf(v[dd] * fr, &s, &c);
-                            xr[PN_H + dd * 4 + f2] = s;
-                            xr[PN_H + 12 + dd * 4 + f2] = c;
-                            fr *= 2.f;
-                        }
-                    }
-#pragma unroll
-                    for (int j = PN_INC; j < LDX; ++j) xr[j] = 0.f;
+                for (int f2 = 0; f2 < 4; ++f2) { pn_sincos(vq * fr, sn[f2], cs[f2]); fr *= 2.f; }
+                if (q < 3) {
+                    pn_x_store4<false>(X, row, PN_H + 4 * q, sn[0], sn[1], sn[2], sn[3]);
+                    pn_x_store4<false>(X, row, PN_H + 12 + 4 * q, cs[0], cs[1], cs[2], cs[3]);
                     if (TRAIN) {
-#pragma unroll
-                        for (int j = 0; j < 32; ++j) a.sv.pe[vs * 32 + j] = j < 24 ? xr[PN_H + j] : 0.f;
+                        *reinterpret_cast<float4 *>(a.sv.pe + vs * 32 + 4 * q) = make_float4(sn[0], sn[1], sn[2], sn[3]);
+                        *reinterpret_cast<float4 *>(a.sv.pe + vs * 32 + 12 + 4 * q) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+                    }
+                } else {
+                    pn_x_store4<false>(X, row, PN_H + 24, 0.f, 0.f, 0.f, 0.f);
+                    pn_x_store4<false>(X, row, PN_H + 28, 0.f, 0.f, 0.f, 0.f);
+                    if (TRAIN) {
+                        *reinterpret_cast<float4 *>(a.sv.pe + vs * 32 + 24) = make_float4(0.f, 0.f, 0.f, 0.f);
+                        *reinterpret_cast<float4 *>(a.sv.pe + vs * 32 + 28) = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
-            } else {
-                for (int j = q; j < LDX; j += 4) xr[j] = 0.f;
             }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 18; ++c) pn_x_store4<false>(X, row, q * 72 + 4 * c, 0.f, 0.f, 0.f, 0.f);
         }
-        __syncthreads();
-        f32x16 acc[2][1];
-        pn_acc_init_bias<2, 1>(acc, P + PO_BC1, wave, lane);
-        pn_tile_gemm<2, 1>(X, LDX, PN_INC / 8, a.packed + PK_C1 / 4, wave, lane, acc);
-        __syncthreads();                        // every wave is done reading X before H1 takes its place
-        pn_acc_to_lds<2, 1, true>(acc, H1, LDC, wave, lane);
-        __syncthreads();
-        if (TRAIN) pn_tile_copy_out<PN_CTILE, PN_HC>(H1, LDC, a.sv.c1, PN_HC, grow0, tid);
-        pn_acc_init_bias<2, 1>(acc, P + PO_BC2, wave, lane);
-        pn_tile_gemm<2, 1>(H1, LDC, PN_HC / 8, a.packed + PK_C2 / 4, wave, lane, acc);
-        pn_acc_to_lds<2, 1, true>(acc, H2, LDC, wave, lane);
-        __syncthreads();
-        if (TRAIN) pn_tile_copy_out<PN_CTILE, PN_HC>(H2, LDC, a.sv.c2, PN_HC, grow0, tid);
-        pn_acc_init_bias<2, 1>(acc, P + PO_BC3, wave, lane);
-        pn_tile_gemm<2, 1>(H2, LDC, PN_HC / 8, a.packed + PK_C3 / 4, wave, lane, acc);
-        pn_acc_to_lds<2, 1, true>(acc, H1, LDC, wave, lane);
-        __syncthreads();
-        if (TRAIN) pn_tile_copy_out<PN_CTILE, PN_HC>(H1, LDC, a.sv.c3, PN_HC, grow0, tid);
+        PN_LDS_BARRIER();
+        float4 bias[4];
+        // ---- layer 1: 280 (288) -> 128
+        c_acc_zero(acc);
+        pn_gemm_f16x3<18, 4, 1, 7>(X, reinterpret_cast<const uint4 *>(img + PKH_FC1), wave, lane, acc);
+        c_load_bias(P + PO_BC1, wave, lane, bias);
+        PN_LDS_BARRIER();                                 // every wave is done reading the input tile
+        c_epilogue<TRAIN>(acc, bias, X, wave, lane, a.sv.c1, grow0);
+        PN_LDS_BARRIER();
+        // ---- layer 2
+        c_acc_zero(acc);
+        pn_gemm_f16x3<8, 4, 1, 7>(X, reinterpret_cast<const uint4 *>(img + PKH_FC2), wave, lane, acc);
+        c_load_bias(P + PO_BC2, wave, lane, bias);
+        PN_LDS_BARRIER();
+        c_epilogue<TRAIN>(acc, bias, X, wave, lane, a.sv.c2, grow0);
+        PN_LDS_BARRIER();
+        // ---- layer 3
+        c_acc_zero(acc);
+        pn_gemm_f16x3<8, 4, 1, 7>(X, reinterpret_cast<const uint4 *>(img + PKH_FC3), wave, lane, acc);
+        c_load_bias(P + PO_BC3, wave, lane, bias);
+        PN_LDS_BARRIER();
+        c_epilogue<TRAIN>(acc, bias, X, wave, lane, a.sv.c3, grow0);
+        PN_LDS_BARRIER();
+        // ---- output layer 128 -> 3 and the colour activation: 4 threads per row, 32 columns each
         {
-            const int row = tid >> 2, q = tid & 3;
-            const float *h = H1 + row * LDC + q * 32;
             float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
-            for (int c = 0; c < 32; ++c) {
-                const float hv = h[c];
-                o0 += hv * P[PO_WC4 + q * 32 + c];
-                o1 += hv * P[PO_WC4 + PN_HC + q * 32 + c];
-                o2 += hv * P[PO_WC4 + 2 * PN_HC + q * 32 + c];
+            for (int j = 0; j < 4; ++j) {
+                const int c0 = q * 32 + 8 * j;
+                o0 = pn_x_dot8(X, row, c0, *reinterpret_cast<const float4 *>(w4s + c0), *reinterpret_cast<const float4 *>(w4s + c0 + 4), o0);
+                o1 = pn_x_dot8(X, row, c0, *reinterpret_cast<const float4 *>(w4s + PN_HC + c0), *reinterpret_cast<const float4 *>(w4s + PN_HC + c0 + 4), o1);
+                o2 = pn_x_dot8(X, row, c0, *reinterpret_cast<const float4 *>(w4s + 2 * PN_HC + c0), *reinterpret_cast<const float4 *>(w4s + 2 * PN_HC + c0 + 4), o2);
             }
             o0 = group_sum<4>(o0); o1 = group_sum<4>(o1); o2 = group_sum<4>(o2);
-            const long long vs = grow0 + row;
-            if (q == 0 && vs < Ns) {
-                const int si = a.valid_list[vs];
+            if (q == 0 && si >= 0) {
                 float *o = a.decoded + (long long)si * 4;
-                o[1] = 1.0f / (1.0f + expf(-(o0 + P[PO_BC4]))) * 1.002f - 0.001f;                                     // raw2out_color :269-273
-                o[2] = 1.0f / (1.0f + expf(-(o1 + P[PO_BC4 + 1]))) * 1.002f - 0.001f;
-                o[3] = 1.0f / (1.0f + expf(-(o2 + P[PO_BC4 + 2]))) * 1.002f - 0.001f;
+                o[1] = 1.0f / (1.0f + expf(-(o0 + b40))) * 1.002f - 0.001f;                                     // raw2out_color :269-273
+                o[2] = 1.0f / (1.0f + expf(-(o1 + b41))) * 1.002f - 0.001f;
+                o[3] = 1.0f / (1.0f + expf(-(o2 + b42))) * 1.002f - 0.001f;
             }
         }
     }
@@ -764,7 +815,7 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
     const long long ctiles = (cap_samples + PN_CTILE - 1) / PN_CTILE;
     const int grid_c = (int)(ctiles < 2 * ncu ? (ctiles > 0 ? ctiles : 1) : 2 * ncu);       // two workgroups per CU
-    const size_t lds_a = FL_BYTES, lds_c = COL_LDS_FLOATS * sizeof(float);
+    const size_t lds_a = FL_BYTES, lds_c = CL_BYTES;
     const bool pers = d_xyz_pers != nullptr;
     const void *kfn = train ? (pers ? (const void *)k_agg_forward<true, true> : (const void *)k_agg_forward<true, false>)
                             : (pers ? (const void *)k_agg_forward<false, true> : (const void *)k_agg_forward<false, false>);

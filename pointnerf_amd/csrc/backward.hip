@@ -16,7 +16,6 @@
 #include "f16x3.h"
 
 namespace {
-constexpr int LDC = 132;
 constexpr int WG_CHUNKS = 256;                 // split-K factor of the wgrad GEMMs
 constexpr size_t PARTIAL_FLOATS = (size_t)WG_CHUNKS * PN_H * PN_IN1P;
 
@@ -40,88 +39,6 @@ struct BwdArgs {
 __device__ __forceinline__ void rot3b(const float *M, float x, float y, float z, bool transpose, float &ox, float &oy, float &oz) {
     if (!transpose) { ox = x * M[0] + y * M[3] + z * M[6]; oy = x * M[1] + y * M[4] + z * M[7]; oz = x * M[2] + y * M[5] + z * M[8]; }
     else { ox = x * M[0] + y * M[1] + z * M[2]; oy = x * M[3] + y * M[4] + z * M[5]; oz = x * M[6] + y * M[7] + z * M[8]; }
-}
-
-// ------------------------------------------------------------------------------ colour backward
-constexpr int COLB_LDS_FLOATS = 2 * PN_CTILE * LDC + PN_CTILE * 4;
-
-__global__ __launch_bounds__(256, 2) void k_color_backward(BwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *D1 = smem;                          // [64][LDC]
-    float *D2 = D1 + PN_CTILE * LDC;            // [64][LDC]
-    float *draw = D2 + PN_CTILE * LDC;          // [64][4] d(pre-sigmoid colour)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Ns = a.counters[0] < a.cap_samples ? a.counters[0] : (int)a.cap_samples;
-    const float *P = a.params;
-    const int cc = tid & 127, half = tid >> 7;
-    float gw4[3] = {0.f, 0.f, 0.f}, gb3 = 0.f, gb2 = 0.f, gb1 = 0.f, gb4 = 0.f;
-
-    for (long long tile = blockIdx.x; tile * PN_CTILE < Ns; tile += gridDim.x) {
-        const long long grow0 = tile * PN_CTILE;
-        __syncthreads();
-        if (tid < PN_CTILE) {
-            const long long vs = grow0 + tid;
-            float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-            if (vs < Ns) {
-                const long long si = a.valid_list[vs];
-                const float *o = a.decoded + si * 4, *g = a.grad_decoded + si * 4;
-                // rgb = sigmoid(raw) * 1.002 - 0.001  ->  d raw = d rgb * 1.002 * s (1 - s)
-                const float s0 = (o[1] + 0.001f) / 1.002f, s1 = (o[2] + 0.001f) / 1.002f, s2 = (o[3] + 0.001f) / 1.002f;
-                d0 = g[1] * 1.002f * s0 * (1.f - s0); d1 = g[2] * 1.002f * s1 * (1.f - s1); d2 = g[3] * 1.002f * s2 * (1.f - s2);
-            }
-            draw[tid * 4] = d0; draw[tid * 4 + 1] = d1; draw[tid * 4 + 2] = d2; draw[tid * 4 + 3] = 0.f;
-        }
-        __syncthreads();
-        // d c3 = (d raw @ Wc4) * lrelu'(c3) ; accumulate d Wc4, d bc4
-        {
-            const float w0 = P[PO_WC4 + cc], w1 = P[PO_WC4 + PN_HC + cc], w2 = P[PO_WC4 + 2 * PN_HC + cc];
-            _Pragma("unroll 4") for (int row = half; row < PN_CTILE; row += 2) {
-                const float d0 = draw[row * 4], d1 = draw[row * 4 + 1], d2 = draw[row * 4 + 2];
-                const float c3 = a.sv.c3[(grow0 + row) * PN_HC + cc];
-                const float v = (d0 * w0 + d1 * w1 + d2 * w2) * pn_lrelu_grad(c3);
-                D1[row * LDC + cc] = v;
-                a.sv.dc3[(grow0 + row) * PN_HC + cc] = v;
-                gw4[0] += d0 * c3; gw4[1] += d1 * c3; gw4[2] += d2 * c3;
-                gb3 += v;
-            }
-            if (tid < 3) _Pragma("unroll 4") for (int row = 0; row < PN_CTILE; ++row) gb4 += draw[row * 4 + tid];
-        }
-        __syncthreads();
-        f32x16 acc[2][1];
-        pn_acc_init_bias<2, 1>(acc, nullptr, wave, lane);
-        pn_tile_gemm<2, 1>(D1, LDC, PN_HC / 8, a.packed + PK_DC3 / 4, wave, lane, acc);
-        pn_acc_to_lds<2, 1, false>(acc, D2, LDC, wave, lane);
-        __syncthreads();
-        pn_tile_mask_pass<PN_CTILE, PN_HC>(D2, LDC, a.sv.c2, PN_HC, a.sv.dc2, PN_HC, grow0, tid);
-        __syncthreads();
-        _Pragma("unroll 4") for (int row = half; row < PN_CTILE; row += 2) gb2 += D2[row * LDC + cc];
-        pn_acc_init_bias<2, 1>(acc, nullptr, wave, lane);
-        pn_tile_gemm<2, 1>(D2, LDC, PN_HC / 8, a.packed + PK_DC2 / 4, wave, lane, acc);
-        pn_acc_to_lds<2, 1, false>(acc, D1, LDC, wave, lane);
-        __syncthreads();
-        pn_tile_mask_pass<PN_CTILE, PN_HC>(D1, LDC, a.sv.c1, PN_HC, a.sv.dc1, PN_HC, grow0, tid);
-        __syncthreads();
-        _Pragma("unroll 4") for (int row = half; row < PN_CTILE; row += 2) gb1 += D1[row * LDC + cc];
-        f32x16 acc2[2][2];
-        pn_acc_init_bias<2, 2>(acc2, nullptr, wave, lane);
-        pn_tile_gemm<2, 2>(D1, LDC, PN_HC / 8, a.packed + PK_DC1 / 4, wave, lane, acc2);
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const int col = pn_acc_col<2>(wave, ct, lane);
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg)
-                    a.sv.dfs[(grow0 + pn_acc_row(rt, reg, lane)) * PN_H + col] = acc2[rt][ct][reg];
-            }
-    }
-    atomicAdd(&a.gparams[PO_WC4 + cc], gw4[0]);
-    atomicAdd(&a.gparams[PO_WC4 + PN_HC + cc], gw4[1]);
-    atomicAdd(&a.gparams[PO_WC4 + 2 * PN_HC + cc], gw4[2]);
-    atomicAdd(&a.gparams[PO_BC3 + cc], gb3);
-    atomicAdd(&a.gparams[PO_BC2 + cc], gb2);
-    atomicAdd(&a.gparams[PO_BC1 + cc], gb1);
-    if (tid < 3) atomicAdd(&a.gparams[PO_BC4 + tid], gb4);
 }
 
 // ------------------------------------------------------------------------------ gradient scale
@@ -152,6 +69,182 @@ __device__ __forceinline__ void pn_scale_from_bits(unsigned mb, float &S, float 
     se = se < 2 ? 2 : (se > 252 ? 252 : se);
     S = __uint_as_float((unsigned)se << 23);
     invS = __uint_as_float((unsigned)(254 - se) << 23);
+}
+
+// ------------------------------------------------------------------------------ colour backward
+// 64 valid samples per tile, the forward's organisation: d rgb -> d(pre-sigmoid) -> d c3 on the VALU (3 x 128 weights), then the
+// dgrad chain d c3 x Wc3 -> d c2 x Wc2 -> d c1 x Wc1[:, :256] -> d f as two-plane f16 GEMMs on gradients that carry the call's
+// power-of-two scale S (k_grad_max).  The LeakyReLU masks come from the fp32 post-activations the forward saved; d c1..d c3 leave as
+// fp32 rows (x 1/S) for the fp32 weight-gradient GEMMs of these layers, d f as fp32 rows (x 1/S) for k_agg_backward.
+// LDS: the tile, d raw [64][4], and the workgroup's running sums of d Wc4 [3][128], d bc3, d bc2, d bc1 [128] (LDS float adds:
+// kept in registers they are 45 loop-carried values per thread next to the GEMM's working set)
+constexpr int CB_DRAW = PN_XBYTES, CB_GACC = CB_DRAW + PN_CTILE * 4 * 4, CB_BYTES = CB_GACC + 6 * PN_HC * 4;
+static_assert(2 * CB_BYTES <= 160 * 1024, "two colour workgroups must fit the 160 KB LDS");
+
+__device__ __forceinline__ void cb_acc_zero(f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+// the saved post-activations of the wave's accumulator elements (requested before the barrier that follows the GEMM)
+__device__ __forceinline__ void cb_load_post(const float *__restrict__ post, long long grow0, int wave, int lane, float4 (&pv)[8]) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            pv[rb * 4 + g] = *reinterpret_cast<const float4 *>(post + (grow0 + 32 * rb + (lane & 31)) * PN_HC + pn_d_feat(wave, g, lane));
+}
+// d(pre-activation) = acc * LeakyReLU'(post): fp32 rows x 1/S to dsave, two planes (saturating) into the tile
+__device__ __forceinline__ void cb_epilogue(const f32x16 (&acc)[2][2], const float4 (&pv)[8], char *X, int wave, int lane, float *__restrict__ dsave,
+                                            long long grow0, float invS) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = pn_d_feat(wave, g, lane), row = 32 * rb + (lane & 31);
+            const float4 p = pv[rb * 4 + g];
+            const float v0 = acc[0][rb][4 * g] * pn_lrelu_grad(p.x), v1 = acc[0][rb][4 * g + 1] * pn_lrelu_grad(p.y);
+            const float v2 = acc[0][rb][4 * g + 2] * pn_lrelu_grad(p.z), v3 = acc[0][rb][4 * g + 3] * pn_lrelu_grad(p.w);
+            pn_f4 t = {v0 * invS, v1 * invS, v2 * invS, v3 * invS};
+            PN_REG_STORE(t, reinterpret_cast<pn_f4 *>(dsave + (grow0 + row) * PN_HC + f0));
+            pn_x_store4<true>(X, row, f0, v0, v1, v2, v3);
+        }
+}
+// column sums of the tile's first 128 columns (the bias gradient of the layer whose d(pre-activation) the tile holds): thread ->
+// 8 columns x 4 rows
+__device__ __forceinline__ void cb_bias_sums(const char *X, int tid, float *__restrict__ gsum) {
+    const int c0 = 8 * (tid & 15), r0 = 4 * (tid >> 4);
+    float gb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const uint4 h = *reinterpret_cast<const uint4 *>(X + (r0 + rr) * PN_XRS + c0 * 2);
+        const uint4 m = *reinterpret_cast<const uint4 *>(X + PN_XPLANE + (r0 + rr) * PN_XRS + c0 * 2);
+        gb[0] = pn_fma2_lo(h.x, m.x, 1.f, gb[0]); gb[1] = pn_fma2_hi(h.x, m.x, 1.f, gb[1]);
+        gb[2] = pn_fma2_lo(h.y, m.y, 1.f, gb[2]); gb[3] = pn_fma2_hi(h.y, m.y, 1.f, gb[3]);
+        gb[4] = pn_fma2_lo(h.z, m.z, 1.f, gb[4]); gb[5] = pn_fma2_hi(h.z, m.z, 1.f, gb[5]);
+        gb[6] = pn_fma2_lo(h.w, m.w, 1.f, gb[6]); gb[7] = pn_fma2_hi(h.w, m.w, 1.f, gb[7]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(gsum + c0 + i, gb[i]);
+}
+
+__global__ __launch_bounds__(256, 2) void k_color_backward(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_cb[];
+    char *X = smem_cb;
+    float *draw = reinterpret_cast<float *>(smem_cb + CB_DRAW);          // [64][4] d(pre-sigmoid colour)
+    const int Ns = a.counters[0] < a.cap_samples ? a.counters[0] : (int)a.cap_samples;
+    const float *P = a.params;
+    const char *img = reinterpret_cast<const char *>(a.packed);
+    float S, invS;
+    pn_scale_from_bits(a.sv.gscale[0], S, invS);
+    float *gacc = reinterpret_cast<float *>(smem_cb + CB_GACC);          // [3][128] d Wc4 | d bc3 | d bc2 (x S) | d bc1 (x S)
+    for (int i = threadIdx.x; i < 6 * PN_HC; i += 256) gacc[i] = 0.f;
+    float gb4 = 0.f;
+
+    f32x16 acc[2][2];
+    for (long long tile = blockIdx.x; tile * PN_CTILE < Ns; tile += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const long long grow0 = tile * PN_CTILE;
+        PN_LDS_BARRIER();
+        if (tid < PN_CTILE) {
+            const long long vs = grow0 + tid;
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+            if (vs < Ns) {
+                const long long si = a.valid_list[vs];
+                const float *o = a.decoded + si * 4, *g = a.grad_decoded + si * 4;
+                // rgb = sigmoid(raw) * 1.002 - 0.001  ->  d raw = d rgb * 1.002 * s (1 - s)
+                const float s0 = (o[1] + 0.001f) / 1.002f, s1 = (o[2] + 0.001f) / 1.002f, s2 = (o[3] + 0.001f) / 1.002f;
+                d0 = g[1] * 1.002f * s0 * (1.f - s0); d1 = g[2] * 1.002f * s1 * (1.f - s1); d2 = g[3] * 1.002f * s2 * (1.f - s2);
+            }
+            *reinterpret_cast<float4 *>(draw + tid * 4) = make_float4(d0, d1, d2, 0.f);
+        }
+        PN_LDS_BARRIER();
+        // ---- d c3 = (d raw @ Wc4) * lrelu'(c3); d Wc4, d bc4, d bc3 accumulate in registers
+        {
+            const int c4 = tid & 31, rg = tid >> 5;
+            float4 c3v[8];
+            float w4[3][4], gw4[3][4], gb3[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { w4[k][i] = P[PO_WC4 + k * PN_HC + 4 * c4 + i]; gw4[k][i] = 0.f; }      // (the colour tensors sit at odd float offsets)
+            }
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) c3v[rr] = *reinterpret_cast<const float4 *>(a.sv.c3 + (grow0 + 8 * rg + rr) * PN_HC + 4 * c4);
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int row = 8 * rg + rr;
+                const float4 d = *reinterpret_cast<const float4 *>(draw + row * 4);
+                const float c[4] = {c3v[rr].x, c3v[rr].y, c3v[rr].z, c3v[rr].w};
+                float u[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    u[i] = (d.x * w4[0][i] + d.y * w4[1][i] + d.z * w4[2][i]) * pn_lrelu_grad(c[i]);
+                    gw4[0][i] += d.x * c[i]; gw4[1][i] += d.y * c[i]; gw4[2][i] += d.z * c[i];
+                    gb3[i] += u[i];
+                }
+                pn_f4 t = {u[0], u[1], u[2], u[3]};
+                PN_STREAM_STORE(t, reinterpret_cast<pn_f4 *>(a.sv.dc3 + (grow0 + row) * PN_HC + 4 * c4));
+                pn_x_store4<true>(X, row, 4 * c4, u[0] * S, u[1] * S, u[2] * S, u[3] * S);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) atomicAdd(gacc + k * PN_HC + 4 * c4 + i, gw4[k][i]);
+                atomicAdd(gacc + 3 * PN_HC + 4 * c4 + i, gb3[i]);
+            }
+            if (tid < 3) {
+#pragma unroll 4
+                for (int row = 0; row < PN_CTILE; ++row) gb4 += draw[row * 4 + tid];
+            }
+        }
+        PN_LDS_BARRIER();
+        float4 pv[8];
+        // ---- d c2 = (d c3 @ Wc3) * lrelu'(c2)
+        cb_acc_zero(acc);
+        pn_gemm_f16x3<8, 4, 1, 7>(X, reinterpret_cast<const uint4 *>(img + PKH_DC3), wave, lane, acc);
+        cb_load_post(a.sv.c2, grow0, wave, lane, pv);
+        PN_LDS_BARRIER();
+        cb_epilogue(acc, pv, X, wave, lane, a.sv.dc2, grow0, invS);
+        PN_LDS_BARRIER();
+        cb_bias_sums(X, tid, gacc + 4 * PN_HC);
+        // ---- d c1 = (d c2 @ Wc2) * lrelu'(c1)
+        cb_acc_zero(acc);
+        pn_gemm_f16x3<8, 4, 1, 7>(X, reinterpret_cast<const uint4 *>(img + PKH_DC2), wave, lane, acc);
+        cb_load_post(a.sv.c1, grow0, wave, lane, pv);
+        PN_LDS_BARRIER();
+        cb_epilogue(acc, pv, X, wave, lane, a.sv.dc1, grow0, invS);
+        PN_LDS_BARRIER();
+        cb_bias_sums(X, tid, gacc + 5 * PN_HC);
+        // ---- d f = d c1 @ Wc1[:, :256]
+        cb_acc_zero(acc);
+        pn_gemm_f16x3<8, 8, 2, 4>(X, reinterpret_cast<const uint4 *>(img + PKH_DC1), 2 * wave, lane, acc);
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    pn_f4 t = {acc[fb][rb][4 * g] * invS, acc[fb][rb][4 * g + 1] * invS, acc[fb][rb][4 * g + 2] * invS, acc[fb][rb][4 * g + 3] * invS};
+                    PN_REG_STORE(t, reinterpret_cast<pn_f4 *>(a.sv.dfs + (grow0 + 32 * rb + (lane & 31)) * PN_H + pn_d_feat(2 * wave + fb, g, lane)));
+                }
+    }
+    PN_LDS_BARRIER();
+    {
+        const int tid = threadIdx.x;
+        for (int i = tid; i < 3 * PN_HC; i += 256) atomicAdd(&a.gparams[PO_WC4 + i], gacc[i]);
+        if (tid < PN_HC) {
+            atomicAdd(&a.gparams[PO_BC3 + tid], gacc[3 * PN_HC + tid]);
+            atomicAdd(&a.gparams[PO_BC2 + tid], gacc[4 * PN_HC + tid] * invS);
+            atomicAdd(&a.gparams[PO_BC1 + tid], gacc[5 * PN_HC + tid] * invS);
+        }
+        if (tid < 3) atomicAdd(&a.gparams[PO_BC4 + tid], gb4);
+    }
 }
 
 // ------------------------------------------------------------------------------ aggregator backward
@@ -782,7 +875,7 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
     const long long ctiles = (n_valid + PN_CTILE - 1) / PN_CTILE;
     const int grid_c = (int)(ctiles < 2 * ncu ? (ctiles > 0 ? ctiles : 1) : 2 * ncu);       // 69 KB of LDS: two workgroups per CU
-    const size_t lds_c = COLB_LDS_FLOATS * sizeof(float), lds_a = BL_BYTES;
+    const size_t lds_c = CB_BYTES, lds_a = BL_BYTES;
     if (hipFuncSetAttribute((const void *)k_color_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipFuncSetAttribute((const void *)k_agg_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
     // the forward left the class partition of the valid samples in the saved area (aggregate.hip: pn_classify)

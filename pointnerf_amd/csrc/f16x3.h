@@ -47,7 +47,10 @@ enum : int {
     PKH_BASE = PK_TOTAL * 4,
     PKH_F1 = PKH_BASE, PKH_F2 = PKH_F1 + PN_IMG(18, 8), PKH_F3 = PKH_F2 + PN_IMG(16, 8), PKH_F4 = PKH_F3 + PN_IMG(17, 8),
     PKH_D4 = PKH_F4 + PN_IMG(16, 8), PKH_D3 = PKH_D4 + PN_IMG(16, 8), PKH_D2 = PKH_D3 + PN_IMG(16, 9), PKH_D1 = PKH_D2 + PN_IMG(16, 8),
-    PKH_END = PKH_D1 + PN_IMG(16, PN_MB_D1)
+    // colour MLP: forward 128 x (288 | 128 | 128), dgrad (128 x 128) x 2 and 256 x 128
+    PKH_FC1 = PKH_D1 + PN_IMG(16, PN_MB_D1), PKH_FC2 = PKH_FC1 + PN_IMG(18, 4), PKH_FC3 = PKH_FC2 + PN_IMG(8, 4),
+    PKH_DC3 = PKH_FC3 + PN_IMG(8, 4), PKH_DC2 = PKH_DC3 + PN_IMG(8, 4), PKH_DC1 = PKH_DC2 + PN_IMG(8, 4),
+    PKH_END = PKH_DC1 + PN_IMG(8, 8)
 };
 
 // streaming stores of the saved planes (dev A/B of the store policy: -DPN_PLAIN_STREAM_STORES, tools/_build only)
@@ -55,6 +58,14 @@ enum : int {
 #define PN_STREAM_STORE(val, ptr) (*(ptr) = (val))
 #else
 #define PN_STREAM_STORE(val, ptr) __builtin_nontemporal_store((val), (ptr))
+#endif
+
+// stores of fp32 rows straight from the accumulator layout (a lane pair writes 32 bytes, the wave's four stores of a row fill one
+// 128-byte line): plain stores, so that L2 merges them into whole lines (dev A/B: -DPN_REG_STORE_NT)
+#ifdef PN_REG_STORE_NT
+#define PN_REG_STORE(val, ptr) __builtin_nontemporal_store((val), (ptr))
+#else
+#define PN_REG_STORE(val, ptr) (*(ptr) = (val))
 #endif
 
 // Workgroup barrier for LDS hazards only.  __syncthreads() carries a full fence: hipcc emits s_waitcnt vmcnt(0) in front of the
@@ -177,9 +188,11 @@ __device__ __forceinline__ void pn_x_axpy4(const char *X, int row, int col, floa
 #endif
 // (Measured and rejected: running the tile's transposing copy-out as a side job between the chunks' MFMA groups -- its stores share the
 //  in-order vmcnt queue with the weight fragments, every chunk then waits for HBM writes: +3 us per GEMM against 2.4 us saved.)
-template <int NC, int MB, int NFB>
+// WPF = chunks of weight fragments requested ahead: 2 covers an L2 round trip when a chunk is 24 MFMAs (two feature blocks); the
+// colour MLP's waves own ONE feature block (6 MFMAs = 0.1 us per chunk) and ask for 7.
+template <int NC, int MB, int NFB, int WPF = PN_WPF>
 __device__ __forceinline__ void pn_gemm_f16x3(const char *X, const uint4 *__restrict__ img, int fb0, int lane, f32x16 (&acc)[2][2], int c0 = 0) {
-    constexpr int PF = PN_WPF < NC ? PN_WPF : NC - 1, NS = PF + 1;
+    constexpr int PF = WPF < NC ? WPF : NC - 1, NS = PF + 1;
     const char *xb = X + (lane & 31) * PN_XRS + (lane >> 5) * 16 + c0 * 32;
     const uint4 *wp = img + ((size_t)c0 * MB + fb0) * 128 + lane;
     uint4 wh[NS][2], wm[NS][2], xh[2][2], xm[2][2];

@@ -3,6 +3,10 @@
 // fibers round-robin, a fiber gives the CPU back only inside a rendezvous (workgroup barrier, wave exchange) or when it
 // ends.  A full pass over the fibers without any progress is a deadlock (divergent barrier / shuffle) and aborts.
 #include <ucontext.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+#include <cstdlib>
 #include <vector>
 #include "hip/hip_runtime.h"
 
@@ -110,3 +114,22 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
     g_body = nullptr; g_cur = nullptr;
 }
 }  // namespace emu
+
+// PN_EMU_BACKTRACE=1: print the native frames of a crash inside an emulated kernel (fibers hide them from Python's faulthandler)
+static void pn_emu_segv(int sig) {
+    void *frames[48];
+    const int n = backtrace(frames, 48);
+    backtrace_symbols_fd(frames, n, 2);
+    _exit(128 + sig);
+}
+__attribute__((constructor)) static void pn_emu_install_segv() {
+    if (getenv("PN_EMU_BACKTRACE")) {
+        static char alt[1 << 16];
+        stack_t ss; ss.ss_sp = alt; ss.ss_size = sizeof(alt); ss.ss_flags = 0;
+        sigaltstack(&ss, nullptr);
+        struct sigaction sa = {};
+        sa.sa_handler = pn_emu_segv; sa.sa_flags = SA_ONSTACK;
+        sigaction(SIGSEGV, &sa, nullptr);
+        sigaction(SIGBUS, &sa, nullptr);
+    }
+}
