@@ -26,27 +26,7 @@ extern "C" int pnerf_mlp_layout(int feat_dim, int64_t *offsets) {
 extern "C" size_t pnerf_mlp_packed_bytes(void) { return (size_t)PKH_END; }
 
 namespace {
-struct PackDesc { int src, ld, trans, Kreal, Nreal, Kpad, N, NT, dst; };
-struct PackTable { PackDesc d[7]; };
-
-// fp32 images of the colour MLP (mlp_common.h)
-__global__ __launch_bounds__(256) void k_pack(PackTable t, const float *__restrict__ params, float *__restrict__ packed) {
-    const PackDesc d = t.d[blockIdx.y];
-    const int total = d.Kpad * d.N;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        const int i = e & 3, lane = (e >> 2) & 63;
-        int rest = e >> 8;                       // (c*4 + w)*NT + ct
-        const int ct = rest % d.NT; rest /= d.NT;
-        const int w = rest & 3, c = rest >> 2;
-        const int k = 8 * c + 4 * (lane >> 5) + i;
-        const int n = w * d.NT * 32 + ct * 32 + (lane & 31);
-        float v = 0.f;
-        if (k < d.Kreal && n < d.Nreal) v = d.trans ? params[d.src + n * d.ld + k] : params[d.src + k * d.ld + n];
-        packed[d.dst + e] = v;
-    }
-}
-
-// two-plane f16 images of the four aggregator layers (f16x3.h): forward W[m][k] (trans = 0: m = output unit, k = input column)
+// two-plane f16 images of the aggregator and colour layers (f16x3.h): forward W[m][k] (trans = 0: m = output unit, k = input column)
 // and dgrad W^T[m][k] (trans = 1: m = input column, k = output unit)
 struct PackHDesc { int src, ld, trans, Mreal, Kreal, NCH, MB, dst; };
 struct PackHTable { PackHDesc d[14]; };
@@ -77,17 +57,6 @@ __global__ __launch_bounds__(256) void k_pack_h(PackHTable t, const float *__res
 
 extern "C" int pnerf_mlp_pack(const float *d_params, void *d_packed, void *stream) {
     if (!d_params || !d_packed) return PNERF_E_INVAL;
-    PackTable t = {{
-        // forward images: B[k][n] = W[n][k]
-        {PO_WC1, PN_INC, 1, PN_INC, PN_HC, PN_INC, PN_HC, 1, PK_C1},
-        {PO_WC2, PN_HC, 1, PN_HC, PN_HC, PN_HC, PN_HC, 1, PK_C2},
-        {PO_WC3, PN_HC, 1, PN_HC, PN_HC, PN_HC, PN_HC, 1, PK_C3},
-        // dgrad images: B[k][n] = W[k][n] (k = output unit, n = input unit, first N inputs only)
-        {PO_WC3, PN_HC, 0, PN_HC, PN_HC, PN_HC, PN_HC, 1, PK_DC3},
-        {PO_WC2, PN_HC, 0, PN_HC, PN_HC, PN_HC, PN_HC, 1, PK_DC2},
-        {PO_WC1, PN_INC, 0, PN_HC, PN_H, PN_HC, PN_H, 2, PK_DC1},
-        {0, 0, 0, 0, 0, 0, 0, 1, 0},
-    }};
     PackHTable th = {{
         {PO_W1, PN_IN1, 0, PN_H, PN_IN1, 18, 8, PKH_F1},
         {PO_W2, PN_H, 0, PN_H, PN_H, 16, 8, PKH_F2},
@@ -106,7 +75,6 @@ extern "C" int pnerf_mlp_pack(const float *d_params, void *d_packed, void *strea
         {PO_WC1, PN_INC, 1, PN_H, PN_HC, 8, 8, PKH_DC1},
     }};
     PnProfScope prof(PNK_PACK, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_pack, dim3(64, 6), dim3(256), 0, (hipStream_t)stream, t, d_params, (float *)d_packed);
     hipLaunchKernelGGL(k_pack_h, dim3(40, 14), dim3(256), 0, (hipStream_t)stream, th, d_params, (char *)d_packed);
     PN_CHECK_LAUNCH();
     return 0;

@@ -41,10 +41,10 @@ typedef _Float16 pn_h8 __attribute__((ext_vector_type(8)));
 #define PN_NF1    288                      // features of the saved k-major X0 and [h2 | extras] planes
 #define PN_MB_D1  7                        // feature blocks of d X0 that are needed (embedding + its encoding: 224 columns)
 
-// ---- images (byte offsets inside the packed buffer, after the fp32 images of the colour MLP)
+// ---- images (byte offsets inside the packed buffer)
 #define PN_IMG(nch, mb) ((nch) * (mb) * 2048)
 enum : int {
-    PKH_BASE = PK_TOTAL * 4,
+    PKH_BASE = 0,
     PKH_F1 = PKH_BASE, PKH_F2 = PKH_F1 + PN_IMG(18, 8), PKH_F3 = PKH_F2 + PN_IMG(16, 8), PKH_F4 = PKH_F3 + PN_IMG(17, 8),
     PKH_D4 = PKH_F4 + PN_IMG(16, 8), PKH_D3 = PKH_D4 + PN_IMG(16, 8), PKH_D2 = PKH_D3 + PN_IMG(16, 9), PKH_D1 = PKH_D2 + PN_IMG(16, 8),
     // colour MLP: forward 128 x (288 | 128 | 128), dgrad (128 x 128) x 2 and 256 x 128

@@ -1,6 +1,5 @@
-// mlp_common.h -- layout of the aggregator MLP, the fp32 MFMA-fragment weight images and the 64-row fp32 tile GEMM
-// (v_mfma_f32_32x32x2_f32) of the COLOUR MLP, and the saved-activation area.  The four 256-wide aggregator layers run on
-// the f16 matrix pipe with two-plane operands: f16x3.h.
+// mlp_common.h -- layout of the aggregator / colour MLP parameters and the saved-activation area.  Every GEMM of the forward and
+// of the dgrad chain runs on the f16 matrix pipe with two-plane operands: f16x3.h.
 #pragma once
 #include "pn_common.h"
 #include <type_traits>
@@ -32,152 +31,11 @@ enum : int {
 };
 static_assert(PO_TOTAL == 341764, "parameter count of the lego-script aggregator");
 
-// packed images (float offsets).  An image of a B operand [Kpad x N] is stored as
-//   float4 img[c][w][ct][lane] ,  element i = B[8c + 4*(lane>>5) + i][w*NT*32 + ct*32 + (lane&31)]
-// (the same bytes serve 4 waves x NT=2 and 8 waves x NT=1: fragment index = column / 32)
-// i.e. exactly what lane `lane` of wave `w` feeds to 4 consecutive 32x32x2 MFMAs of column tile ct.
-enum : int {
-    PK_F1 = 0, PK_F2 = PK_F1 + PN_IN1P * PN_H, PK_F3 = PK_F2 + PN_H * PN_H, PK_F4 = PK_F3 + (PN_H + 8) * PN_H,
-    PK_C1 = PK_F4 + PN_H * PN_H, PK_C2 = PK_C1 + PN_INC * PN_HC, PK_C3 = PK_C2 + PN_HC * PN_HC,
-    PK_D4 = PK_C3 + PN_HC * PN_HC, PK_D3 = PK_D4 + PN_H * PN_H, PK_D2 = PK_D3 + PN_H * PN_H, PK_D1 = PK_D2 + PN_H * PN_H,
-    PK_DC3 = PK_D1 + PN_H * PN_H, PK_DC2 = PK_DC3 + PN_HC * PN_HC, PK_DC1 = PK_DC2 + PN_HC * PN_HC,
-    PK_TOTAL = PK_DC1 + PN_HC * PN_H
-};
-
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// streaming store of saved activations: ~70 GB per step pass through the L2 that also holds the 2.7 MB of packed weights every
-// wave re-reads continuously; non-temporal keeps them from displacing the weights
 typedef float pn_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void pn_store_stream(float *p, const float4 &v) {
-#ifdef PN_PLAIN_STREAM_STORES       // dev: A/B of the store policy (tools/_build only)
-    *reinterpret_cast<float4 *>(p) = v;
-#else
-    pn_f4 t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<pn_f4 *>(p));
-#endif
-}
 
-__device__ __forceinline__ float pn_lrelu(float v) { return v > 0.f ? v : 0.01f * v; }
 __device__ __forceinline__ float pn_lrelu_grad(float post) { return post > 0.f ? 1.f : 0.01f; }
-
-// C[(MT*32) x (4 waves * NT * 32)] += A[(MT*32) x 8*nchunks] * B   (A in LDS, row stride lda floats, lda % 4 == 0;
-// B = packed image).  Each wave owns NT column tiles x all MT row tiles.  K order inside a chunk is
-// {0,4},{1,5},{2,6},{3,7} (lanes 0-31 / 32-63), identical for A and B, so the sum is a permutation of the
-// textbook order.  One chunk is prefetched ahead.
-template <int MT, int NT>
-__device__ __forceinline__ void pn_mfma_chunk(const float4 (&a)[MT], const float4 (&b)[NT], f32x16 (&acc)[MT][NT]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
-            const float bv = i == 0 ? b[ct].x : (i == 1 ? b[ct].y : (i == 2 ? b[ct].z : b[ct].w));
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const float av = i == 0 ? a[mt].x : (i == 1 ? a[mt].y : (i == 2 ? a[mt].z : a[mt].w));
-                acc[mt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt][ct], 0, 0, 0);
-            }
-        }
-    }
-}
-
-// Two explicit register sets, the loop unrolled by two: chunk c+1's operands are requested before chunk c's 16 MFMAs
-// and first used after them, with no register copies in between.  (A single-set "next = load; ...; cur = next" form made
-// hipcc sink the copies into the middle of the MFMA block behind s_waitcnt vmcnt(0): every chunk then waited for an L2
-// round trip after ~6 MFMAs, and a workgroup running alone reached only ~80 % of the MFMA rate.)
-template <int MT, int NT, int NW = 4>
-__device__ __forceinline__ void pn_tile_gemm(const float *__restrict__ A, int lda, int nchunks,
-                                             const float4 *__restrict__ Wp, int wave, int lane, f32x16 (&acc)[MT][NT]) {
-    const float *ap = A + (lane & 31) * lda + 4 * (lane >> 5);
-    const float4 *wp = Wp + (wave * NT) * 64 + lane;
-    float4 a0[MT], b0[NT], a1[MT], b1[NT];
-    auto load = [&](int c, float4 (&a)[MT], float4 (&b)[NT]) {
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) b[ct] = wp[(c * NW * NT + ct) * 64];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4 *>(ap + mt * 32 * lda + 8 * c);
-    };
-    load(0, a0, b0);
-#pragma unroll 1
-    for (int c = 0; c < nchunks; c += 2) {
-        if (c + 1 < nchunks) load(c + 1, a1, b1);
-        pn_mfma_chunk<MT, NT>(a0, b0, acc);
-        if (c + 2 < nchunks) load(c + 2, a0, b0);
-        if (c + 1 < nchunks) pn_mfma_chunk<MT, NT>(a1, b1, acc);
-    }
-}
-
-// accumulator element (rt, ct, reg) of wave `wave` sits at row / col:
-__device__ __forceinline__ int pn_acc_row(int rt, int reg, int lane) { return rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
-template <int NT> __device__ __forceinline__ int pn_acc_col(int wave, int ct, int lane) { return wave * NT * 32 + ct * 32 + (lane & 31); }
-
-template <int MT, int NT>
-__device__ __forceinline__ void pn_acc_init_bias(f32x16 (&acc)[MT][NT], const float *__restrict__ bias, int wave, int lane) {
-#pragma unroll
-    for (int ct = 0; ct < NT; ++ct) {
-        const float bv = bias ? bias[pn_acc_col<NT>(wave, ct, lane)] : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) acc[mt][ct][reg] = bv;
-    }
-}
-
-// ---- wide epilogues: accumulators -> LDS (dword, conflict-free), then whole-row float4 traffic LDS <-> HBM.
-// A C-fragment lane owns 16*MT*NT scattered dwords; storing them straight to HBM costs that many dword stores per lane
-// per layer (store-issue bound).  Going through the LDS tile that the next layer needs anyway turns that into
-// dwordx4 traffic.
-template <int MT, int NT, bool LRELU>
-__device__ __forceinline__ void pn_acc_to_lds(f32x16 (&acc)[MT][NT], float *__restrict__ H, int ldh, int wave, int lane) {
-#pragma unroll
-    for (int rt = 0; rt < MT; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
-            const int col = pn_acc_col<NT>(wave, ct, lane);
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float v = acc[rt][ct][reg];
-                H[pn_acc_row(rt, reg, lane) * ldh + col] = LRELU ? pn_lrelu(v) : v;
-            }
-        }
-}
-
-// G[grow0 + row][0..W) = H[row][0..W) for the ROWS rows of the tile (W = 256 or 128), float4 per lane
-template <int ROWS, int W, int NTHR = 256>
-__device__ __forceinline__ void pn_tile_copy_out(const float *__restrict__ H, int ldh, float *__restrict__ G, int ldg, long long grow0, int tid) {
-    constexpr int PER = ROWS * W / 4 / NTHR;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int e = tid + i * NTHR, row = e / (W / 4), c4 = e - row * (W / 4);
-        *reinterpret_cast<float4 *>(G + (grow0 + row) * ldg + c4 * 4) = *reinterpret_cast<const float4 *>(H + row * ldh + c4 * 4);
-    }
-}
-
-// in place: H = H * LeakyReLU'(S) with S the saved post-activation in HBM; the result also goes to D (HBM)
-template <int ROWS, int W, int NTHR = 256>
-__device__ __forceinline__ void pn_tile_mask_pass(float *__restrict__ H, int ldh, const float *__restrict__ S, int lds_, float *__restrict__ D,
-                                                  int ldd, long long grow0, int tid) {
-    constexpr int PER = ROWS * W / 4 / NTHR;
-    float4 sv[PER];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int e = tid + i * NTHR, row = e / (W / 4), c4 = e - row * (W / 4);
-        sv[i] = *reinterpret_cast<const float4 *>(S + (grow0 + row) * lds_ + c4 * 4);
-    }
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int e = tid + i * NTHR, row = e / (W / 4), c4 = e - row * (W / 4);
-        float4 v = *reinterpret_cast<const float4 *>(H + row * ldh + c4 * 4);
-        v.x *= pn_lrelu_grad(sv[i].x); v.y *= pn_lrelu_grad(sv[i].y); v.z *= pn_lrelu_grad(sv[i].z); v.w *= pn_lrelu_grad(sv[i].w);
-        *reinterpret_cast<float4 *>(H + row * ldh + c4 * 4) = v;
-        *reinterpret_cast<float4 *>(D + (grow0 + row) * ldd + c4 * 4) = v;
-    }
-}
-
-// ---- 1-bit LeakyReLU masks, in the accumulator layout.  A lane owns the same 64 (row, feature) elements of a layer's output in
-// the forward (where it applies bias + LeakyReLU to its accumulators) and in the backward (where it multiplies its dgrad
-// accumulators by LeakyReLU'), so the sign bits travel as ONE 8-byte word per thread per layer.
-// Written and read fully coalesced ([tile][layer][thread]).
 
 template <int... I, class F> __device__ __forceinline__ void pn_static_for_impl(std::integer_sequence<int, I...>, F &&f) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void pn_static_for(F &&f) { pn_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
