@@ -462,6 +462,8 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         PN_TR(pn_trace_bwd, 9);
         // ---- layer 2: dY2 -> d h1
         pn_copy_out_kmajor<PN_H>(X, a.sv.dy2k, rg_total, gtile * 8, tid);
+        // (Measured and rejected: pulling the next tile's h4 planes / d f rows / sign words into L2 from here with 4-byte LDS-DMA
+        //  reads, one per 128-byte line: 16.65 ms against 16.19 ms -- the load phase is not waiting for HBM.)
         b_acc_zero(acc);
         PN_TR(pn_trace_bwd, 10);
         pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D2), 2 * wave, lane, acc);
