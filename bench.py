@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--render-only", action="store_true", help="supplementary: inference (render, no backward) rays/s")
     ap.add_argument("--no-overlap-comm", action="store_true", help="N > 1: all-reduce the point gradients after the whole backward instead of behind the weight-gradient GEMMs")
+    ap.add_argument("--point-grads", default="auto", choices=("auto", "dense", "sparse"),
+                    help="N > 1: exchange of the per-point gradients: dense all-reduce (one bucket, overlapped), sparse touched-row exchange, auto = sparse from 6 M points")
     ap.add_argument("--zero1", action="store_true", help="N > 1: shard the point-parameter Adam (reduce-scatter + all-gather) instead of all-reducing the gradients")
     return ap.parse_args()
 
@@ -164,6 +166,7 @@ def main():
     # update and its state over the ranks (reduce-scatter / all-gather instead of all-reduce)
     from pointnerf_amd.optim import FusedAdam, ShardedAdam
     zero1 = args.zero1 and world > 1
+    sparse = world > 1 and not zero1 and (args.point_grads == "sparse" or (args.point_grads == "auto" and n_points >= 6_000_000))
     opt_mlp = FusedAdam(mlp_params, lr=opt.lr, betas=(0.9, 0.999))
     opt_pts = ShardedAdam(pt_params, lr=opt.plr, betas=(0.9, 0.999)) if zero1 else FusedAdam(pt_params, lr=opt.plr, betas=(0.9, 0.999))
 
@@ -181,8 +184,14 @@ def main():
         loss.backward()
         # no-op at N=1; RCCL over xGMI otherwise.  The three point tensors only the renderer writes (88 % of the bytes) start
         # their all-reduce as soon as the input-gradient kernels are done, under the weight-gradient GEMMs
-        early = [] if (zero1 or args.no_overlap_comm) else [npnt.points_embeding, npnt.points_dir, npnt.points_color]
-        pdist.allreduce_grads(mlp_params, [] if zero1 else pt_params, ready_event=FusedRender.point_grads_ready if early else None, early_params=early)
+        if sparse:
+            # large clouds: a rank's rays touch a few percent of the points -- exchange the touched rows only (dist.sparse_allreduce_rows)
+            touched = pdist.touched_rows(npnt.querier.last_dense["sample_pidx"], n_points)
+            pdist.sparse_allreduce_rows([p.grad for p in pt_params], touched)
+            pdist.allreduce_grads(mlp_params, [])
+        else:
+            early = [] if (zero1 or args.no_overlap_comm) else [npnt.points_embeding, npnt.points_dir, npnt.points_color]
+            pdist.allreduce_grads(mlp_params, [] if zero1 else pt_params, ready_event=FusedRender.point_grads_ready if early else None, early_params=early)
         opt_mlp.step(); opt_pts.step()
         return loss, model.last_stats
 
@@ -261,7 +270,7 @@ def main():
                "neighbor_rows_per_s": rows * world * args.steps / dt, "valid_samples_per_s": smp * world * args.steps / dt,
                "config": {"workload": "BASELINE.json %s, %d neural points, K=%d, SR=%d, D=%d, %d rays/GPU/step, fwd+loss+bwd+Adam, grid cached"
                                       % (cfg_name, n_points, opt.K, opt.SR, opt.z_depth_dim, args.rays),
-                          "parallelism": "ray-shard dp%d, point cloud + MLP replicated" % world, "world_size": world, "ms_per_step_by_rank": per_rank_ms,
+                          "parallelism": "ray-shard dp%d, point cloud + MLP replicated" % world, "point_grad_exchange": ("none" if world == 1 else ("zero1 reduce-scatter" if zero1 else ("sparse touched rows" if sparse else "dense all-reduce, one bucket, overlapped"))), "world_size": world, "ms_per_step_by_rank": per_rank_ms,
                           "valid_samples_per_step": smp, "neighbor_rows_per_step": rows,
                           "rays_hit_per_step": float(np.mean([s["rays_hit"] for s in stats])), "final_loss": float(loss.item()),
                           "device_allocs_in_timed_region": int(extra_allocs), "setup_steps": 2,

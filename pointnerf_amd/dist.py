@@ -9,9 +9,13 @@ Collectives per step:
   * 2 floats  -- global element counts that normalise the two loss means (so that the SUM of per-rank gradients is
                  exactly the gradient of the single-process loss over the whole batch);
   * 1.37 MB   -- MLP gradients, flattened into one buffer (latency-bound, one all-reduce);
-  * N x 39 f32 -- dense per-point gradients (312 MB at N = 2M), one all-reduce per tensor, in place.
+  * N x 39 f32 -- dense per-point gradients (312 MB at N = 2M): embedding + dir + colour (38 N) as ONE in-place all-reduce of
+                 the renderer's gradient bucket, issued on a side stream behind the library's "point gradients final" event so
+                 that it overlaps the weight-gradient GEMMs; the confidences (N, they also receive the zero-one loss) afterwards.
 xGMI is point-to-point (7 links per GPU): a ring all-reduce of S bytes moves 2(n-1)/n S over one link per GPU, so the
-point-gradient payload is the scaling limiter; a touched-rows (sparse) exchange is the "next" step.
+point-gradient payload is the scaling limiter.  For large clouds (a rank's rays touch a few percent of 6-20 M points) the
+dense exchange is replaced by ``sparse_allreduce_rows``: all-gather of (row id, row) of the touched rows only, added in rank
+order on every rank (bitwise identical replicas, same sum as the dense all-reduce up to fp32 association).
 """
 import torch
 import torch.distributed as dist
@@ -81,11 +85,19 @@ def allreduce_grads(mlp_params, point_params, ready_event=None, early_params=())
     if early:
         dev = early[0].grad.device
         comm = _COMM_STREAMS.setdefault(dev, torch.cuda.Stream(device=dev))
+        # embedding, dir and colour gradients are the head of one bucket (fused.FusedRender.backward): ONE collective when all three
+        # are reduced early, else one per tensor
+        bk = FusedRender.point_grad_bucket
+        whole = bk is not None and sorted(p.grad.data_ptr() for p in early) == sorted(bk[2])
         with torch.cuda.stream(comm):
             comm.wait_event(ready_event)
-            for p in early:
-                p.grad.record_stream(comm)
-                dist.all_reduce(p.grad)
+            if whole:
+                bk[0].record_stream(comm)
+                dist.all_reduce(bk[0][:bk[1]])
+            else:
+                for p in early:
+                    p.grad.record_stream(comm)
+                    dist.all_reduce(p.grad)
         point_params = [p for p in point_params if all(p is not q for q in early)]
     gs = [p.grad for p in mlp_params if p.grad is not None]
     if gs:
@@ -99,3 +111,55 @@ def allreduce_grads(mlp_params, point_params, ready_event=None, early_params=())
             dist.all_reduce(p.grad)
     if comm is not None:
         torch.cuda.current_stream(comm.device).wait_stream(comm)
+
+
+def touched_rows(pidx, n_points):
+    """Sorted ids of the points a rank's neighbor table references (``pidx`` int tensor, -1 = empty slot)."""
+    flag = torch.zeros(n_points + 1, dtype=torch.bool, device=pidx.device)
+    flag[pidx.reshape(-1).long() + 1] = True          # slot 0 collects the -1 entries
+    return torch.nonzero(flag[1:]).reshape(-1)
+
+
+def sparse_allreduce_rows(grads, touched, group=None):
+    """Sum over ranks of dense per-point gradients ``grads`` (list of [N, c_i] tensors, each rank's contribution zero outside its own
+    ``touched`` rows) by exchanging only touched rows: all-gather (ids padded with -1 to the largest count, rows [cap, sum c_i]),
+    then every rank zeroes its touched rows and adds the blocks of ALL ranks in rank order -- the same additions in the same order
+    everywhere, so the replicas stay bitwise identical (a dense ring all-reduce has that property by construction).
+    Bytes received per rank: W * cap * (4 + 4 sum c_i), against 2 (W - 1) / W * 4 N sum c_i for the dense ring."""
+    W = dist.get_world_size(group)
+    if W == 1:
+        return
+    dev = grads[0].device
+    assert all(g.is_contiguous() and g.dim() >= 2 for g in grads)
+    flat = [g.view(-1, g.shape[-1]) for g in grads]         # views: the additions below land in the callers' tensors
+    cols = [g.shape[1] for g in flat]
+    cap = torch.tensor([touched.numel()], dtype=torch.int64, device=dev)
+    dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=group)
+    cap = max(int(cap.item()), 1)
+    ids = torch.full((cap,), -1, dtype=torch.int64, device=dev)
+    ids[:touched.numel()] = touched
+    rows = torch.zeros(cap, sum(cols), dtype=torch.float32, device=dev)
+    if touched.numel():
+        rows[:touched.numel()] = torch.cat([g.index_select(0, touched) for g in flat], dim=1)
+    all_ids = torch.empty(W * cap, dtype=torch.int64, device=dev)
+    all_rows = torch.empty(W * cap, sum(cols), dtype=torch.float32, device=dev)
+    if dist.get_backend(group) == "gloo":                  # (CPU tests)
+        dist.all_gather(list(all_ids.view(W, cap).unbind(0)), ids, group=group)
+        dist.all_gather(list(all_rows.view(W, cap, -1).unbind(0)), rows, group=group)
+    else:
+        dist.all_gather_into_tensor(all_ids, ids, group=group)
+        dist.all_gather_into_tensor(all_rows, rows, group=group)
+    if touched.numel():
+        for g in flat:
+            g.index_fill_(0, touched, 0.0)
+    for r in range(W):
+        i = all_ids[r * cap:(r + 1) * cap]
+        keep = i >= 0
+        i = i[keep]
+        if i.numel() == 0:
+            continue
+        blk = all_rows[r * cap:(r + 1) * cap][keep]
+        o = 0
+        for g, c in zip(flat, cols):
+            g.index_add_(0, i, blk[:, o:o + c])
+            o += c

@@ -37,6 +37,7 @@ class FusedRender(torch.autograd.Function):
 
     point_grads_ready = None          # torch.cuda.Event of the latest backward (only when env["want_grad_event"])
     point_grad_ptrs = frozenset()     # data pointers of the point-gradient tensors the latest backward wrote
+    point_grad_bucket = None          # (flat bucket, floats of its head [embedding | dir | colour], their data pointers)
 
     @staticmethod
     def forward(ctx, env, emb, conf, pdir, color, *mlp_params):
@@ -65,7 +66,17 @@ class FusedRender(torch.autograd.Function):
         dev = g_color.device
         gflat = torch.zeros_like(env["flat"])
         names = ("points_embeding", "points_conf", "points_dir", "points_color")
-        grads = {n: torch.zeros(shp, dtype=torch.float32, device=dev) for n, shp in zip(names, ctx.shapes)}
+        # ONE zero-filled bucket for the four point-gradient tensors, [embedding | dir | colour | conf]: the three tensors that are final
+        # at the library's ready event are contiguous at its head, so a data-parallel caller reduces them with one collective
+        # (dist.allreduce_grads); the four gradients autograd receives are views of it
+        order = (0, 2, 3, 1)
+        sizes = [int(torch.Size(shp).numel()) for shp in ctx.shapes]
+        offs, o = {}, 0
+        for i in order:
+            offs[i] = o
+            o += (sizes[i] + 3) // 4 * 4                # every view starts on a 16-byte boundary
+        bucket = torch.zeros(o, dtype=torch.float32, device=dev)
+        grads = {n: bucket[offs[i]:offs[i] + sizes[i]].view(ctx.shapes[i]) for i, n in enumerate(names)}
         ev = None
         if env.get("want_grad_event"):            # data-parallel training: see pnerf_point_grads.ready_event
             ev = torch.cuda.Event()
@@ -78,6 +89,7 @@ class FusedRender(torch.autograd.Function):
         FusedRender.point_grads_ready = ev
         # what the early all-reduce may touch: exactly the tensors this backward wrote (dist.allreduce_grads checks p.grad against them)
         FusedRender.point_grad_ptrs = {grads[n].data_ptr() for n in names}
+        FusedRender.point_grad_bucket = (bucket, offs[1], tuple(grads[n].data_ptr() for n in ("points_embeding", "points_dir", "points_color")))
         if fwd["saved"] is not None:
             ops.ARENA.give(fwd["saved"])  # hand the activation arena back for the next step
         fwd["saved"] = None

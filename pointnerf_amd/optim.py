@@ -54,7 +54,14 @@ class FusedAdam(torch.optim.Optimizer):
 
 
 class ShardedAdam:
-    """ZeRO-1 Adam over a process group: state and update are sharded by rank, parameters stay replicated."""
+    """ZeRO-1 Adam over a process group: state and update are sharded by rank, parameters stay replicated.
+
+    The parameters are re-homed at construction into ONE persistent flat buffer (every ``p.data`` becomes a view of it; the buffer
+    is padded to world x shard floats), and a second persistent flat buffer of the same layout receives the gradients.  A step
+    is then: copy the gradients into their slots (skipped for a gradient that already IS its slot: see ``grad_views``), ONE
+    reduce-scatter straight out of the gradient buffer, the Adam update of this rank's shard in place in the parameter buffer,
+    ONE all-gather straight into the parameter buffer -- no per-step allocation, no padded copies of parameters or gradients.
+    Shard boundaries cross tensor boundaries (Adam is element-wise), so the shards are equal whatever the tensor sizes."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None, update=None):
         self.params = [p for p in params]
@@ -64,45 +71,53 @@ class ShardedAdam:
         dist = torch.distributed
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.state = []
+        dev = self.params[0].device
+        self.offsets, o = [], 0
         for p in self.params:
-            shard = (p.numel() + self.world - 1) // self.world
-            shard = (shard + 3) // 4 * 4                     # float4 alignment of every shard
-            self.state.append(dict(shard=shard, exp_avg=torch.zeros(shard, dtype=torch.float32, device=p.device),
-                                   exp_avg_sq=torch.zeros(shard, dtype=torch.float32, device=p.device)))
+            self.offsets.append(o)
+            o += (p.numel() + 3) // 4 * 4                 # every tensor starts on a 16-byte boundary
+        self.shard = ((o + self.world - 1) // self.world + 3) // 4 * 4
+        total = self.shard * self.world
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                view = self.flat_param[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+        self.exp_avg = torch.zeros(self.shard, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(self.shard, dtype=torch.float32, device=dev)
+
+    def grad_views(self):
+        """The gradient slots, one per parameter: a producer that writes its gradients there (``p.grad = view``) saves the copy."""
+        return [self.flat_grad[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.offsets)]
 
     @torch.no_grad()
     def step(self):
         dist = torch.distributed
         self.step_count += 1
-        for p, st in zip(self.params, self.state):
+        for p, o in zip(self.params, self.offsets):
+            slot = self.flat_grad[o:o + p.numel()]
             if p.grad is None:
-                continue
-            n, shard, W = p.numel(), st["shard"], self.world
-            gpad = torch.zeros(shard * W, dtype=torch.float32, device=p.device)
-            gpad[:n] = p.grad.reshape(-1)
-            gs = torch.empty(shard, dtype=torch.float32, device=p.device)
-            if W > 1:
-                if dist.get_backend(self.group) == "gloo":       # gloo has no reduce_scatter: all-reduce and slice (CPU tests only)
-                    dist.all_reduce(gpad, group=self.group)
-                    gs.copy_(gpad[self.rank * shard:(self.rank + 1) * shard])
-                else:
-                    dist.reduce_scatter_tensor(gs, gpad, group=self.group)
+                slot.zero_()
+            elif p.grad.data_ptr() != slot.data_ptr():
+                slot.copy_(p.grad.reshape(-1))
+        W, shard = self.world, self.shard
+        mine = slice(self.rank * shard, (self.rank + 1) * shard)
+        gs = self.flat_grad[mine]
+        if W > 1:
+            if dist.get_backend(self.group) == "gloo":       # gloo has no reduce_scatter: all-reduce in place (CPU tests only)
+                dist.all_reduce(self.flat_grad, group=self.group)
             else:
-                gs.copy_(gpad)
-            ppad = torch.zeros(shard * W, dtype=torch.float32, device=p.device)
-            ppad[:n] = p.data.reshape(-1)
-            ps = ppad[self.rank * shard:(self.rank + 1) * shard].clone()
-            self._update(ps, gs, st["exp_avg"], st["exp_avg_sq"], float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                         self.step_count)
-            if W > 1:
-                if dist.get_backend(self.group) == "gloo":
-                    dist.all_gather(list(ppad.view(W, shard).unbind(0)), ps, group=self.group)
-                else:
-                    dist.all_gather_into_tensor(ppad, ps, group=self.group)
+                dist.reduce_scatter_tensor(gs, self.flat_grad, group=self.group)      # in place: the output is this rank's slice of the input
+        ps = self.flat_param[mine]
+        self._update(ps, gs, self.exp_avg, self.exp_avg_sq, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                     self.step_count)
+        if W > 1:
+            if dist.get_backend(self.group) == "gloo":
+                dist.all_gather(list(self.flat_param.view(W, shard).unbind(0)), ps.clone(), group=self.group)
             else:
-                ppad.copy_(ps)
-            p.data.copy_(ppad[:n].view_as(p))
+                dist.all_gather_into_tensor(self.flat_param, ps, group=self.group)     # in place: the input is this rank's slice of the output
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:

@@ -116,3 +116,45 @@ def test_model_shell_loss_items_are_globally_normalised(tmp_path):
     for k, v in one.items():
         s = got[0][k] + got[1][k]
         assert abs(s - v) <= 1e-6 * max(1.0, abs(v)), (k, s, v)
+
+
+def _sparse_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, K = 5000, 8
+    gen = torch.Generator().manual_seed(100 + rank)
+    n_samp = [300, 0, 450][rank % 3]                        # one rank touches nothing at all
+    pidx = torch.randint(0, N, (n_samp, K), generator=gen, dtype=torch.int32)
+    if n_samp:
+        pidx[torch.rand(n_samp, K, generator=gen) < 0.3] = -1  # empty neighbor slots
+    touched = pdist.touched_rows(pidx, N)
+    assert touched.numel() == len(set(pidx[pidx >= 0].tolist())) and bool((touched[1:] > touched[:-1]).all())
+    shapes = [(1, N, 32), (1, N, 1), (1, N, 3), (1, N, 3)]
+    dense = []
+    for shp in shapes:
+        g = torch.zeros(shp)
+        g[0, touched] = torch.randn(touched.numel(), shp[-1], generator=gen)
+        dense.append(g)
+    ref = [g.clone() for g in dense]
+    for g in ref:
+        dist.all_reduce(g)
+    pdist.sparse_allreduce_rows(dense, touched)
+    torch.save((dense, ref), os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sparse_touched_row_exchange_equals_dense_allreduce(tmp_path):
+    """three ranks: the touched-row exchange gives the dense all-reduce's sums (fp32 association aside) and BITWISE the same
+    tensors on every rank"""
+    world = 3
+    port = 29500 + (os.getpid() + 777) % 2000
+    mp.spawn(_sparse_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(world)]
+    for r in range(world):
+        for got, ref in zip(*res[r]):
+            assert torch.allclose(got, ref, rtol=0, atol=2e-6)
+            assert float(ref.abs().max()) > 0
+    for r in range(1, world):
+        for a, b in zip(res[0][0], res[r][0]):
+            assert torch.equal(a, b)

@@ -53,3 +53,29 @@ def test_bench_two_ranks_on_one_gpu():
     # ZeRO-1 sharding of the point-parameter Adam is the same update: the loss after 3 steps agrees to summation order
     z = _two_ranks(["--zero1"], 7)
     assert abs(z["config"]["final_loss"] - d["config"]["final_loss"]) <= 1e-5 * max(1.0, abs(d["config"]["final_loss"]))
+    assert d["config"]["point_grad_exchange"].startswith("dense") and z["config"]["point_grad_exchange"].startswith("zero1")
+    # the touched-row exchange (the default from 6 M points) is the same sum
+    s = _two_ranks(["--point-grads", "sparse"], 11)
+    assert s["config"]["point_grad_exchange"].startswith("sparse")
+    assert abs(s["config"]["final_loss"] - d["config"]["final_loss"]) <= 1e-5 * max(1.0, abs(d["config"]["final_loss"]))
+
+
+def test_point_gradients_reach_autograd_as_views_of_one_bucket():
+    """what the one-collective early all-reduce relies on: after loss.backward() the .grad of the embedding / dir / colour parameters
+    ARE the renderer's views (not autograd clones), contiguous at the head of the bucket"""
+    import torch
+    import bench
+    from pointnerf_amd import config
+    from pointnerf_amd.fused import FusedRender
+    dev = torch.device("cuda:0")
+    opt = config.bench_lego_opt(is_train=1)
+    model = bench.build_model(opt, 200_000, dev)
+    inp = bench.step_inputs(0, 0, 1, 2048, dev)
+    out = model(**inp)
+    bench.loss_fn(opt, out, inp, 1).backward()
+    npnt = model.neural_points
+    bucket, head, ptrs = FusedRender.point_grad_bucket
+    got = [npnt.points_embeding.grad, npnt.points_dir.grad, npnt.points_color.grad]
+    assert [g.data_ptr() for g in got] == list(ptrs)
+    assert got[0].data_ptr() == bucket.data_ptr() and head >= sum(g.numel() for g in got)
+    assert float(bucket[:head].abs().sum()) > 0
