@@ -77,20 +77,21 @@ __global__ __launch_bounds__(TPB) void k_probe(PnGridDev g, RayGen rg, int R, in
         if (JITTER) {
             float seg = 0.f;
             if (d < D) seg = rg.mid[d] * (1.0f + rg.jitter * (pn_uniform(rg.seed, (unsigned long long)r * D + d) - 0.5f));
-            // end points = near + running sum of the segment lengths IN SEQUENCE, accumulated in double and rounded to fp32 per element:
-            // bit for bit torch.cumsum of the reference's CPU path (diff_ray_marching.py:376-383; ATen's CPU cumsum accumulates
-            // floats in double), so that with the same uniforms the jittered samples are the reference's.  One serial chain per
-            // ray (a shuffle scan would round differently): 64 readlane + add steps per chunk, ~10 us for a whole batch.
-            double run = carry;
-            float inc = 0.f, prev = 0.f;
-#pragma unroll 8
-            for (int j = 0; j < 64; ++j) {
-                const float sj = __shfl(seg, j, 64);
-                const float before = (float)run;
-                run = run + (double)sj;
-                if (lane == j) { inc = (float)run; prev = before; }
+            // end points = near + running sum of the segment lengths, accumulated in double and rounded to fp32 per element: bit
+            // for bit torch.cumsum of the reference's CPU path (diff_ray_marching.py:376-383; ATen's CPU cumsum accumulates floats
+            // in double), so that with the same uniforms the jittered samples are the reference's.  The double sums are EXACT
+            // (D <= a few thousand fp32 terms within a factor 1.35 of each other need 24 + 12 + 1 < 53 significand bits), so the
+            // order of the additions is free: a 6-step wave scan gives the sequential sum's bits (tests: the jitter parity cases of
+            // tests/test_gpu_query.py; the 64-step serial chain this replaces cost 0.34 ms per batch).
+            double run = (double)seg;
+#pragma unroll
+            for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                const double up = __shfl_up(run, dlt, 64);
+                if (lane >= dlt) run += up;
             }
-            carry = run;
+            run += carry;
+            const float inc = (float)run, prev = (float)(run - (double)seg);
+            carry = __shfl(run, 63, 64);
             const float e1 = rg.near_d + inc, e0 = rg.near_d + prev;
             if (d < D) {
                 float t = (e0 + e1) * 0.5f;
