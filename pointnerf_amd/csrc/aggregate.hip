@@ -126,7 +126,7 @@ size_t pn_saved_bytes(long long n_valid, int K, long long *rows_out, long long *
     if (samples_out) *samples_out = samples;
     size_t b = 0;
     b += 2 * pn_align((size_t)rows / 8 * PN_NF1 * 32) + 2 * pn_align((size_t)rows / 8 * PN_H * 32);      // x0k, h2k | h1k, h3k
-    b += 4 * pn_align((size_t)rows / 8 * PN_H * 32) + pn_align((size_t)rows * 32 * 32);                // dy1k..dy4k | h4r
+    b += 4 * pn_align((size_t)rows / 8 * PN_H * 16) + pn_align((size_t)rows * 32 * 32);                // dy1k..dy4k (one plane) | h4r
     b += pn_align((size_t)rows * 4) + pn_align((size_t)rows * 16) + pn_align((size_t)tiles * 3 * PN_NTHR * 8) + pn_align(16);
     b += pn_cls_bytes(samples);
     b += 2 * pn_align((size_t)samples * PN_H * 4) + pn_align((size_t)samples * 32 * 4) + 6 * pn_align((size_t)samples * PN_HC * 4);
@@ -140,8 +140,8 @@ PnSaved pn_saved_carve(void *base, long long n_valid, int K) {
     const size_t rg = (size_t)s.rows / 8;
     s.x0k = cv.take<uint4>(rg * PN_NF1 * 2); s.h2k = cv.take<uint4>(rg * PN_NF1 * 2);
     s.h1k = cv.take<uint4>(rg * PN_H * 2); s.h3k = cv.take<uint4>(rg * PN_H * 2);
-    s.dy1k = cv.take<uint4>(rg * PN_H * 2); s.dy2k = cv.take<uint4>(rg * PN_H * 2);
-    s.dy3k = cv.take<uint4>(rg * PN_H * 2); s.dy4k = cv.take<uint4>(rg * PN_H * 2);
+    s.dy1k = cv.take<uint4>(rg * PN_H); s.dy2k = cv.take<uint4>(rg * PN_H);
+    s.dy3k = cv.take<uint4>(rg * PN_H); s.dy4k = cv.take<uint4>(rg * PN_H);
     s.h4r = cv.take<uint4>((size_t)s.rows * 32 * 2);
     s.arow = cv.take<float>((size_t)s.rows); s.rmeta = cv.take<int4>((size_t)s.rows);
     s.lmask = cv.take<unsigned long long>((size_t)(s.rows / PN_TILE) * 3 * PN_NTHR);
@@ -253,7 +253,7 @@ __global__ void k_cls_zero_gaps(PnSaved sv, int ncls) {
     const int which = blockIdx.x;                      // 8 arrays x 2 planes
     const int nf = which < 2 ? PN_NF1 : PN_H;
     const long long rg_total = sv.rows / 8;
-    for (int plane = 0; plane < 2; ++plane) {
+    for (int plane = 0; plane < (which < 4 ? 2 : 1); ++plane) {      // (the dY arrays hold one plane)
         uint4 *p = arrs[which] + ((long long)plane * rg_total + gap * 8) * nf;
         for (int i = threadIdx.x; i < 8 * nf; i += blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
     }

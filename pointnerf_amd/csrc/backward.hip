@@ -311,7 +311,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
     const int Ns = a.cls_info[PN_CI_COUNT + a.cls];
     const long long vb = a.cls_info[PN_CI_VBASE + a.cls], tb = a.cls_info[PN_CI_TBASE + a.cls];
     a.sv.dfs += vb * PN_H;
-    const long long ntiles = ((long long)Ns + TS - 1) / TS, rg_total = a.sv.rows / 8;
+    const long long ntiles = ((long long)Ns + TS - 1) / TS;
     const float *P = a.params;
     const char *img = reinterpret_cast<const char *>(a.packed);
     float S, invS;
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 3);
         // ---- layer 4: dY4 -> d h3
-        pn_copy_out_kmajor<PN_H>(X, a.sv.dy4k, rg_total, gtile * 8, tid);
+        pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy4k, gtile * 8, tid);
         b_acc_zero(acc);
         PN_TR(pn_trace_bwd, 4);
         pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D4), 2 * wave, lane, acc);
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 6);
         // ---- layer 3: dY3 -> d h2, and the extras block (input columns 256..262 of W3), K split over the waves
-        pn_copy_out_kmajor<PN_H>(X, a.sv.dy3k, rg_total, gtile * 8, tid);
+        pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy3k, gtile * 8, tid);
         b_acc_zero(acc);
         PN_TR(pn_trace_bwd, 7);
         pn_gemm_f16x3<16, 9, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D3), 2 * wave, lane, acc);
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 9);
         // ---- layer 2: dY2 -> d h1
-        pn_copy_out_kmajor<PN_H>(X, a.sv.dy2k, rg_total, gtile * 8, tid);
+        pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy2k, gtile * 8, tid);
         // (Measured and rejected: pulling the next tile's h4 planes / d f rows / sign words into L2 from here with 4-byte LDS-DMA
         //  reads, one per 128-byte line: 16.65 ms against 16.19 ms -- the load phase is not waiting for HBM.)
         b_acc_zero(acc);
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 12);
         // ---- layer 1: dY1 -> d X0 (columns 0..223), fp32 into LDS
-        pn_copy_out_kmajor<PN_H>(X, a.sv.dy1k, rg_total, gtile * 8, tid);
+        pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy1k, gtile * 8, tid);
         b_acc_zero(acc);
         PN_TR(pn_trace_bwd, 13);
         if (wave < 3) pn_gemm_f16x3<16, PN_MB_D1, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D1), 2 * wave, lane, acc);
@@ -716,7 +716,7 @@ template <int NFB>
 __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, const uint4 *__restrict__ B, long long rg_total,
                                                    const int *__restrict__ d_tiles, float *__restrict__ partial) {
     constexpr int AU = 2 * 256, BU = 2 * NFB;                 // units (16 B) of one plane of a stage: 2 row groups = 16 rows
-    constexpr int STAGE = 2 * AU + 2 * BU;                    // [A h | A m | B h | B m]
+    constexpr int STAGE = AU + 2 * BU;                        // [A h | B h | B m]
     constexpr int NI = STAGE / 64, NIW = (NI + 7) / 8;        // wave-instructions per stage, per wave (the last ones are padded)
     constexpr int NST = 4;
     static_assert(STAGE % 64 == 0, "a stage is a whole number of 1 KB wave copies");
@@ -745,8 +745,8 @@ __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, 
             const int j = pad ? 0 : wave + 8 * i, u0 = 64 * j;
             const uint4 *dst = smem_w + (pad ? NST * STAGE : buf * STAGE + u0);
             const uint4 *src;
-            if (u0 < 2 * AU) { const int p = u0 / AU, u = u0 - p * AU; src = A + ((long long)p * rg_total + rg) * 256 + u; }
-            else { const int v = u0 - 2 * AU, p = v / BU, u = v - p * BU; src = B + ((long long)p * rg_total + rg) * NFB + u; }
+            if (u0 < AU) src = A + rg * 256 + u0;
+            else { const int v = u0 - AU, p = v / BU, u = v - p * BU; src = B + ((long long)p * rg_total + rg) * NFB + u; }
             __builtin_amdgcn_global_load_lds(src + lane, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
     };
@@ -768,30 +768,27 @@ __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, 
 #endif
             const uint4 *st = smem_w + (s & 3) * STAGE;
             const uint4 *fa = st + (lane >> 5) * 256 + (lane & 31);
-            const uint4 *fb = st + 2 * AU + (lane >> 5) * NFB + (lane & 31);
-            pn_h8 ah[4], am[4], bh[2], bm[2];
+            const uint4 *fb = st + AU + (lane >> 5) * NFB + (lane & 31);
+            pn_h8 ah[4], bh[2], bm[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { ah[i] = __builtin_bit_cast(pn_h8, fa[(4 * wm + i) * 32]); am[i] = __builtin_bit_cast(pn_h8, fa[AU + (4 * wm + i) * 32]); }
+            for (int i = 0; i < 4; ++i) ah[i] = __builtin_bit_cast(pn_h8, fa[(4 * wm + i) * 32]);
 #pragma unroll
             for (int i = 0; i < 2; ++i) { bh[i] = __builtin_bit_cast(pn_h8, fb[(2 * wn + i) * 32]); bm[i] = __builtin_bit_cast(pn_h8, fb[BU + (2 * wn + i) * 32]); }
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < 2; ++p)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p == 2 ? am[i] : ah[i], p == 1 ? bm[j] : bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], p == 1 ? bm[j] : bh[j], acc[i][j], 0, 0, 0);
             // tail tile: row tile 4 wm + wn of dW x columns 256..287
             const pn_h8 tah = wn == 0 ? ah[0] : wn == 1 ? ah[1] : wn == 2 ? ah[2] : ah[3];
-            const pn_h8 tam = wn == 0 ? am[0] : wn == 1 ? am[1] : wn == 2 ? am[2] : am[3];
             if (NFB > 256) {
                 const pn_h8 tbh = __builtin_bit_cast(pn_h8, fb[256]), tbm = __builtin_bit_cast(pn_h8, fb[BU + 256]);
                 acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbh, acct, 0, 0, 0);
                 acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbm, acct, 0, 0, 0);
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tam, tbh, acct, 0, 0, 0);
             } else {
                 acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, ones, acct, 0, 0, 0);
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tam, ones, acct, 0, 0, 0);
             }
         }
     }
@@ -843,7 +840,7 @@ int launch_wgrad_f16(const uint4 *A, const uint4 *B, long long rg_total, const i
     const long long tiles = rows_max / PN_TILE;
     if (tiles < chunks) chunks = (int)(tiles > 0 ? tiles : 1);
     if ((size_t)chunks * 256 * 288 > PARTIAL_FLOATS) return PNERF_E_WS;
-    constexpr size_t lds = ((size_t)4 * (2 * 2 * 256 + 2 * 2 * NFB) + 64) * 16;       // four stages + the pad slot
+    constexpr size_t lds = ((size_t)4 * (2 * 256 + 2 * 2 * NFB) + 64) * 16;           // four stages [A h | B h | B m] + the pad slot
     if (hipFuncSetAttribute((const void *)k_wgrad_f16<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PNERF_E_LAUNCH;
     { PnProfScope prof(PNK_WGRAD, s);
     hipLaunchKernelGGL(k_wgrad_f16<NFB>, dim3(chunks), dim3(512), lds, s, A, B, rg_total, d_tiles, partial); }

@@ -103,9 +103,25 @@ __device__ __forceinline__ void pn_split2(float x0, float x1, unsigned &h, unsig
         : "=&v"(m) : "v"(x0), "v"(x1), "v"(h));
 #endif
 }
-// the same with the value clamped to the f16 range first (gradients: their scale is chosen per call, an outlier must saturate, not poison)
+// Gradients: the value is clamped to the f16 range first (their scale is chosen per call, an outlier must saturate, not poison) and
+// the high plane is rounded to NEAREST (v_cvt_pk_f16_f32, new on gfx950), the residual as before.  h + m is the same 22-bit number
+// for the dgrad GEMMs; h ALONE is then the best single f16 for the value (|x - h| <= 2^-12 |x|, unbiased), which is what the
+// weight-gradient GEMM streams for its dY operand (one plane instead of two: see k_wgrad_f16 for the error budget).
 __device__ __forceinline__ void pn_split2_sat(float x0, float x1, unsigned &h, unsigned &m) {
-    pn_split2(__builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f), h, m);
+    x0 = __builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f);
+    x1 = __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f);
+    pn_h2 hh;
+    hh[0] = (_Float16)x0; hh[1] = (_Float16)x1;
+    h = __builtin_bit_cast(unsigned, hh);
+#ifdef PN_EMU
+    pn_h2 mm;
+    mm[0] = (_Float16)(x0 - (float)hh[0]);
+    mm[1] = (_Float16)(x1 - (float)hh[1]);
+    m = __builtin_bit_cast(unsigned, mm);
+#else
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(m) : "v"(x0), "v"(x1), "v"(h));
+#endif
 }
 __device__ __forceinline__ float pn_h_lo(unsigned p) { return (float)__builtin_bit_cast(pn_h2, p)[0]; }
 __device__ __forceinline__ float pn_h_hi(unsigned p) { return (float)__builtin_bit_cast(pn_h2, p)[1]; }
@@ -248,6 +264,27 @@ typedef short pn_s4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint2 pn_lds_read_tr16(const char *p) {
     const pn_s4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) pn_s4 *)p);
     return __builtin_bit_cast(uint2, r);
+}
+// the high plane only ([rg_total][NF] units): the dY operand of the weight-gradient GEMM
+template <int NF>
+__device__ __forceinline__ void pn_copy_out_kmajor_h(const char *X, uint4 *__restrict__ dst, long long rg0, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int blk = ((lane >> 2) & 3) * PN_XRS + ((lane >> 4) * 16 + (lane & 3) * 4) * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rg = wave * 2 + i;
+        const char *src = X + rg * 8 * PN_XRS + blk;
+        uint4 *d = dst + (rg0 + rg) * NF;
+#pragma unroll
+        for (int j = 0; j < (NF + 63) / 64; ++j) {
+            const int f = lane + 64 * j;
+            const uint2 lo = pn_lds_read_tr16(src + j * 128), hi = pn_lds_read_tr16(src + 4 * PN_XRS + j * 128);
+            if (f < NF) {
+                pn_f4 t = {__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y)};
+                PN_STREAM_STORE(t, reinterpret_cast<pn_f4 *>(d + f));
+            }
+        }
+    }
 }
 template <int NF>
 __device__ __forceinline__ void pn_copy_out_kmajor(const char *X, uint4 *__restrict__ dst, long long rg_total, long long rg0, int tid) {

@@ -44,7 +44,7 @@ template <int N, class F> __device__ __forceinline__ void pn_static_for(F &&f) {
 struct PnSaved {
     // per neighbor row (rows = row tiles * 64), f16 plane pairs (f16x3.h):
     uint4 *x0k, *h1k, *h2k, *h3k;       // k-major [2][rows / 8][NF] inputs of the four layers (NF = 288, 256, 288, 256): what the weight-gradient GEMM streams
-    uint4 *dy1k, *dy2k, *dy3k, *dy4k;   // k-major [2][rows / 8][256] output gradients of the four layers, SCALED by the backward's power-of-two scale
+    uint4 *dy1k, *dy2k, *dy3k, *dy4k;   // k-major [rows / 8][256] output gradients of the four layers (ONE f16 plane, round to nearest), SCALED by the backward's power-of-two scale
     uint4 *h4r;                         // row-major [2][rows][32] last activation (alpha head / K-weighted sums of the backward)
     float *arow;                        // per row: pre-activation of the alpha head
     int4 *rmeta;                        // per row: {sample id or -1, point id or -1, bits(normalised weight), bits(final weight)}

@@ -42,9 +42,11 @@ def split_inputs():
 def split_expected(x, sat):
     from test_split_f16_cpu import f16_rtz
     x = np.asarray(x, np.float32)
-    if sat:
+    if sat:         # the gradient form (pn_split2_sat): clamp, then the high plane rounded to nearest even (v_cvt_pk_f16_f32)
         x = np.clip(x, -65504.0, 65504.0)
-    h = f16_rtz(x)
+        h = x.astype(np.float16)
+    else:
+        h = f16_rtz(x)
     with np.errstate(over="ignore"):
         m = (x - h.astype(np.float32)).astype(np.float32).astype(np.float16)
     return h, m
