@@ -202,6 +202,10 @@ __device__ __forceinline__ void pn_x_axpy4(const char *X, int row, int col, floa
 #define PN_GEMM_PRIO_BEGIN() ((void)0)
 #define PN_GEMM_PRIO_END() ((void)0)
 #endif
+// (Measured, round 2: with every chunk reading chunk 0's fragments -- the weight stream then hits L1 -- the forward is 11 % and the
+//  backward 15 % faster: that is what the L2 -> L1 weight traffic (1.07 MB per 64-row tile and workgroup) costs, and the bound on what
+//  a larger register blocking could recover.  A prefetch distance of 3 chunks instead of 2, starting the CU's second workgroup half
+//  a tile late, streaming loads of the saved activations: no change.)
 // (Measured and rejected: running the tile's transposing copy-out as a side job between the chunks' MFMA groups -- its stores share the
 //  in-order vmcnt queue with the weight fragments, every chunk then waits for HBM writes: +3 us per GEMM against 2.4 us saved.)
 // WPF = chunks of weight fragments requested ahead: 2 covers an L2 round trip when a chunk is 24 MFMAs (two feature blocks); the
