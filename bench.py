@@ -197,6 +197,18 @@ def main():
         opt_mlp.step(); opt_pts.step()
         return loss, model.last_stats
 
+    if not args.render_only:
+        # size the activation arena for the largest of the batches that will be run (their neighbor tables differ: up to 2x between
+        # poses of the Barn-scale configuration); the query alone tells the number of valid samples
+        from pointnerf_amd import _lib as L
+        biggest = 0
+        with torch.no_grad():
+            for inp in inputs:
+                dense = npnt.query_dense(inp)              # (the jitter draws differ from the timed steps': the counts agree to a percent, the reserve has 15 % headroom)
+                biggest = max(biggest, int(dense["counters"][0].item()))
+        need = int(L.lib().pnerf_agg_saved_bytes(biggest, int(opt.K)))
+        if need <= ops.arena_budget_bytes():
+            ops.ARENA.reserve(int(need * 1.05), dev)
     stats = []
     # set-up, not warm-up: two untimed steps on the first batch size the activation arena (one ~80 GB hipMalloc) and let the caching
     # allocator settle, so that the measurement does not depend on how many warm-up steps the caller asks for

@@ -217,6 +217,12 @@ class Arena:
         if t is not None:
             self.free.append(t)
 
+    def reserve(self, nbytes, device):
+        """make sure one free block of at least ``nbytes`` exists (a caller that knows its largest step sizes the arena once,
+        instead of paying a ~2 s hipFree + hipMalloc of tens of GB when a later step is 15 % larger than every earlier one)"""
+        if not any(t.numel() >= nbytes and t.device == device for t in self.free):
+            self.give(self.take(nbytes, device))
+
 
 ARENA = Arena()
 

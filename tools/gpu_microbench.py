@@ -64,9 +64,30 @@ for rep in range(3):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
 vox = dict(ms=dt * 1e3, points=int(raw.shape[0]), voxels=int(cen.shape[0]), vox_res=320, bytes=raw.shape[0] * (12 * 4 + 8) + 320 ** 3 * 16)
 vox["GBps"] = vox["bytes"] / dt / 1e9
+# grid (brick map) build from scratch -- what every prune / grow event costs (the reference rebuilds its hash on EVERY query)
+from pointnerf_amd.point_query import lighting_fast_querier, clear_grid_cache
+grid_ms = {}
+for name, (label, make_opt, points_fn, n_pts, rays_fn) in bench._cfg().items():
+    if name == "chair":
+        continue
+    o2 = make_opt(is_train=0)
+    x2 = torch.from_numpy(points_fn(n_pts)).to(dev)
+    q2 = lighting_fast_querier(dev, o2)
+    d2 = rays_fn(0, 4096)
+    rd2, cp2 = torch.from_numpy(d2["raydir"]).to(dev), torch.from_numpy(d2["campos"]).to(dev)
+    for rep in range(3):
+        clear_grid_cache()
+        ops.prof_collect()
+        q2.query_dense(x2[None], x2.shape[0], float(d2["near"].min()), float(d2["far"].max()), rd2, cp2)
+        torch.cuda.synchronize()
+        pr = ops.prof_collect()
+    gi = q2.last_grid_info
+    grid_ms[name] = dict(points=int(n_pts), build_ms=pr["grid_build"][0] / max(pr["grid_build"][1], 1), occupied_cells=int(gi["n_occ"]), max_points_per_cell=int(gi["max_cnt"]))
+    del x2, q2
 for k, v in res.items():
     v["GBps"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
     v["frac_of_8TBps"] = v["GBps"] / 8000.0
 res["full_image_800x800"] = full
 res["voxel_downsample_2M_res320"] = vox
+res["grid_build"] = grid_ms
 print(json.dumps(res, indent=1))

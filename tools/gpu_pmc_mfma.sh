@@ -22,7 +22,8 @@ for d in ('/tmp/pmc1','/tmp/pmc2'):
         print(k)
         for c,x in v.items(): print('    %-28s %.4e  per launch %.4e (%d)' % (c, x, x/max(n[k][c],1), n[k][c]))
         if 'GRBM_GUI_ACTIVE' in v and 'SQ_VALU_MFMA_BUSY_CYCLES' in v:
-            print('    MFMA busy / (GUI_ACTIVE * 256 CU * 4 SIMD): %.3f' % (v['SQ_VALU_MFMA_BUSY_CYCLES']/(v['GRBM_GUI_ACTIVE']*1024)))
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
+            print('    MFMA busy / (GUI_ACTIVE / 8 XCD * 1024 SIMD): %.3f' % (v['SQ_VALU_MFMA_BUSY_CYCLES']/(v['GRBM_GUI_ACTIVE']/8*1024)))
         if 'SQ_WAVE_CYCLES' in v:
             w=v['SQ_WAVE_CYCLES']
             for c in ('SQ_WAIT_ANY','SQ_ACTIVE_INST_ANY','SQ_WAIT_INST_ANY'):
