@@ -8,8 +8,8 @@
 //     ostart[n_occ+1]   offsets into pts of the occupied cells, in (brick, cell-in-brick) order
 //     pts[M] float4     (x, y, z, bitcast point index), sorted by (brick, cell, point index)
 //     occ bits [G/32]   occupancy dilated by query_size, plain (x, y, z) bit order (the ray probe's field)
-// A cell lookup is one 16-byte brick record (4 bytes per 16 cells: the whole table is 9.6 MB at lego size and lives in L2 -- the
-// dense CSR offset array it replaces was 153 MB and cost one HBM sector per visited cell, 5x the algorithmic traffic of the
+// A cell lookup is one 16-byte brick record (4 bytes per 16 cells: the whole table is 2.2 MB at lego size and lives in L2 -- the
+// dense CSR offset array it replaces was 35.5 MB and cost one HBM sector per visited cell: 5x the algorithmic traffic of the
 // neighbor query, profiles/traffic.json of round 2), and only for cells that hold points a rank (popcount) -> ostart -> records
 // walk.  The 27 cells of a sample's neighbourhood fall into <= 8 bricks, and their records are adjacent in memory.
 // Points of a cell are contiguous and in ascending point index, which IS the reference's canonical serial order;
