@@ -36,13 +36,13 @@ FLOP_SAMPLE_WGRAD = 2 * (280 * 128 + 2 * 128 * 128)
 # multiply-add (csrc/f16x3.h), so the matrix pipe executes 3x the algorithmic flops; its roofline is the dense f16 peak
 F16_PRODUCTS = 3
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense BF16/F16 MFMA (measured 2178-2495)
-PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense (only the colour MLP's three weight-gradient GEMMs still use it)
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense (no kernel of the path uses it any more)
 PEAK_HBM_GBS = 8000.0
 # algorithmic HBM bytes of the weight-gradient GEMMs per neighbor row, read once: the inputs of the four layers as two f16 planes
 # (2 x 2 B x (288 + 256 + 288 + 256)) and their output gradients as one f16 plane (2 B x 4 x 256)
 BYTES_ROW_WGRAD = 2 * 2 * (288 + 256 + 288 + 256) + 2 * 4 * 256
-# ... of the colour MLP's three fp32 weight-gradient GEMMs per valid sample (f 256 + view encoding 32, c1, c2, d c1..d c3 as fp32 rows)
-BYTES_SAMPLE_WGRAD = 4 * (288 + 128 + 128 + 3 * 128)
+# ... of the colour MLP's three weight-gradient GEMMs per valid sample ([f | view encoding] 288, c1, c2 as two planes; d c1..d c3 one plane)
+BYTES_SAMPLE_WGRAD = 2 * 2 * (288 + 128 + 128) + 2 * 3 * 128
 # ... of the training forward (gather 168 B + the saved planes x0 288, h1 256, [h2|extras] 288, h3 256, h4 256 columns + row metadata)
 BYTES_ROW_FWD = 168 + 2 * 2 * (288 + 256 + 288 + 256 + 256) + 16 + 4 + 96
 # ... of the backward (h4 planes + sign words + metadata read; four dY planes written)
@@ -295,9 +295,9 @@ def main():
                           "arithmetic": "f32 inputs / outputs / accumulation throughout; every GEMM of the forward and of the input-gradient chain "
                                         "(aggregator and colour MLP) runs on v_mfma_f32_32x32x16_f16 with every f32 operand carried as two f16 planes "
                                         "(x = h + m to 2^-22) and three products per multiply-add (h*h + h*m + m*h), f32 accumulate: sigma/RGB within "
-                                        "1.1e-6 of the f32 oracle at this configuration (bar 1e-4); the weight-gradient GEMMs of the four 256-wide layers "
+                                        "1.1e-6 of the f32 oracle at this configuration (bar 1e-4); the weight-gradient GEMMs (aggregator and colour layers) "
                                         "stream the inputs as two planes and the output gradients as ONE f16 plane rounded to nearest (two products; "
-                                        "error budget: tests/test_split_f16_cpu.py), those of the colour MLP run on v_mfma_f32_32x32x2_f32", **extra}}
+                                        "error budget: tests/test_split_f16_cpu.py)", **extra}}
         if prof is not None:
             per = {k: {"ms_per_launch": ms / max(n, 1), "launches": n, "ms_per_step": ms / args.steps} for k, (ms, n) in prof.items() if n > 0}
             # algorithmic work per step of the three dominant kernels

@@ -129,7 +129,9 @@ size_t pn_saved_bytes(long long n_valid, int K, long long *rows_out, long long *
     b += 4 * pn_align((size_t)rows / 8 * PN_H * 16) + pn_align((size_t)rows * 32 * 32);                // dy1k..dy4k (one plane) | h4r
     b += pn_align((size_t)rows * 4) + pn_align((size_t)rows * 16) + pn_align((size_t)tiles * 3 * PN_NTHR * 8) + pn_align(16);
     b += pn_cls_bytes(samples);
-    b += 2 * pn_align((size_t)samples * PN_H * 4) + pn_align((size_t)samples * 32 * 4) + 6 * pn_align((size_t)samples * PN_HC * 4);
+    b += 2 * pn_align((size_t)samples * PN_H * 4) + pn_align((size_t)samples * PN_HC * 4);                         // fs, dfs | c3
+    b += pn_align((size_t)samples / 8 * PN_NF1 * 32) + 2 * pn_align((size_t)samples / 8 * PN_HC * 32);              // xck | c1k, c2k
+    b += 3 * pn_align((size_t)samples / 8 * PN_HC * 16) + pn_align((size_t)samples / PN_CTILE * 2 * 256 * 4);       // dc1k..dc3k | cmask
     return b;
 }
 
@@ -147,10 +149,11 @@ PnSaved pn_saved_carve(void *base, long long n_valid, int K) {
     s.lmask = cv.take<unsigned long long>((size_t)(s.rows / PN_TILE) * 3 * PN_NTHR);
     s.gscale = cv.take<unsigned>(4);
     s.fs = cv.take<float>((size_t)s.samples * PN_H); s.dfs = cv.take<float>((size_t)s.samples * PN_H);
-    s.pe = cv.take<float>((size_t)s.samples * 32);
-    s.c1 = cv.take<float>((size_t)s.samples * PN_HC); s.c2 = cv.take<float>((size_t)s.samples * PN_HC);
-    s.c3 = cv.take<float>((size_t)s.samples * PN_HC); s.dc1 = cv.take<float>((size_t)s.samples * PN_HC);
-    s.dc2 = cv.take<float>((size_t)s.samples * PN_HC); s.dc3 = cv.take<float>((size_t)s.samples * PN_HC);
+    s.c3 = cv.take<float>((size_t)s.samples * PN_HC);
+    const size_t rgc = (size_t)s.samples / 8;
+    s.xck = cv.take<uint4>(rgc * PN_NF1 * 2); s.c1k = cv.take<uint4>(rgc * PN_HC * 2); s.c2k = cv.take<uint4>(rgc * PN_HC * 2);
+    s.dc1k = cv.take<uint4>(rgc * PN_HC); s.dc2k = cv.take<uint4>(rgc * PN_HC); s.dc3k = cv.take<uint4>(rgc * PN_HC);
+    s.cmask = cv.take<unsigned>((size_t)s.samples / PN_CTILE * 2 * 256);
     pn_cls_carve(cv.take<char>(pn_cls_bytes(s.samples)), s.samples, s);
     return s;
 }
@@ -637,9 +640,11 @@ __device__ __forceinline__ void c_load_bias(const float *__restrict__ bias, int 
         b[g] = make_float4(p[0], p[1], p[2], p[3]);
     }
 }
-// bias + LeakyReLU of the wave's feature block: fp32 rows to `save` (training), two planes into the tile
-template <bool TRAIN>
-__device__ __forceinline__ void c_epilogue(const f32x16 (&acc)[2][2], const float4 (&bias)[4], char *X, int wave, int lane, float *__restrict__ save, long long grow0) {
+// bias + LeakyReLU of the wave's feature block, two planes into the tile.  Training: SAVE32 -> the fp32 rows to `save` (the last layer:
+// the backward needs its values); else the sign bits of the lane's 32 pre-activations (rb, g, i order, first element in bit 31)
+template <bool TRAIN, bool SAVE32>
+__device__ __forceinline__ unsigned c_epilogue(const f32x16 (&acc)[2][2], const float4 (&bias)[4], char *X, int wave, int lane, float *__restrict__ save, long long grow0) {
+    unsigned mw = 0u;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -647,14 +652,19 @@ __device__ __forceinline__ void c_epilogue(const f32x16 (&acc)[2][2], const floa
             const int f0 = pn_d_feat(wave, g, lane), row = 32 * rb + (lane & 31);
             const float4 b = bias[g];
             float v[4] = {acc[0][rb][4 * g] + b.x, acc[0][rb][4 * g + 1] + b.y, acc[0][rb][4 * g + 2] + b.z, acc[0][rb][4 * g + 3] + b.w};
+            if (TRAIN && !SAVE32) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mw = __builtin_amdgcn_alignbit(mw, __float_as_uint(v[i]), 31);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.01f * v[i]);
-            if (TRAIN) {
+            if (TRAIN && SAVE32) {
                 pn_f4 t = {v[0], v[1], v[2], v[3]};
                 PN_REG_STORE(t, reinterpret_cast<pn_f4 *>(save + (grow0 + row) * PN_HC + f0));
             }
             pn_x_store4<false>(X, row, f0, v[0], v[1], v[2], v[3]);
         }
+    return mw;
 }
 __device__ __forceinline__ void c_acc_zero(f32x16 (&acc)[2][2]) {
 #pragma unroll
@@ -701,17 +711,9 @@ __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
                 if (q < 3) {
                     pn_x_store4<false>(X, row, PN_H + 4 * q, sn[0], sn[1], sn[2], sn[3]);
                     pn_x_store4<false>(X, row, PN_H + 12 + 4 * q, cs[0], cs[1], cs[2], cs[3]);
-                    if (TRAIN) {
-                        *reinterpret_cast<float4 *>(a.sv.pe + vs * 32 + 4 * q) = make_float4(sn[0], sn[1], sn[2], sn[3]);
-                        *reinterpret_cast<float4 *>(a.sv.pe + vs * 32 + 12 + 4 * q) = make_float4(cs[0], cs[1], cs[2], cs[3]);
-                    }
                 } else {
                     pn_x_store4<false>(X, row, PN_H + 24, 0.f, 0.f, 0.f, 0.f);
                     pn_x_store4<false>(X, row, PN_H + 28, 0.f, 0.f, 0.f, 0.f);
-                    if (TRAIN) {
-                        *reinterpret_cast<float4 *>(a.sv.pe + vs * 32 + 24) = make_float4(0.f, 0.f, 0.f, 0.f);
-                        *reinterpret_cast<float4 *>(a.sv.pe + vs * 32 + 28) = make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
                 }
             }
         } else {
@@ -720,26 +722,32 @@ __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
         }
         PN_LDS_BARRIER();
         float4 bias[4];
-        // ---- layer 1: 280 (288) -> 128
+        const long long rgc_total = a.sv.samples / 8;
+        // ---- layer 1: 280 (288) -> 128.  Training: every layer's input tile leaves k-major for the weight-gradient GEMM
+        if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.xck, rgc_total, tile * 8, tid);
         c_acc_zero(acc);
         pn_gemm_f16x3<18, 4, 1, 7>(X, reinterpret_cast<const uint4 *>(img + PKH_FC1), wave, lane, acc);
         c_load_bias(P + PO_BC1, wave, lane, bias);
         PN_LDS_BARRIER();                                 // every wave is done reading the input tile
-        c_epilogue<TRAIN>(acc, bias, X, wave, lane, a.sv.c1, grow0);
+        unsigned mw = c_epilogue<TRAIN, false>(acc, bias, X, wave, lane, nullptr, grow0);
+        if (TRAIN) a.sv.cmask[(tile * 2 + 0) * 256 + tid] = mw;
         PN_LDS_BARRIER();
         // ---- layer 2
+        if (TRAIN) pn_copy_out_kmajor<PN_HC>(X, a.sv.c1k, rgc_total, tile * 8, tid);
         c_acc_zero(acc);
         pn_gemm_f16x3<8, 4, 1, 7>(X, reinterpret_cast<const uint4 *>(img + PKH_FC2), wave, lane, acc);
         c_load_bias(P + PO_BC2, wave, lane, bias);
         PN_LDS_BARRIER();
-        c_epilogue<TRAIN>(acc, bias, X, wave, lane, a.sv.c2, grow0);
+        mw = c_epilogue<TRAIN, false>(acc, bias, X, wave, lane, nullptr, grow0);
+        if (TRAIN) a.sv.cmask[(tile * 2 + 1) * 256 + tid] = mw;
         PN_LDS_BARRIER();
         // ---- layer 3
+        if (TRAIN) pn_copy_out_kmajor<PN_HC>(X, a.sv.c2k, rgc_total, tile * 8, tid);
         c_acc_zero(acc);
         pn_gemm_f16x3<8, 4, 1, 7>(X, reinterpret_cast<const uint4 *>(img + PKH_FC3), wave, lane, acc);
         c_load_bias(P + PO_BC3, wave, lane, bias);
         PN_LDS_BARRIER();
-        c_epilogue<TRAIN>(acc, bias, X, wave, lane, a.sv.c3, grow0);
+        c_epilogue<TRAIN, true>(acc, bias, X, wave, lane, a.sv.c3, grow0);
         PN_LDS_BARRIER();
         // ---- output layer 128 -> 3 and the colour activation: 4 threads per row, 32 columns each
         {

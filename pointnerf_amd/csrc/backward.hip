@@ -10,7 +10,7 @@
 //   k_agg_backward   : TS samples x K rows per tile; (d sigma, d f) -> alpha head, K-weighted sums,
 //                      block3/block1 dgrad on MFMA, PE chain rule, atomic scatter-add into the
 //                      embedding / colour / dir / conf gradients of the touched points only
-//   k_wgrad_lds      : dW = dY^T X as split-K MFMA GEMMs over the saved activations, full dW tile
+//   k_wgrad_f16      : dW = dY^T X as split-K MFMA GEMMs over the saved k-major f16 planes, full dW tile
 //                      resident in accumulators, deterministic partial-sum reduction
 // LeakyReLU masks: 1 bit per element, written by the forward in the accumulator layout (layers 1-3), sign of the saved h4 (layer 4).
 #include "f16x3.h"
@@ -74,8 +74,8 @@ __device__ __forceinline__ void pn_scale_from_bits(unsigned mb, float &S, float 
 // ------------------------------------------------------------------------------ colour backward
 // 64 valid samples per tile, the forward's organisation: d rgb -> d(pre-sigmoid) -> d c3 on the VALU (3 x 128 weights), then the
 // dgrad chain d c3 x Wc3 -> d c2 x Wc2 -> d c1 x Wc1[:, :256] -> d f as two-plane f16 GEMMs on gradients that carry the call's
-// power-of-two scale S (k_grad_max).  The LeakyReLU masks come from the fp32 post-activations the forward saved; d c1..d c3 leave as
-// fp32 rows (x 1/S) for the fp32 weight-gradient GEMMs of these layers, d f as fp32 rows (x 1/S) for k_agg_backward.
+// power-of-two scale S (k_grad_max).  The LeakyReLU masks are the forward's sign words (c1, c2) and the saved fp32 c3; d c1..d c3 leave
+// k-major as one f16 plane (scaled) for the weight-gradient GEMMs of these layers, d f as fp32 rows (x 1/S) for k_agg_backward.
 // LDS: the tile, d raw [64][4], and the workgroup's running sums of d Wc4 [3][128], d bc3, d bc2, d bc1 [128] (LDS float adds:
 // kept in registers they are 45 loop-carried values per thread next to the GEMM's working set)
 constexpr int CB_DRAW = PN_XBYTES, CB_GACC = CB_DRAW + PN_CTILE * 4 * 4, CB_BYTES = CB_GACC + 6 * PN_HC * 4;
@@ -89,28 +89,18 @@ __device__ __forceinline__ void cb_acc_zero(f32x16 (&acc)[2][2]) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
-// the saved post-activations of the wave's accumulator elements (requested before the barrier that follows the GEMM)
-__device__ __forceinline__ void cb_load_post(const float *__restrict__ post, long long grow0, int wave, int lane, float4 (&pv)[8]) {
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            pv[rb * 4 + g] = *reinterpret_cast<const float4 *>(post + (grow0 + 32 * rb + (lane & 31)) * PN_HC + pn_d_feat(wave, g, lane));
-}
-// d(pre-activation) = acc * LeakyReLU'(post): fp32 rows x 1/S to dsave, two planes (saturating) into the tile
-__device__ __forceinline__ void cb_epilogue(const f32x16 (&acc)[2][2], const float4 (&pv)[8], char *X, int wave, int lane, float *__restrict__ dsave,
-                                            long long grow0, float invS) {
+// d(pre-activation) = acc * LeakyReLU' (sign bits of the forward's pre-activations, same lane -> element map): two planes
+// (saturating, high plane rounded to nearest) into the tile
+__device__ __forceinline__ void cb_epilogue(const f32x16 (&acc)[2][2], unsigned mw, char *X, int wave, int lane) {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int f0 = pn_d_feat(wave, g, lane), row = 32 * rb + (lane & 31);
-            const float4 p = pv[rb * 4 + g];
-            const float v0 = acc[0][rb][4 * g] * pn_lrelu_grad(p.x), v1 = acc[0][rb][4 * g + 1] * pn_lrelu_grad(p.y);
-            const float v2 = acc[0][rb][4 * g + 2] * pn_lrelu_grad(p.z), v3 = acc[0][rb][4 * g + 3] * pn_lrelu_grad(p.w);
-            pn_f4 t = {v0 * invS, v1 * invS, v2 * invS, v3 * invS};
-            PN_REG_STORE(t, reinterpret_cast<pn_f4 *>(dsave + (grow0 + row) * PN_HC + f0));
-            pn_x_store4<true>(X, row, f0, v0, v1, v2, v3);
+            const int f0 = pn_d_feat(wave, g, lane), row = 32 * rb + (lane & 31), e = rb * 16 + g * 4;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = acc[0][rb][4 * g + i] * ((int)(mw << (e + i)) < 0 ? 0.01f : 1.f);
+            pn_x_store4<true>(X, row, f0, v[0], v[1], v[2], v[3]);
         }
 }
 // column sums of the tile's first 128 columns (the bias gradient of the layer whose d(pre-activation) the tile holds): thread ->
@@ -140,6 +130,7 @@ __global__ __launch_bounds__(256, 2) void k_color_backward(BwdArgs a) {
     const char *img = reinterpret_cast<const char *>(a.packed);
     float S, invS;
     pn_scale_from_bits(a.sv.gscale[0], S, invS);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.sv.cls_info[PN_CI_CTILES] = (Ns + PN_CTILE - 1) / PN_CTILE;       // for the weight-gradient GEMMs
     float *gacc = reinterpret_cast<float *>(smem_cb + CB_GACC);          // [3][128] d Wc4 | d bc3 | d bc2 (x S) | d bc1 (x S)
     for (int i = threadIdx.x; i < 6 * PN_HC; i += 256) gacc[i] = 0.f;
     float gb4 = 0.f;
@@ -188,8 +179,6 @@ __global__ __launch_bounds__(256, 2) void k_color_backward(BwdArgs a) {
                     gw4[0][i] += d.x * c[i]; gw4[1][i] += d.y * c[i]; gw4[2][i] += d.z * c[i];
                     gb3[i] += u[i];
                 }
-                pn_f4 t = {u[0], u[1], u[2], u[3]};
-                PN_STREAM_STORE(t, reinterpret_cast<pn_f4 *>(a.sv.dc3 + (grow0 + row) * PN_HC + 4 * c4));
                 pn_x_store4<true>(X, row, 4 * c4, u[0] * S, u[1] * S, u[2] * S, u[3] * S);
             }
 #pragma unroll
@@ -204,23 +193,24 @@ __global__ __launch_bounds__(256, 2) void k_color_backward(BwdArgs a) {
             }
         }
         PN_LDS_BARRIER();
-        float4 pv[8];
         // ---- d c2 = (d c3 @ Wc3) * lrelu'(c2)
+        pn_copy_out_kmajor_h<PN_HC>(X, a.sv.dc3k, tile * 8, tid);
+        const unsigned mw2 = a.sv.cmask[(tile * 2 + 1) * 256 + tid], mw1 = a.sv.cmask[(tile * 2 + 0) * 256 + tid];
         cb_acc_zero(acc);
         pn_gemm_f16x3<8, 4, 1, 7>(X, reinterpret_cast<const uint4 *>(img + PKH_DC3), wave, lane, acc);
-        cb_load_post(a.sv.c2, grow0, wave, lane, pv);
         PN_LDS_BARRIER();
-        cb_epilogue(acc, pv, X, wave, lane, a.sv.dc2, grow0, invS);
+        cb_epilogue(acc, mw2, X, wave, lane);
         PN_LDS_BARRIER();
         cb_bias_sums(X, tid, gacc + 4 * PN_HC);
         // ---- d c1 = (d c2 @ Wc2) * lrelu'(c1)
+        pn_copy_out_kmajor_h<PN_HC>(X, a.sv.dc2k, tile * 8, tid);
         cb_acc_zero(acc);
         pn_gemm_f16x3<8, 4, 1, 7>(X, reinterpret_cast<const uint4 *>(img + PKH_DC2), wave, lane, acc);
-        cb_load_post(a.sv.c1, grow0, wave, lane, pv);
         PN_LDS_BARRIER();
-        cb_epilogue(acc, pv, X, wave, lane, a.sv.dc1, grow0, invS);
+        cb_epilogue(acc, mw1, X, wave, lane);
         PN_LDS_BARRIER();
         cb_bias_sums(X, tid, gacc + 5 * PN_HC);
+        pn_copy_out_kmajor_h<PN_HC>(X, a.sv.dc1k, tile * 8, tid);
         // ---- d f = d c1 @ Wc1[:, :256]
         cb_acc_zero(acc);
         pn_gemm_f16x3<8, 8, 2, 4>(X, reinterpret_cast<const uint4 *>(img + PKH_DC1), 2 * wave, lane, acc);
@@ -524,174 +514,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
     }
 }
 
-// ------------------------------------------------------------------------------ weight gradients
-// partial[chunk][m][n] = sum_{r in chunk} A[r][m] B[r][n]   (A = dY [rows,lda], B = X [rows,ldb])
-// Block tile (WM*MT*32) x (WN*NT*32); the whole tile lives in MFMA accumulators.  Both operands are staged through LDS
-// (each element leaves L2 once per workgroup instead of once per wave that needs it): KB rows of A [KB x Mtot] and B [KB x Ntile] per stage, double-buffered, next stage's global
-// loads in flight during the current stage's MFMAs.  Row strides are exact multiples of 32 floats, so the fragment
-// reads (lane -> column) are conflict-free and lanes l / l+32 (adjacent rows) never share a service group.
-// TAIL: the B operand has 32 more columns in a second array Bt (x0[:, 256:288] for W1, the view PE for the colour layer).
-// They ride in the same pass over A instead of a second kernel that re-reads all of dY: wave w (< MTOT/32) owns the extra
-// 32 x 32 tile of row tile w -- one more MFMA per k-step next to its MT*NT.
-template <int MT, int NT, int WM, int WN, int KB, bool TAIL>
-__global__ __launch_bounds__(WM *WN * 64) void k_wgrad_lds(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
-                                                           const float *__restrict__ Bt, int ldbt,
-                                                           long long rows, const int *__restrict__ d_tiles, int rows_per_chunk, float *__restrict__ partial, int Ntot) {
-    constexpr int NTHR = WM * WN * 64, MTOT = WM * MT * 32, NTILE = WN * NT * 32;
-    if (d_tiles) {      // the tiles the aggregator kernels actually used are known on the device only: re-split them over the chunks
-        const long long r = (long long)(*d_tiles) * PN_TILE;
-        rows = r < rows ? r : rows;
-        long long rpc = (rows + gridDim.y - 1) / gridDim.y;
-        rpc = (rpc + 63) / 64 * 64;
-        rows_per_chunk = (int)(rpc < 64 ? 64 : rpc);
-    }
-    constexpr int A4 = KB * MTOT / 4 / NTHR, B4 = KB * NTILE / 4 / NTHR;      // float4 per thread per stage
-    constexpr int T4 = KB * 32 / 4;                                            // float4 of the tail stage (threads < T4 carry one)
-    static_assert(A4 * 4 * NTHR == KB * MTOT && B4 * 4 * NTHR == KB * NTILE, "stage must divide evenly");
-    static_assert(T4 <= NTHR, "tail stage: one float4 per thread");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem;                           // [2][KB][MTOT]
-    float *Bs = smem + 2 * KB * MTOT;           // [2][KB][NTILE]
-    float *Ts = Bs + 2 * KB * NTILE;            // [2][KB][32]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int m0 = wm * MT * 32, n0l = wn * NT * 32, n0 = blockIdx.x * NTILE;
-    const bool tail_wave = TAIL && wave < MTOT / 32;
-    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
-    long long r1 = r0 + rows_per_chunk;
-    if (r1 > rows) r1 = rows;
-    f32x16 acc[MT][NT], acct;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) acct[reg] = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) acc[mt][nt][reg] = 0.f;
-    float4 ra[A4], rb[B4], rt = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto gload = [&](long long r) {
-#pragma unroll
-        for (int i = 0; i < A4; ++i) {
-            const int e = (tid + i * NTHR) * 4, kr = e / MTOT, c = e - kr * MTOT;
-            ra[i] = (r + kr < r1) ? *reinterpret_cast<const float4 *>(A + (r + kr) * lda + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < B4; ++i) {
-            const int e = (tid + i * NTHR) * 4, kr = e / NTILE, c = e - kr * NTILE;
-            rb[i] = (r + kr < r1) ? *reinterpret_cast<const float4 *>(B + (r + kr) * ldb + n0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (TAIL && tid < T4) {
-            const int kr = tid / 8, c = (tid % 8) * 4;
-            rt = (r + kr < r1) ? *reinterpret_cast<const float4 *>(Bt + (r + kr) * ldbt + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto lstore = [&](int bufi) {
-#pragma unroll
-        for (int i = 0; i < A4; ++i) *reinterpret_cast<float4 *>(As + bufi * KB * MTOT + (tid + i * NTHR) * 4) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B4; ++i) *reinterpret_cast<float4 *>(Bs + bufi * KB * NTILE + (tid + i * NTHR) * 4) = rb[i];
-        if (TAIL && tid < T4) *reinterpret_cast<float4 *>(Ts + bufi * KB * 32 + tid * 4) = rt;
-    };
-    if (r0 < r1) {
-        gload(r0);
-        lstore(0);
-        __syncthreads();
-        int cur = 0;
-        for (long long r = r0; r < r1; r += KB) {
-            const bool more = r + KB < r1;
-            if (more) gload(r + KB);
-            const float *ap = As + cur * KB * MTOT + (lane >> 5) * MTOT + m0 + (lane & 31);
-            const float *bp = Bs + cur * KB * NTILE + (lane >> 5) * NTILE + n0l + (lane & 31);
-            const float *atp = As + cur * KB * MTOT + (lane >> 5) * MTOT + wave * 32 + (lane & 31);
-            const float *tp = Ts + cur * KB * 32 + (lane >> 5) * 32 + (lane & 31);
-#pragma unroll 4
-            for (int k = 0; k < KB; k += 2) {
-                float av[MT], bv[NT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) av[mt] = ap[k * MTOT + mt * 32];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[nt] = bp[k * NTILE + nt * 32];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
-                if (tail_wave) acct = __builtin_amdgcn_mfma_f32_32x32x2f32(atp[k * MTOT], tp[k * 32], acct, 0, 0, 0);
-            }
-            if (more) lstore(cur ^ 1);
-            __syncthreads();
-            cur ^= 1;
-        }
-    }
-    float *out = partial + (size_t)blockIdx.y * MTOT * Ntot;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int m = m0 + mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                const int n = n0 + n0l + nt * 32 + (lane & 31);
-                out[(size_t)m * Ntot + n] = acc[mt][nt][reg];
-            }
-    if (tail_wave) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int m = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-            out[(size_t)m * Ntot + NTILE + (lane & 31)] = acct[reg];        // TAIL kernels run with a single column block (gridDim.x == 1)
-        }
-    }
-}
-
-// sum the split-K partials: grad[dst + m*ldc + n] += sum_c partial[c][m][n]   (n < Nreal)
-// 256 threads: wave w sums chunks w, w + 4, ... of 64 consecutive outputs (eight loads in flight per lane), the four partial sums are
-// combined in a fixed order -- deterministic, and 4 x 8 times the bytes in flight of one thread per output
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial, int chunks, int Mtot, int Ntot, int Nreal, float *__restrict__ grad, int dst, int ldc) {
-    __shared__ float part[4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + lane;
-    const size_t stride = (size_t)Mtot * Ntot;
-    float s = 0.f;
-    if (e < Mtot * Ntot) {
-#pragma unroll 8
-        for (int c = w; c < chunks; c += 4) s += partial[c * stride + e];
-    }
-    part[w][lane] = s;
-    __syncthreads();
-    if (w == 0 && e < Mtot * Ntot) {
-        const int m = e / Ntot, n = e - m * Ntot;
-        if (n < Nreal) grad[dst + m * ldc + n] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-    }
-}
-
-// Ntot / Nreal: padded / real number of B columns INCLUDING the 32-column tail when Bt != nullptr
-template <int MT, int NT, int WM, int WN, int KB, bool TAIL>
-int launch_wgrad_lds(const float *A, int lda, const float *B, int ldb, const float *Bt, int ldbt, long long rows, const int *d_tiles, float *partial, int Ntot, int Nreal,
-                     float *grad, int dst, int ldc, hipStream_t s) {
-    constexpr int Mtot = WM * MT * 32, NTILE = WN * NT * 32;
-    const int ntiles = TAIL ? 1 : Ntot / NTILE;
-    if (TAIL && Ntot != NTILE + 32) return PNERF_E_INVAL;
-    int chunks = WG_CHUNKS / ntiles;
-    if ((size_t)chunks * Mtot * Ntot > PARTIAL_FLOATS) chunks = (int)(PARTIAL_FLOATS / ((size_t)Mtot * Ntot));     // the tail widens the tile
-    long long rpc = (rows + chunks - 1) / chunks;
-    rpc = (rpc + 63) / 64 * 64;
-    if (rpc < 64) rpc = 64;
-    chunks = (int)((rows + rpc - 1) / rpc);
-    if (chunks < 1) chunks = 1;
-    if ((size_t)chunks * Mtot * Ntot > PARTIAL_FLOATS) return PNERF_E_WS;
-    const size_t lds = (size_t)2 * KB * (Mtot + NTILE + (TAIL ? 32 : 0)) * sizeof(float);
-    if (hipFuncSetAttribute((const void *)k_wgrad_lds<MT, NT, WM, WN, KB, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PNERF_E_LAUNCH;
-    { PnProfScope prof(PNK_WGRAD, s);
-    hipLaunchKernelGGL((k_wgrad_lds<MT, NT, WM, WN, KB, TAIL>), dim3(ntiles, chunks), dim3(WM * WN * 64), lds, s, A, lda, B, ldb, Bt, ldbt, rows, d_tiles, (int)rpc, partial, Ntot); }
-    PnProfScope prof(PNK_WGRAD_REDUCE, s);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(pn_cdiv((long long)Mtot * Ntot, 64)), dim3(256), 0, s, partial, chunks, Mtot, Ntot, Nreal, grad, dst, ldc);
-    PN_CHECK_LAUNCH();
-    return 0;
-}
-
-
-// ------------------------------------------------------------------------------ weight gradients of the four 256-wide layers
+// ------------------------------------------------------------------------------ weight gradients (aggregator and colour layers)
 // dW[m][n] = sum_rows dY[row][m] X[row][n] on the f16 pipe: both operands arrive as ready-made two-plane fragments (the
 // producers wrote them k-major: f16x3.h), so the kernel is glds -> LDS -> ds_read_b128 -> MFMA with no conversion work:
 //   256 x (256 + 32) block (all of dW plus a 32-column tail) in the accumulators of 8 waves (2 (M) x 4 (N), 4 x 2 tiles each +
@@ -712,13 +535,20 @@ template <int N> __device__ __forceinline__ void pn_wait_vm_stages(int stages) {
     else if (stages == 1) PN_WAIT_VMCNT(N);
     else PN_WAIT_VMCNT(0);
 }
-template <int NFB>
+// MF = features of dY (rows of dW): 256 (aggregator layers: 2 (M) x 4 (N) waves, 4 x 2 tiles each) or 128 (colour layers: 2 x 2 tiles each for
+// NFB = 288, 2 x 1 for NFB = 128).  Tail tile (one per wave, m-tile by wave): NFB == 288 -> the operand's columns 256..287; MF == 256 and
+// NFB == 256 -> the constant ones fragment (bias gradient); MF == 128 and NFB == 128 -> none (those bias sums come from k_color_backward).
+// tiles_per = rows per tile of *d_tiles / 16 (the aggregator counts 64-row tiles, and so does the colour MLP).
+template <int NFB, int MF>
 __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, const uint4 *__restrict__ B, long long rg_total,
                                                    const int *__restrict__ d_tiles, float *__restrict__ partial) {
-    constexpr int AU = 2 * 256, BU = 2 * NFB;                 // units (16 B) of one plane of a stage: 2 row groups = 16 rows
+    constexpr int AU = 2 * MF, BU = 2 * NFB;                  // units (16 B) of one plane of a stage: 2 row groups = 16 rows
     constexpr int STAGE = AU + 2 * BU;                        // [A h | B h | B m]
     constexpr int NI = STAGE / 64, NIW = (NI + 7) / 8;        // wave-instructions per stage, per wave (the last ones are padded)
     constexpr int NST = 4;
+    constexpr int MTW = MF / 64, NTW = NFB >= 256 ? 2 : 1;    // m-tiles / main n-tiles per wave
+    constexpr int NMAIN = 4 * NTW * 32;                       // columns covered by the main tiles
+    constexpr bool TAIL_B = NFB > NMAIN, TAIL_ONES = !TAIL_B && MF == 256;
     static_assert(STAGE % 64 == 0, "a stage is a whole number of 1 KB wave copies");
     extern __shared__ __attribute__((aligned(16))) uint4 smem_w[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -728,12 +558,14 @@ __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, 
     // device only.
     const long long stages = (long long)(*d_tiles) * (PN_TILE / 16);
     const int nst = stages > (long long)blockIdx.x ? (int)((stages - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
-    f32x16 acc[4][2], acct;
+    f32x16 acc[MTW][NTW], acct;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         acct[r] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; }
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[i][j][r] = 0.f;
     }
     // stage s -> buffer: wave-instruction j copies units [64 j, 64 j + 64) of the stage's concatenated runs; every wave issues
     // exactly NIW instructions (a wave without a piece of its own re-reads the stage's first KB into the pad slot)
@@ -745,13 +577,15 @@ __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, 
             const int j = pad ? 0 : wave + 8 * i, u0 = 64 * j;
             const uint4 *dst = smem_w + (pad ? NST * STAGE : buf * STAGE + u0);
             const uint4 *src;
-            if (u0 < AU) src = A + rg * 256 + u0;
+            if (u0 < AU) src = A + rg * MF + u0;
             else { const int v = u0 - AU, p = v / BU, u = v - p * BU; src = B + ((long long)p * rg_total + rg) * NFB + u; }
             __builtin_amdgcn_global_load_lds(src + lane, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
     };
     pn_h8 ones = {0, 0, 0, 0, 0, 0, 0, 0};
     if ((lane & 31) == 0) ones = pn_h8{1, 1, 1, 1, 1, 1, 1, 1};
+    // the wave's tail tile: m-tile 4 wm + wn of 8 (MF = 256), m-tile 2 wm + wn of 4 for the waves wn < 2 (MF = 128)
+    const bool has_tail = (TAIL_B || TAIL_ONES) && (MF == 256 || wn < 2);
     if (nst > 0) {
         issue(0, 0);
         if (nst > 1) issue(1, 1);
@@ -760,70 +594,70 @@ __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, 
             // stage s has landed for every wave, and every wave is done with stage s - 1 (whose buffer the next issue overwrites)
             pn_wait_vm_stages<NIW>(nst - 1 - s);
             __builtin_amdgcn_s_barrier();
-#ifndef PN_WG_NOLOAD          // dev ablations (tools/_build only): timing without the loads / without the MFMAs, results meaningless
             if (s + 3 < nst) issue(s + 3, (s + 3) & 3);
-#endif
-#ifdef PN_WG_NOMFMA
-            continue;
-#endif
             const uint4 *st = smem_w + (s & 3) * STAGE;
-            const uint4 *fa = st + (lane >> 5) * 256 + (lane & 31);
+            const uint4 *fa = st + (lane >> 5) * MF + (lane & 31);
             const uint4 *fb = st + AU + (lane >> 5) * NFB + (lane & 31);
-            pn_h8 ah[4], bh[2], bm[2];
+            pn_h8 ah[MTW], bh[NTW], bm[NTW];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ah[i] = __builtin_bit_cast(pn_h8, fa[(4 * wm + i) * 32]);
+            for (int i = 0; i < MTW; ++i) ah[i] = __builtin_bit_cast(pn_h8, fa[(MTW * wm + i) * 32]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { bh[i] = __builtin_bit_cast(pn_h8, fb[(2 * wn + i) * 32]); bm[i] = __builtin_bit_cast(pn_h8, fb[BU + (2 * wn + i) * 32]); }
+            for (int i = 0; i < NTW; ++i) { bh[i] = __builtin_bit_cast(pn_h8, fb[(NTW * wn + i) * 32]); bm[i] = __builtin_bit_cast(pn_h8, fb[BU + (NTW * wn + i) * 32]); }
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MTW; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NTW; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], p == 1 ? bm[j] : bh[j], acc[i][j], 0, 0, 0);
-            // tail tile: row tile 4 wm + wn of dW x columns 256..287
-            const pn_h8 tah = wn == 0 ? ah[0] : wn == 1 ? ah[1] : wn == 2 ? ah[2] : ah[3];
-            if (NFB > 256) {
-                const pn_h8 tbh = __builtin_bit_cast(pn_h8, fb[256]), tbm = __builtin_bit_cast(pn_h8, fb[BU + 256]);
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbh, acct, 0, 0, 0);
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbm, acct, 0, 0, 0);
-            } else {
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, ones, acct, 0, 0, 0);
+            if (has_tail) {
+                pn_h8 tah;
+                if (MF == 256) tah = wn == 0 ? ah[0] : wn == 1 ? ah[1] : wn == 2 ? ah[MTW > 2 ? 2 : 0] : ah[MTW > 3 ? 3 : 0];
+                else tah = wn == 0 ? ah[0] : ah[MTW > 1 ? 1 : 0];
+                if (TAIL_B) {
+                    const pn_h8 tbh = __builtin_bit_cast(pn_h8, fb[NMAIN]), tbm = __builtin_bit_cast(pn_h8, fb[BU + NMAIN]);
+                    acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbh, acct, 0, 0, 0);
+                    acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbm, acct, 0, 0, 0);
+                } else {
+                    acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, ones, acct, 0, 0, 0);
+                }
             }
         }
     }
     float *out = partial + (size_t)blockIdx.x * 256 * 288;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MTW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = (4 * wm + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                out[(size_t)m * 288 + (2 * wn + j) * 32 + (lane & 31)] = acc[i][j][r];
+                const int m = (MTW * wm + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                out[(size_t)m * 288 + (NTW * wn + j) * 32 + (lane & 31)] = acc[i][j][r];
             }
+    if (has_tail) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = (4 * wm + wn) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        out[(size_t)m * 288 + 256 + (lane & 31)] = acct[r];
+        for (int r = 0; r < 16; ++r) {
+            const int m = (MTW * wm + wn) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            out[(size_t)m * 288 + 256 + (lane & 31)] = acct[r];
+        }
     }
 }
 
-// grad_w[m * ldc + n] += invS * sum_c partial[c][m][n]  (n < Nreal);  grad_b[m] += invS * sum_c partial[c][m][bias_col]
-__global__ __launch_bounds__(256) void k_wgrad_reduce_f16(const float *__restrict__ partial, int chunks, int Nreal, int bias_col, const unsigned *__restrict__ gscale,
+// grad_w[m * ldc + n] += invS * sum_c partial[c][m][n]  (m < Mreal, n < Nreal);  grad_b[m] += invS * sum_c partial[c][m][bias_col]
+__global__ __launch_bounds__(256) void k_wgrad_reduce_f16(const float *__restrict__ partial, int chunks, int Mreal, int Nreal, int bias_col, const unsigned *__restrict__ gscale,
                                                           float *__restrict__ grad, int dst_w, int ldc, int dst_b) {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
     const size_t stride = (size_t)256 * 288;
     float s = 0.f;
-    if (e < 256 * 288) {
+    if (e < Mreal * 288) {
 #pragma unroll 8
         for (int c = w; c < chunks; c += 4) s += partial[c * stride + e];
     }
     part[w][lane] = s;
     __syncthreads();
-    if (w == 0 && e < 256 * 288) {
+    if (w == 0 && e < Mreal * 288) {
         float S, invS;
         pn_scale_from_bits(gscale[0], S, invS);
         const int m = e / 288, n = e - m * 288;
@@ -833,19 +667,19 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_f16(const float *__restric
     }
 }
 
-template <int NFB>
+template <int NFB, int MF>
 int launch_wgrad_f16(const uint4 *A, const uint4 *B, long long rg_total, const int *d_tiles, long long rows_max, float *partial, const unsigned *gscale,
                      float *grad, int dst_w, int ldc, int Nreal, int bias_col, int dst_b, hipStream_t s) {
     int chunks = WG_CHUNKS;
     const long long tiles = rows_max / PN_TILE;
     if (tiles < chunks) chunks = (int)(tiles > 0 ? tiles : 1);
     if ((size_t)chunks * 256 * 288 > PARTIAL_FLOATS) return PNERF_E_WS;
-    constexpr size_t lds = ((size_t)4 * (2 * 256 + 2 * 2 * NFB) + 64) * 16;           // four stages [A h | B h | B m] + the pad slot
-    if (hipFuncSetAttribute((const void *)k_wgrad_f16<NFB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PNERF_E_LAUNCH;
+    constexpr size_t lds = ((size_t)4 * (2 * MF + 2 * 2 * NFB) + 64) * 16;            // four stages [A h | B h | B m] + the pad slot
+    if (hipFuncSetAttribute((const void *)k_wgrad_f16<NFB, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PNERF_E_LAUNCH;
     { PnProfScope prof(PNK_WGRAD, s);
-    hipLaunchKernelGGL(k_wgrad_f16<NFB>, dim3(chunks), dim3(512), lds, s, A, B, rg_total, d_tiles, partial); }
+    hipLaunchKernelGGL((k_wgrad_f16<NFB, MF>), dim3(chunks), dim3(512), lds, s, A, B, rg_total, d_tiles, partial); }
     PnProfScope prof(PNK_WGRAD_REDUCE, s);
-    hipLaunchKernelGGL(k_wgrad_reduce_f16, dim3(pn_cdiv(256LL * 288, 64)), dim3(256), 0, s, partial, chunks, Nreal, bias_col, gscale, grad, dst_w, ldc, dst_b);
+    hipLaunchKernelGGL(k_wgrad_reduce_f16, dim3(pn_cdiv((long long)MF * 288, 64)), dim3(256), 0, s, partial, chunks, MF, Nreal, bias_col, gscale, grad, dst_w, ldc, dst_b);
     PN_CHECK_LAUNCH();
     return 0;
 }
@@ -906,13 +740,17 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     const int *dt = sv.cls_info + PN_CI_TILES;
     int rc;
     float *g = d_grad_params;
-    if ((rc = launch_wgrad_f16<PN_NF1>(sv.dy1k, sv.x0k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W1, PN_IN1, PN_IN1, PN_ONES1, PO_B1, s))) return rc;
-    if ((rc = launch_wgrad_f16<PN_H>(sv.dy2k, sv.h1k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W2, PN_H, PN_H, PN_H, PO_B2, s))) return rc;
-    if ((rc = launch_wgrad_f16<PN_NF1>(sv.dy3k, sv.h2k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W3, PN_IN3, PN_IN3, PN_ONES3, PO_B3, s))) return rc;
-    if ((rc = launch_wgrad_f16<PN_H>(sv.dy4k, sv.h3k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W4, PN_H, PN_H, PN_H, PO_B4, s))) return rc;
-    if ((rc = launch_wgrad_lds<2, 2, 2, 4, 16, true>(sv.dc1, PN_HC, sv.fs, PN_H, sv.pe, 32, smp, nullptr, d_partials, 288, PN_INC, g, PO_WC1, PN_INC, s))) return rc;
-    if ((rc = launch_wgrad_lds<2, 1, 2, 4, 16, false>(sv.dc2, PN_HC, sv.c1, PN_HC, nullptr, 0, smp, nullptr, d_partials, 128, 128, g, PO_WC2, PN_HC, s))) return rc;
-    if ((rc = launch_wgrad_lds<2, 1, 2, 4, 16, false>(sv.dc3, PN_HC, sv.c2, PN_HC, nullptr, 0, smp, nullptr, d_partials, 128, 128, g, PO_WC3, PN_HC, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_NF1, PN_H>(sv.dy1k, sv.x0k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W1, PN_IN1, PN_IN1, PN_ONES1, PO_B1, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_H, PN_H>(sv.dy2k, sv.h1k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W2, PN_H, PN_H, PN_H, PO_B2, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_NF1, PN_H>(sv.dy3k, sv.h2k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W3, PN_IN3, PN_IN3, PN_ONES3, PO_B3, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_H, PN_H>(sv.dy4k, sv.h3k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W4, PN_H, PN_H, PN_H, PO_B4, s))) return rc;
+    // the three colour layers: samples instead of neighbor rows, 128 output features; their bias gradients were summed by k_color_backward
+    const long long rgc = sv.samples / 8;
+    const int *ct = sv.cls_info + PN_CI_CTILES;
+    (void)smp;
+    if ((rc = launch_wgrad_f16<PN_NF1, PN_HC>(sv.dc1k, sv.xck, rgc, ct, sv.samples, d_partials, sv.gscale, g, PO_WC1, PN_INC, PN_INC, -1, 0, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_HC, PN_HC>(sv.dc2k, sv.c1k, rgc, ct, sv.samples, d_partials, sv.gscale, g, PO_WC2, PN_HC, PN_HC, -1, 0, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_HC, PN_HC>(sv.dc3k, sv.c2k, rgc, ct, sv.samples, d_partials, sv.gscale, g, PO_WC3, PN_HC, PN_HC, -1, 0, s))) return rc;
     return 0;
 }
 

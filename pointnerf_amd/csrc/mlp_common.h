@@ -51,7 +51,10 @@ struct PnSaved {
     unsigned long long *lmask;          // [row tiles][3 layers h1..h3][PN_NTHR]: LeakyReLU sign bits in the accumulator layout
     unsigned *gscale;                   // [4]: bits of max |d decoded| over the valid samples (the backward derives its scale from it)
     // per valid sample (padded to colour tiles * 64)
-    float *fs, *pe, *c1, *c2, *c3, *dfs, *dc1, *dc2, *dc3;
+    float *fs, *dfs, *c3;               // fp32 rows: aggregated feature [256] and its gradient, last colour post-activation [128]
+    uint4 *xck, *c1k, *c2k;             // k-major [2][samples / 8][288 | 128 | 128] inputs of the three colour layers ([f | view encoding | 0], c1, c2)
+    uint4 *dc1k, *dc2k, *dc3k;          // k-major [samples / 8][128] their output gradients (one plane, scaled)
+    unsigned *cmask;                    // [colour tiles][2 layers c1, c2][256]: LeakyReLU sign bits in the accumulator layout
     // sample classes (aggregate.hip: pn_classify): the valid samples re-listed class by class, and where each class lives
     int *cls_list;                      // [samples] sample ids, class 0 first
     int *cls_info;                      // PN_CI_* words
@@ -59,7 +62,7 @@ struct PnSaved {
     long long rows, samples;
 };
 // cls_info words: per class c (< PN_NCLS): number of samples, first position in cls_list, first tile; then totals
-enum : int { PN_NCLS = 3, PN_CI_COUNT = 0, PN_CI_VBASE = 4, PN_CI_TBASE = 8, PN_CI_TILES = 12, PN_CI_WORDS = 16 };
+enum : int { PN_NCLS = 3, PN_CI_COUNT = 0, PN_CI_VBASE = 4, PN_CI_TBASE = 8, PN_CI_TILES = 12, PN_CI_CTILES = 13 /* colour tiles of the step */, PN_CI_WORDS = 16 };
 int pn_class_slots(int K, int kc[3]);
 int pn_classify(const PnSaved &sv, const int32_t *d_valid_list, const int32_t *d_counters, const int32_t *d_pidx, int K, long long n_valid, bool train, hipStream_t s);
 size_t pn_cls_bytes(long long samples);
