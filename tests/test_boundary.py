@@ -99,3 +99,24 @@ def test_ctypes_structs_mirror_the_header(tmp_path):
     sizes, offs = [list(map(int, l.split())) for l in subprocess.check_output([str(exe)]).decode().splitlines()]
     assert sizes == [ctypes.sizeof(_lib.GridParams), ctypes.sizeof(_lib.Camera), ctypes.sizeof(_lib.Points), ctypes.sizeof(_lib.PointGrads)]
     assert offs == [_lib.PointGrads.ready_event.offset, _lib.Points.n.offset, _lib.Camera.has_bg.offset]
+
+
+def test_querier_reads_query_size_at_call_time(monkeypatch):
+    """Pins the one deliberate behavioural difference of the querier that changes probe results: the reference caches
+    ``opt.query_size`` at construction (point_query.py:39-42) and so ignores ``probe_hole``'s enlargement of it (run/train_ft.py:428);
+    this querier reads it per call, i.e. the probe really runs with ``prob_kernel_size``."""
+    from pointnerf_amd import ops, config
+    from pointnerf_amd.point_query import lighting_fast_querier, clear_grid_cache
+    seen = []
+    monkeypatch.setattr(ops, "grid_hyperparameters", lambda opt, xyz: ([0] * 6, [1, 1, 1], [4, 4, 4], 0.1))
+    monkeypatch.setattr(ops, "make_grid_params", lambda rg, vs, vd, ks, qs, P, max_o, radius: seen.append(tuple(int(q) for q in qs)) or object())
+    monkeypatch.setattr(ops, "build_grid", lambda gp, xyz: object())
+    opt = config.lego_opt()
+    q = lighting_fast_querier(torch.device("cpu"), opt)
+    xyz = torch.zeros(1, 10, 3)
+    clear_grid_cache()
+    q._grid(xyz, 10)
+    opt.query_size = [5, 5, 5]                     # what probe_hole does between two queries of the same cloud
+    q._grid(xyz, 10)
+    assert seen == [(3, 3, 3), (5, 5, 5)], seen   # a new grid, dilated with the new size: not the cached one, not the constructor's value
+    clear_grid_cache()
