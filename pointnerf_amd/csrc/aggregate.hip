@@ -426,13 +426,16 @@ __device__ __forceinline__ void f_epilogue(const f32x16 (&acc)[2][2], const floa
             for (int g = 0; g < 4; ++g) {
                 const int f0 = pn_d_feat(2 * wave + fb, g, lane);
                 const float4 b = bias[fb * 4 + g];
-                float v[4] = {acc[fb][rb][4 * g] + b.x, acc[fb][rb][4 * g + 1] + b.y, acc[fb][rb][4 * g + 2] + b.z, acc[fb][rb][4 * g + 3] + b.w};
+                // bias add and the 0.01 x of the LeakyReLU as packed fp32 operations (v_pk_add_f32 / v_pk_mul_f32: two elements per issue)
+                const pn_f2 v01 = pn_f2{acc[fb][rb][4 * g], acc[fb][rb][4 * g + 1]} + pn_f2{b.x, b.y};
+                const pn_f2 v23 = pn_f2{acc[fb][rb][4 * g + 2], acc[fb][rb][4 * g + 3]} + pn_f2{b.z, b.w};
+                const pn_f2 s01 = v01 * 0.01f, s23 = v23 * 0.01f;
+                float v[4] = {v01[0], v01[1], v23[0], v23[1]};
                 if (BITS) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) mw[fb] = __builtin_amdgcn_alignbit(mw[fb], __float_as_uint(v[i]), 31);
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.01f * v[i]);
+                v[0] = fmaxf(v[0], s01[0]); v[1] = fmaxf(v[1], s01[1]); v[2] = fmaxf(v[2], s23[0]); v[3] = fmaxf(v[3], s23[1]);
                 pn_x_store4<false>(X, 32 * rb + (lane & 31), f0, v[0], v[1], v[2], v[3]);
             }
     mask = ((unsigned long long)mw[1] << 32) | mw[0];

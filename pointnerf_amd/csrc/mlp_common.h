@@ -34,6 +34,7 @@ static_assert(PO_TOTAL == 341764, "parameter count of the lego-script aggregator
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 typedef float pn_f4 __attribute__((ext_vector_type(4)));
+typedef float pn_f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float pn_lrelu_grad(float post) { return post > 0.f ? 1.f : 0.01f; }
 
