@@ -22,6 +22,9 @@ for k in sorted(set(f) | set(w)):
     # read, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is used as reported (uncalibrated).
     per_step_bytes = (2.0 * fk[0] + wk[0]) * 1024.0 / steps
     launches_per_step = max(fk[1], wk[1]) / steps
+    if k in ("neighbors", "probe"):        # one launch per step; bench.py also runs them outside its steps (arena sizing): average per launch
+        per_step_bytes = (2.0 * fk[0] / max(fk[1], 1) + wk[0] / max(wk[1], 1)) * 1024.0
+        launches_per_step = 1.0
     summary[k] = {"FETCH_SIZE_KiB_total": fk[0], "WRITE_SIZE_KiB_total": wk[0], "launches": max(fk[1], wk[1]),
                   "hbm_bytes_per_step_corrected": per_step_bytes, "launches_per_step": launches_per_step}
     traffic[k] = per_step_bytes
