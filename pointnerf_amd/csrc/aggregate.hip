@@ -9,9 +9,9 @@
 //   gather (embedding 128 B + xyz/dir/colour/conf) -> X0[64x288] in LDS (sin/cos PE computed in place)
 //   -> 284->256->256 -> (+7) ->256->256 on the f16 matrix pipe with two-plane operands (f16x3.h: fp32-accurate, 5.3x the
 //   fp32 MFMA rate), weights streamed from an L2-resident fragment-ordered image -> alpha head + K-weighted sums
-//   (sigma, f[256]) -> f to HBM -> colour kernel: 64 samples per tile, 280->128->128->128->3 (fp32 MFMA).
-// Two workgroups (4 waves each) share a CU: while one is in an element-wise phase (feature build, epilogue, K-sums) the
-// other's GEMM has the matrix pipe.  In training mode the operands of the weight-gradient GEMMs are written once, already
+//   (sigma, f[256]) -> f to HBM -> colour kernel: 64 samples per tile, 280->128->128->128->3 on the same two-plane GEMMs.
+// Two workgroups (4 waves each) share a CU: the second one hides the first one's latencies (its VALU / LDS work does not run under
+// the first one's MFMAs: tools/gemm_probe.hip).  In training mode the operands of the weight-gradient GEMMs are written once, already
 // split into their f16 planes and transposed to the k-major order that kernel streams.
 #include "f16x3.h"
 
