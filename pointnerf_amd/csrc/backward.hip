@@ -530,8 +530,12 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
 #else
 #define PN_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #endif
+#ifndef PN_WG_STAGES
+#define PN_WG_STAGES 4          // (measured: 3, 4 and 5 stages give 9.02 / 9.09 / 9.05 ms -- the HBM stream is what limits)
+#endif
 template <int N> __device__ __forceinline__ void pn_wait_vm_stages(int stages) {       // wait until at most `stages` x N of this wave's loads are outstanding
-    if (stages >= 2) PN_WAIT_VMCNT(2 * N);
+    if (stages >= 3) PN_WAIT_VMCNT(3 * N);
+    else if (stages == 2) PN_WAIT_VMCNT(2 * N);
     else if (stages == 1) PN_WAIT_VMCNT(N);
     else PN_WAIT_VMCNT(0);
 }
@@ -545,7 +549,7 @@ __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, 
     constexpr int AU = 2 * MF, BU = 2 * NFB;                  // units (16 B) of one plane of a stage: 2 row groups = 16 rows
     constexpr int STAGE = AU + 2 * BU;                        // [A h | B h | B m]
     constexpr int NI = STAGE / 64, NIW = (NI + 7) / 8;        // wave-instructions per stage, per wave (the last ones are padded)
-    constexpr int NST = 4;
+    constexpr int NST = PN_WG_STAGES;                         // ring depth: NST - 1 stages in flight
     constexpr int MTW = MF / 64, NTW = NFB >= 256 ? 2 : 1;    // m-tiles / main n-tiles per wave
     constexpr int NMAIN = 4 * NTW * 32;                       // columns covered by the main tiles
     constexpr bool TAIL_B = NFB > NMAIN, TAIL_ONES = !TAIL_B && MF == 256;
@@ -587,15 +591,14 @@ __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, 
     // the wave's tail tile: m-tile 4 wm + wn of 8 (MF = 256), m-tile 2 wm + wn of 4 for the waves wn < 2 (MF = 128)
     const bool has_tail = (TAIL_B || TAIL_ONES) && (MF == 256 || wn < 2);
     if (nst > 0) {
-        issue(0, 0);
-        if (nst > 1) issue(1, 1);
-        if (nst > 2) issue(2, 2);
+#pragma unroll
+        for (int i = 0; i < NST - 1; ++i) if (nst > i) issue(i, i);
         for (int s = 0; s < nst; ++s) {
             // stage s has landed for every wave, and every wave is done with stage s - 1 (whose buffer the next issue overwrites)
-            pn_wait_vm_stages<NIW>(nst - 1 - s);
+            pn_wait_vm_stages<NIW>(nst - 1 - s < NST - 2 ? nst - 1 - s : NST - 2);
             __builtin_amdgcn_s_barrier();
-            if (s + 3 < nst) issue(s + 3, (s + 3) & 3);
-            const uint4 *st = smem_w + (s & 3) * STAGE;
+            if (s + NST - 1 < nst) issue(s + NST - 1, (s + NST - 1) % NST);
+            const uint4 *st = smem_w + (s % NST) * STAGE;
             const uint4 *fa = st + (lane >> 5) * MF + (lane & 31);
             const uint4 *fb = st + AU + (lane >> 5) * NFB + (lane & 31);
             pn_h8 ah[MTW], bh[NTW], bm[NTW];
@@ -674,7 +677,7 @@ int launch_wgrad_f16(const uint4 *A, const uint4 *B, long long rg_total, const i
     const long long tiles = rows_max / PN_TILE;
     if (tiles < chunks) chunks = (int)(tiles > 0 ? tiles : 1);
     if ((size_t)chunks * 256 * 288 > PARTIAL_FLOATS) return PNERF_E_WS;
-    constexpr size_t lds = ((size_t)4 * (2 * MF + 2 * 2 * NFB) + 64) * 16;            // four stages [A h | B h | B m] + the pad slot
+    constexpr size_t lds = ((size_t)PN_WG_STAGES * (2 * MF + 2 * 2 * NFB) + 64) * 16;   // the stages [A h | B h | B m] + the pad slot
     if (hipFuncSetAttribute((const void *)k_wgrad_f16<NFB, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PNERF_E_LAUNCH;
     { PnProfScope prof(PNK_WGRAD, s);
     hipLaunchKernelGGL((k_wgrad_f16<NFB, MF>), dim3(chunks), dim3(512), lds, s, A, B, rg_total, d_tiles, partial); }
