@@ -1,6 +1,6 @@
 """GPU parity of the HIP backward (ray-march, colour MLP, aggregator MLP dgrad, gather scatter-add, weight-grad
-GEMMs) against torch.autograd over the CPU oracle.  Tolerance: 1e-3 of each tensor's max |grad| (fp32
-accumulation-order noise); the oracle's own gradients are pinned to the reference modules' gradients by
+GEMMs) against torch.autograd over the CPU oracle.  Tolerances: see _check (5e-4 of each MLP tensor's max |grad|, 2e-4 / 5e-3
+for the per-point tensors); the oracle's own gradients are pinned to the reference modules' gradients by
 tests/test_oracle_golden.py."""
 import numpy as np
 import pytest
@@ -12,7 +12,6 @@ from pointnerf_amd import config, scenes, ops
 from oracle import pyref
 
 pytestmark = pytest.mark.gpu
-RTOL = 1e-3
 
 
 def _hip_grads(opt, xyz, attrs, inp, mlp, probe_hit):
@@ -44,17 +43,22 @@ def _oracle_grads(opt, xyz, attrs, inp, mlp, probe=None):
 
 
 def _check(name, a, b):
-    """>= 99.9 % of the elements within RTOL of the tensor's max |grad|, and no element beyond 10x that.
-    The slack exists because LeakyReLU's derivative is discontinuous: among ~1e8 hidden activations a handful
-    have |pre-activation| < 1e-7, where an ulp of summation-order noise flips 1 <-> 0.01 for that unit of that
-    row on one side only (measured on MI355X: 3 of 8192 points, err 2e-3 of max; everything else <= 1e-5)."""
+    """MLP tensors: every element within 5e-4 of the tensor's max |grad| (measured on MI355X over all cases of this file: worst 1.95e-4, on
+    block1.0 of a 12-ray case; typical 1e-5 -- fp32 accumulation order on our side and on the oracle's, plus the one-plane dY of the
+    weight-gradient GEMM, tests/test_split_f16_cpu.py).
+    Point tensors: >= 99.8 % of the elements within 2e-4 of max |grad|, and no element beyond 5e-3 (measured worst 1.1e-3).  The slack
+    exists because LeakyReLU's derivative is discontinuous: among ~1e8 hidden activations a handful have |pre-activation| < 1e-7, where an
+    ulp of summation-order noise flips 1 <-> 0.01 for that unit of that row on one side only; tests/test_gpu_bench_config.py attributes
+    every such outlier to a kinked row explicitly at the bench configuration."""
     scale = max(float(b.abs().max()), 1e-8)
     e = (a - b).abs()
     err = float(e.max())
-    frac_bad = float((e > RTOL * scale).float().mean())
+    point = name.startswith("points_")
+    tol, cap = (2e-4, 5e-3) if point else (5e-4, 5e-4)
+    frac_bad = float((e > tol * scale).float().mean())
     print("%-28s max|grad| %.3e  err %.3e  rel %.2e  frac>tol %.1e" % (name, scale, err, err / scale, frac_bad))
-    assert frac_bad <= 1e-3, (name, frac_bad)
-    assert err <= 10 * RTOL * scale, (name, err, scale)
+    assert frac_bad <= (2e-3 if point else 0.0), (name, frac_bad)
+    assert err <= cap * scale, (name, err, scale)
 
 
 def _run(opt, xyz, attrs, inp, mlp):
