@@ -120,19 +120,28 @@ __global__ __launch_bounds__(TPB) void k_probe(PnGridDev g, RayGen rg, int R, in
 }
 
 // one thread per (ray, slot)
+// One thread per SELECTED sample: sel_off = exclusive scan of the rays' sample counts, thread t finds its ray by bisection (17 steps in
+// an L2-resident table) and its slot s = t - sel_off[r].  The dense [R, SR] outputs are pre-filled (-1 / 0) by memsets, so the 70 % of
+// the rays that miss the scene and the unused tail slots of the others cost no lanes (the dense launch kept ~25 % of its lanes busy).
 template <int KMAX>
-__global__ __launch_bounds__(TPB) void k_neighbors(PnGridDev g, int ks0, float radius2, long long total, int SR, int K,
-                                                   const float *__restrict__ sample_loc, const int *__restrict__ sel_cnt,
+__global__ __launch_bounds__(TPB) void k_neighbors(PnGridDev g, int ks0, float radius2, int R, int SR, int K,
+                                                   const float *__restrict__ sample_loc, const int *__restrict__ sel_off,
                                                    int *__restrict__ sample_pidx, int *__restrict__ sample_nn) {
-    const long long index = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (index >= total) return;
-    const int r = (int)(index / SR), s = (int)(index - (long long)r * SR);
+    const long long total_sel = sel_off[R];
+    for (long long t = (long long)blockIdx.x * TPB + threadIdx.x; t < total_sel; t += (long long)gridDim.x * TPB) {
+    int lo = 0, hi = R;                                  // invariant: sel_off[lo] <= t < sel_off[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (sel_off[mid] <= (int)t) lo = mid; else hi = mid;
+    }
+    const int r = lo, s = (int)t - sel_off[lo];
+    const long long index = (long long)r * SR + s;
     int out[KMAX];
     float buf[KMAX];
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) { out[j] = -1; buf[j] = 0.f; }
     int kid = 0;
-    if (s < sel_cnt[r]) {
+    {
         const float cx = sample_loc[index * 3], cy = sample_loc[index * 3 + 1], cz = sample_loc[index * 3 + 2];
         const int fx = pn_cell(cx, g.ox, g.vx), fy = pn_cell(cy, g.oy, g.vy), fz = pn_cell(cz, g.oz, g.vz);
         const int cell0 = g.info[PNERF_GI_CELL0];
@@ -185,6 +194,7 @@ __global__ __launch_bounds__(TPB) void k_neighbors(PnGridDev g, int ks0, float r
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) if (j < K) o[j] = out[j];
     sample_nn[index] = min(kid, K);
+    }
 }
 
 // does the ray have any sample with a neighbor?  + global tallies.  One wavefront walks RAYS_PER_WAVE rays and the
@@ -224,7 +234,8 @@ extern "C" int pnerf_debug_uniform(uint64_t seed, uint64_t first, int64_t n, flo
 }
 
 extern "C" size_t pnerf_query_workspace_bytes(int R, int SR) {
-    return pn_align((size_t)(R > 0 ? R : 1) * sizeof(int)) + pn_align(pn_scan_scratch_ints((long long)R * SR) * sizeof(int));
+    return pn_align((size_t)(R > 0 ? R : 1) * sizeof(int)) + pn_align((size_t)(R > 0 ? R + 1 : 2) * sizeof(int)) +
+           pn_align(pn_scan_scratch_ints((long long)R * SR) * sizeof(int));
 }
 
 extern "C" int pnerf_query(const pnerf_grid_params *gp, const void *d_grid_ws, const float *d_raypos,
@@ -244,6 +255,7 @@ extern "C" int pnerf_query(const pnerf_grid_params *gp, const void *d_grid_ws, c
     if (R == 0) return 0;
     PnCarver cv(d_query_ws, ws_bytes);
     int *sel_cnt = cv.take<int>(R);
+    int *sel_off = cv.take<int>(R + 1);
     int *scan = cv.take<int>(pn_scan_scratch_ints((long long)R * SR));
     PnGridDev g = pn_grid_dev(gp, d_grid_ws, 0);
     RayGen rg;
@@ -259,9 +271,17 @@ extern "C" int pnerf_query(const pnerf_grid_params *gp, const void *d_grid_ws, c
     const float radius2 = gp->radius * gp->radius;     // fp32 product, as .cu:410
     const int nbk = pn_cdiv(total, TPB);
     { PnProfScope prof(PNK_NEIGHBORS, s);
-    if (K <= 4) hipLaunchKernelGGL(k_neighbors<4>, dim3(nbk), dim3(TPB), 0, s, g, gp->kernel_size[0], radius2, total, SR, K, d_sample_loc, sel_cnt, d_sample_pidx, d_sample_nn);
-    else if (K <= 8) hipLaunchKernelGGL(k_neighbors<8>, dim3(nbk), dim3(TPB), 0, s, g, gp->kernel_size[0], radius2, total, SR, K, d_sample_loc, sel_cnt, d_sample_pidx, d_sample_nn);
-    else hipLaunchKernelGGL(k_neighbors<16>, dim3(nbk), dim3(TPB), 0, s, g, gp->kernel_size[0], radius2, total, SR, K, d_sample_loc, sel_cnt, d_sample_pidx, d_sample_nn);
+    int rc = pn_exclusive_scan_i32(sel_cnt, sel_off, R, scan, s);
+    if (rc) return rc;
+    if (hipMemsetAsync(d_sample_pidx, 0xFF, (size_t)total * K * sizeof(int), s) != hipSuccess) return PNERF_E_LAUNCH;      // -1 everywhere
+    if (hipMemsetAsync(d_sample_nn, 0, (size_t)total * sizeof(int), s) != hipSuccess) return PNERF_E_LAUNCH;
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) != hipSuccess) return PNERF_E_LAUNCH;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
+    const int grid = nbk < 16 * ncu ? nbk : 16 * ncu;
+    if (K <= 4) hipLaunchKernelGGL(k_neighbors<4>, dim3(grid), dim3(TPB), 0, s, g, gp->kernel_size[0], radius2, R, SR, K, d_sample_loc, sel_off, d_sample_pidx, d_sample_nn);
+    else if (K <= 8) hipLaunchKernelGGL(k_neighbors<8>, dim3(grid), dim3(TPB), 0, s, g, gp->kernel_size[0], radius2, R, SR, K, d_sample_loc, sel_off, d_sample_pidx, d_sample_nn);
+    else hipLaunchKernelGGL(k_neighbors<16>, dim3(grid), dim3(TPB), 0, s, g, gp->kernel_size[0], radius2, R, SR, K, d_sample_loc, sel_off, d_sample_pidx, d_sample_nn);
     }
     PnProfScope prof(PNK_COMPACT, s);
     hipLaunchKernelGGL(k_ray_hit, dim3(pn_cdiv(R, (TPB / 64) * RAYS_PER_WAVE)), dim3(TPB), 0, s, R, SR, sel_cnt, d_sample_nn, d_ray_hit, d_counters);
