@@ -78,6 +78,7 @@ def parse():
     ap.add_argument("--no-overlap-comm", action="store_true", help="N > 1: all-reduce the point gradients after the whole backward instead of behind the weight-gradient GEMMs")
     ap.add_argument("--point-grads", default="auto", choices=("auto", "dense", "sparse"),
                     help="N > 1: exchange of the per-point gradients: dense all-reduce (one bucket, overlapped), sparse touched-row exchange, auto = sparse from 6 M points")
+    ap.add_argument("--unfused-zero-one", action="store_true", help="A/B: the zero-one regulariser as the reference's chain of ATen ops on a materialised conf_coefficient")
     ap.add_argument("--zero1", action="store_true", help="N > 1: shard the point-parameter Adam (reduce-scatter + all-gather) instead of all-reducing the gradients")
     return ap.parse_args()
 
@@ -162,6 +163,7 @@ def main():
     opt = opt_fn(is_train=0 if args.render_only else 1)
     model = build_model(opt, n_points, dev, points_fn)
     agg, npnt = model.aggregator, model.neural_points
+    model.fused_zero_one = not args.unfused_zero_one     # the zero-one regulariser as one fused pass over the neighbor table (ops.ZeroOneConf)
     mlp_params = [p for p in agg.parameters() if p.requires_grad]
     pt_params = [p for p in (npnt.points_embeding, npnt.points_conf, npnt.points_dir, npnt.points_color) if p.requires_grad]
     # the reference's two Adam instances (mvs_points_volumetric_model.py:80-91) as one-pass HIP updates; --zero1 shards the

@@ -100,6 +100,17 @@ int pnerf_gather_rows(const float *d_src, int n_src, int width, const int32_t *d
 int pnerf_scatter_add_rows(const float *d_grad_rows, const int32_t *d_idx, int64_t n_idx, int width,
                            float *d_grad_src, int n_src, void *stream);
 
+/* ---- the zero-one regulariser on the neighbor slots' confidences, fused (gather + gradient_clamp of
+ * models/aggregators/point_aggregators.py:722-724,812 + loss_zero_one of models/base_rendering_model.py:630-641 + their backward).
+ * forward: d_partial[b], b < pnerf_zero_one_blocks(n_idx), = per-block sums of log(v) + log(1 - v) over the n_idx slots
+ * (v = clamp(clamp(conf[max(idx, 0)], 1e-4, 1), eps, 1 - eps)); the caller adds them and divides by its (global) element count.
+ * backward: d_grad_conf[max(idx, 0)] += d_gscale[0] * (1 / v - 1 / (1 - v)) where the clamp to [eps, 1 - eps] was inactive. */
+int pnerf_zero_one_blocks(int64_t n_idx);
+int pnerf_zero_one_forward(const float *d_conf, int n_points, const int32_t *d_idx, int64_t n_idx, float eps,
+                           float *d_partial, void *stream);
+int pnerf_zero_one_backward(const float *d_conf, int n_points, const int32_t *d_idx, int64_t n_idx, float eps,
+                            const float *d_gscale, float *d_grad_conf, void *stream);
+
 /* ---- aggregator MLP + renderer (PointAggregator.forward/viewmlp,
  * models/aggregators/point_aggregators.py:488-644,727-814; ray-dist,
  * models/neural_points_volumetric_model.py:271-279; ray_march,

@@ -227,7 +227,83 @@ __global__ __launch_bounds__(TPB) void k_scatter_add_rows(const float *__restric
     __syncthreads();
     if (use_lds && threadIdx.x < width && row0[threadIdx.x] != 0.f) atomicAdd(&grad_src[threadIdx.x], row0[threadIdx.x]);
 }
+
+// ---- the zero-one regulariser on the confidences of the hit rays' neighbor slots, fused --------------------------------------------
+// Reference: conf_coefficient = gradient_clamp(points_conf[clamp(sample_pidx, min=0)], 1e-4, 1) (point_aggregators.py:722-724, 812) and
+// loss_zero_one = mean(log(v) + log(1 - v)), v = clamp(conf_coefficient, eps, 1 - eps) (base_rendering_model.py:630-641): a gather, two
+// clamps, two logs, a reduction and their autograd mirror over [R'', SR, K] elements (84 M at configs[3]) -- ~20 element-wise passes
+// in ATen.  Here: one pass that sums the terms per block (the caller adds the per-block partials: deterministic), one pass that
+// adds  g * (1 / v - 1 / (1 - v)) [eps <= c' <= 1 - eps]  into the confidence gradient, with the point-0 flood of the empty slots
+//  reduced per block first.
+__device__ __forceinline__ float pn_zero_one_value(const float *__restrict__ conf, int n, int p, float eps, bool &inside) {
+    p = p < 0 ? 0 : (p >= n ? n - 1 : p);
+    const float c = fminf(fmaxf(conf[p], 1e-4f), 1.0f);         // gradient_clamp: clamp forward, identity backward
+    inside = c >= eps && c <= 1.f - eps;                        // torch.clamp's backward mask (bounds included)
+    return fminf(fmaxf(c, eps), 1.f - eps);
+}
+__global__ __launch_bounds__(TPB) void k_zero_one_forward(const float *__restrict__ conf, int n, const int *__restrict__ idx, long long n_idx, float eps,
+                                                          float *__restrict__ partial) {
+    __shared__ float red[TPB / 64];
+    float acc = 0.f;
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < n_idx; e += (long long)gridDim.x * TPB) {
+        bool inside;
+        const float v = pn_zero_one_value(conf, n, idx[e], eps, inside);
+        acc += logf(v) + logf(1.f - v);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < TPB / 64; ++w) t += red[w];
+        partial[blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(TPB) void k_zero_one_backward(const float *__restrict__ conf, int n, const int *__restrict__ idx, long long n_idx, float eps,
+                                                           const float *__restrict__ gscale, float *__restrict__ grad_conf) {
+    __shared__ float row0;
+    if (threadIdx.x == 0) row0 = 0.f;
+    __syncthreads();
+    const float gs = gscale[0];
+    float mine0 = 0.f;
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < n_idx; e += (long long)gridDim.x * TPB) {
+        const int p = idx[e];
+        bool inside;
+        const float v = pn_zero_one_value(conf, n, p, eps, inside);
+        if (!inside) continue;
+        const float g = gs * (1.f / v - 1.f / (1.f - v));
+        if (p <= 0) mine0 += g;
+        else atomicAdd(&grad_conf[p >= n ? n - 1 : p], g);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine0 += __shfl_xor(mine0, off, 64);
+    if ((threadIdx.x & 63) == 0 && mine0 != 0.f) atomicAdd(&row0, mine0);
+    __syncthreads();
+    if (threadIdx.x == 0 && row0 != 0.f) atomicAdd(&grad_conf[0], row0);
+}
 }  // namespace
+
+extern "C" int pnerf_zero_one_blocks(int64_t n_idx) {
+    const long long b = (n_idx + TPB - 1) / TPB;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+extern "C" int pnerf_zero_one_forward(const float *d_conf, int n_points, const int32_t *d_idx, int64_t n_idx, float eps, float *d_partial, void *stream) {
+    if (!d_conf || !d_partial || n_points <= 0 || n_idx < 0 || (n_idx > 0 && !d_idx)) return PNERF_E_INVAL;
+    PnProfScope prof(PNK_GATHER, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_zero_one_forward, dim3(pnerf_zero_one_blocks(n_idx)), dim3(TPB), 0, (hipStream_t)stream, d_conf, n_points, d_idx, (long long)n_idx, eps, d_partial);
+    PN_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pnerf_zero_one_backward(const float *d_conf, int n_points, const int32_t *d_idx, int64_t n_idx, float eps, const float *d_gscale,
+                                       float *d_grad_conf, void *stream) {
+    if (n_idx == 0) return 0;
+    if (!d_conf || !d_idx || !d_gscale || !d_grad_conf || n_points <= 0 || n_idx < 0) return PNERF_E_INVAL;
+    PnProfScope prof(PNK_GATHER, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_zero_one_backward, dim3(pnerf_zero_one_blocks(n_idx)), dim3(TPB), 0, (hipStream_t)stream, d_conf, n_points, d_idx, (long long)n_idx, eps, d_gscale, d_grad_conf);
+    PN_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int pnerf_gather_rows(const float *d_src, int n_src, int width, const int32_t *d_idx, int64_t n_idx, float *d_dst, void *stream) {
     if (n_idx == 0) return 0;                      // nothing to gather (a chunk of rays that hit nothing): pointers may be null

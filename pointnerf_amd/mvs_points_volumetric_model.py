@@ -141,6 +141,7 @@ class MvsPointsVolumetricModel:
                                                         num_viewdir_freqs=getattr(opt, "num_viewdir_freqs", 0)).to(self.device)
         if self.device.type == "cuda":
             self.aggregator.flatten_()
+            self.net_ray_marching.fused_zero_one = True      # compute_losses takes the fused zero-one pass (ops.ZeroOneConf)
         self.model_names = ["ray_marching"]
 
     def get_networks(self):
@@ -289,6 +290,14 @@ class MvsPointsVolumetricModel:
             self.loss_total = self.loss_total + (loss * opt.color_loss_weights[i] + 1e-6 / W)
             setattr(self, "loss_" + name, loss)
         for i, name in enumerate(opt.zero_one_loss_items):
+            if name == "conf_coefficient" and "_zero_one" in out:      # fused form (NeuralPointsRayMarching.fused_zero_one)
+                from . import ops
+                conf, pidx_hit = out["_zero_one"]
+                n = pdist.global_counts(pidx_hit.numel(), device=dev)[0]
+                loss = ops.zero_one_conf_sum(conf, pidx_hit, opt.zero_epsilon) / n.clamp(min=1.0)
+                self.loss_total = self.loss_total + loss * opt.zero_one_loss_weights[i]
+                setattr(self, "loss_" + name, loss)
+                continue
             if name not in out:
                 continue
             val = torch.clamp(out[name], opt.zero_epsilon, 1 - opt.zero_epsilon)

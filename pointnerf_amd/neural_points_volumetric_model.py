@@ -99,7 +99,13 @@ class NeuralPointsRayMarching(nn.Module):
         output["coarse_is_background"] = take(bg_trans)[None, :, None]
         output["ray_mask"] = hit.to(torch.int8)[None]
         want_w = (opt.sparse_loss_weight > 0) or ("conf_coefficient" in opt.zero_one_loss_items) or getattr(opt, "prob", 0) != 0
-        if want_w:
+        # ``fused_zero_one`` (ours; set by callers whose loss goes through dist.hot_path_loss / the model shell of this package): when the
+        # only consumer of conf_coefficient is the zero-one regulariser, hand out what that loss needs -- (points_conf, the hit rays'
+        # neighbor table) under "_zero_one" -- instead of materialising weight / conf_coefficient [1, R'', SR, K] (ops.ZeroOneConf)
+        only_zero_one = getattr(self, "fused_zero_one", False) and opt.sparse_loss_weight <= 0 and getattr(opt, "prob", 0) == 0
+        if want_w and only_zero_one:
+            output["_zero_one"] = (self.neural_points.points_conf, take(dense["sample_pidx"]))
+        elif want_w:
             output["weight"] = take(weight)[None].detach()
             output["blend_weight"] = take(blend_w)[None, ..., None].detach()
             conf = self.neural_points.points_conf

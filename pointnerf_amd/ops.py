@@ -338,6 +338,37 @@ def gather_rows(src, idx):
     return GatherRows.apply(src, idx)
 
 
+class ZeroOneConf(torch.autograd.Function):
+    """sum over the neighbor slots of  log(v) + log(1 - v),  v = clamp(gradient_clamp(conf[max(pidx, 0)], 1e-4, 1), eps, 1 - eps): the
+    numerator of the reference's ``loss_zero_one`` on ``conf_coefficient`` (models/base_rendering_model.py:630-641) without materialising
+    the [R'', SR, K] tensor -- one HIP pass forward, one backward (pnerf_zero_one_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, conf, pidx, eps):
+        lib = L.lib()
+        c = conf.detach().reshape(-1)
+        _need_cuda(c, "points_conf")
+        idx = pidx.reshape(-1)
+        nb = lib.pnerf_zero_one_blocks(idx.numel())
+        part = torch.empty(nb, dtype=torch.float32, device=c.device)
+        L.check(lib.pnerf_zero_one_forward(_ptr(c), c.numel(), _ptr(idx), idx.numel(), float(eps), _ptr(part), _stream()), "pnerf_zero_one_forward")
+        ctx.save_for_backward(c, idx)
+        ctx.eps, ctx.shape = float(eps), conf.shape
+        return part.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        c, idx = ctx.saved_tensors
+        grad = torch.zeros_like(c)
+        gs = g.detach().reshape(1).to(torch.float32).contiguous()
+        L.check(L.lib().pnerf_zero_one_backward(_ptr(c), c.numel(), _ptr(idx), idx.numel(), ctx.eps, _ptr(gs), _ptr(grad), _stream()), "pnerf_zero_one_backward")
+        return grad.view(ctx.shape), None, None
+
+
+def zero_one_conf_sum(conf, pidx, eps):
+    return ZeroOneConf.apply(conf, pidx.contiguous(), eps)
+
+
 # ------------------------------------------------------------------------------------------ profiling
 def prof_enable(on=True):
     L.lib().pnerf_prof_enable(1 if on else 0)

@@ -123,3 +123,26 @@ def test_emulated_neighbor_query_bit_exact(monkeypatch, seed, n, K, SR, size, kw
     q = pyref.query(opt, xyz, inp)
     assert int((q["sample_pidx"] >= 0).sum()) > 50
     TQ._assert_same(q, *TQ._native_op(opt, xyz, inp, q["hp"]))
+
+
+def test_emulated_fused_zero_one_loss_matches_the_torch_chain():
+    """ops.ZeroOneConf (one fused pass forward, one backward) against the chain it replaces: gather with the -1 -> point 0 rule,
+    gradient_clamp, clamp(eps, 1 - eps), log + log(1 - .), sum; value and the gradient on points_conf"""
+    from pointnerf_amd import ops
+    from pointnerf_amd.neural_points_volumetric_model import gradient_clamp
+    g = torch.Generator().manual_seed(3)
+    N, M, eps = 500, 6000, 1e-3
+    conf = torch.rand(1, N, 1, generator=g) * 1.2 - 0.1                 # some below 1e-4 / eps, some above 1 - eps and above 1
+    conf[0, :5, 0] = torch.tensor([0.0, 1e-4, 1e-3, 1 - 1e-3, 1.0])     # the clamp bounds themselves
+    pidx = torch.randint(-1, N, (M,), generator=g, dtype=torch.int32)
+    pidx[torch.rand(M, generator=g) < 0.4] = -1                         # empty slots: the point-0 flood
+    a = conf.clone().requires_grad_(True)
+    cc = gradient_clamp(a.reshape(-1)[pidx.long().clamp(min=0)])
+    v = cc.clamp(eps, 1 - eps)
+    ref = (torch.log(v) + torch.log(1 - v)).sum()
+    (ref * 0.37).backward()
+    b = conf.clone().requires_grad_(True)
+    got = ops.zero_one_conf_sum(b, pidx, eps)
+    (got * 0.37).backward()
+    assert abs(float(got) - float(ref)) <= 2e-5 * abs(float(ref))
+    assert torch.allclose(b.grad, a.grad, rtol=2e-5, atol=1e-5 * float(a.grad.abs().max()))

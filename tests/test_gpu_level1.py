@@ -254,3 +254,27 @@ def test_prune_and_grow_between_steps_keep_parity():
         full = pyref.fill_invalid(ref, inp)
     assert torch.equal(out["ray_mask"].cpu(), ref["ray_mask"])
     assert float((out["coarse_raycolor"].cpu() - full["coarse_raycolor"]).abs().max()) <= 1e-4
+
+
+def test_fused_zero_one_loss_matches_the_torch_chain():
+    """ops.ZeroOneConf against gather + gradient_clamp + clamp + logs + sum on the device, 20 M slots with the point-0 flood"""
+    from pointnerf_amd import ops
+    from pointnerf_amd.neural_points_volumetric_model import gradient_clamp
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    N, M, eps = 300_000, 20_000_000, 1e-3
+    conf = (torch.rand(1, N, 1, generator=g) * 1.2 - 0.1).to(dev)
+    pidx = torch.randint(-1, N, (M,), generator=g, dtype=torch.int32)
+    pidx[torch.rand(M, generator=g) < 0.5] = -1
+    pidx = pidx.to(dev)
+    a = conf.clone().requires_grad_(True)
+    cc = gradient_clamp(ops.gather_rows(a.reshape(-1, 1), pidx)[..., 0])
+    v = cc.clamp(eps, 1 - eps)
+    ref = (torch.log(v) + torch.log(1 - v)).sum() / M
+    ref.backward()
+    b = conf.clone().requires_grad_(True)
+    got = ops.zero_one_conf_sum(b, pidx, eps) / M
+    got.backward()
+    assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref))
+    scale = float(a.grad.abs().max())
+    assert float((b.grad - a.grad).abs().max()) <= 1e-4 * scale      # point 0 collects ~1e7 terms on both sides: fp32 summation order
