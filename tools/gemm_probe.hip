@@ -85,11 +85,12 @@ int main() {
     char *img; float *out;
     hipMalloc(&img, 4 * PN_IMG(16, 8)); hipMemset(img, 0x2c, 4 * PN_IMG(16, 8));
     hipMalloc(&out, 4096);
+    // the same TOTAL other-phase work per tile for both organisations: B has twice the threads, so half the per-thread counts
     const int cfg[5][3] = {{0, 0, 0}, {6, 0, 0}, {0, 2500, 0}, {0, 0, 600}, {0, 1250, 300}};
     for (int c = 0; c < 5; ++c) {
         run<4>("A: 4 waves x (2 fb x 2 rb)", img, out, 256, 100, cfg[c][0], cfg[c][1], cfg[c][2]);
         run<4>("A: 4 waves x (2 fb x 2 rb)", img, out, 512, 100, cfg[c][0], cfg[c][1], cfg[c][2]);
-        run<8>("B: 8 waves x (1 fb x 2 rb)", img, out, 512, 100, cfg[c][0], cfg[c][1], cfg[c][2]);
+        run<8>("B: 8 waves x (1 fb x 2 rb), same total other work", img, out, 512, 100, cfg[c][0], cfg[c][1] / 2, cfg[c][2] / 2);
     }
     return 0;
 }
