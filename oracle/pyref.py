@@ -28,7 +28,10 @@ Reference followed (under /root/reference), function by function:
 
 Parity pin: the reference's own PointAggregator / ray_march / near_far_linear_ray_generation
 import and run on CPU in the authoring container; tests/golden/make_golden.py stores their
-outputs on seeded inputs and tests/test_oracle_golden.py checks this file against them.
+outputs on seeded inputs and tests/test_oracle_golden.py checks this file against them.  The blocks of
+modules that cannot be imported here (ray_dist, fill_invalid, the opt.prob == 1 outputs, probe_hole, test(),
+construct_vox_points_closest) are exec'ed from the reference's SOURCE TEXT by the same script
+(refblocks.npz, refshell.npz) and pinned by tests/test_oracle_golden.py and tests/test_reference_pins.py.
 Only the lego-script configuration of the aggregator (agg_dist_pers=20,
 linear kernel, agg_intrp_order=2, LeakyReLU, apply_pnt_mask=1, *_xyz_mode None) is restated.
 """
@@ -321,7 +324,8 @@ def to_torch_inputs(d):
 
 
 def probe_outputs(out, points):
-    """neural_points_volumetric_model.py:331-362 (opt.prob == 1) on the oracle's render() result."""
+    """neural_points_volumetric_model.py:331-362 (opt.prob == 1) on the oracle's render() result.  Pinned bit for bit against the
+    reference's own statements (exec'ed from the source text: tests/golden/refshell.npz, tests/test_reference_pins.py)."""
     q = out["query"]
     op = out["coarse_point_opacity"]
     mx, ind = torch.max(op, dim=-1, keepdim=True)
@@ -344,7 +348,8 @@ def vox_points_closest(xyz, vox_res, space_min=None, space_max=None):
     """models/mvs/mvs_utils.py:537-561 (construct_vox_points_closest) restated on CPU without torch_scatter, in the canonical
     order of the HIP path: voxels in torch.unique(dim=0) order, centroid = fp32 sum in point order / count, closest member by
     fp32 sqrt(dx^2 + dy^2 + dz^2), ties to the lowest index.  Points outside a caller-given box are dropped.
-    Parity unpinned by the reference (torch_scatter is absent here); the voxel list is pinned against torch.unique in the tests."""
+    Pinned against the reference function itself, exec'ed from its source text with pure-torch scatter_mean / scatter_min
+    (tests/golden/refshell.npz, tests/test_reference_pins.py): voxel list, centroids and closest members identical."""
     xyz = xyz.float()
     if space_min is None:
         xyz_min, xyz_max = torch.min(xyz, dim=-2)[0], torch.max(xyz, dim=-2)[0]
@@ -434,7 +439,8 @@ def rank_ray_miss(new_id, newloss, inds, losses):
 
 
 def probe_hole_mask(ray_mask, opacity, far_dist, raycolor, gt, bg, edge, opacity_thresh, far_thresh=-1.0):
-    """run/train_ft.py:489-500 + bloat_inds :532-540 as index loops over numpy [H,W,*] maps."""
+    """run/train_ft.py:489-500 + bloat_inds :532-540 as index loops over numpy [H,W,*] maps.  Pinned against the reference's
+    probe_hole exec'ed from its source text on stand-in model / dataset objects (tests/test_reference_pins.py)."""
     H, W = edge.shape
     miss = (ray_mask < 1) & (np.linalg.norm(gt - bg, axis=-1) > 0.002) & edge
     near = np.zeros((H, W), np.float32)
@@ -449,7 +455,8 @@ def probe_hole_mask(ray_mask, opacity, far_dist, raycolor, gt, bg, edge, opacity
 
 def test_view_losses(canvas, gt_rays, pixel_idx, ray_mask, height, width):
     """run/train_ft.py:330-372 for one view with numpy: canvas [H,W,3] rendered colours, gt_rays [P,3] and pixel_idx [P,2]
-    (px, py) in row-major pixel order, ray_mask [P] bool.  Returns {item: mse, item_psnr: psnr}."""
+    (px, py) in row-major pixel order, ray_mask [P] bool.  Returns {item: mse, item_psnr: psnr}.  Pinned against the reference's
+    test() exec'ed from its source text on stand-in model / dataset / visualizer objects (tests/test_reference_pins.py)."""
     edge = np.zeros((height, width), bool)
     edge[pixel_idx[:, 1], pixel_idx[:, 0]] = True
     gt = np.zeros((height * width, 3), np.float32)

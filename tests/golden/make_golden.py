@@ -13,6 +13,9 @@ What is pinned (the reference has no tests or golden vectors of it
     uniforms for the call), and two pure-torch blocks of models/neural_points_volumetric_model.py that cannot be imported
     (the module needs absent third-party packages) and are therefore exec'ed FROM THE REFERENCE'S SOURCE TEXT: the ray_dist
     block (:271-279) and fill_invalid (:87-123)
+  * refshell.npz (python tests/golden/make_golden.py --shell): the opt.prob == 1 outputs of the forward (:331-362),
+    construct_vox_points_closest (models/mvs/mvs_utils.py:537-561), probe_hole (run/train_ft.py:417-540) and test()
+    (run/train_ft.py:252-414), all exec'ed from the reference's source text -- see ref_shell()
 Inputs are NOT stored: they are regenerated from seeds by pointnerf_amd/scenes.py,
 oracle/pyref.init_mlp_params and the C oracle query, all deterministic.
 """
@@ -136,9 +139,121 @@ def ref_blocks():
     print("refblocks ok", {k: v.shape for k, v in fix.items()})
 
 
+def _ref_lines(path, first, last, must_start):
+    """lines first..last (1-based, inclusive) of a reference source file, dedented; asserts the block is the expected one"""
+    import textwrap
+    src = open(path).read().split("\n")
+    block = textwrap.dedent("\n".join(src[first - 1:last]))
+    assert block.lstrip().startswith(must_start), (path, first, block[:120])
+    return block
+
+
+def _cpu_text(block):
+    """the reference's functions place their tensors on "cuda"; the same statements on the CPU (a textual substitution of
+    the device name, nothing else)"""
+    return block.replace('"cuda"', '"cpu"').replace("'cuda'", "'cpu'").replace(".cuda()", ".cpu()")
+
+
+def scatter_mean(src, index, dim=0):
+    """torch_scatter.scatter_mean on the CPU (the package is absent here): fp32 sums in element order / counts"""
+    n = int(index.max()) + 1
+    out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype).index_add_(0, index, src)
+    cnt = torch.zeros(n, dtype=src.dtype).index_add_(0, index, torch.ones(len(index), dtype=src.dtype))
+    return out / cnt.view((-1,) + (1,) * (src.dim() - 1))
+
+
+def scatter_min(src, index, dim=0):
+    """torch_scatter.scatter_min for 1-D src: (minimum per group, position of its FIRST occurrence) -- the CPU kernel of
+    torch_scatter 2.0.8 updates on a strict `<` while walking the elements in order"""
+    o1 = torch.argsort(src, stable=True)
+    o2 = o1[torch.argsort(index[o1], stable=True)]
+    gi = index[o2]
+    first = torch.cat([torch.tensor([True]), gi[1:] != gi[:-1]])
+    arg = o2[first]
+    return src[arg], arg
+
+
+def ref_shell():
+    """refshell.npz: four blocks of the reference that cannot be imported here (absent third-party packages), exec'ed FROM THE
+    REFERENCE'S SOURCE TEXT on seeded inputs:
+      * the opt.prob == 1 outputs of NeuralPointsRayMarching.forward (models/neural_points_volumetric_model.py:331-362)
+      * construct_vox_points_closest (models/mvs/mvs_utils.py:537-561) with the two torch_scatter calls served by the pure-torch
+        stand-ins above
+      * probe_hole + bloat_inds (run/train_ft.py:417-540) and test() (run/train_ft.py:252-414) on the stand-in model / dataset /
+        visualizer of tests/shell_fakes.py (device name "cuda" -> "cpu" in the text)"""
+    import types
+    import shell_fakes as SF
+    from shell_fakes import vox_cloud, shell_probe_setup, shell_test_setup
+    fix = {}
+    # ---- (a) probe outputs: the forward body's own statements on the oracle's tensors
+    opt, xyz, attrs, inp, mlp = build_case("small_k8")
+    points = dict(xyz=xyz, **attrs)
+    out = pyref.render(opt, points, mlp, inp)
+    q = out["query"]
+    nb = pyref.gather_neighbors(points, q["sample_pidx"], inp["camrotc2w"][0], inp["campos"][0])
+    block = _ref_lines("/root/reference/models/neural_points_volumetric_model.py", 331, 362, "if self.opt.prob == 1 and output[")
+    env = dict(torch=torch, self=types.SimpleNamespace(opt=types.SimpleNamespace(prob=1)),
+               output={"coarse_point_opacity": out["coarse_point_opacity"].detach()}, sample_pnt_mask=nb["mask"],
+               weight=out["weight"].detach(), conf_coefficient=out["conf_coefficient"].detach(), sample_loc_w=q["sample_loc_w"],
+               sampled_xyz=nb["xyz"], sampled_color=nb["color"], sampled_dir=nb["dir"], sampled_conf=nb["conf"], sampled_embedding=nb["emb"])
+    exec(block, env)
+    for k in ("ray_max_shading_opacity", "ray_max_sample_loc_w", "ray_max_far_dist", "shading_avg_color", "shading_avg_dir",
+              "shading_avg_conf", "shading_avg_embedding"):
+        fix["prob_" + k] = env["output"][k].numpy()
+    # ---- (b) voxel down-sampling of the initial cloud
+    fn = _ref_lines("/root/reference/models/mvs/mvs_utils.py", 537, 561, "def construct_vox_points_closest(")
+    env = dict(torch=torch, scatter_mean=scatter_mean, scatter_min=scatter_min, print=lambda *a, **k: None)
+    exec(fn, env)
+    for tag, (n, res, seed) in dict(a=(5000, 24, 3), b=(20000, 40, 5)).items():
+        pts = vox_cloud(n, seed)
+        cen, gidx, midx = env["construct_vox_points_closest"](pts.clone(), res)
+        fix["vox_%s_centroid" % tag], fix["vox_%s_grid" % tag], fix["vox_%s_min_idx" % tag] = cen.numpy(), gidx.numpy(), midx.numpy()
+    pts = vox_cloud(3000, 7)
+    smin, smax = pts.min(0)[0] - 0.01, pts.max(0)[0] + 0.01                        # a caller-given box that holds every point
+    cen, gidx, midx = env["construct_vox_points_closest"](pts.clone(), 16, space_min=smin, space_max=smax)
+    fix["vox_c_centroid"], fix["vox_c_grid"], fix["vox_c_min_idx"] = cen.numpy(), gidx.numpy(), midx.numpy()
+    # ---- (c) probe_hole on the stand-ins
+    src_probe = _cpu_text(_ref_lines("/root/reference/run/train_ft.py", 417, 530, "def probe_hole(model, dataset, visualizer, opt, bg_info"))
+    src_bloat = _cpu_text(_ref_lines("/root/reference/run/train_ft.py", 532, 540, "def bloat_inds(inds, shift, height, width):"))
+
+    class _Bar:
+        def __init__(self, it): self.it = it
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+        def __iter__(self): return iter(self.it)
+        def set_description(self, s): pass
+    import random
+    env = dict(torch=torch, np=np, random=random, tqdm=_Bar, masking=None)
+    exec(src_bloat, env); exec(src_probe, env)
+    for tag, far_thresh in (("near", -1.0), ("far", 0.012)):
+        o, model, data = shell_probe_setup(far_thresh)
+        add = env["probe_hole"](model, data, SF.RecordingVisualizer(), o, None, test_steps=150, opacity_thresh=0.3)
+        for name, t in zip(("xyz", "embedding", "color", "dir", "conf"), add):
+            fix["probe_%s_%s" % (tag, name)] = t.numpy()
+        assert model.opt.prob == 0 and set(model.seen) == {(1, (7, 7, 7))} and len(add[0]) > 10, (set(model.seen), len(add[0]))
+    # ---- (d) test() on the stand-ins
+    src_test = _cpu_text(_ref_lines("/root/reference/run/train_ft.py", 252, 414, "def test(model, dataset, visualizer, opt, bg_info"))
+    import time
+    env = dict(torch=torch, np=np, time=time, mse2psnr=lambda x: -10.0 * torch.log(x) / np.log(10.0), report_metrics=lambda *a, **k: None,
+               print=lambda *a, **k: None)
+    exec(src_test, env)
+    o, model, data = shell_test_setup()
+    vis = SF.RecordingVisualizer()
+    psnr = env["test"](model, data, vis, o, None, test_steps=0, lpips=False)
+    fix["test_psnr"] = np.float64(psnr)
+    fix["test_items"] = np.array([[a["coarse_raycolor"], a["ray_masked_coarse_raycolor"]] for a in vis.acc], dtype=np.float64)
+    fix["test_canvas"] = np.stack([v["coarse_raycolor"] for _, v in vis.shown])
+    np.savez_compressed(os.path.join(HERE, "refshell.npz"), **fix)
+    print("refshell ok", {k: v.shape for k, v in fix.items()})
+
+
+
 if __name__ == "__main__":
     if "--blocks" in sys.argv:
         ref_blocks()
+    elif "--shell" in sys.argv:
+        ref_shell()
     else:
         main()
         ref_blocks()
+        ref_shell()
