@@ -168,7 +168,7 @@ def main():
     pt_params = [p for p in (npnt.points_embeding, npnt.points_conf, npnt.points_dir, npnt.points_color) if p.requires_grad]
     # the reference's two Adam instances (mvs_points_volumetric_model.py:80-91) as one-pass HIP updates; --zero1 shards the
     # update and its state over the ranks (reduce-scatter / all-gather instead of all-reduce)
-    from pointnerf_amd.optim import FusedAdam, ShardedAdam
+    from pointnerf_amd.optim import FusedAdam, ShardedAdam, step_all
     zero1 = args.zero1 and world > 1
     sparse = world > 1 and not zero1 and (args.point_grads == "sparse" or (args.point_grads == "auto" and n_points >= 6_000_000))
     opt_mlp = FusedAdam(mlp_params, lr=opt.lr, betas=(0.9, 0.999))
@@ -189,14 +189,16 @@ def main():
         # no-op at N=1; RCCL over xGMI otherwise.  The three point tensors only the renderer writes (88 % of the bytes) start
         # their all-reduce as soon as the input-gradient kernels are done, under the weight-gradient GEMMs
         if sparse:
-            # large clouds: a rank's rays touch a few percent of the points -- exchange the touched rows only (dist.sparse_allreduce_rows)
-            touched = pdist.touched_rows(npnt.querier.last_dense["sample_pidx"], n_points)
-            pdist.sparse_allreduce_rows([p.grad for p in pt_params], touched)
+            # large clouds: a rank's rays touch a few percent of the points -- exchange the touched rows only (dist.sparse_allreduce_rows);
+            # the row list and the largest count over the ranks were prepared right after the query (model.after_query) and read with the
+            # step's one host read, so nothing in here synchronises
+            ids, cnt, cap = model.sparse_plan
+            pdist.sparse_allreduce_rows([p.grad for p in pt_params], ids[:cnt].long(), cap=cap)
             pdist.allreduce_grads(mlp_params, [])
         else:
             early = [] if (zero1 or args.no_overlap_comm) else [npnt.points_embeding, npnt.points_dir, npnt.points_color]
             pdist.allreduce_grads(mlp_params, [] if zero1 else pt_params, ready_event=FusedRender.point_grads_ready if early else None, early_params=early)
-        opt_mlp.step(); opt_pts.step()
+        step_all([opt_mlp, opt_pts])          # both Adam instances in one launch (ShardedAdam, when --zero1, steps on its own)
         return loss, model.last_stats
 
     if not args.render_only:
@@ -211,6 +213,8 @@ def main():
         need = int(L.lib().pnerf_agg_saved_bytes(biggest, int(opt.K)))
         if need <= ops.arena_budget_bytes():
             ops.ARENA.reserve(int(need * 1.05), dev)
+    if sparse:
+        model.plan_sparse = lambda dense: pdist.plan_sparse_exchange(dense["sample_pidx"], n_points)
     stats = []
     # set-up, not warm-up: two untimed steps on the first batch size the activation arena (one ~80 GB hipMalloc) and let the caching
     # allocator settle, so that the measurement does not depend on how many warm-up steps the caller asks for

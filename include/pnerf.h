@@ -223,6 +223,13 @@ int pnerf_raymarch_backward(const float *d_ray_dist, const uint8_t *d_ray_valid,
  * All four arrays hold n floats (16-byte aligned arrays take the float4 path); step counts from 1 (the value torch keeps in state['step']). */
 int pnerf_adam_step(float *d_param, const float *d_grad, float *d_exp_avg, float *d_exp_avg_sq, int64_t n,
                     double lr, double beta1, double beta2, double eps, int64_t step, void *stream);
+/* the same update for a list of tensors in ONE launch (per 24 tensors): each entry carries its own size, learning rate and step count,
+ * so both of the reference's optimizers (MLP: 18 tensors at lr, points: 4 tensors at plr) are one call.  `tensors` is a HOST array. */
+typedef struct pnerf_adam_tensor {
+    float *param; const float *grad; float *exp_avg; float *exp_avg_sq;
+    int64_t n; double lr; int64_t step;
+} pnerf_adam_tensor;
+int pnerf_adam_step_multi(const pnerf_adam_tensor *tensors, int count, double beta1, double beta2, double eps, void *stream);
 
 /* ---- point initialisation: voxel down-sampling of a raw cloud (models/mvs/mvs_utils.py:537-561 construct_vox_points_closest,
  * called at run/train_ft.py:138-139).  Voxel of a point = floor((p - space_min) / vox_size) per axis (fp32), points outside
@@ -246,6 +253,10 @@ int pnerf_debug_uniform(uint64_t seed, uint64_t first, int64_t n, float *d_out, 
 /* the two-plane split of csrc/f16x3.h on n floats (n even): d_h / d_m [n] f16 (high plane: round toward zero; residual plane: round to
  * nearest of x - h); sat != 0 clamps to the f16 range first (the gradient form).  Tests compare it bit for bit with the numpy restatement. */
 int pnerf_debug_split(const float *d_x, int64_t n, void *d_h, void *d_m, int sat, void *stream);
+/* the positional encoding the aggregator kernels evaluate (csrc/f16x3.h pn_pe_octaves; reference models/helpers/networks.py:175-190):
+ * d_out[i][f] = {sin(x_i 2^f), cos(x_i 2^f)}, f < nfreq <= 5, d_out [n][nfreq][2] f32.  Tests measure it against float64 for |x| up to
+ * thousands (trained embeddings are not confined to the initialisation's (-0.5, 0.5)). */
+int pnerf_debug_pe(const float *d_x, int64_t n, int nfreq, float *d_out, void *stream);
 
 /* ---- per-kernel timing (HIP events recorded on the launch stream; off by default) --------------- */
 int pnerf_prof_enable(int on);

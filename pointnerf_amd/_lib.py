@@ -39,6 +39,11 @@ class Points(ctypes.Structure):
                 ("color", c_void_p), ("n", ctypes.c_int32), ("feat_dim", ctypes.c_int32)]
 
 
+class AdamTensor(ctypes.Structure):
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
+                ("n", ctypes.c_int64), ("lr", ctypes.c_double), ("step", ctypes.c_int64)]
+
+
 class PointGrads(ctypes.Structure):
     _fields_ = [("embedding", c_void_p), ("conf", c_void_p), ("dir", c_void_p), ("color", c_void_p), ("ready_event", c_void_p)]
 
@@ -62,6 +67,7 @@ PROTOTYPES = {
     "pnerf_voxel_downsample_workspace_bytes": (c_size_t, [c_i64, c_int, c_int, c_int]),
     "pnerf_voxel_downsample": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pnerf_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_i64, c_void_p]),
+    "pnerf_adam_step_multi": (c_int, [ctypes.POINTER(AdamTensor), c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_void_p]),
     "pnerf_mlp_layout": (c_int, [c_int, ctypes.POINTER(c_i64)]),
     "pnerf_mlp_packed_bytes": (c_size_t, []),
     "pnerf_mlp_pack": (c_int, [c_void_p, c_void_p, c_void_p]),
@@ -89,6 +95,7 @@ PROTOTYPES = {
     "pnerf_debug_mfma_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "pnerf_debug_uniform": (c_int, [ctypes.c_uint64, ctypes.c_uint64, c_i64, c_void_p, c_void_p]),
     "pnerf_debug_split": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_int, c_void_p]),
+    "pnerf_debug_pe": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     "pnerf_prof_enable": (c_int, [c_int]),
     "pnerf_prof_kernel_count": (c_int, []),
     "pnerf_prof_kernel_name": (ctypes.c_char_p, [c_int]),

@@ -108,6 +108,31 @@ extern "C" int pnerf_debug_split(const float *d_x, int64_t n, void *d_h, void *d
     return 0;
 }
 
+namespace {
+template <int NF> __global__ __launch_bounds__(256) void k_debug_pe(const float *__restrict__ x, long long n, float *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float s[NF], c[NF];
+        pn_pe_octaves<NF>(x[i], s, c);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) { out[(i * NF + f) * 2] = s[f]; out[(i * NF + f) * 2 + 1] = c[f]; }
+    }
+}
+}  // namespace
+extern "C" int pnerf_debug_pe(const float *d_x, int64_t n, int nfreq, float *d_out, void *stream) {
+    if (!d_x || !d_out || n < 0 || nfreq < 1 || nfreq > 5) return PNERF_E_INVAL;
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    switch (nfreq) {
+        case 1: hipLaunchKernelGGL(k_debug_pe<1>, dim3(64), dim3(256), 0, s, d_x, (long long)n, d_out); break;
+        case 2: hipLaunchKernelGGL(k_debug_pe<2>, dim3(64), dim3(256), 0, s, d_x, (long long)n, d_out); break;
+        case 3: hipLaunchKernelGGL(k_debug_pe<3>, dim3(64), dim3(256), 0, s, d_x, (long long)n, d_out); break;
+        case 4: hipLaunchKernelGGL(k_debug_pe<4>, dim3(64), dim3(256), 0, s, d_x, (long long)n, d_out); break;
+        default: hipLaunchKernelGGL(k_debug_pe<5>, dim3(64), dim3(256), 0, s, d_x, (long long)n, d_out); break;
+    }
+    PN_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pnerf_debug_mfma_f16(const void *d_a, const void *d_b, float *d_out, void *stream) {
     if (!d_a || !d_b || !d_out) return PNERF_E_INVAL;
     hipLaunchKernelGGL(k_debug_mfma_f16, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint4 *)d_a, (const uint4 *)d_b, d_out);
@@ -358,39 +383,28 @@ __device__ __forceinline__ void f_build(const FwdArgs &a, const FGather &G, char
     const float d3 = ppx * pcz - spx * scz, d4 = ppy * pcz - spy * scz, d5 = pcz - scz;
     const float da = q == 0 ? d0 : q == 1 ? d1 : q == 2 ? d2 : d3;
     const float db = q == 0 ? d4 : d5;
-    // the thread's 8 embedding dims and their 3 octaves (one sin / cos pair, exact double-angle steps for the octaves)
+    // the thread's 8 embedding dims and their 3 octaves
     const float e[8] = {G.e0.x, G.e0.y, G.e0.z, G.e0.w, G.e1.x, G.e1.y, G.e1.z, G.e1.w};
     pn_x_store4<false>(X, row, EPT * q, e[0], e[1], e[2], e[3]);
     pn_x_store4<false>(X, row, EPT * q + 4, e[4], e[5], e[6], e[7]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int dd = EPT * q + i;
-        float s, c;
-        pn_sincos(e[i], s, c);
-        float v[6];
-#pragma unroll
-        for (int f = 0; f < 3; ++f) {
-            v[2 * f] = s; v[2 * f + 1] = c;
-            const float s2 = 2.f * s * c;
-            c = 1.f - 2.f * s * s; s = s2;
-        }
-        pn_x_store2(X, row, PN_F + dd * 6, v[0], v[1]);
-        pn_x_store2(X, row, PN_F + dd * 6 + 2, v[2], v[3]);
-        pn_x_store2(X, row, PN_F + dd * 6 + 4, v[4], v[5]);
+        float s[3], c[3];
+        pn_pe_octaves<3>(e[i], s, c);
+        pn_x_store2(X, row, PN_F + dd * 6, s[0], c[0]);
+        pn_x_store2(X, row, PN_F + dd * 6 + 2, s[1], c[1]);
+        pn_x_store2(X, row, PN_F + dd * 6 + 4, s[2], c[2]);
     }
     // PE5 of distance components q and q + 4
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int comp = q + 4 * j;
         if (comp < 6) {
-            float s, c;
-            pn_sincos(j == 0 ? da : db, s, c);
+            float s[5], c[5];
+            pn_pe_octaves<5>(j == 0 ? da : db, s, c);
 #pragma unroll
-            for (int f = 0; f < 5; ++f) {
-                pn_x_store2(X, row, PN_F * 7 + (comp * 5 + f) * 2, s, c);
-                const float s2 = 2.f * s * c;
-                c = 1.f - 2.f * s * s; s = s2;
-            }
+            for (int f = 0; f < 5; ++f) pn_x_store2(X, row, PN_F * 7 + (comp * 5 + f) * 2, s[f], c[f]);
         }
     }
     if (q == 3) pn_x_store4<false>(X, row, PN_ONES1, 1.f, 0.f, 0.f, 0.f);
@@ -708,9 +722,7 @@ __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
                 float v[3], sn[4], cs[4];
                 rot3(a.cam.rw2c, a.raydir[3 * r], a.raydir[3 * r + 1], a.raydir[3 * r + 2], true, v[0], v[1], v[2]);
                 const float vq = q == 0 ? v[0] : (q == 1 ? v[1] : v[2]);
-                float fr = 1.f;
-#pragma unroll
-                for (int f2 = 0; f2 < 4; ++f2) { pn_sincos(vq * fr, sn[f2], cs[f2]); fr *= 2.f; }
+                pn_pe_octaves<4>(vq, sn, cs);
                 if (q < 3) {
                     pn_x_store4<false>(X, row, PN_H + 4 * q, sn[0], sn[1], sn[2], sn[3]);
                     pn_x_store4<false>(X, row, PN_H + 12 + 4 * q, cs[0], cs[1], cs[2], cs[3]);

@@ -489,15 +489,13 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
 #pragma unroll
             for (int i = 0; i < EPT; ++i) {
                 const int dd = EPT * q + i;
-                float s, c;
-                pn_sincos(e[i], s, c);
+                float s[3], c[3];
+                pn_pe_octaves<3>(e[i], s, c);
                 float g = dr_[dd], fr = 1.f;
 #pragma unroll
                 for (int f = 0; f < 3; ++f) {
                     const float2 t = *reinterpret_cast<const float2 *>(dr_ + PN_F + dd * 6 + 2 * f);
-                    g += fr * (t.x * c - t.y * s);
-                    const float s2 = 2.f * s * c;
-                    c = 1.f - 2.f * s * s; s = s2;
+                    g += fr * (t.x * c[f] - t.y * s[f]);
                     fr *= 2.f;
                 }
                 atomicAdd(&a.g_emb[(long long)rp * PN_F + dd], g * invS);

@@ -77,16 +77,31 @@ enum : int {
 #define PN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
-// sin / cos of the positional encodings: v_sin_f32 / v_cos_f32 (one multiply + one transcendental each) unless built with
-// -DPN_EXACT_SINCOS; the parity bars of tests/test_gpu_render.py and test_gpu_backward.py hold for both
-__device__ __forceinline__ void pn_sincos(float x, float &s, float &c) {
-#ifdef PN_EXACT_SINCOS
-    sincosf(x, &s, &c);
+// sin / cos of the positional encodings (networks.py:175-190: sin(x 2^f), cos(x 2^f), f = 0 .. NF-1).  Every octave is reduced on its
+// own to revolutions r in [-0.5, 0.5] with a two-term 1 / 2pi -- x 2^f is exact, k = rint(x 2^f / 2pi), r = fma(x 2^f, HI, -k) + x 2^f LO:
+// the angle error is <= 2 x 2 pi 2^-25 = 3.7e-7 rad for EVERY octave and every |x| < 2^20 (learned embeddings reach several units) -- and
+// then evaluated by v_sin_f32 / v_cos_f32 (input in revolutions).  Round 2 took one __sinf / __cosf of x (a single-term x / 2pi, error
+// growing with |x|) and doubled the angle by recurrence (error doubling per octave); same instruction count within 30 %.
+// -DPN_EXACT_SINCOS: libm's sincosf per octave (dev A/B only).
+template <int NF>
+__device__ __forceinline__ void pn_pe_octaves(float x, float (&s)[NF], float (&c)[NF]) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const float xf = x * (float)(1 << f);
+#if defined(PN_EXACT_SINCOS) || defined(PN_EMU)
+        sincosf(xf, &s[f], &c[f]);
 #else
-    s = __sinf(x); c = __cosf(x);
+        const float k = __builtin_rintf(xf * 0.15915494f);
+        const float r = __builtin_fmaf(xf, 6.4206382e-9f, __builtin_fmaf(xf, 0.15915494f, -k));     // 1 / 2pi = 0.15915494f (= 0.159154936671257) + 6.4206382e-9
+        s[f] = __builtin_amdgcn_sinf(r); c[f] = __builtin_amdgcn_cosf(r);
 #endif
+    }
 }
 
+// RANGE of the two-plane form: |x| <= 65504 (the largest finite f16).  v_cvt_pkrtz never produces inf, so beyond that h saturates at
+// 65504 and the residual x - h overflows the f16 range for |x| > ~1.3e5 (inf in the residual plane = NaN out of the MFMA), where the fp32
+// GEMM this replaces would still have been finite.  Activations of this network are O(1..100); weights are checked when they are packed
+// (PointAggregator.check_range, when a checkpoint is re-homed into the flat parameter vector); gradients go through pn_split2_sat.
 // (x0, x1) -> packed high plane (round toward zero) and packed residual plane (round to nearest): three instructions,
 // v_cvt_pkrtz_f16_f32 and one v_fma_mix{lo,hi}_f16 per element (m = f16(x * 1.0 - h), the fused form of "convert back, subtract,
 // convert"; hipcc does not form it by itself: 5 instructions).  tests: pnerf_debug_split against the numpy restatement, bit for bit

@@ -106,11 +106,21 @@ def allreduce_grads(mlp_params, point_params, ready_event=None, early_params=())
         point_params = [p for p in point_params if all(p is not q for q in early)]
     gs = [p.grad for p in mlp_params if p.grad is not None]
     if gs:
-        flat = torch.cat([g.reshape(-1) for g in gs])
-        dist.all_reduce(flat)
-        o = 0
-        for g in gs:
-            g.copy_(flat[o:o + g.numel()].view_as(g)); o += g.numel()
+        # the renderer's backward returns the MLP gradients as views of ONE flat buffer in parameter order (fused.FusedRender.backward:
+        # gflat): when autograd handed them through unchanged they are contiguous in memory and the all-reduce runs in place on that
+        # buffer -- no torch.cat, no copy back
+        esz = gs[0].element_size()
+        contiguous = all(g.is_contiguous() and g.dtype == gs[0].dtype for g in gs) and \
+            all(gs[i].data_ptr() + gs[i].numel() * esz == gs[i + 1].data_ptr() for i in range(len(gs) - 1))
+        st0 = gs[0].untyped_storage().data_ptr()
+        if contiguous and all(g.untyped_storage().data_ptr() == st0 for g in gs):
+            dist.all_reduce(gs[0].as_strided((sum(g.numel() for g in gs),), (1,), gs[0].storage_offset()))
+        else:
+            flat = torch.cat([g.reshape(-1) for g in gs])
+            dist.all_reduce(flat)
+            o = 0
+            for g in gs:
+                g.copy_(flat[o:o + g.numel()].view_as(g)); o += g.numel()
     for p in point_params:
         if p.grad is not None:
             dist.all_reduce(p.grad)
@@ -118,19 +128,52 @@ def allreduce_grads(mlp_params, point_params, ready_event=None, early_params=())
         torch.cuda.current_stream(comm.device).wait_stream(comm)
 
 
+def touched_flags(pidx, n_points):
+    """[n_points] 0/1 int32 flags of the points a rank's gradients can be non-zero for (``pidx`` int tensor, -1 = empty slot).
+    Row 0 is touched whenever ANY slot is empty: empty slots read point 0 like the reference (neural_points.py:709 clamps the index),
+    and the zero-one regulariser differentiates through that read into points_conf[0] (k_zero_one_backward / the unfused gather)."""
+    flag = torch.zeros(n_points + 1, dtype=torch.int32, device=pidx.device)
+    flag[pidx.reshape(-1).long() + 1] = 1             # slot 0 collects the -1 entries
+    flag[1] |= flag[0]
+    return flag[1:]
+
+
 def touched_rows(pidx, n_points):
-    """Sorted ids of the points a rank's neighbor table references (``pidx`` int tensor, -1 = empty slot)."""
-    flag = torch.zeros(n_points + 1, dtype=torch.bool, device=pidx.device)
-    flag[pidx.reshape(-1).long() + 1] = True          # slot 0 collects the -1 entries
-    return torch.nonzero(flag[1:]).reshape(-1)
+    """Sorted ids of the touched points (see touched_flags).  One host synchronisation (nonzero): the step-time callers use
+    ``plan_sparse_exchange`` instead, which folds the count into the step's one existing host read."""
+    return torch.nonzero(touched_flags(pidx, n_points)).reshape(-1)
 
 
-def sparse_allreduce_rows(grads, touched, group=None):
+def plan_sparse_exchange(pidx, n_points, group=None):
+    """Everything ``sparse_allreduce_rows`` needs, computed right after the query and BEFORE the step's one host read: returns
+    (ids [n_points] int32 device tensor whose first ``count`` entries are the sorted touched rows, counts [2] int64 DEVICE tensor =
+    (this rank's count, max count over the ranks)).  The caller reads ``counts`` together with the query counters (one synchronisation
+    for the step) and passes (ids, count, cap) on.  The compaction runs in libpnerf_hip.so on device tensors; gloo / CPU tensors (tests)
+    take torch.nonzero."""
+    flags = touched_flags(pidx, n_points)
+    if flags.is_cuda:
+        from . import ops
+        ids, counters = ops.compact_valid(flags)                  # ascending indices of the flags > 0, count in counters[0]
+        cnt = counters[:1].to(torch.int64)
+    else:
+        nz = torch.nonzero(flags).reshape(-1).to(torch.int32)
+        ids = torch.zeros(n_points, dtype=torch.int32)
+        ids[:nz.numel()] = nz
+        cnt = torch.tensor([nz.numel()], dtype=torch.int64)
+    cap = cnt.clone()
+    if world() > 1:
+        dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=group)
+    return ids, torch.cat([cnt, cap])
+
+
+def sparse_allreduce_rows(grads, touched, group=None, cap=None):
     """Sum over ranks of dense per-point gradients ``grads`` (list of [N, c_i] tensors, each rank's contribution zero outside its own
     ``touched`` rows) by exchanging only touched rows: all-gather (ids padded with -1 to the largest count, rows [cap, sum c_i]),
     then every rank zeroes its touched rows and adds the blocks of ALL ranks in rank order -- the same additions in the same order
     everywhere, so the replicas stay bitwise identical (a dense ring all-reduce has that property by construction).
-    Bytes received per rank: W * cap * (4 + 4 sum c_i), against 2 (W - 1) / W * 4 N sum c_i for the dense ring."""
+    Bytes received per rank: W * cap * (4 + 4 sum c_i), against 2 (W - 1) / W * 4 N sum c_i for the dense ring.
+    ``cap`` = the largest touched count over the ranks when the caller already knows it (``plan_sparse_exchange``: no host
+    synchronisation in here then)."""
     W = dist.get_world_size(group)
     if W == 1:
         return
@@ -138,9 +181,11 @@ def sparse_allreduce_rows(grads, touched, group=None):
     assert all(g.is_contiguous() and g.dim() >= 2 for g in grads)
     flat = [g.view(-1, g.shape[-1]) for g in grads]         # views: the additions below land in the callers' tensors
     cols = [g.shape[1] for g in flat]
-    cap = torch.tensor([touched.numel()], dtype=torch.int64, device=dev)
-    dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=group)
-    cap = max(int(cap.item()), 1)
+    if cap is None:                                        # (callers without a plan: one collective + one host read here)
+        cap = torch.tensor([touched.numel()], dtype=torch.int64, device=dev)
+        dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=group)
+        cap = int(cap.item())
+    cap = max(int(cap), 1)
     ids = torch.full((cap,), -1, dtype=torch.int64, device=dev)
     ids[:touched.numel()] = touched
     rows = torch.zeros(cap, sum(cols), dtype=torch.float32, device=dev)

@@ -35,9 +35,13 @@ class FusedRender(torch.autograd.Function):
     vector ``env['flat']`` the kernels read, and are passed only so that autograd (and DDP-style hooks) see them:
     backward returns one gradient per parameter, each a view into a single flat gradient buffer."""
 
+    # Class-level state describing the LATEST backward only: ONE render per optimisation step is assumed (every reference script; with
+    # two renders in one graph the early all-reduce of dist.allreduce_grads falls back to the ordinary path for the earlier one, which
+    # is safe -- its gradient tensors are not in point_grad_ptrs -- but not overlapped).
     point_grads_ready = None          # torch.cuda.Event of the latest backward (only when env["want_grad_event"])
     point_grad_ptrs = frozenset()     # data pointers of the point-gradient tensors the latest backward wrote
     point_grad_bucket = None          # (flat bucket, floats of its head [embedding | dir | colour], their data pointers)
+    last_chunks = None                # (rays per chunk, rays) when the latest backward recomputed by ray chunks, else None
 
     @staticmethod
     def forward(ctx, env, emb, conf, pdir, color, *mlp_params):
@@ -64,6 +68,7 @@ class FusedRender(torch.autograd.Function):
         if not env["train"] or (fwd["saved"] is None and not ctx.recompute):
             raise RuntimeError("pointnerf_amd: backward through a render that was run with train=False")
         dev = g_color.device
+        FusedRender.last_chunks = None
         gflat = torch.zeros_like(env["flat"])
         names = ("points_embeding", "points_conf", "points_dir", "points_color")
         # ONE zero-filled bucket for the four point-gradient tensors, [embedding | dir | colour | conf]: the three tensors that are final
@@ -112,7 +117,7 @@ def _backward_in_chunks(env, pts, g_color, gflat, grads, ev):
     per_ray = max(lib.pnerf_agg_saved_bytes(env["n_valid"], K) / max(R, 1), 1.0)
     step = max(int(0.8 * budget / per_ray), 1)
     todo = [(r0, min(r0 + step, R)) for r0 in range(0, R, step)]
-    last = None
+    last, handed = None, False
     while todo:
         r0, r1 = todo.pop(0)
         nn = dense["sample_nn"][r0:r1]
@@ -128,9 +133,17 @@ def _backward_in_chunks(env, pts, g_color, gflat, grads, ev):
         rd = env["raydir"][r0:r1]
         f = ops.render_forward(env["cam"], pts, env["packed"], env["flat"], rd, sub, r1 - r0, SR, K, n_c, True)
         last = (r0, r1)
+        # the library re-records the event between this chunk's input-gradient kernels and its weight-gradient GEMMs: only sound for
+        # the chunk that is processed LAST (every earlier chunk's atomics must be behind it)
+        handed = ev is not None and not todo
         ops.render_backward(env["cam"], pts, env["packed"], env["flat"], rd, sub, r1 - r0, SR, K, n_c, f, g_color[r0:r1], gflat, grads,
-                            ready_event=ev if not todo else None)
+                            ready_event=ev if handed else None)
         ops.ARENA.give(f["saved"])
+    if ev is not None and not handed:
+        # the trailing run(s) of rays had no valid sample (or nothing was processed at all): the event still carries its record from
+        # BEFORE the first chunk -- re-record it behind everything that was enqueued, or a data-parallel caller would all-reduce the
+        # bucket while the chunks' atomics are still landing in it
+        ev.record()
     FusedRender.last_chunks = None if last is None else (step, R)
 
 

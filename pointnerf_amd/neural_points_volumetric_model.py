@@ -60,7 +60,15 @@ class NeuralPointsRayMarching(nn.Module):
             ops.reserve_pool(16 * R * int(opt.SR) * int(opt.K) * 4, raydir.device)
             self._pool_rays = R
         dense = npnt.query_dense(dict(campos=campos, raydir=raydir, near=near, far=far))
-        counters = dense["counters"].cpu()                    # the one sync: sizes the activation arena
+        # data-parallel callers that exchange touched rows only (dist.plan_sparse_exchange) prepare the row list here, so that its two
+        # counts travel with the one host read below instead of synchronising a second time after the backward
+        plan = getattr(self, "plan_sparse", None)
+        plan = plan(dense) if (plan is not None and train) else None
+        if plan is not None:
+            both = torch.cat([dense["counters"].to(torch.int64), plan[1]]).cpu()
+            counters, self.sparse_plan = both[:8], (plan[0], int(both[8]), int(both[9]))
+        else:
+            counters = dense["counters"].cpu()                # the one sync: sizes the activation arena
         n_valid = int(counters[0])
         self.last_stats = dict(n_valid_samples=n_valid, rays_hit=int(counters[1]), n_selected=int(counters[2]),
                                n_neighbor_rows=int(counters[3]), rays=R)

@@ -26,16 +26,33 @@ def _adam_hip(p, g, m, v, lr, b1, b2, eps, step):
                                 ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)), "pnerf_adam_step")
 
 
+def _adam_hip_multi(items, b1, b2, eps):
+    """items: [(p, g, m, v, lr, step)] -> ONE pnerf_adam_step_multi call (one launch per 24 tensors)"""
+    lib = L.lib()
+    arr = (L.AdamTensor * len(items))()
+    for a, (p, g, m, v, lr, step) in zip(arr, items):
+        n = p.numel()
+        for t in (p, g, m, v):
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.numel() == n):
+                raise ValueError("FusedAdam: parameters, gradients and state must be contiguous fp32 device tensors of one size")
+        a.param, a.grad, a.exp_avg, a.exp_avg_sq, a.n, a.lr, a.step = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, step
+    L.check(lib.pnerf_adam_step_multi(arr, len(items), b1, b2, eps, ctypes.c_void_p(torch.cuda.current_stream(items[0][0].device).cuda_stream)),
+            "pnerf_adam_step_multi")
+
+
 class FusedAdam(torch.optim.Optimizer):
-    """torch.optim.Adam(params, lr, betas, eps) semantics (no weight decay, no amsgrad) in one HIP pass per tensor."""
+    """torch.optim.Adam(params, lr, betas, eps) semantics (no weight decay, no amsgrad): one HIP pass over p, g, m, v, and ONE launch for
+    all tensors that share (betas, eps) -- every group of this optimizer in the training loop's use."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, update=None):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
-        self._update = update or _adam_hip          # tests on CPU inject a torch restatement; the product path is the HIP kernel
+        self._update = update                       # tests on CPU inject a per-tensor torch restatement; the product path is the HIP kernel
 
     @torch.no_grad()
-    def step(self, closure=None):
-        loss = closure() if closure is not None else None
+    def collect(self):
+        """Advance the step counters and return the update list {(b1, b2, eps): [(p, g, m, v, lr, step)]} WITHOUT applying it
+        (``step`` / ``step_all`` launch it)."""
+        batches = {}
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -48,9 +65,38 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                self._update(p.data, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                             int(st["step"].item()))
+                batches.setdefault((float(b1), float(b2), float(group["eps"])), []).append(
+                    (p.data, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), int(st["step"].item())))
+        return batches
+
+    def _apply(self, batches):
+        for (b1, b2, eps), items in batches.items():
+            if self._update is not None:
+                for (p, g, m, v, lr, step) in items:
+                    self._update(p, g, m, v, lr, b1, b2, eps, step)
+            else:
+                _adam_hip_multi(items, b1, b2, eps)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        self._apply(self.collect())
         return loss
+
+
+def step_all(optimizers):
+    """Step several optimizers; the FusedAdam instances among them with ONE launch per (betas, eps) -- the reference's two optimizers
+    (MLP at lr, points at plr, same betas and eps) become one kernel.  Equivalent to calling ``step()`` on each."""
+    merged, host = {}, None
+    for o in optimizers:
+        if isinstance(o, FusedAdam) and o._update is None:
+            for k, items in o.collect().items():
+                merged.setdefault(k, []).extend(items)
+            host = o
+        else:
+            o.step()
+    if host is not None:
+        host._apply(merged)
 
 
 class ShardedAdam:
@@ -94,9 +140,19 @@ class ShardedAdam:
 
     @torch.no_grad()
     def step(self):
+        """One sharded update.  Two contracts differ from torch.optim.Adam / FusedAdam and are checked or stated here:
+          * a parameter whose ``.grad`` is None contributes a ZERO gradient (the collective needs every slot on every rank) and is still
+            updated -- its moments decay and it keeps moving on momentum -- whereas Adam skips it.  Freeze a tensor by taking it out of
+            the optimizer (rebuild it: the training loop does that on prune / grow anyway), not by leaving its gradient unset;
+          * the parameters must still live in ``flat_param``: anything that replaces ``p.data`` / the Parameter objects (prune, grow,
+            ``flatten_()``) detaches them from this optimizer -- rebuild it afterwards.  Checked below."""
         dist = torch.distributed
         self.step_count += 1
+        base = self.flat_param.data_ptr()
         for p, o in zip(self.params, self.offsets):
+            if p.data_ptr() != base + 4 * o:
+                raise RuntimeError("ShardedAdam: a parameter no longer lives in the optimizer's flat buffer (its storage was replaced after "
+                                   "construction, e.g. by prune / grow / flatten_()): rebuild the optimizer")
             slot = self.flat_grad[o:o + p.numel()]
             if p.grad is None:
                 slot.zero_()

@@ -88,7 +88,20 @@ class PointAggregator(nn.Module):
                 params[k].data = flat[o:o + n].view(shp)
             self._flat = flat
             self._state = MLPState(flat)
+            self.check_range()
         return self._flat
+
+    def check_range(self):
+        """The two-plane f16 form of the GEMM operands (csrc/f16x3.h) holds |x| <= 65504; the fp32 GEMMs it replaces had the whole
+        fp32 range.  Weights are checked whenever they are (re)homed into the flat vector -- after ``.to(device)`` / ``load_state_dict``,
+        i.e. when a checkpoint arrives -- and a violation raises instead of rendering NaN.  (Activations of this network are O(1..100);
+        gradients are clamped by the kernels.)  One host read; not on the step path."""
+        if self._flat is None:
+            return
+        amax = float(self._flat.detach().abs().max())
+        if not (amax <= 65504.0):                       # also catches NaN / inf
+            raise ValueError("PointAggregator: a weight of magnitude %g (or a non-finite one) exceeds the range of the two-plane f16 "
+                             "arithmetic of libpnerf_hip.so (|w| <= 65504)" % amax)
 
     def mlp_state(self):
         self.flatten_()

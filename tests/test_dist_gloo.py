@@ -128,7 +128,13 @@ def _sparse_worker(rank, world, port, out_dir):
     if n_samp:
         pidx[torch.rand(n_samp, K, generator=gen) < 0.3] = -1  # empty neighbor slots
     touched = pdist.touched_rows(pidx, N)
-    assert touched.numel() == len(set(pidx[pidx >= 0].tolist())) and bool((touched[1:] > touched[:-1]).all())
+    # row 0 counts as touched whenever a slot is empty: empty slots read point 0 and the zero-one regulariser differentiates through it
+    expect = set(pidx[pidx >= 0].tolist()) | ({0} if bool((pidx < 0).any()) else set())
+    assert set(touched.tolist()) == expect and bool((touched[1:] > touched[:-1]).all())
+    # the plan form (no host read inside the exchange): same ids, the largest count over the ranks alongside
+    ids, counts = pdist.plan_sparse_exchange(pidx, N)
+    cnt, cap = int(counts[0]), int(counts[1])
+    assert cnt == touched.numel() and torch.equal(ids[:cnt].long(), touched) and cap >= cnt
     shapes = [(1, N, 32), (1, N, 1), (1, N, 3), (1, N, 3)]
     dense = []
     for shp in shapes:
@@ -138,7 +144,7 @@ def _sparse_worker(rank, world, port, out_dir):
     ref = [g.clone() for g in dense]
     for g in ref:
         dist.all_reduce(g)
-    pdist.sparse_allreduce_rows(dense, touched)
+    pdist.sparse_allreduce_rows(dense, touched, cap=cap)
     torch.save((dense, ref), os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()

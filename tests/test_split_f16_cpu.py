@@ -83,3 +83,24 @@ def test_single_plane_dY_weight_gradient_error_budget():
         rms, worst = float(np.sqrt(np.mean((got - ref) ** 2)) / mx), float(np.abs(got - ref).max() / mx)
         print("single-plane dY, %s: rms %.2e max %.2e of max|dW|" % (name, rms, worst))
         assert rms <= bar_rms and worst <= bar_max, name
+
+
+def test_octave_range_reduction_keeps_the_angle():
+    """csrc/f16x3.h pn_pe_octaves in numpy (fp32 steps, the two fmas exact-then-rounded): the angle handed to v_sin_f32 / v_cos_f32 is
+    within 4e-7 rad (two roundings of 2^-25 revolutions) of x 2^f mod 2 pi for every octave and |x| up to 3000; a single-term x / 2pi (round 2) is off by up to |x 2^f| 6e-8"""
+    rng = np.random.default_rng(0)
+    HI, LO = np.float32(0.15915494), np.float32(6.4206382e-9)
+    for span in (0.5, 10.0, 3000.0):
+        x = rng.uniform(-span, span, 200000).astype(np.float32)
+        for f in range(5):
+            xf = (x * np.float32(2 ** f)).astype(np.float32)                     # exact
+            k = np.rint((xf * HI).astype(np.float32))
+            r = (xf.astype(np.float64) * np.float64(HI) - k).astype(np.float32)     # fma: one rounding
+            r = (xf.astype(np.float64) * np.float64(LO) + r.astype(np.float64)).astype(np.float32)
+            assert float(np.abs(r).max()) <= 0.5 + 1e-3
+            true = xf.astype(np.float64) / (2 * np.pi) - k
+            err = np.abs(r.astype(np.float64) - true) * 2 * np.pi
+            assert float(err.max()) <= 4e-7, (span, f, float(err.max()))
+            single = np.abs((xf * HI).astype(np.float32).astype(np.float64) - xf.astype(np.float64) / (2 * np.pi)) * 2 * np.pi
+            if span >= 10.0 and f == 4:
+                assert float(single.max()) > 10 * float(err.max())
