@@ -75,6 +75,7 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=12288, help="rays of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--render-only", action="store_true", help="supplementary: inference (render, no backward) rays/s")
+    ap.add_argument("--inference-products", type=int, default=3, choices=(2, 3), help="--render-only: MFMA products per multiply-add of the inference forward (3 = fp32-class, default; 2 = weights' high plane only)")
     ap.add_argument("--no-overlap-comm", action="store_true", help="N > 1: all-reduce the point gradients after the whole backward instead of behind the weight-gradient GEMMs")
     ap.add_argument("--point-grads", default="auto", choices=("auto", "dense", "sparse"),
                     help="N > 1: exchange of the per-point gradients: dense all-reduce (one bucket, overlapped), sparse touched-row exchange, auto = sparse from 6 M points")
@@ -161,6 +162,8 @@ def main():
     if args.config == "chair":
         args.rays = min(args.rays, 4096)               # configs[0] is a 64x64 crop
     opt = opt_fn(is_train=0 if args.render_only else 1)
+    if args.render_only:
+        ops.set_inference_products(args.inference_products)
     model = build_model(opt, n_points, dev, points_fn)
     agg, npnt = model.aggregator, model.neural_points
     model.fused_zero_one = not args.unfused_zero_one     # the zero-one regulariser as one fused pass over the neighbor table (ops.ZeroOneConf)
@@ -282,7 +285,7 @@ def main():
         rays_total = args.rays * world * args.steps
         rows = float(np.mean([s["n_neighbor_rows"] for s in stats])); smp = float(np.mean([s["n_valid_samples"] for s in stats]))
         headline = args.config == "lego"
-        name = "rays/sec (render only, supplementary)" if args.render_only else "rays/sec (render+bwd)"
+        name = ("rays/sec (render only, %d products per multiply-add, supplementary)" % args.inference_products) if args.render_only else "rays/sec (render+bwd)"
         out = {"metric": name + (" NeRF-synth lego 800^2, K=8, 128 samp/ray" if headline else " %s, K=%d, %d samp/ray" % (cfg_name, opt.K, opt.SR)),
                "value": rays_total / dt, "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "median_ms_per_step": median_ms,

@@ -174,6 +174,14 @@ int pnerf_render_forward(const pnerf_camera *cam, const pnerf_points *pts, const
                          float *d_bg_trans, float *d_blend_w,
                          void *d_saved, int64_t n_valid_max, void *d_ws, size_t ws_bytes, void *stream);
 
+/* Arithmetic of the INFERENCE forward (d_saved == NULL; pnerf_render_forward and pnerf_agg_forward): every fp32 GEMM operand is two f16
+ * planes and a multiply-add is 3 MFMA products (default: fp32-class accuracy, sigma / RGB ~1e-6 from an fp32 evaluation) or 2 (the
+ * weights' residual plane dropped: a third of the matrix work and half of the weight stream less; measured ray colour / RGB ~2e-5 and
+ * sigma ~1e-5 of its magnitude from fp32 -- RGB inside the 1e-4 bar, sigma only relative to its scale, which is why it is an OPTION for
+ * render / evaluation loops and not the default; nothing differentiates through it).  Training forwards always run 3.  Returns the
+ * previous setting, or PNERF_E_INVAL for n not in {2, 3}.  Process-wide. */
+int pnerf_set_inference_products(int n);
+
 /* Backward of pnerf_render_forward for dL/d(ray_color) = d_grad_ray_color [R,3]:
  * accumulates dL/d(MLP params) into d_grad_params (flat, pnerf_mlp_layout order) and
  * dL/d(point tensors) into pg.  n_valid = the n_valid_max given to the forward call;

@@ -467,7 +467,7 @@ __device__ __forceinline__ void f_acc_zero(f32x16 (&acc)[2][2]) {
 #ifdef PN_PHASE_TRACE
 PN_TR_DECL(pn_trace_fwd);
 #endif
-template <bool TRAIN, bool PERS>
+template <bool TRAIN, bool PERS, int NP>
 __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_f[];
     char *X = smem_f;
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.x0k, rg_total, gtile * 8, tid);
         f_acc_zero(acc);
         PN_TR(pn_trace_fwd, 2);
-        pn_gemm_f16x3<18, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_F1), 2 * wave, lane, acc);
+        pn_gemm_f16x3<18, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F1), 2 * wave, lane, acc);
         f_load_bias(P + PO_B1, wave, lane, bias);           // (requested before the barrier: the wait for the slowest wave covers the L2 round trip)
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 3);
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h1k, rg_total, gtile * 8, tid);
         f_acc_zero(acc);
         PN_TR(pn_trace_fwd, 5);
-        pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_F2), 2 * wave, lane, acc);
+        pn_gemm_f16x3<16, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F2), 2 * wave, lane, acc);
         f_load_bias(P + PO_B2, wave, lane, bias);           // (requested before the barrier: the wait for the slowest wave covers the L2 round trip)
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 6);
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.h2k, rg_total, gtile * 8, tid);
         f_acc_zero(acc);
         PN_TR(pn_trace_fwd, 8);
-        pn_gemm_f16x3<17, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_F3), 2 * wave, lane, acc);
+        pn_gemm_f16x3<17, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F3), 2 * wave, lane, acc);
         f_load_bias(P + PO_B3, wave, lane, bias);           // (requested before the barrier: the wait for the slowest wave covers the L2 round trip)
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 9);
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h3k, rg_total, gtile * 8, tid);
         f_acc_zero(acc);
         PN_TR(pn_trace_fwd, 11);
-        pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_F4), 2 * wave, lane, acc);
+        pn_gemm_f16x3<16, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F4), 2 * wave, lane, acc);
         PN_TR(pn_trace_fwd, 12);
         // the next tile's point data and the indices of the two after it: requested here, consumed at the top of the next
         // iteration -- their HBM latency passes under the element-wise tail of this tile
@@ -690,7 +690,7 @@ __device__ __forceinline__ void c_acc_zero(f32x16 (&acc)[2][2]) {
         for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
 }
 
-template <bool TRAIN>
+template <bool TRAIN, int NP>
 __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     char *X = smem_c;
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
         // ---- layer 1: 280 (288) -> 128.  Training: every layer's input tile leaves k-major for the weight-gradient GEMM
         if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.xck, rgc_total, tile * 8, tid);
         c_acc_zero(acc);
-        pn_gemm_f16x3<18, 4, 1, 7>(X, reinterpret_cast<const uint4 *>(img + PKH_FC1), wave, lane, acc);
+        pn_gemm_f16x3<18, 4, 1, 7, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_FC1), wave, lane, acc);
         c_load_bias(P + PO_BC1, wave, lane, bias);
         PN_LDS_BARRIER();                                 // every wave is done reading the input tile
         unsigned mw = c_epilogue<TRAIN, false>(acc, bias, X, wave, lane, nullptr, grow0);
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
         // ---- layer 2
         if (TRAIN) pn_copy_out_kmajor<PN_HC>(X, a.sv.c1k, rgc_total, tile * 8, tid);
         c_acc_zero(acc);
-        pn_gemm_f16x3<8, 4, 1, 7>(X, reinterpret_cast<const uint4 *>(img + PKH_FC2), wave, lane, acc);
+        pn_gemm_f16x3<8, 4, 1, 7, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_FC2), wave, lane, acc);
         c_load_bias(P + PO_BC2, wave, lane, bias);
         PN_LDS_BARRIER();
         mw = c_epilogue<TRAIN, false>(acc, bias, X, wave, lane, nullptr, grow0);
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
         // ---- layer 3
         if (TRAIN) pn_copy_out_kmajor<PN_HC>(X, a.sv.c2k, rgc_total, tile * 8, tid);
         c_acc_zero(acc);
-        pn_gemm_f16x3<8, 4, 1, 7>(X, reinterpret_cast<const uint4 *>(img + PKH_FC3), wave, lane, acc);
+        pn_gemm_f16x3<8, 4, 1, 7, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_FC3), wave, lane, acc);
         c_load_bias(P + PO_BC3, wave, lane, bias);
         PN_LDS_BARRIER();
         c_epilogue<TRAIN, true>(acc, bias, X, wave, lane, a.sv.c3, grow0);
@@ -786,6 +786,15 @@ __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
 }
 }  // namespace
 
+// products per multiply-add of the INFERENCE forward (training always runs three): see f16x3.h NP and include/pnerf.h
+static int pn_inference_products = 3;
+extern "C" int pnerf_set_inference_products(int n) {
+    if (n != 2 && n != 3) return PNERF_E_INVAL;
+    const int old = pn_inference_products;
+    pn_inference_products = n;
+    return old;
+}
+
 // shared with render.hip
 int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, const float *d_params, const void *d_packed,
                           const float *d_raydir, const float *d_sample_loc, const float *d_xyz_pers, const float *d_loc_pers,
@@ -808,9 +817,11 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     const int grid_c = (int)(ctiles < 2 * ncu ? (ctiles > 0 ? ctiles : 1) : 2 * ncu);       // two workgroups per CU
     const size_t lds_a = FL_BYTES, lds_c = CL_BYTES;
     const bool pers = d_xyz_pers != nullptr;
-    const void *kfn = train ? (pers ? (const void *)k_agg_forward<true, true> : (const void *)k_agg_forward<true, false>)
-                            : (pers ? (const void *)k_agg_forward<false, true> : (const void *)k_agg_forward<false, false>);
-    const void *cfn = train ? (const void *)k_color_forward<true> : (const void *)k_color_forward<false>;
+    const bool np2 = !train && pn_inference_products == 2;      // inference with the weights' high plane only (f16x3.h: NP)
+    const void *kfn = train ? (pers ? (const void *)k_agg_forward<true, true, 3> : (const void *)k_agg_forward<true, false, 3>)
+                    : np2   ? (pers ? (const void *)k_agg_forward<false, true, 2> : (const void *)k_agg_forward<false, false, 2>)
+                            : (pers ? (const void *)k_agg_forward<false, true, 3> : (const void *)k_agg_forward<false, false, 3>);
+    const void *cfn = train ? (const void *)k_color_forward<true, 3> : np2 ? (const void *)k_color_forward<false, 2> : (const void *)k_color_forward<false, 3>;
     if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipFuncSetAttribute(cfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
     int rc = pn_classify(sv, d_valid_list, d_counters, d_sample_pidx, K, cap_samples, train, s);
@@ -824,17 +835,20 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
             a.cls = j; a.K = kc[j]; a.TS = pn_tile_samples(kc[j]);
             const long long tiles = (cap_samples + a.TS - 1) / a.TS;
             const int grid_a = (int)(tiles < 2LL * ncu ? (tiles > 0 ? tiles : 1) : 2LL * ncu);     // two workgroups per CU
-            if (train && pers) hipLaunchKernelGGL((k_agg_forward<true, true>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
-            else if (train) hipLaunchKernelGGL((k_agg_forward<true, false>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
-            else if (pers) hipLaunchKernelGGL((k_agg_forward<false, true>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
-            else hipLaunchKernelGGL((k_agg_forward<false, false>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            if (train && pers) hipLaunchKernelGGL((k_agg_forward<true, true, 3>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            else if (train) hipLaunchKernelGGL((k_agg_forward<true, false, 3>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            else if (np2 && pers) hipLaunchKernelGGL((k_agg_forward<false, true, 2>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            else if (np2) hipLaunchKernelGGL((k_agg_forward<false, false, 2>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            else if (pers) hipLaunchKernelGGL((k_agg_forward<false, true, 3>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            else hipLaunchKernelGGL((k_agg_forward<false, false, 3>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
         }
     }
     a.K = K; a.TS = pn_tile_samples(K); a.valid_list = sv.cls_list;      // the colour MLP walks the class-ordered list: f rows are in that order
     {
         PnProfScope prof(PNK_COLOR_FWD, s);
-        if (train) hipLaunchKernelGGL(k_color_forward<true>, dim3(grid_c), dim3(256), lds_c, s, a);
-        else hipLaunchKernelGGL(k_color_forward<false>, dim3(grid_c), dim3(256), lds_c, s, a);
+        if (train) hipLaunchKernelGGL((k_color_forward<true, 3>), dim3(grid_c), dim3(256), lds_c, s, a);
+        else if (np2) hipLaunchKernelGGL((k_color_forward<false, 2>), dim3(grid_c), dim3(256), lds_c, s, a);
+        else hipLaunchKernelGGL((k_color_forward<false, 3>), dim3(grid_c), dim3(256), lds_c, s, a);
     }
     PN_CHECK_LAUNCH();
     return 0;

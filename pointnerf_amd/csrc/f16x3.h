@@ -225,8 +225,13 @@ __device__ __forceinline__ void pn_x_axpy4(const char *X, int row, int col, floa
 //  in-order vmcnt queue with the weight fragments, every chunk then waits for HBM writes: +3 us per GEMM against 2.4 us saved.)
 // WPF = chunks of weight fragments requested ahead: 2 covers an L2 round trip when a chunk is 24 MFMAs (two feature blocks); the
 // colour MLP's waves own ONE feature block (6 MFMAs = 0.1 us per chunk) and ask for 7.
-template <int NC, int MB, int NFB, int WPF = PN_WPF>
+// NP = products per multiply-add: 3 (h*h + h*m + m*h, fp32-class accuracy: training and the gradient chain) or 2 (the WEIGHTS' residual
+// plane dropped: an inference OPTION (pnerf_set_inference_products) -- measured 1.6e-5 on ray colour at configs[1], bar 1e-4, but sigma only
+// to ~1e-5 of its magnitude; rejected for training because a systematic
+// perturbation of the weights flips LeakyReLU sides between forward and backward; a third of the MFMAs and half of the weight stream less).
+template <int NC, int MB, int NFB, int WPF = PN_WPF, int NP = 3>
 __device__ __forceinline__ void pn_gemm_f16x3(const char *X, const uint4 *__restrict__ img, int fb0, int lane, f32x16 (&acc)[2][2], int c0 = 0) {
+    static_assert(NP == 2 || NP == 3, "two or three products");
     constexpr int PF = WPF < NC ? WPF : NC - 1, NS = PF + 1;
     const char *xb = X + (lane & 31) * PN_XRS + (lane >> 5) * 16 + c0 * 32;
     const uint4 *wp = img + ((size_t)c0 * MB + fb0) * 128 + lane;
@@ -234,7 +239,7 @@ __device__ __forceinline__ void pn_gemm_f16x3(const char *X, const uint4 *__rest
     auto load_w = [&](auto cc) {
         constexpr int c = decltype(cc)::value, s = c % NS;
 #pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) { wh[s][fb] = wp[(c * MB + fb) * 128]; wm[s][fb] = wp[(c * MB + fb) * 128 + 64]; }
+        for (int fb = 0; fb < NFB; ++fb) { wh[s][fb] = wp[(c * MB + fb) * 128]; if (NP == 3) wm[s][fb] = wp[(c * MB + fb) * 128 + 64]; }
     };
     auto load_x = [&](auto cc) {
         constexpr int c = decltype(cc)::value, s = c & 1;
@@ -255,7 +260,7 @@ __device__ __forceinline__ void pn_gemm_f16x3(const char *X, const uint4 *__rest
         //  an exposed L2 round trip per chunk, measured 30 % of the MFMA rate)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll

@@ -369,6 +369,15 @@ def zero_one_conf_sum(conf, pidx, eps):
     return ZeroOneConf.apply(conf, pidx.contiguous(), eps)
 
 
+def set_inference_products(n):
+    """Products per multiply-add of the inference forward: 3 (default, fp32-class accuracy, what the training forward always runs) or
+    2 (render / evaluation option: ~1.5x less matrix work, ray colour within ~2e-5 of fp32).  Returns the previous setting."""
+    old = L.lib().pnerf_set_inference_products(int(n))
+    if old < 0:
+        raise ValueError("inference products must be 2 or 3")
+    return old
+
+
 # ------------------------------------------------------------------------------------------ profiling
 def prof_enable(on=True):
     L.lib().pnerf_prof_enable(1 if on else 0)

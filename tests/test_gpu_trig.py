@@ -77,3 +77,45 @@ def test_backward_with_trained_magnitude_embeddings():
         _check(k, gm[k], gm_o[k])
     for k in gp_o:
         _check(k, gp[k], gp_o[k])
+
+
+def test_weight_range_check_raises_instead_of_rendering_nan():
+    """the two-plane f16 operands hold |w| <= 65504 (csrc/f16x3.h): a checkpoint beyond that is refused when it is re-homed"""
+    from pointnerf_amd.point_aggregators import PointAggregator
+    opt, xyz, attrs, inp, mlp = build_case("small_k4")
+    agg = PointAggregator(opt).to(DEV)
+    bad = {k: v.clone() for k, v in mlp.items()}
+    bad["block1.0.weight"][3, 5] = 1.0e5
+    agg.load_state_dict(bad)
+    agg._flat = None
+    with pytest.raises(ValueError):
+        agg.flatten_()
+
+
+@pytest.mark.parametrize("name", ["small_k8", "small_k4"])
+def test_two_product_inference_option(name):
+    """pnerf_set_inference_products(2): the weights' residual plane dropped in the inference forward.  Ray colour / RGB within 1e-4 of the
+    fp32 oracle (the north-star bar), sigma within 1e-4 of its largest value; the default (3) is restored and stays at the 1e-6 level."""
+    from pointnerf_amd import ops
+    opt, xyz, attrs, inp, mlp = build_case(name)
+    ref = pyref.render(opt, dict(xyz=xyz, **attrs), mlp, inp)
+    assert ops.set_inference_products(2) == 3
+    try:
+        dense, fwd2, _ = hip_render(opt, xyz, attrs, inp, mlp)
+        torch.cuda.synchronize()
+    finally:
+        assert ops.set_inference_products(3) == 2
+    dense, fwd3, _ = hip_render(opt, xyz, attrs, inp, mlp)
+    torch.cuda.synchronize()
+    hit = (dense["ray_hit"] > 0).cpu()
+    rv, d_ref = ref["ray_valid"][0], ref["decoded_features"][0]
+    smax = float(d_ref[..., 0].abs().max())
+    out = {}
+    for tag, fwd in (("2", fwd2), ("3", fwd3)):
+        dec = fwd["decoded"].cpu()[hit]
+        out[tag] = (float((dec[..., 0] - d_ref[..., 0])[rv].abs().max()) / smax, float((dec[..., 1:] - d_ref[..., 1:])[rv].abs().max()),
+                    float((fwd["ray_color"].cpu()[hit] - ref["coarse_raycolor"][0]).abs().max()))
+    print("%s: (sigma err / max sigma, rgb err, ray colour err) two products %s, three products %s, max sigma %.3g" % (name, out["2"], out["3"], smax))
+    assert max(out["2"]) <= 1e-4 and max(out["3"]) <= 1e-5
+    with pytest.raises(ValueError):
+        ops.set_inference_products(4)
