@@ -38,6 +38,9 @@ F16_PRODUCTS = 3
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense BF16/F16 MFMA (measured 2178-2495)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense (no kernel of the path uses it any more)
 PEAK_HBM_GBS = 8000.0
+# roofline.traffic is NOT measured inside a bench run: it is read from the committed PMC summary (separate rocprofv3 --pmc passes of this
+# same command, FETCH x 2 + WRITE per the guide; tools/gpu_round_profile.sh regenerates it)
+TRAFFIC_SOURCE = "profiles/traffic.json (static: rocprofv3 --pmc passes of this command, not measured in this run)"
 # algorithmic HBM bytes of the weight-gradient GEMMs per neighbor row, read once: the inputs of the four layers as two f16 planes
 # (2 x 2 B x (288 + 256 + 288 + 256)) and their output gradients as one f16 plane (2 B x 4 x 256)
 BYTES_ROW_WGRAD = 2 * 2 * (288 + 256 + 288 + 256) + 2 * 4 * 256
@@ -129,14 +132,65 @@ def cpu_baseline(opt, n_points, rays, threads, points_fn=None, rays_fn=None):
     d = (rays_fn or scenes.random_rays)(0, 65536)
     d["raydir"], d["gt_image"] = d["raydir"][:, :rays], d["gt_image"][:, :rays]
     inp = pyref.to_torch_inputs(d)
+    # the serial voxel-grid build over all points (the C oracle rebuilds it on every query, like the reference): timed on its own with a
+    # one-ray query, so that the sample's seconds can be read with and without it
+    one = dict(inp)
+    one["raydir"], one["gt_image"] = inp["raydir"][:, :1], inp["gt_image"][:, :1]
     t0 = time.time()
-    out = pyref.render(opt, dict(xyz=xyz, **attrs), mlp, inp, nthreads=threads)
+    pyref.query(opt, xyz, one, nthreads=threads)
+    t_grid = time.time() - t0
+    t0 = time.time()
+    q = pyref.query(opt, xyz, inp, nthreads=threads)
+    t_query = time.time() - t0
+    t0 = time.time()
+    out = pyref.render(opt, dict(xyz=xyz, **attrs), mlp, inp, q=q, nthreads=threads)
     loss = pyref.training_loss(opt, out, inp)
     loss.backward()
-    dt = time.time() - t0
+    t_render = time.time() - t0
+    dt = t_query + t_render
     return dict(value=rays / dt, unit="rays/s", cores=threads, kind="port",
-                sample="first %d rays of step 0 of the same workload (query incl. serial grid build over %d points, "
-                       "aggregator+ray-march fwd, loss, backward), %.1f s" % (rays, xyz.shape[0], dt))
+                value_without_grid_build=rays / max(dt - t_grid, 1e-9),
+                seconds={"grid_build_serial": t_grid, "query_incl_grid_build": t_query, "aggregator_raymarch_loss_backward": t_render},
+                sample="first %d rays of step 0 of the same workload: query %.1f s (of which the serial grid build over %d points %.1f s), "
+                       "aggregator + ray-march forward, loss, backward %.1f s" % (rays, t_query, xyz.shape[0], t_grid, t_render))
+
+
+def rccl_selftest(dev, rank, world):
+    """One small instance of every collective form the step uses, before anything is timed: a 1 KB all-reduce, an all_gather_into_tensor
+    (gloo: all_gather), a reduce_scatter_tensor, and the side-stream in-place all-reduce of a bucket head behind an event with
+    record_stream (dist.allreduce_grads).  Raises on a wrong sum; rank 0 reports on stderr (stdout carries the one JSON line)."""
+    import torch.distributed as dist
+    backend = dist.get_backend()
+    x = torch.full((256,), float(rank + 1), device=dev)
+    dist.all_reduce(x)
+    want = world * (world + 1) / 2.0
+    assert float(x[0]) == want and float(x[-1]) == want, "all_reduce: %r != %r" % (float(x[0]), want)
+    mine = torch.full((64,), float(rank), device=dev)
+    allv = torch.empty(64 * world, device=dev)
+    if backend == "gloo":
+        dist.all_gather(list(allv.view(world, 64).unbind(0)), mine)
+    else:
+        dist.all_gather_into_tensor(allv, mine)
+    assert allv.view(world, 64)[:, 0].tolist() == [float(r) for r in range(world)], "all_gather_into_tensor"
+    if backend != "gloo":
+        buf = torch.arange(world * 32, device=dev, dtype=torch.float32)
+        out = buf[rank * 32:(rank + 1) * 32]
+        dist.reduce_scatter_tensor(out, buf)                       # in place, as optim.ShardedAdam does
+        assert float(out[0]) == world * rank * 32.0, "reduce_scatter_tensor"
+    bucket = torch.full((1 << 16,), float(rank + 1), device=dev)
+    ev = torch.cuda.Event()
+    ev.record()
+    comm = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(comm):
+        comm.wait_event(ev)
+        bucket.record_stream(comm)
+        dist.all_reduce(bucket[:1 << 15])
+    torch.cuda.current_stream(dev).wait_stream(comm)
+    assert float(bucket[0]) == want and float(bucket[-1]) == float(rank + 1), "side-stream bucket all-reduce"
+    torch.cuda.synchronize()
+    if rank == 0:
+        print("rccl_selftest: ok  backend=%s world=%d HSA_ENABLE_IPC_MODE_LEGACY=%s" % (backend, world, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")),
+              file=sys.stderr, flush=True)
 
 
 def main():
@@ -154,6 +208,8 @@ def main():
     dev = torch.device("cuda", local)
     from pointnerf_amd import ops, dist as pdist
     from pointnerf_amd.fused import FusedRender
+    if world > 1:
+        rccl_selftest(dev, rank, world)
 
     # is_train=1: the reference trains with 30 % segment jitter (point_query.py:81); the in-kernel RNG path is what a
     # training step runs, so it is what is timed (parity runs -- tests/ -- use jitter off, where results are bit-defined)
@@ -177,10 +233,12 @@ def main():
     opt_mlp = FusedAdam(mlp_params, lr=opt.lr, betas=(0.9, 0.999))
     opt_pts = ShardedAdam(pt_params, lr=opt.plr, betas=(0.9, 0.999)) if zero1 else FusedAdam(pt_params, lr=opt.plr, betas=(0.9, 0.999))
 
+    comm_marks = None                         # (event pairs around the gradient exchange on the main stream; filled in the timed region)
     total = args.warmup + args.steps
     inputs = [step_inputs(i, rank, world, args.rays, dev, rays_fn) for i in range(total)]   # resident in HBM before timing
 
     def one_step(inp):
+        nonlocal comm_marks
         if args.render_only:
             with torch.no_grad():
                 out = model(**inp)
@@ -189,6 +247,9 @@ def main():
         out = model(**inp)
         loss = loss_fn(opt, out, inp, world)
         loss.backward()
+        if world > 1 and comm_marks is not None:
+            comm_marks.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+            comm_marks[-1][0].record()
         # no-op at N=1; RCCL over xGMI otherwise.  The three point tensors only the renderer writes (88 % of the bytes) start
         # their all-reduce as soon as the input-gradient kernels are done, under the weight-gradient GEMMs
         if sparse:
@@ -201,6 +262,8 @@ def main():
         else:
             early = [] if (zero1 or args.no_overlap_comm) else [npnt.points_embeding, npnt.points_dir, npnt.points_color]
             pdist.allreduce_grads(mlp_params, [] if zero1 else pt_params, ready_event=FusedRender.point_grads_ready if early else None, early_params=early)
+        if world > 1 and comm_marks is not None:
+            comm_marks[-1][1].record()        # main stream: backward done -> every gradient summed = the communication that did NOT hide
         step_all([opt_mlp, opt_pts])          # both Adam instances in one launch (ShardedAdam, when --zero1, steps on its own)
         return loss, model.last_stats
 
@@ -234,6 +297,7 @@ def main():
     torch.cuda.synchronize()
     allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # step boundaries on the stream the kernels run on
+    comm_marks = [] if world > 1 else None
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.warmup, total):
@@ -276,10 +340,21 @@ def main():
     if not np.isfinite(float(loss.item())):
         raise SystemExit("bench.py: non-finite loss after %d steps -- the timed path produced NaN/Inf, the number would be meaningless" % total)
     per_rank_ms = [dt / args.steps * 1e3]
+    exposed_ms = replica_spread = None
     if world > 1:                                   # self-check for the scaling record: the RCCL world and every rank's own step time
         t_all = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
         torch.distributed.all_gather(t_all, torch.tensor([dt_local / args.steps * 1e3], device=dev, dtype=torch.float64))
         per_rank_ms = [float(t.item()) for t in t_all]
+        # gradient exchange that did not hide under compute, per rank: main-stream time from "backward enqueued" to "all gradients summed"
+        mine = float(np.mean([a.elapsed_time(b) for a, b in comm_marks])) if comm_marks else 0.0
+        e_all = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        torch.distributed.all_gather(e_all, torch.tensor([mine], device=dev, dtype=torch.float64))
+        exposed_ms = [float(t.item()) for t in e_all]
+        # the replicas must stay IDENTICAL (every rank applies the same summed gradients): per-tensor checksums, largest difference to rank 0
+        chk = torch.stack([p.detach().double().sum() for p in pt_params + mlp_params] + [p.detach().double().abs().sum() for p in pt_params])
+        c_all = [torch.zeros_like(chk) for _ in range(world)]
+        torch.distributed.all_gather(c_all, chk)
+        replica_spread = float(max((c - c_all[0]).abs().max() for c in c_all))
     if rank == 0:
         from pointnerf_amd.fused import FusedRender
         rays_total = args.rays * world * args.steps
@@ -289,11 +364,12 @@ def main():
         out = {"metric": name + (" NeRF-synth lego 800^2, K=8, 128 samp/ray" if headline else " %s, K=%d, %d samp/ray" % (cfg_name, opt.K, opt.SR)),
                "value": rays_total / dt, "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "median_ms_per_step": median_ms,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32 in / out / accumulate; GEMM operands as 2 x f16 planes (22-bit) on the f16 MFMA, 3 products per multiply-add", "data": "synthetic",
                "neighbor_rows_per_s": rows * world * args.steps / dt, "valid_samples_per_s": smp * world * args.steps / dt,
                "config": {"workload": "BASELINE.json %s, %d neural points, K=%d, SR=%d, D=%d, %d rays/GPU/step, fwd+loss+bwd+Adam, grid cached"
                                       % (cfg_name, n_points, opt.K, opt.SR, opt.z_depth_dim, args.rays),
-                          "parallelism": "ray-shard dp%d, point cloud + MLP replicated" % world, "point_grad_exchange": ("none" if world == 1 else ("zero1 reduce-scatter" if zero1 else ("sparse touched rows" if sparse else "dense all-reduce, one bucket, overlapped"))), "world_size": world, "ms_per_step_by_rank": per_rank_ms,
+                          "parallelism": "ray-shard dp%d, point cloud + MLP replicated" % world, "point_grad_exchange": ("none" if world == 1 else ("zero1 reduce-scatter" if zero1 else ("sparse touched rows" if sparse else "dense all-reduce, one bucket, overlapped"))), "world_size": world, "ms_per_step_by_rank": per_rank_ms, "ms_allreduce_exposed_by_rank": exposed_ms, "replica_param_checksum_spread": replica_spread,
                           "valid_samples_per_step": smp, "neighbor_rows_per_step": rows,
                           "rays_hit_per_step": float(np.mean([s["rays_hit"] for s in stats])), "final_loss": float(loss.item()),
                           "device_allocs_in_timed_region": int(extra_allocs), "setup_steps": 2,
@@ -321,14 +397,18 @@ def main():
             def mfma_entry(k):      # executed f16 products against the dense f16 MFMA peak
                 t = per[k]["ms_per_step"] * 1e-3
                 return {"bound": "mfma", "kernel": k, "achieved": F16_PRODUCTS * alg_flop[k] / t / 1e12, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": F16_PRODUCTS * alg_flop[k] / t / 1e12 / PEAK_F16_MFMA_TFLOPS, "traffic": traffic.get(k),
+                        "frac": F16_PRODUCTS * alg_flop[k] / t / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                        "frac_algorithmic": alg_flop[k] / t / 1e12 / PEAK_F16_MFMA_TFLOPS,       # SURVEY 8d flops (no x3) against the same peak
+                        "frac_note": "frac = executed f16 products (3 per algorithmic multiply-add) / dense f16 MFMA peak = matrix-pipe utilisation; "
+                                     "frac_algorithmic = SURVEY 8d flops / the same peak",
+                        "traffic": traffic.get(k), "traffic_source": TRAFFIC_SOURCE,
                         "algorithmic_tflops_f32_equivalent": alg_flop[k] / t / 1e12, "f16_products_per_multiply_add": F16_PRODUCTS,
                         "algorithmic_flop_per_step": alg_flop[k], "ms_per_step": per[k]["ms_per_step"]}
 
             def hbm_entry(k):
                 t = per[k]["ms_per_step"] * 1e-3
                 return {"bound": "hbm", "kernel": k, "achieved": alg_byte[k] / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": alg_byte[k] / t / 1e9 / PEAK_HBM_GBS, "traffic": traffic.get(k), "algorithmic_bytes_per_step": alg_byte[k],
+                        "frac": alg_byte[k] / t / 1e9 / PEAK_HBM_GBS, "traffic": traffic.get(k), "traffic_source": TRAFFIC_SOURCE, "algorithmic_bytes_per_step": alg_byte[k],
                         "ms_per_step": per[k]["ms_per_step"]}
             heavy = [k for k in ("agg_forward", "agg_backward", "wgrad") if k in per]
             if heavy:

@@ -39,7 +39,15 @@ def _two_ranks(extra, port_off):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(29600 + (os.getpid() + port_off) % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--rays", "4096", "--points", "300000", "--cpu-rays", "0"] + extra
-    return _last_json(subprocess.check_output(cmd, cwd=ROOT, env=env, timeout=900, stderr=subprocess.STDOUT))
+    out = subprocess.check_output(cmd, cwd=ROOT, env=env, timeout=900, stderr=subprocess.STDOUT)
+    assert b"rccl_selftest: ok" in out and b"world=2" in out, out.decode()[-2000:]        # every collective form of the step ran once before the timing
+    d = _last_json(out)
+    c = d["config"]
+    assert len(c["ms_allreduce_exposed_by_rank"]) == 2 and all(t >= 0 for t in c["ms_allreduce_exposed_by_rank"])
+    # every rank applied the same summed gradients: the replicas' parameters are bitwise identical (incl. points_conf[0], which collects
+    # the zero-one regulariser's empty-slot terms: ADVICE round 2 on the sparse exchange)
+    assert c["replica_param_checksum_spread"] == 0.0, c["replica_param_checksum_spread"]
+    return d
 
 
 def test_bench_two_ranks_on_one_gpu():
