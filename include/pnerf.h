@@ -176,9 +176,9 @@ int pnerf_render_forward(const pnerf_camera *cam, const pnerf_points *pts, const
 
 /* Arithmetic of the INFERENCE forward (d_saved == NULL; pnerf_render_forward and pnerf_agg_forward): every fp32 GEMM operand is two f16
  * planes and a multiply-add is 3 MFMA products (default: fp32-class accuracy, sigma / RGB ~1e-6 from an fp32 evaluation) or 2 (the
- * weights' residual plane dropped: a third of the matrix work and half of the weight stream less; measured ray colour / RGB ~2e-5 and
- * sigma ~1e-5 of its magnitude from fp32 -- RGB inside the 1e-4 bar, sigma only relative to its scale, which is why it is an OPTION for
- * render / evaluation loops and not the default; nothing differentiates through it).  Training forwards always run 3.  Returns the
+ * weights' residual plane dropped: a third of the matrix work and half of the weight stream less; measured: rendered ray colour 1e-6 ..
+ * 2e-5 from fp32, inside the 1e-4 bar, but per-sample sigma / RGB 2e-4 .. 4e-4, outside it -- which is why it is an OPTION for previews
+ * and evaluation loops and not the default; nothing differentiates through it).  Training forwards always run 3.  Returns the
  * previous setting, or PNERF_E_INVAL for n not in {2, 3}.  Process-wide. */
 int pnerf_set_inference_products(int n);
 

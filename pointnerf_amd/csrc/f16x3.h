@@ -226,8 +226,8 @@ __device__ __forceinline__ void pn_x_axpy4(const char *X, int row, int col, floa
 // WPF = chunks of weight fragments requested ahead: 2 covers an L2 round trip when a chunk is 24 MFMAs (two feature blocks); the
 // colour MLP's waves own ONE feature block (6 MFMAs = 0.1 us per chunk) and ask for 7.
 // NP = products per multiply-add: 3 (h*h + h*m + m*h, fp32-class accuracy: training and the gradient chain) or 2 (the WEIGHTS' residual
-// plane dropped: an inference OPTION (pnerf_set_inference_products) -- measured 1.6e-5 on ray colour at configs[1], bar 1e-4, but sigma only
-// to ~1e-5 of its magnitude; rejected for training because a systematic
+// plane dropped: an inference OPTION (pnerf_set_inference_products) -- rendered ray colour within 2e-5 of fp32, per-sample sigma / RGB only
+// within 4e-4 (outside the 1e-4 bar: not the default); rejected for training because a systematic
 // perturbation of the weights flips LeakyReLU sides between forward and backward; a third of the MFMAs and half of the weight stream less).
 template <int NC, int MB, int NFB, int WPF = PN_WPF, int NP = 3>
 __device__ __forceinline__ void pn_gemm_f16x3(const char *X, const uint4 *__restrict__ img, int fb0, int lane, f32x16 (&acc)[2][2], int c0 = 0) {
