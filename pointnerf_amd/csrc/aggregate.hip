@@ -342,8 +342,8 @@ struct FGather {               // what a thread holds of one tile row (4 threads
 };
 
 // sample id of row `row` of tile `tile` (or -1)
-__device__ __forceinline__ int f_sample_of(const FwdArgs &a, long long tile, int row, int Ns) {
-    const int ls = row / a.K;
+__device__ __forceinline__ int f_sample_of(const FwdArgs &a, long long tile, int row, int Ns, unsigned kinv) {
+    const int ls = pn_row_div(row, kinv);
     const long long vs = tile * a.TS + ls;
     return (ls < a.TS && vs < Ns) ? a.valid_list[vs] : -1;
 }
@@ -427,14 +427,24 @@ __device__ __forceinline__ void f_build(const FwdArgs &a, const FGather &G, char
 // epilogue of a layer: accumulators + bias, LeakyReLU, sign bits, both planes -> the tile (columns 0..255).
 // Sign word: one v_alignbit_b32 per element shifts the element's sign bit into a 32-bit accumulator (MSB first), element
 // e = ((fb * 2 + rb) * 4 + g) * 4 + i of a lane -> bit 31 - (e & 31) of half e >> 5; bit set = negative = slope 0.01 in the backward
-__device__ __forceinline__ void f_load_bias(const float *__restrict__ bias, int wave, int lane, float4 (&b)[8]) {
+// The bias is the accumulators' INITIAL value (D = W X^T + b: a lane's element (fb, rb, g, i) belongs to feature pn_d_feat(..) + i, the
+// same for both row blocks): requested before the tile's copy-out, in the accumulators when the GEMM starts -- the epilogue then holds
+// no global data at all (round 2 loaded it behind the GEMM, and behind the next tile's gather in the in-order vmcnt queue).
+__device__ __forceinline__ void f_acc_bias(const float *__restrict__ bias, int wave, int lane, f32x16 (&acc)[2][2]) {
 #pragma unroll
     for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) b[fb * 4 + g] = *reinterpret_cast<const float4 *>(bias + pn_d_feat(2 * wave + fb, g, lane));
+        for (int g = 0; g < 4; ++g) {
+            const float4 b = *reinterpret_cast<const float4 *>(bias + pn_d_feat(2 * wave + fb, g, lane));
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) { acc[fb][rb][4 * g] = b.x; acc[fb][rb][4 * g + 1] = b.y; acc[fb][rb][4 * g + 2] = b.z; acc[fb][rb][4 * g + 3] = b.w; }
+        }
 }
+// epilogue of a layer: LeakyReLU of the accumulators (bias included), sign bits, both planes -> the tile (columns 0..255).
+// Sign word: one v_alignbit_b32 per element shifts the element's sign bit into a 32-bit accumulator (MSB first), element
+// e = ((fb * 2 + rb) * 4 + g) * 4 + i of a lane -> bit 31 - (e & 31) of half e >> 5; bit set = negative = slope 0.01 in the backward
 template <bool BITS>
-__device__ __forceinline__ void f_epilogue(const f32x16 (&acc)[2][2], const float4 (&bias)[8], char *X, int wave, int lane, unsigned long long &mask) {
+__device__ __forceinline__ void f_epilogue(const f32x16 (&acc)[2][2], char *X, int wave, int lane, unsigned long long &mask) {
     unsigned mw[2] = {0u, 0u};
 #pragma unroll
     for (int fb = 0; fb < 2; ++fb)
@@ -443,17 +453,13 @@ __device__ __forceinline__ void f_epilogue(const f32x16 (&acc)[2][2], const floa
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int f0 = pn_d_feat(2 * wave + fb, g, lane);
-                const float4 b = bias[fb * 4 + g];
-                // bias add and the 0.01 x of the LeakyReLU as packed fp32 operations (v_pk_add_f32 / v_pk_mul_f32: two elements per issue)
-                const pn_f2 v01 = pn_f2{acc[fb][rb][4 * g], acc[fb][rb][4 * g + 1]} + pn_f2{b.x, b.y};
-                const pn_f2 v23 = pn_f2{acc[fb][rb][4 * g + 2], acc[fb][rb][4 * g + 3]} + pn_f2{b.z, b.w};
-                const pn_f2 s01 = v01 * 0.01f, s23 = v23 * 0.01f;
-                float v[4] = {v01[0], v01[1], v23[0], v23[1]};
+                float v[4] = {acc[fb][rb][4 * g], acc[fb][rb][4 * g + 1], acc[fb][rb][4 * g + 2], acc[fb][rb][4 * g + 3]};
                 if (BITS) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) mw[fb] = __builtin_amdgcn_alignbit(mw[fb], __float_as_uint(v[i]), 31);
                 }
-                v[0] = fmaxf(v[0], s01[0]); v[1] = fmaxf(v[1], s01[1]); v[2] = fmaxf(v[2], s23[0]); v[3] = fmaxf(v[3], s23[1]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.01f * v[i]);
                 pn_x_store4<false>(X, 32 * rb + (lane & 31), f0, v[0], v[1], v[2], v[3]);
             }
     mask = ((unsigned long long)mw[1] << 32) | mw[0];
@@ -480,6 +486,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
     int *sidx = reinterpret_cast<int *>(wnrm + PN_TILE);
     const int tid0 = threadIdx.x;
     const int K = a.K, TS = a.TS;
+    const unsigned kinv = pn_kinv(K);
     // this launch processes one sample class: its list, its run of tiles, its range of per-sample rows
     const int Ns = a.cls_info[PN_CI_COUNT + a.cls];
     const long long vb = a.cls_info[PN_CI_VBASE + a.cls], tb = a.cls_info[PN_CI_TBASE + a.cls];
@@ -499,8 +506,8 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
     int si0, si1, si2, p0, p1;
     FGather G;
     {
-        const int row = tid0 / TPR, q = tid0 % TPR, k = row % K;
-        si0 = f_sample_of(a, tile, row, Ns); si1 = f_sample_of(a, tile + stride, row, Ns); si2 = f_sample_of(a, tile + 2 * stride, row, Ns);
+        const int row = tid0 / TPR, q = tid0 % TPR, k = row - pn_row_div(row, kinv) * K;
+        si0 = f_sample_of(a, tile, row, Ns, kinv); si1 = f_sample_of(a, tile + stride, row, Ns, kinv); si2 = f_sample_of(a, tile + 2 * stride, row, Ns, kinv);
         p0 = si0 >= 0 ? a.pidx[(long long)si0 * a.Kstride + k] : -1;
         p1 = si1 >= 0 ? a.pidx[(long long)si1 * a.Kstride + k] : -1;
         f_gather<PERS>(a, G, si0, p0, q);
@@ -514,14 +521,14 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         // registers (every LDS / bias / image address of every unrolled store) and spill
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), row = tid / TPR, q = tid % TPR, k = row % K;
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), row = tid / TPR, q = tid % TPR, k = row - pn_row_div(row, kinv) * K;
         const long long gtile = tb + tile;               // tile index inside the saved area
         PN_LDS_BARRIER();                                 // the previous tile's readers are done with X and the row arrays
         PN_TR(pn_trace_fwd, 0); PN_TR_HWID(pn_trace_fwd);
         f_build<PERS>(a, G, X, exb, wraw, sidx, si0, p0, row, q);
         PN_LDS_BARRIER();
         if (q == 0) {      // weights of the row: normalise over the K slots, multiply by the clamped confidence (:801-811)
-            const int ls = row / K;
+            const int ls = pn_row_div(row, kinv);
             float wn = 0.f, w = 0.f;
             if (si0 >= 0) {
                 float sum = 0.f;
@@ -534,29 +541,26 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
             if (TRAIN) a.sv.rmeta[gtile * PN_TILE + row] = make_int4(si0, si0 >= 0 ? p0 : -1, __float_as_int(wn), __float_as_int(w));
         }
         unsigned long long mask;
-        float4 bias[8];
         PN_TR(pn_trace_fwd, 1);
         // ---- layer 1: 288 -> 256
+        f_acc_bias(P + PO_B1, wave, lane, acc);
         if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.x0k, rg_total, gtile * 8, tid);
-        f_acc_zero(acc);
         PN_TR(pn_trace_fwd, 2);
         pn_gemm_f16x3<18, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F1), 2 * wave, lane, acc);
-        f_load_bias(P + PO_B1, wave, lane, bias);           // (requested before the barrier: the wait for the slowest wave covers the L2 round trip)
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 3);
-        f_epilogue<TRAIN>(acc, bias, X, wave, lane, mask);
+        f_epilogue<TRAIN>(acc, X, wave, lane, mask);
         if (TRAIN) a.sv.lmask[(gtile * 3 + 0) * PN_NTHR + tid] = mask;
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 4);
         // ---- layer 2: 256 -> 256
+        f_acc_bias(P + PO_B2, wave, lane, acc);
         if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h1k, rg_total, gtile * 8, tid);
-        f_acc_zero(acc);
         PN_TR(pn_trace_fwd, 5);
         pn_gemm_f16x3<16, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F2), 2 * wave, lane, acc);
-        f_load_bias(P + PO_B2, wave, lane, bias);           // (requested before the barrier: the wait for the slowest wave covers the L2 round trip)
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 6);
-        f_epilogue<TRAIN>(acc, bias, X, wave, lane, mask);
+        f_epilogue<TRAIN>(acc, X, wave, lane, mask);
         if (TRAIN) a.sv.lmask[(gtile * 3 + 1) * PN_NTHR + tid] = mask;
         if (tid < PN_TILE) {     // the row's extras next to h2: columns 256..262, the ones column, zeros up to 271
             const float4 u = *reinterpret_cast<const float4 *>(exb + tid * 8), v = *reinterpret_cast<const float4 *>(exb + tid * 8 + 4);
@@ -568,35 +572,33 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 7);
         // ---- layer 3: 256 + 7 -> 256
+        f_acc_bias(P + PO_B3, wave, lane, acc);
         if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.h2k, rg_total, gtile * 8, tid);
-        f_acc_zero(acc);
         PN_TR(pn_trace_fwd, 8);
         pn_gemm_f16x3<17, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F3), 2 * wave, lane, acc);
-        f_load_bias(P + PO_B3, wave, lane, bias);           // (requested before the barrier: the wait for the slowest wave covers the L2 round trip)
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 9);
-        f_epilogue<TRAIN>(acc, bias, X, wave, lane, mask);
+        f_epilogue<TRAIN>(acc, X, wave, lane, mask);
         if (TRAIN) a.sv.lmask[(gtile * 3 + 2) * PN_NTHR + tid] = mask;
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 10);
         // ---- layer 4: 256 -> 256
+        f_acc_bias(P + PO_B4, wave, lane, acc);
         if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h3k, rg_total, gtile * 8, tid);
-        f_acc_zero(acc);
         PN_TR(pn_trace_fwd, 11);
         pn_gemm_f16x3<16, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F4), 2 * wave, lane, acc);
         PN_TR(pn_trace_fwd, 12);
         // the next tile's point data and the indices of the two after it: requested here, consumed at the top of the next
-        // iteration -- their HBM latency passes under the element-wise tail of this tile
+        // iteration -- their HBM latency passes under the element-wise tail of this tile (nothing of this tile waits for memory any more)
         const float cf_cur = G.cf;
         (void)cf_cur;
         const int si_next = si1, p_next = p1;
         if (tile + stride < ntiles) f_gather<PERS>(a, G, si1, p1, q);
         const int p2 = si2 >= 0 ? a.pidx[(long long)si2 * a.Kstride + k] : -1;
-        const int si3 = f_sample_of(a, tile + 3 * stride, row, Ns);
-        f_load_bias(P + PO_B4, wave, lane, bias);
+        const int si3 = f_sample_of(a, tile + 3 * stride, row, Ns, kinv);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 13);
-        f_epilogue<false>(acc, bias, X, wave, lane, mask);
+        f_epilogue<false>(acc, X, wave, lane, mask);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 14);
         // ---- alpha head (256 -> 1, softplus(x - 1), raw2out_density :262-265): 4 threads per row, 8-column groups interleaved

@@ -298,6 +298,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
     float *dx = reinterpret_cast<float *>(smem_b);
     const int tid0 = threadIdx.x;
     const int K = a.K, TS = a.TS;
+    const unsigned kinv = pn_kinv(K);
     const int Ns = a.cls_info[PN_CI_COUNT + a.cls];
     const long long vb = a.cls_info[PN_CI_VBASE + a.cls], tb = a.cls_info[PN_CI_TBASE + a.cls];
     a.sv.dfs += vb * PN_H;
@@ -310,6 +311,14 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
     float4 gw5v = make_float4(0.f, 0.f, 0.f, 0.f);      // d W5 of columns 4 (tid & 63) .. + 3 (scaled)
     float gb5t = 0.f;
     f32x16 acc[2][2];
+    // row metadata of the tile (threads 0..63: one row each), fetched ONE TILE AHEAD: the d sigma of a row hangs off its sample id, and
+    // two dependent HBM round trips at the top of every tile were 4 of the 6 us of the load phase
+    int4 rm_cur = make_int4(-1, -1, 0, 0);
+    float ar_cur = 0.f;
+    if (tid0 < PN_TILE && (long long)blockIdx.x < ntiles) {
+        rm_cur = a.sv.rmeta[(tb + blockIdx.x) * PN_TILE + tid0];
+        ar_cur = a.sv.arow[(tb + blockIdx.x) * PN_TILE + tid0];
+    }
     PN_TR_ITER_DECL;
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         PN_TR_ITER_NEXT;
@@ -319,38 +328,72 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         const long long gtile = tb + tile;
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 0); PN_TR_HWID(pn_trace_bwd);
-        // ---- load: sign words, row metadata, h4 planes
+        // ---- load: sign words, d sigma of the rows, the h4 planes (-> LDS before the barrier), the next tile's row metadata: one burst
         const unsigned long long m1 = a.sv.lmask[(gtile * 3 + 0) * PN_NTHR + tid], m2 = a.sv.lmask[(gtile * 3 + 1) * PN_NTHR + tid],
                                  m3 = a.sv.lmask[(gtile * 3 + 2) * PN_NTHR + tid];
+        float dsg_v = 0.f;
+        if (tid < PN_TILE && rm_cur.x >= 0) dsg_v = a.grad_decoded[(long long)rm_cur.x * 4];
+        pn_f4 h4v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = tid + PN_NTHR * i, plane = e >> 11, r = (e >> 5) & 63, u = e & 31;
+            h4v[i] = *reinterpret_cast<const pn_f4 *>(a.sv.h4r + ((long long)plane * a.sv.rows + gtile * PN_TILE + r) * 32 + u);
+        }
+        int4 rm_nxt = make_int4(-1, -1, 0, 0);
+        float ar_nxt = 0.f;
+        if (tid < PN_TILE && tile + gridDim.x < ntiles) {
+            rm_nxt = a.sv.rmeta[(gtile + gridDim.x) * PN_TILE + tid];
+            ar_nxt = a.sv.arow[(gtile + gridDim.x) * PN_TILE + tid];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (tid < PN_TILE) {
-            const int4 rm = a.sv.rmeta[gtile * PN_TILE + tid];
-            sidx[tid] = rm.x; prow[tid] = rm.y;
-            wnrm[tid] = __int_as_float(rm.z); wrow[tid] = __int_as_float(rm.w);
-            xrow[tid] = a.sv.arow[gtile * PN_TILE + tid];
-            dsg[tid] = rm.x >= 0 ? a.grad_decoded[(long long)rm.x * 4] * S : 0.f;
+            sidx[tid] = rm_cur.x; prow[tid] = rm_cur.y;
+            wnrm[tid] = __int_as_float(rm_cur.z); wrow[tid] = __int_as_float(rm_cur.w);
+            xrow[tid] = ar_cur;
+            dsg[tid] = dsg_v * S;
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int e = tid + PN_NTHR * i, plane = e >> 11, r = (e >> 5) & 63, u = e & 31;
-            *reinterpret_cast<uint4 *>(X + plane * PN_XPLANE + r * PN_XRS + u * 16) = a.sv.h4r[((long long)plane * a.sv.rows + gtile * PN_TILE + r) * 32 + u];
+            *reinterpret_cast<pn_f4 *>(X + plane * PN_XPLANE + r * PN_XRS + u * 16) = h4v[i];
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // the d f row of the thread's tile row (it follows from the tile index alone; rows past the class's last sample read allocated,
+        // unused memory and are ignored below): requested before the barrier, consumed behind it
+        const float *dfrow = a.sv.dfs + (tile * TS + pn_row_div(row, kinv)) * PN_H;
+        float4 dfa[8], dfb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c0 = 8 * (q + 4 * j);
+            dfa[j] = *reinterpret_cast<const float4 *>(dfrow + c0); dfb[j] = *reinterpret_cast<const float4 *>(dfrow + c0 + 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        rm_cur = rm_nxt; ar_cur = ar_nxt;
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 1);
         // ---- alpha head backward (4 threads per row): d w_k = d sigma alpha_k + d f . h4_k ; d x = d sigma w sigmoid(x)
         const int rsi = sidx[row], rp = prow[row];
+        // the d f values of the dY4 pass (thread -> columns 4 (tid & 63) .. + 3 of rows (tid >> 6) + 4 i): requested now, consumed behind the
+        // next barrier -- their L2 / HBM latency passes under the alpha-head arithmetic
+        float4 gq[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = (tid >> 6) + 4 * i;
+            gq[i] = *reinterpret_cast<const float4 *>(a.sv.dfs + (tile * TS + pn_row_div(r, kinv)) * PN_H + (tid & 63) * 4);
+        }
         float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;       // the row's embedding values (for its gradient at the end of the tile)
         if (rp >= 0) {
             const float *ep = a.emb + (long long)rp * PN_F + EPT * q;
             e0 = *reinterpret_cast<const float4 *>(ep); e1 = *reinterpret_cast<const float4 *>(ep + 4);
         }
+        __builtin_amdgcn_sched_barrier(0);
         {
             float dotf = 0.f;
             if (rsi >= 0) {
-                const float *df = a.sv.dfs + (tile * TS + row / K) * PN_H;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int c0 = 8 * (q + 4 * j);
-                    dotf = pn_x_dot8(X, row, c0, *reinterpret_cast<const float4 *>(df + c0), *reinterpret_cast<const float4 *>(df + c0 + 4), dotf);
+                    dotf = pn_x_dot8(X, row, c0, dfa[j], dfb[j], dotf);
                 }
             }
             dotf = group_sum_b<TPR>(dotf) * S;
@@ -373,13 +416,6 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         {
             const int c4 = tid & 63;
             const float4 w5 = *reinterpret_cast<const float4 *>(w5s + c4 * 4);
-            float4 gq[16];                                   // the d f values of the 16 rows, requested in one burst (the accumulators are dead here)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int r = (tid >> 6) + 4 * i;
-                gq[i] = sidx[r] >= 0 ? *reinterpret_cast<const float4 *>(a.sv.dfs + (tile * TS + r / K) * PN_H + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int r = (tid >> 6) + 4 * i;

@@ -72,6 +72,10 @@ size_t pn_saved_bytes(long long n_valid, int K, long long *rows_out, long long *
 PnSaved pn_saved_carve(void *base, long long n_valid, int K);
 
 __host__ __device__ inline int pn_tile_samples(int K) { return PN_TILE / K; }
+// row / K for a tile row (row < 64, K <= 64) without an integer division (a runtime division is ~35 instructions, and the tile kernels
+// did one per row they touch): kinv = ceil(2^16 / K), row / K = (row * kinv) >> 16 exactly for row * K < 2^16
+__device__ __forceinline__ unsigned pn_kinv(int K) { return (65536u + (unsigned)K - 1u) / (unsigned)K; }
+__device__ __forceinline__ int pn_row_div(int row, unsigned kinv) { return (int)(((unsigned)row * kinv) >> 16); }
 
 
 // ---- dev-only phase timeline (build with EXTRA_DEFS=-DPN_PHASE_TRACE into tools/_build; tools/gpu_phase_trace.py reads it) ----------
