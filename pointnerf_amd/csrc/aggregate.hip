@@ -474,6 +474,87 @@ __device__ __forceinline__ void f_acc_zero(f32x16 (&acc)[2][2]) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 
+// softplus(x) = log(1 + e^x) (raw2out_density, networks.py:262-267) on the hardware exponential / logarithm: absolute error <= 2e-7 for
+// x <= 20 (log of 1 + e^x, e^x >= 0: the argument is >= 1, v_log_f32 / v_exp_f32 are good to an ulp), the identity above
+__device__ __forceinline__ float pn_softplus(float x) {
+#ifdef PN_EMU
+    return x > 20.f ? x : log1pf(expf(x));
+#else
+    return x > 20.f ? x : __logf(1.0f + __expf(x));
+#endif
+}
+
+// ---- the tile's tail in ONE pass over the h4 tile, for K in {1, 2, 4, 8} (the rows of a sample then never straddle a thread's 8 rows):
+// thread -> columns 8 (tid & 31) .. + 7 of rows 8 (tid >> 5) .. + 7.  Per row: both planes read once (ds_read_b128), streamed to HBM as
+// the backward's h4 (training), dotted with the alpha head's weights and added, weighted, to the thread's per-sample sums f.  The rows'
+// alpha dot products are then reduced over the 32 lanes that share the rows by a transposing butterfly (8 -> 4 -> 2 -> 1 values per
+// lane: 7 + 2 shuffles instead of 8 x 5), softplus runs once per row, sigma is summed over a sample's rows by log2(KC) more shuffles.
+// Round 2 made three passes (alpha head, h4 copy, K-sums: 64 LDS reads per thread and two barriers); this is 16 reads and no barrier.
+template <int KC, bool TRAIN>
+__device__ __forceinline__ void f_tail(const FwdArgs &a, const char *X, const float *w5s, const float *wrow, const int *sidx, float b5,
+                                       long long tile, long long gtile, int tid) {
+    constexpr int NS = 8 / KC;                      // samples per thread
+    const int lane = tid & 63, cg = tid & 31, r0 = 8 * (tid >> 5);
+    const float4 wa = *reinterpret_cast<const float4 *>(w5s + 8 * cg), wb = *reinterpret_cast<const float4 *>(w5s + 8 * cg + 4);
+    float pa[8];
+    float4 fa[NS], fb[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) fa[j] = fb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = r0 + i;
+        const uint4 h = *reinterpret_cast<const uint4 *>(X + r * PN_XRS + cg * 16);
+        const uint4 m = *reinterpret_cast<const uint4 *>(X + PN_XPLANE + r * PN_XRS + cg * 16);
+        if (TRAIN) {
+            pn_f4 th = {__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(h.z), __uint_as_float(h.w)};
+            pn_f4 tm = {__uint_as_float(m.x), __uint_as_float(m.y), __uint_as_float(m.z), __uint_as_float(m.w)};
+            PN_STREAM_STORE(th, reinterpret_cast<pn_f4 *>(a.sv.h4r + (gtile * PN_TILE + r) * 32 + cg));
+            PN_STREAM_STORE(tm, reinterpret_cast<pn_f4 *>(a.sv.h4r + (a.sv.rows + gtile * PN_TILE + r) * 32 + cg));
+        }
+        float s = 0.f;
+        s = pn_fma2_lo(h.x, m.x, wa.x, s); s = pn_fma2_hi(h.x, m.x, wa.y, s); s = pn_fma2_lo(h.y, m.y, wa.z, s); s = pn_fma2_hi(h.y, m.y, wa.w, s);
+        s = pn_fma2_lo(h.z, m.z, wb.x, s); s = pn_fma2_hi(h.z, m.z, wb.y, s); s = pn_fma2_lo(h.w, m.w, wb.z, s); s = pn_fma2_hi(h.w, m.w, wb.w, s);
+        pa[i] = s;
+        const float w = wrow[r];
+        float4 &f0 = fa[i / KC], &f1 = fb[i / KC];
+        f0.x = pn_fma2_lo(h.x, m.x, w, f0.x); f0.y = pn_fma2_hi(h.x, m.x, w, f0.y); f0.z = pn_fma2_lo(h.y, m.y, w, f0.z); f0.w = pn_fma2_hi(h.y, m.y, w, f0.w);
+        f1.x = pn_fma2_lo(h.z, m.z, w, f1.x); f1.y = pn_fma2_hi(h.z, m.z, w, f1.y); f1.z = pn_fma2_lo(h.w, m.w, w, f1.z); f1.w = pn_fma2_hi(h.w, m.w, w, f1.w);
+    }
+    // f rows of the thread's samples (class-ordered list: the colour MLP reads them in that order)
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const long long vs = tile * (PN_TILE / KC) + (r0 / KC) + j;
+        if (vs < a.cap_samples) {
+            *reinterpret_cast<float4 *>(a.sv.fs + vs * PN_H + 8 * cg) = fa[j];
+            *reinterpret_cast<float4 *>(a.sv.fs + vs * PN_H + 8 * cg + 4) = fb[j];
+        }
+    }
+    // transposing butterfly over the 32 lanes of the row set: after the three halving steps a lane holds ONE row's partial sum,
+    // row index i = 4 b4 + 2 b3 + b2 (bits of the lane), then two full steps over bits 1, 0
+    {
+        const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float send = b4 ? pa[j] : pa[j + 4], keep = b4 ? pa[j + 4] : pa[j]; pa[j] = keep + __shfl_xor(send, 16, 64); }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const float send = b3 ? pa[j] : pa[j + 2], keep = b3 ? pa[j + 2] : pa[j]; pa[j] = keep + __shfl_xor(send, 8, 64); }
+        { const float send = b2 ? pa[0] : pa[1], keep = b2 ? pa[1] : pa[0]; pa[0] = keep + __shfl_xor(send, 4, 64); }
+        pa[0] += __shfl_xor(pa[0], 2, 64);
+        pa[0] += __shfl_xor(pa[0], 1, 64);
+        const int i = ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1), r = r0 + i;
+        const float x = pa[0] + b5 - 1.0f;
+        float sg = pn_softplus(x) * wrow[r];
+        if (TRAIN && (lane & 3) == 0) a.sv.arow[gtile * PN_TILE + r] = x;
+        // sigma of a sample = sum over its KC rows: rows i differ in the low log2(KC) bits of i = lane bits 2 .. (b2 is i's bit 0)
+        if (KC >= 2) sg += __shfl_xor(sg, 4, 64);
+        if (KC >= 4) sg += __shfl_xor(sg, 8, 64);
+        if (KC >= 8) sg += __shfl_xor(sg, 16, 64);
+        if ((lane & 3) == 0 && (i % KC) == 0) {
+            const int si = sidx[r];
+            if (si >= 0) a.decoded[(long long)si * 4] = sg;
+        }
+    }
+}
+
 #ifdef PN_PHASE_TRACE
 PN_TR_DECL(pn_trace_fwd);
 #endif
@@ -601,7 +682,15 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         f_epilogue<false>(acc, X, wave, lane, mask);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 14);
-        // ---- alpha head (256 -> 1, softplus(x - 1), raw2out_density :262-265): 4 threads per row, 8-column groups interleaved
+        if (K == 8 || K == 4 || K == 2 || K == 1) {
+            // ---- alpha head + h4 copy + K-weighted sums + sigma in one pass (f_tail)
+            if (K == 8) f_tail<8, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
+            else if (K == 4) f_tail<4, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
+            else if (K == 2) f_tail<2, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
+            else f_tail<1, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
+            PN_TR(pn_trace_fwd, 15);
+        } else {
+        // ---- (any other K: three passes) alpha head (256 -> 1, softplus(x - 1), raw2out_density :262-265): 4 threads per row, 8-column groups interleaved
         {
             float s = 0.f;
 #pragma unroll
@@ -612,7 +701,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
             s = group_sum<TPR>(s);
             if (q == 0) {
                 const float x = s + b5 - 1.0f;
-                wraw[row] = (x > 20.f ? x : log1pf(expf(x))) * wrow[row];
+                wraw[row] = pn_softplus(x) * wrow[row];
                 if (TRAIN) a.sv.arow[gtile * PN_TILE + row] = x;
             }
         }
@@ -642,6 +731,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
                 for (int kk = 0; kk < K; ++kk) sg += wraw[tid * K + kk];
                 a.decoded[(long long)si * 4] = sg;
             }
+        }
         }
         si0 = si_next; p0 = p_next; si1 = si2; p1 = p2; si2 = si3;
         PN_TR(pn_trace_fwd, 16);

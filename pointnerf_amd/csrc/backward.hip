@@ -286,6 +286,112 @@ __device__ __forceinline__ void b_epilogue(const f32x16 (&acc)[2][2], unsigned l
     }
 }
 
+// Waves run in lockstep: a value one lane wrote to LDS is visible to the other lanes of the SAME wave after the LDS queue has drained.
+// (The host emulation runs lanes as fibers: there it has to be a rendezvous.)
+#ifdef PN_EMU
+#define PN_WAVE_LDS_SYNC() __syncthreads()
+#else
+#define PN_WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+__device__ __forceinline__ float pn_softplus_b(float x) {
+#ifdef PN_EMU
+    return x > 20.f ? x : log1pf(expf(x));
+#else
+    return x > 20.f ? x : __logf(1.0f + __expf(x));
+#endif
+}
+__device__ __forceinline__ float pn_sigmoid_b(float x) {
+#ifdef PN_EMU
+    return x > 20.f ? 1.f : 1.0f / (1.0f + expf(-x));
+#else
+    return x > 20.f ? 1.f : __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+#endif
+}
+
+// ---- the tile's front in ONE pass over the h4 tile, for K in {1, 2, 4, 8} (the forward's f_tail mapping: thread -> columns
+// 8 (tid & 31) .. + 7 of rows 8 (tid >> 5) .. + 7, i.e. whole samples): alpha-head backward (d f . h4 per row by the transposing butterfly,
+// d conf, d x), then dY4 = (w d f + d x W5) * LeakyReLU'(h4) written IN PLACE -- a thread only rewrites the elements it alone reads, so
+// there is no barrier between the two halves; d x of a row reaches the 32 lanes that share the row through LDS inside the wave.
+// dfr[2 j], dfr[2 j + 1] = the thread's 8 columns of the d f row of its sample j (KC >= 4), dfb0 = where they come from.  gw5 = d W5 of the thread's 8 columns (scaled).
+template <int KC>
+__device__ __forceinline__ void b_front(const BwdArgs &a, char *X, const float *w5s, const float *wrow, const float *wnrm, const float *dsg, const float *xrow,
+                                        float *draw, const int *sidx, const int *prow, const float4 (&dfr)[4], const float *dfb0, float S, float invS, int tid,
+                                        float (&gw5)[8], float &gb5t) {
+    const int lane = tid & 63, cg = tid & 31, r0 = 8 * (tid >> 5);
+    // the d f values of row i's sample: from the registers filled before the barrier (KC = 8, 4: one or two samples per thread), else
+    // (KC = 2, 1: the rare classes, four or eight samples per thread) straight from memory
+    auto df_of = [&](int j, float4 &ga, float4 &gb) {
+        if (KC >= 4) { ga = dfr[2 * j]; gb = dfr[2 * j + 1]; }
+        else { ga = *reinterpret_cast<const float4 *>(dfb0 + j * PN_H); gb = *reinterpret_cast<const float4 *>(dfb0 + j * PN_H + 4); }
+    };
+    float pd[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = r0 + i, j = i / KC;
+        const uint4 h = *reinterpret_cast<const uint4 *>(X + r * PN_XRS + cg * 16);
+        const uint4 m = *reinterpret_cast<const uint4 *>(X + PN_XPLANE + r * PN_XRS + cg * 16);
+        float4 ga, gb;
+        df_of(j, ga, gb);
+        float s = 0.f;
+        s = pn_fma2_lo(h.x, m.x, ga.x, s); s = pn_fma2_hi(h.x, m.x, ga.y, s); s = pn_fma2_lo(h.y, m.y, ga.z, s); s = pn_fma2_hi(h.y, m.y, ga.w, s);
+        s = pn_fma2_lo(h.z, m.z, gb.x, s); s = pn_fma2_hi(h.z, m.z, gb.y, s); s = pn_fma2_lo(h.w, m.w, gb.z, s); s = pn_fma2_hi(h.w, m.w, gb.w, s);
+        pd[i] = s;
+    }
+    {   // transposing butterfly (f_tail): afterwards a lane holds the d f . h4 of row r0 + 4 b4 + 2 b3 + b2
+        const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float send = b4 ? pd[j] : pd[j + 4], keep = b4 ? pd[j + 4] : pd[j]; pd[j] = keep + __shfl_xor(send, 16, 64); }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const float send = b3 ? pd[j] : pd[j + 2], keep = b3 ? pd[j + 2] : pd[j]; pd[j] = keep + __shfl_xor(send, 8, 64); }
+        { const float send = b2 ? pd[0] : pd[1], keep = b2 ? pd[1] : pd[0]; pd[0] = keep + __shfl_xor(send, 4, 64); }
+        pd[0] += __shfl_xor(pd[0], 2, 64);
+        pd[0] += __shfl_xor(pd[0], 1, 64);
+        const int r = r0 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+        if ((lane & 3) == 0) {
+            float dr = 0.f;
+            if (sidx[r] >= 0) {
+                const float x = xrow[r], dotf = pd[0] * S;
+                const float alpha = pn_softplus_b(x), sg = pn_sigmoid_b(x);
+                const int rp = prow[r];
+                // w = wn * clamp(conf) with a straight-through clamp (gradiant_clamp, point_aggregators.py:722-724)
+                if (rp >= 0) atomicAdd(&a.g_conf[rp], (dsg[r] * alpha + dotf) * wnrm[r] * invS);
+                dr = dsg[r] * wrow[r] * sg;
+            }
+            draw[r] = dr;
+        }
+    }
+    PN_WAVE_LDS_SYNC();
+    const float4 wa = *reinterpret_cast<const float4 *>(w5s + 8 * cg), wb = *reinterpret_cast<const float4 *>(w5s + 8 * cg + 4);
+    const float w5[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+    float drsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = r0 + i, j = i / KC;
+        const uint4 h = *reinterpret_cast<const uint4 *>(X + r * PN_XRS + cg * 16);
+        const uint4 m = *reinterpret_cast<const uint4 *>(X + PN_XPLANE + r * PN_XRS + cg * 16);
+        const bool live = sidx[r] >= 0;          // a row without a sample: its d f values are whatever memory held (0 x NaN is NaN)
+        const float dr = draw[r], w = wrow[r] * S;
+        drsum += dr;
+        const float hv[8] = {pn_h_lo(h.x) + pn_h_lo(m.x), pn_h_hi(h.x) + pn_h_hi(m.x), pn_h_lo(h.y) + pn_h_lo(m.y), pn_h_hi(h.y) + pn_h_hi(m.y),
+                             pn_h_lo(h.z) + pn_h_lo(m.z), pn_h_hi(h.z) + pn_h_hi(m.z), pn_h_lo(h.w) + pn_h_lo(m.w), pn_h_hi(h.w) + pn_h_hi(m.w)};
+        float4 ga, gb;
+        df_of(j, ga, gb);
+        const float g[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+        float o[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            o[c] = live ? (w * g[c] + dr * w5[c]) * pn_lrelu_grad(hv[c]) : 0.f;
+            gw5[c] += dr * hv[c];
+        }
+        unsigned oh[4], om[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pn_split2_sat(o[2 * c], o[2 * c + 1], oh[c], om[c]);
+        *reinterpret_cast<uint4 *>(X + r * PN_XRS + cg * 16) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
+        *reinterpret_cast<uint4 *>(X + PN_XPLANE + r * PN_XRS + cg * 16) = make_uint4(om[0], om[1], om[2], om[3]);
+    }
+    if (cg == 0) gb5t += drsum;
+}
+
 #ifdef PN_PHASE_TRACE
 PN_TR_DECL(pn_trace_bwd);
 #endif
@@ -308,7 +414,9 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
     float S, invS;
     pn_scale_from_bits(a.sv.gscale[0], S, invS);
     if (tid0 < PN_H) w5s[tid0] = P[PO_W5 + tid0];
-    float4 gw5v = make_float4(0.f, 0.f, 0.f, 0.f);      // d W5 of columns 4 (tid & 63) .. + 3 (scaled)
+    const bool one_pass = K == 8 || K == 4 || K == 2 || K == 1;       // b_front (whole samples per thread); other K: the two-pass front
+    float4 gw5v = make_float4(0.f, 0.f, 0.f, 0.f);      // two-pass front: d W5 of columns 4 (tid & 63) .. + 3 (scaled)
+    float gw5[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // one-pass front: d W5 of columns 8 (tid & 31) .. + 7 (scaled)
     float gb5t = 0.f;
     f32x16 acc[2][2];
     // row metadata of the tile (threads 0..63: one row each), fetched ONE TILE AHEAD: the d sigma of a row hangs off its sample id, and
@@ -358,42 +466,42 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
             *reinterpret_cast<pn_f4 *>(X + plane * PN_XPLANE + r * PN_XRS + u * 16) = h4v[i];
         }
         __builtin_amdgcn_sched_barrier(0);
-        // the d f row of the thread's tile row (it follows from the tile index alone; rows past the class's last sample read allocated,
-        // unused memory and are ignored below): requested before the barrier, consumed behind it
-        const float *dfrow = a.sv.dfs + (tile * TS + pn_row_div(row, kinv)) * PN_H;
-        float4 dfa[8], dfb[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c0 = 8 * (q + 4 * j);
-            dfa[j] = *reinterpret_cast<const float4 *>(dfrow + c0); dfb[j] = *reinterpret_cast<const float4 *>(dfrow + c0 + 4);
+        // one-pass front: the d f rows of the thread's samples (they follow from the tile index alone; rows past the class's last sample
+        // read allocated, unused memory and are ignored): requested before the barrier, consumed behind it
+        float4 dfr[4];
+        const float *dfb0 = a.sv.dfs + (tile * TS + pn_row_div(8 * (tid >> 5), kinv)) * PN_H + 8 * (tid & 31);
+        if (K == 8 || K == 4) {
+            dfr[0] = *reinterpret_cast<const float4 *>(dfb0); dfr[1] = *reinterpret_cast<const float4 *>(dfb0 + 4);
+            if (K == 4) { dfr[2] = *reinterpret_cast<const float4 *>(dfb0 + PN_H); dfr[3] = *reinterpret_cast<const float4 *>(dfb0 + PN_H + 4); }
         }
         __builtin_amdgcn_sched_barrier(0);
         rm_cur = rm_nxt; ar_cur = ar_nxt;
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 1);
-        // ---- alpha head backward (4 threads per row): d w_k = d sigma alpha_k + d f . h4_k ; d x = d sigma w sigmoid(x)
-        const int rsi = sidx[row], rp = prow[row];
-        // the d f values of the dY4 pass (thread -> columns 4 (tid & 63) .. + 3 of rows (tid >> 6) + 4 i): requested now, consumed behind the
-        // next barrier -- their L2 / HBM latency passes under the alpha-head arithmetic
-        float4 gq[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = (tid >> 6) + 4 * i;
-            gq[i] = *reinterpret_cast<const float4 *>(a.sv.dfs + (tile * TS + pn_row_div(r, kinv)) * PN_H + (tid & 63) * 4);
-        }
+        const int rp = prow[row];
         float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;       // the row's embedding values (for its gradient at the end of the tile)
         if (rp >= 0) {
             const float *ep = a.emb + (long long)rp * PN_F + EPT * q;
             e0 = *reinterpret_cast<const float4 *>(ep); e1 = *reinterpret_cast<const float4 *>(ep + 4);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (one_pass) {
+            // ---- alpha head backward + dY4 in one pass (b_front)
+            if (K == 8) b_front<8>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
+            else if (K == 4) b_front<4>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
+            else if (K == 2) b_front<2>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
+            else b_front<1>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
+            PN_TR(pn_trace_bwd, 2);
+        } else {
+        // ---- (any other K: two passes) alpha head backward (4 threads per row): d w_k = d sigma alpha_k + d f . h4_k ; d x = d sigma w sigmoid(x)
+        const int rsi = sidx[row];
         {
             float dotf = 0.f;
             if (rsi >= 0) {
+                const float *df = a.sv.dfs + (tile * TS + pn_row_div(row, kinv)) * PN_H;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int c0 = 8 * (q + 4 * j);
-                    dotf = pn_x_dot8(X, row, c0, dfa[j], dfb[j], dotf);
+                    dotf = pn_x_dot8(X, row, c0, *reinterpret_cast<const float4 *>(df + c0), *reinterpret_cast<const float4 *>(df + c0 + 4), dotf);
                 }
             }
             dotf = group_sum_b<TPR>(dotf) * S;
@@ -401,8 +509,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
                 float dr = 0.f;
                 if (rsi >= 0) {
                     const float x = xrow[row];
-                    const float alpha = x > 20.f ? x : log1pf(expf(x));
-                    const float sg = x > 20.f ? 1.f : 1.0f / (1.0f + expf(-x));
+                    const float alpha = pn_softplus_b(x), sg = pn_sigmoid_b(x);
                     // w = wn * clamp(conf) with a straight-through clamp (gradiant_clamp, point_aggregators.py:722-724)
                     if (rp >= 0) atomicAdd(&a.g_conf[rp], (dsg[row] * alpha + dotf) * wnrm[row] * invS);
                     dr = dsg[row] * wrow[row] * sg;
@@ -416,6 +523,13 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         {
             const int c4 = tid & 63;
             const float4 w5 = *reinterpret_cast<const float4 *>(w5s + c4 * 4);
+            float4 gq[16];                                   // the d f values of the 16 rows, requested in one burst (the accumulators are dead here)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = (tid >> 6) + 4 * i;
+                gq[i] = *reinterpret_cast<const float4 *>(a.sv.dfs + (tile * TS + pn_row_div(r, kinv)) * PN_H + c4 * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int r = (tid >> 6) + 4 * i;
@@ -434,6 +548,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
                 pn_x_store4<true>(X, r, c4 * 4, o.x, o.y, o.z, o.w);
             }
             if (tid < PN_TILE) gb5t += draw[tid];
+        }
         }
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 3);
@@ -540,7 +655,12 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         PN_TR(pn_trace_bwd, 16);
     }
     // flush the register-resident partial sums
-    {
+    if (one_pass) {
+        const int cg = tid0 & 31;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) atomicAdd(&a.gparams[PO_W5 + 8 * cg + c], gw5[c] * invS);
+        if (cg == 0) atomicAdd(&a.gparams[PO_B5], gb5t * invS);
+    } else {
         const int c4 = tid0 & 63;
         atomicAdd(&a.gparams[PO_W5 + c4 * 4], gw5v.x * invS); atomicAdd(&a.gparams[PO_W5 + c4 * 4 + 1], gw5v.y * invS);
         atomicAdd(&a.gparams[PO_W5 + c4 * 4 + 2], gw5v.z * invS); atomicAdd(&a.gparams[PO_W5 + c4 * 4 + 3], gw5v.w * invS);

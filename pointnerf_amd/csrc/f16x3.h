@@ -53,8 +53,11 @@ enum : int {
     PKH_END = PKH_DC1 + PN_IMG(8, 8)
 };
 
-// streaming stores of the saved planes (dev A/B of the store policy: -DPN_PLAIN_STREAM_STORES, tools/_build only)
-#ifdef PN_PLAIN_STREAM_STORES
+// streaming stores of the saved planes (dev A/B of the store policy: -DPN_PLAIN_STREAM_STORES, tools/_build only; -DPN_NO_STREAM_STORES drops
+// them altogether: results are garbage, the timing tells what the stores cost)
+#if defined(PN_NO_STREAM_STORES)
+#define PN_STREAM_STORE(val, ptr) ((void)(val), (void)(ptr))
+#elif defined(PN_PLAIN_STREAM_STORES)
 #define PN_STREAM_STORE(val, ptr) (*(ptr) = (val))
 #else
 #define PN_STREAM_STORE(val, ptr) __builtin_nontemporal_store((val), (ptr))

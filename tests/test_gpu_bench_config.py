@@ -73,7 +73,9 @@ def test_bench_config_forward_and_gradients():
               (k, e_ours, e_o32, rms_ours, rms_o32, frac))
         # as close to the exact gradient as the fp32 oracle is, in the mean; isolated kink flips (an output unit's row of dW and its bias
         # entry) bounded by 1e-4 of the tensor's maximum and rare
-        if not (rms_ours <= max(4.0 * rms_o32, 5e-6) and e_ours <= max(3.0 * e_o32, 1e-4) and frac * d.numel() <= max(2.0, 2e-3 * d.numel())):
+        # (ONE flipped unit of one row / sample changes that unit's whole row of dW: up to shp[-1] elements, e.g. 280 of the 35 840 of
+        #  color_branch.0.weight = 0.8 % -- the count allowance is therefore at least one row)
+        if not (rms_ours <= max(4.0 * rms_o32, 5e-6) and e_ours <= max(3.0 * e_o32, 1e-4) and frac * d.numel() <= max(2.0, 2e-3 * d.numel(), float(shp[-1]))):
             failures.append((k, e_ours, e_o32, rms_ours, rms_o32, frac))
     assert not failures, failures
 
