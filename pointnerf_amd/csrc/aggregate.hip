@@ -623,11 +623,14 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         }
         unsigned long long mask;
         PN_TR(pn_trace_fwd, 1);
-        // ---- layer 1: 288 -> 256
+        // ---- layer 1: 288 -> 256.  Training: the layer's input tile is copied out (k-major planes for the weight-gradient GEMM) BEHIND the
+        // layer's GEMM, not in front of it: vmcnt counts loads and stores of a wave in ONE in-order queue, so a GEMM that starts right
+        // behind 20 stores waits for their acknowledgements from HBM before its first weight fragment counts as arrived (round 2 order:
+        // every GEMM phase carried 1 .. 3 us of that).  Behind the GEMM the stores have the epilogue and two barriers to drain.
         f_acc_bias(P + PO_B1, wave, lane, acc);
-        if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.x0k, rg_total, gtile * 8, tid);
         PN_TR(pn_trace_fwd, 2);
         pn_gemm_f16x3<18, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F1), 2 * wave, lane, acc);
+        if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.x0k, rg_total, gtile * 8, tid);      // (behind the GEMM: see below)
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 3);
         f_epilogue<TRAIN>(acc, X, wave, lane, mask);
@@ -636,9 +639,9 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         PN_TR(pn_trace_fwd, 4);
         // ---- layer 2: 256 -> 256
         f_acc_bias(P + PO_B2, wave, lane, acc);
-        if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h1k, rg_total, gtile * 8, tid);
         PN_TR(pn_trace_fwd, 5);
         pn_gemm_f16x3<16, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F2), 2 * wave, lane, acc);
+        if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h1k, rg_total, gtile * 8, tid);      // (behind the GEMM: see below)
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 6);
         f_epilogue<TRAIN>(acc, X, wave, lane, mask);
@@ -654,9 +657,9 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         PN_TR(pn_trace_fwd, 7);
         // ---- layer 3: 256 + 7 -> 256
         f_acc_bias(P + PO_B3, wave, lane, acc);
-        if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.h2k, rg_total, gtile * 8, tid);
         PN_TR(pn_trace_fwd, 8);
         pn_gemm_f16x3<17, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F3), 2 * wave, lane, acc);
+        if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.h2k, rg_total, gtile * 8, tid);      // (behind the GEMM: see below)
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 9);
         f_epilogue<TRAIN>(acc, X, wave, lane, mask);
@@ -665,9 +668,9 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         PN_TR(pn_trace_fwd, 10);
         // ---- layer 4: 256 -> 256
         f_acc_bias(P + PO_B4, wave, lane, acc);
-        if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h3k, rg_total, gtile * 8, tid);
         PN_TR(pn_trace_fwd, 11);
         pn_gemm_f16x3<16, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F4), 2 * wave, lane, acc);
+        if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h3k, rg_total, gtile * 8, tid);
         PN_TR(pn_trace_fwd, 12);
         // the next tile's point data and the indices of the two after it: requested here, consumed at the top of the next
         // iteration -- their HBM latency passes under the element-wise tail of this tile (nothing of this tile waits for memory any more)

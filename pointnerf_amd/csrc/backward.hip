@@ -553,23 +553,24 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 3);
         // ---- layer 4: dY4 -> d h3
-        pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy4k, gtile * 8, tid);
+        // (every dY tile is copied out BEHIND its GEMM: stores and loads of a wave share one in-order vmcnt queue, see the forward)
         b_acc_zero(acc);
         PN_TR(pn_trace_bwd, 4);
         pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D4), 2 * wave, lane, acc);
+        pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy4k, gtile * 8, tid);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 5);
         b_epilogue(acc, m3, X, wave, lane);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 6);
         // ---- layer 3: dY3 -> d h2, and the extras block (input columns 256..262 of W3), K split over the waves
-        pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy3k, gtile * 8, tid);
         b_acc_zero(acc);
         PN_TR(pn_trace_bwd, 7);
         pn_gemm_f16x3<16, 9, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D3), 2 * wave, lane, acc);
         f32x16 acce[2][2];
         b_acc_zero(acce);
         pn_gemm_f16x3<4, 9, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D3), 8, lane, acce, 4 * wave);
+        pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy3k, gtile * 8, tid);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 8);
         b_epilogue(acc, m2, X, wave, lane);
@@ -602,23 +603,23 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 9);
         // ---- layer 2: dY2 -> d h1
-        pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy2k, gtile * 8, tid);
         // (Measured and rejected: pulling the next tile's h4 planes / d f rows / sign words into L2 from here with 4-byte LDS-DMA
         //  reads, one per 128-byte line: 16.65 ms against 16.19 ms -- the load phase is not waiting for HBM.)
         b_acc_zero(acc);
         PN_TR(pn_trace_bwd, 10);
         pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D2), 2 * wave, lane, acc);
+        pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy2k, gtile * 8, tid);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 11);
         b_epilogue(acc, m1, X, wave, lane);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 12);
         // ---- layer 1: dY1 -> d X0 (columns 0..223), fp32 into LDS
-        pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy1k, gtile * 8, tid);
         b_acc_zero(acc);
         PN_TR(pn_trace_bwd, 13);
         if (wave < 3) pn_gemm_f16x3<16, PN_MB_D1, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D1), 2 * wave, lane, acc);
         else pn_gemm_f16x3<16, PN_MB_D1, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D1), 6, lane, acc);
+        pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy1k, gtile * 8, tid);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 14);
 #pragma unroll
@@ -654,12 +655,27 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         }
         PN_TR(pn_trace_bwd, 16);
     }
-    // flush the register-resident partial sums
+    // flush the register-resident partial sums: a workgroup that had no tile has nothing to add; the others first add up their eight row
+    // sets in LDS -- atomics of every workgroup on the same 256 addresses serialise in L2 (2048 per workgroup made the two small sample
+    // classes' launches 1 ms each)
+    if ((long long)blockIdx.x >= ntiles) return;
     if (one_pass) {
-        const int cg = tid0 & 31;
+        const int cg = tid0 & 31, rs = tid0 >> 5;
+        float *red = reinterpret_cast<float *>(smem_b);            // [8 row sets][256 columns] over the tile's space
+        PN_LDS_BARRIER();
 #pragma unroll
-        for (int c = 0; c < 8; ++c) atomicAdd(&a.gparams[PO_W5 + 8 * cg + c], gw5[c] * invS);
-        if (cg == 0) atomicAdd(&a.gparams[PO_B5], gb5t * invS);
+        for (int c = 0; c < 8; ++c) red[rs * PN_H + 8 * cg + c] = gw5[c];
+        if (cg == 0) red[8 * PN_H + rs] = gb5t;
+        PN_LDS_BARRIER();
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += red[r * PN_H + tid0];
+        atomicAdd(&a.gparams[PO_W5 + tid0], t * invS);
+        if (tid0 == 0) {
+            float b = 0.f;
+            for (int r = 0; r < 8; ++r) b += red[8 * PN_H + r];
+            atomicAdd(&a.gparams[PO_B5], b * invS);
+        }
     } else {
         const int c4 = tid0 & 63;
         atomicAdd(&a.gparams[PO_W5 + c4 * 4], gw5v.x * invS); atomicAdd(&a.gparams[PO_W5 + c4 * 4 + 1], gw5v.y * invS);
