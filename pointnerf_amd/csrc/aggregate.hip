@@ -217,6 +217,8 @@ struct FwdArgs {
     const int *pidx, *valid_list, *counters;
     const int *cls_list, *cls_info;     // sample classes (pn_classify); cls = the class this launch processes
     int cls, Kstride;                   // K = neighbor slots PROCESSED per sample of this class, Kstride = slots per sample in pidx / weight
+    int save_x0;                        // training: also save the X0 planes (only the stand-alone aggregator, whose perspective coordinates come
+                                        // from the caller; the fused path's weight-gradient GEMM rebuilds X0 from the gather: k_wgrad_x0)
     int R, SR, K, TS;
     long long cap_samples;      // capacity (in valid samples) of fs / saved buffers
     float *decoded, *weight;
@@ -630,7 +632,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         f_acc_bias(P + PO_B1, wave, lane, acc);
         PN_TR(pn_trace_fwd, 2);
         pn_gemm_f16x3<18, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F1), 2 * wave, lane, acc);
-        if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.x0k, rg_total, gtile * 8, tid);      // (behind the GEMM: see below)
+        if (TRAIN && a.save_x0) pn_copy_out_kmajor<PN_NF1>(X, a.sv.x0k, rg_total, gtile * 8, tid);      // (behind the GEMM: see above)
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 3);
         f_epilogue<TRAIN>(acc, X, wave, lane, mask);
@@ -899,9 +901,10 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
                           const float *d_raydir, const float *d_sample_loc, const float *d_xyz_pers, const float *d_loc_pers,
                           const int32_t *d_sample_pidx,
                           const int32_t *d_valid_list, const int32_t *d_counters, int R, int SR, int K,
-                          float *d_decoded, float *d_weight, const PnSaved &sv, long long cap_samples, bool train,
+                          float *d_decoded, float *d_weight, const PnSaved &sv, long long cap_samples, bool train, bool save_x0,
                           hipStream_t s) {
     FwdArgs a;
+    a.save_x0 = save_x0 ? 1 : 0;
     a.cam = *cam;
     a.xyz = pts->xyz; a.emb = pts->embedding; a.conf = pts->conf; a.dir = pts->dir; a.color = pts->color;
     a.params = d_params; a.packed = (const float4 *)d_packed;

@@ -14,14 +14,14 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
                           const float *d_raydir, const float *d_sample_loc, const float *d_xyz_pers, const float *d_loc_pers,
                           const int32_t *d_sample_pidx,
                           const int32_t *d_valid_list, const int32_t *d_counters, int R, int SR, int K,
-                          float *d_decoded, float *d_weight, const PnSaved &sv, long long cap_samples, bool train,
+                          float *d_decoded, float *d_weight, const PnSaved &sv, long long cap_samples, bool train, bool save_x0,
                           hipStream_t s);
 int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, const float *d_params, const void *d_packed,
                            const float *d_raydir, const float *d_sample_loc, const int32_t *d_sample_pidx,
                            const int32_t *d_valid_list, const int32_t *d_counters, int R, int SR, int K,
                            const float *d_decoded, const float *d_weight, const float *d_grad_decoded,
                            const PnSaved &sv, long long n_valid, float *d_grad_params, const pnerf_point_grads *pg,
-                           float *d_partials, hipStream_t s);
+                           float *d_partials, bool x0_saved, hipStream_t s);
 size_t pn_wgrad_partials_bytes();
 
 namespace {
@@ -369,7 +369,7 @@ extern "C" int pnerf_render_forward(const pnerf_camera *cam, const pnerf_points 
     if (hipMemsetAsync(d_weight, 0, (size_t)R * SR * K * sizeof(float), s) != hipSuccess) return PNERF_E_LAUNCH;
     if (n_valid_max > 0) {
         rc = pn_agg_forward_launch(cam, pts, d_params, d_packed_mlp, d_raydir, d_sample_loc, nullptr, nullptr, d_sample_pidx, d_valid_list, d_counters,
-                                   R, SR, K, d_decoded, d_weight, sv, n_valid_max, train, s);
+                                   R, SR, K, d_decoded, d_weight, sv, n_valid_max, train, /*save_x0=*/false, s);
         if (rc) return rc;
     }
     RmArgs ra;
@@ -406,7 +406,7 @@ extern "C" int pnerf_render_backward(const pnerf_camera *cam, const pnerf_points
     PN_CHECK_LAUNCH();
     PnSaved sv = pn_saved_carve(d_saved, n_valid, K);
     return pn_agg_backward_launch(cam, pts, d_params, d_packed_mlp, d_raydir, d_sample_loc, d_sample_pidx, d_valid_list, d_counters,
-                                  R, SR, K, d_decoded, d_weight, grad_decoded, sv, n_valid, d_grad_params, pg, partials, s);
+                                  R, SR, K, d_decoded, d_weight, grad_decoded, sv, n_valid, d_grad_params, pg, partials, /*x0_saved=*/false, s);
 }
 
 extern "C" size_t pnerf_render_backward_workspace_bytes(int R, int SR) {
@@ -454,7 +454,7 @@ extern "C" int pnerf_agg_forward(const pnerf_camera *cam, const pnerf_points *pt
     if (hipMemsetAsync(d_weight, 0, (size_t)R * SR * K * sizeof(float), s) != hipSuccess) return PNERF_E_LAUNCH;
     if (n_valid_max == 0) return 0;
     return pn_agg_forward_launch(cam, pts, d_params, d_packed_mlp, d_raydir, d_sample_loc, d_xyz_pers, d_loc_pers, d_sample_pidx,
-                                 d_valid_list, d_counters, R, SR, K, d_decoded, d_weight, sv, n_valid_max, train, s);
+                                 d_valid_list, d_counters, R, SR, K, d_decoded, d_weight, sv, n_valid_max, train, /*save_x0=*/train, s);
 }
 
 extern "C" int pnerf_agg_backward(const pnerf_camera *cam, const pnerf_points *pts, const void *d_packed_mlp, const float *d_params,
@@ -471,7 +471,7 @@ extern "C" int pnerf_agg_backward(const pnerf_camera *cam, const pnerf_points *p
     PnSaved sv = pn_saved_carve(d_saved, n_valid, K);
     return pn_agg_backward_launch(cam, pts, d_params, d_packed_mlp, d_raydir, d_sample_loc, d_sample_pidx, d_valid_list, d_counters,
                                   R, SR, K, d_decoded, d_weight, d_grad_decoded, sv, n_valid, d_grad_params, pg, (float *)d_ws,
-                                  (hipStream_t)stream);
+                                  /*x0_saved=*/true, (hipStream_t)stream);
 }
 
 // ray_march(ray_dist, ray_valid, ray_features, radiance, alpha, bg_color)   models/rendering/diff_ray_marching.py:508-554
