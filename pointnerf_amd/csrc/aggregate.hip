@@ -279,15 +279,18 @@ __global__ void k_cls_gather(ClsArgs c, int which, const int *__restrict__ pos, 
 }
 
 // the padding tile of every class: zero rows in everything the weight-gradient GEMMs read
-__global__ void k_cls_zero_gaps(PnSaved sv, int ncls) {
+__global__ void k_cls_zero_gaps(PnSaved sv, int ncls, int save_x0) {
     const int c = blockIdx.y;
     if (c >= ncls) return;
+    // x0k holds EITHER the whole X0 (288-column layout: the stand-alone aggregator) OR its last 64 columns (64-column layout: the fused
+    // path) -- the two layouts overlap, only the one in use may be zeroed
+    if ((blockIdx.x == 0 && !save_x0) || (blockIdx.x == 8 && save_x0)) return;
     const long long gap = (c + 1 < PN_NCLS ? sv.cls_info[PN_CI_TBASE + c + 1] : sv.cls_info[PN_CI_TILES]) - 1;
-    uint4 *arrs[8] = {sv.x0k, sv.h2k, sv.h1k, sv.h3k, sv.dy1k, sv.dy2k, sv.dy3k, sv.dy4k};
-    const int which = blockIdx.x;                      // 8 arrays x 2 planes
-    const int nf = which < 2 ? PN_NF1 : PN_H;
+    uint4 *arrs[9] = {sv.x0k, sv.h2k, sv.h1k, sv.h3k, sv.dy1k, sv.dy2k, sv.dy3k, sv.dy4k, sv.x0k};
+    const int which = blockIdx.x;                      // 8 arrays (two planes or one) + x0k in its 64-column layout (the fused path: k_wgrad_x0)
+    const int nf = which == 8 ? 64 : which < 2 ? PN_NF1 : PN_H;
     const long long rg_total = sv.rows / 8;
-    for (int plane = 0; plane < (which < 4 ? 2 : 1); ++plane) {      // (the dY arrays hold one plane)
+    for (int plane = 0; plane < ((which < 4 || which == 8) ? 2 : 1); ++plane) {      // (the dY arrays hold one plane)
         uint4 *p = arrs[which] + ((long long)plane * rg_total + gap * 8) * nf;
         for (int i = threadIdx.x; i < 8 * nf; i += blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
     }
@@ -304,7 +307,7 @@ int pn_class_slots(int K, int kc[PN_NCLS]) {
 }
 
 int pn_classify(const PnSaved &sv, const int32_t *d_valid_list, const int32_t *d_counters, const int32_t *d_pidx, int K, long long n_valid,
-                bool train, hipStream_t s) {
+                bool train, bool save_x0, hipStream_t s) {
     ClsArgs c;
     c.valid_list = d_valid_list; c.counters = d_counters; c.pidx = d_pidx; c.K = K; c.n = (int)n_valid;
     c.ncls = pn_class_slots(K, c.kc);
@@ -319,7 +322,7 @@ int pn_classify(const PnSaved &sv, const int32_t *d_valid_list, const int32_t *d
         if (rc) return rc;
         hipLaunchKernelGGL(k_cls_gather, dim3(256), dim3(256), 0, s, c, j, pos, cnt, sv.cls_list, sv.cls_info);
     }
-    if (train) hipLaunchKernelGGL(k_cls_zero_gaps, dim3(8, c.ncls), dim3(256), 0, s, sv, c.ncls);
+    if (train) hipLaunchKernelGGL(k_cls_zero_gaps, dim3(9, c.ncls), dim3(256), 0, s, sv, c.ncls, save_x0 ? 1 : 0);
     PN_CHECK_LAUNCH();
     return 0;
 }
@@ -632,7 +635,10 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         f_acc_bias(P + PO_B1, wave, lane, acc);
         PN_TR(pn_trace_fwd, 2);
         pn_gemm_f16x3<18, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F1), 2 * wave, lane, acc);
-        if (TRAIN && a.save_x0) pn_copy_out_kmajor<PN_NF1>(X, a.sv.x0k, rg_total, gtile * 8, tid);      // (behind the GEMM: see above)
+        if (TRAIN) {           // (behind the GEMM: see above)
+            if (a.save_x0) pn_copy_out_kmajor<PN_NF1>(X, a.sv.x0k, rg_total, gtile * 8, tid);
+            else pn_copy_out_kmajor_cols64<224>(X, a.sv.x0k, rg_total, gtile * 8, tid);       // the fused path: only the last 64 columns (k_wgrad_x0)
+        }
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 3);
         f_epilogue<TRAIN>(acc, X, wave, lane, mask);
@@ -926,7 +932,7 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     const void *cfn = train ? (const void *)k_color_forward<true, 3> : np2 ? (const void *)k_color_forward<false, 2> : (const void *)k_color_forward<false, 3>;
     if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipFuncSetAttribute(cfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
-    int rc = pn_classify(sv, d_valid_list, d_counters, d_sample_pidx, K, cap_samples, train, s);
+    int rc = pn_classify(sv, d_valid_list, d_counters, d_sample_pidx, K, cap_samples, train, save_x0, s);
     if (rc) return rc;
     a.cls_list = sv.cls_list; a.cls_info = sv.cls_info; a.Kstride = K;
     int kc[PN_NCLS];

@@ -858,40 +858,41 @@ int launch_wgrad_f16(const uint4 *A, const uint4 *B, long long rg_total, const i
 }
 
 
-// ------------------------------------------------------------------------------ layer-1 weight gradients with X0 REBUILT from the gather
-// dW1 = dY1^T X0.  X0 = [e | PE3(e) | PE5(dists) | 1 | 0 0 0] is a function of 168 bytes per row (the point's embedding and position, the
-// sample's position, the camera), but as two saved f16 planes it is 1152 bytes per row written by the forward and read back here --
-// a fifth of the forward's HBM writes and of this kernel's reads, with the kernel at its HBM roof.  So the fused path does not save X0:
-// this kernel streams dY1 (one plane, 512 B/row) like k_wgrad_f16 and builds the X0 fragments of every 16-row stage in LDS itself.
-// Everything that comes from memory arrives by LDS-DMA with per-lane source addresses, in a FIXED number of wave-instructions per
-// iteration, so that the hand-counted vmcnt waits of the ring stay exact:
+// ------------------------------------------------------------------------------ layer-1 weight gradients with X0 REBUILT from the embedding
+// dW1 = dY1^T X0,  X0 = [e (32) | PE3(e) (192) | PE5(dists) (60) | 1 | 0 0 0].  As two saved f16 planes X0 is 1152 bytes per row written by
+// the forward and read back here -- a fifth of the forward's HBM writes and of this kernel's reads, and both kernels pay for every byte
+// (dropping the forward's saves altogether makes it 21 % faster).  224 of the 288 columns are a function of the point's 32 embedding
+// values (128 bytes): the fused path therefore saves only the LAST 64 columns (distance encoding, ones column: x0t, 256 B/row) and this
+// kernel rebuilds columns 0 .. 223 of every 16-row stage in LDS from the gathered embedding rows.
+// Everything that comes from memory arrives by LDS-DMA with per-lane source addresses, TWO wave-instructions per wave and iteration, so
+// that the hand-counted vmcnt waits of the rings stay exact:
 //   iteration i issues   dY1 of stage i + 3 (8 pieces of 1 KB, one per wave) | row metadata (sample, point) of stage i + 7 (wave 0) |
-//                        embedding rows (waves 1, 2), point positions (wave 3), sample positions (wave 4) of stage i + 4, addressed with
-//                        the metadata that landed three iterations earlier;
-//   iteration i waits for everything issued up to iteration i - 3, multiplies stage i (dY1 ring slot x X0 buffer i & 1) and builds the X0
-//   buffer of stage i + 1 from the gather slot that has just landed: thread -> (row group, embedding dim, row in group) for the 7
-//   features of an embedding dim, the first 96 threads additionally -> (row, distance component) for its 10 features; values are split
-//   into the two planes exactly as the forward splits them (pn_split2) and written as 2-byte elements of the k-major units.
-// Rows without a sample / point (tile padding, the classes' gap tiles whose metadata is whatever memory held) are clamped to valid
-// indices: their dY rows are zero, X0 only has to be finite.
+//                        the 16 embedding rows of stage i + 4 (waves 1, 2), addressed with the metadata that landed three iterations
+//                        earlier | the saved last-64-column planes of stage i + 3 (waves 3 .. 6) | a pad piece (wave 7);
+//   iteration i waits for everything issued up to iteration i - 3, multiplies stage i (dY1 ring slot x [built columns | saved columns])
+//   and builds columns 0 .. 223 of stage i + 1 into the other X0 buffer: thread -> (row group, embedding dim, row in group); the 7 values
+//   are split into the two planes exactly as the forward splits them (pn_split2) and written as 2-byte elements of the k-major units.
+// Rows without a point (tile padding, the classes' gap tiles whose metadata is whatever memory held) are clamped to a valid point:
+// their dY rows are zero, X0 only has to be finite (the gap tiles of x0t are zeroed by k_cls_zero_gaps).
 struct WgX0Args {
-    pnerf_camera cam;
     const int4 *rmeta;
-    const float *emb, *xyz, *loc;
+    const float *emb;
+    const uint4 *x0t;                 // [2 planes][rows / 8][64] units: columns 224 .. 287 of X0
+    long long rg_total;
     int n_points;
-    long long n_samples;
 };
 constexpr int WX_AU = 2 * PN_H;                     // dY1 units of a stage (one plane, 16 rows)
-constexpr int WX_BU = 2 * PN_NF1;                   // X0 units of one plane of a stage
-constexpr int WX_NST = 4, WX_RMD = 7, WX_GD = 4;    // dY ring depth; metadata runs 7 stages ahead, gathers 4
+constexpr int WX_NB = 224;                          // columns rebuilt here
+constexpr int WX_BU = 2 * WX_NB;                    // their units of one plane of a stage
+constexpr int WX_TU = 2 * 2 * 64;                   // saved-column units of a stage: [plane][rg][64]
+constexpr int WX_NST = 4, WX_RMD = 7, WX_GD = 4;    // ring depth of dY1 / saved columns; metadata runs 7 stages ahead, embedding rows 4
 constexpr int WX_RM_SLOTS = 8, WX_G_SLOTS = 4;
-constexpr int WX_G_UNITS = 128 + 16 + 16;           // gather slot: 16 embedding rows (2 KB) + xyz (64 x 4 B) + sample loc (64 x 4 B)
-constexpr int WX_OFF_B = WX_NST * WX_AU, WX_OFF_RM = WX_OFF_B + 2 * 2 * WX_BU, WX_OFF_G = WX_OFF_RM + WX_RM_SLOTS * 16,
-              WX_OFF_PAD = WX_OFF_G + WX_G_SLOTS * WX_G_UNITS, WX_UNITS = WX_OFF_PAD + 64;
+constexpr int WX_OFF_T = WX_NST * WX_AU, WX_OFF_B = WX_OFF_T + WX_NST * WX_TU, WX_OFF_RM = WX_OFF_B + 2 * 2 * WX_BU,
+              WX_OFF_G = WX_OFF_RM + WX_RM_SLOTS * 16, WX_OFF_PAD = WX_OFF_G + WX_G_SLOTS * 128, WX_UNITS = WX_OFF_PAD + 64;
 static_assert(WX_UNITS * 16 <= 160 * 1024, "k_wgrad_x0 LDS");
 
 __device__ __forceinline__ void wx_store_h16(char *buf, int plane, int rg, int f, int rlow, unsigned short v) {
-    *reinterpret_cast<unsigned short *>(buf + ((plane * WX_BU + rg * PN_NF1 + f) * 16) + rlow * 2) = v;
+    *reinterpret_cast<unsigned short *>(buf + ((plane * WX_BU + rg * WX_NB + f) * 16) + rlow * 2) = v;
 }
 // two values -> both planes of features f0, f1 (row rlow of row group rg)
 __device__ __forceinline__ void wx_put2(char *buf, int rg, int rlow, int f0, int f1, float v0, float v1) {
@@ -902,154 +903,126 @@ __device__ __forceinline__ void wx_put2(char *buf, int rg, int rlow, int f0, int
 }
 
 __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, WgX0Args g, const int *__restrict__ d_tiles, float *__restrict__ partial) {
-    constexpr int MF = PN_H, NFB = PN_NF1, MTW = 4, NTW = 2, NMAIN = 256;
+    constexpr int MF = PN_H, MTW = 4;
     extern __shared__ __attribute__((aligned(16))) uint4 smem_x[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const long long stages = (long long)(*d_tiles) * (PN_TILE / 16);
     const int nst = stages > (long long)blockIdx.x ? (int)((stages - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
     auto stage_rg = [&](int s) { return 2LL * ((long long)blockIdx.x + (long long)gridDim.x * s); };       // first row group (8 rows) of local stage s
-    f32x16 acc[MTW][NTW], acct;
+    f32x16 acc[MTW][2], acct;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         acct[r] = 0.f;
 #pragma unroll
-        for (int i = 0; i < MTW; ++i)
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) acc[i][j][r] = 0.f;
+        for (int i = 0; i < MTW; ++i) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; }
     }
     char *lds = reinterpret_cast<char *>(smem_x);
-    // ---- issue helpers: every call is exactly ONE wave-instruction for the calling wave (a stage past the end reads the pad slot's source)
+    // ---- issue helpers: each call is exactly ONE wave-instruction of the calling wave (a stage past the end re-reads a valid source into the pad)
     auto issue_a = [&](int s) {
         const bool ok = s < nst;
-        const uint4 *src = ok ? A + stage_rg(s) * MF + 64 * wave + lane : A + lane;
+        const uint4 *src = A + (ok ? stage_rg(s) * MF + 64 * wave : 0) + lane;
         const uint4 *dst = smem_x + (ok ? (s % WX_NST) * WX_AU + 64 * wave : WX_OFF_PAD);
         __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     };
-    auto issue_rm = [&](int s) {                   // wave 0: the 16 rows' (sample, point, ., .) records
-        const bool ok = s < nst;
-        const int4 *src = ok ? g.rmeta + stage_rg(s) * 8 + (lane & 15) : g.rmeta + (lane & 15);
-        const uint4 *dst = smem_x + (ok ? WX_OFF_RM + (s % WX_RM_SLOTS) * 16 : WX_OFF_PAD);
-        if (lane < 16) __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-    };
-    auto row_ids = [&](int s, int r, int &si, int &p) {      // clamped (sample, point) of row r of local stage s, from the metadata ring
-        const int4 rm = *reinterpret_cast<const int4 *>(smem_x + WX_OFF_RM + (s % WX_RM_SLOTS) * 16 + r);
-        si = rm.x < 0 ? 0 : ((long long)rm.x >= g.n_samples ? (int)(g.n_samples - 1) : rm.x);
-        p = rm.y < 0 ? 0 : (rm.y >= g.n_points ? g.n_points - 1 : rm.y);
-    };
-    auto issue_gather = [&](int s) {               // waves 1 .. 4 (one wave-instruction each)
-        const bool ok = s < nst;
-        char *slot = lds + (size_t)(ok ? WX_OFF_G + (s % WX_G_SLOTS) * WX_G_UNITS : WX_OFF_PAD) * 16;
-        int si = 0, p = 0;
-        if (wave == 1 || wave == 2) {              // embedding rows 8 (wave - 1) .. + 7: lane = piece * 8 + row -> slot [piece][row] x 16 B
-            const int r = 8 * (wave - 1) + (lane & 7), piece = lane >> 3;
-            if (ok) row_ids(s, r, si, p);
-            const float *src = g.emb + (long long)p * PN_F + piece * 4;
-            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(slot + (wave - 1) * 1024), 16, 0, 0);
-        } else {                                   // wave 3: point positions, wave 4: sample positions; lane = 3 row + component
-            const int r = lane / 3 < 16 ? lane / 3 : 15, c = lane - 3 * (lane / 3);
-            if (ok) row_ids(s, r, si, p);
-            const float *src = wave == 3 ? g.xyz + (long long)p * 3 + c : g.loc + (long long)si * 3 + c;
-            if (lane < 48) __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(slot + 2048 + (wave - 3) * 256), 4, 0, 0);
+    auto issue_second = [&](int s_rm, int s_g, int s_t) {
+        if (wave == 0) {                               // the 16 rows' (sample, point, ., .) records of stage s_rm
+            const bool ok = s_rm < nst;
+            const int4 *src = g.rmeta + (ok ? stage_rg(s_rm) * 8 : 0) + (lane & 15);
+            const uint4 *dst = smem_x + (ok ? WX_OFF_RM + (s_rm % WX_RM_SLOTS) * 16 : WX_OFF_PAD);
+            if (lane < 16) __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        } else if (wave <= 2) {                        // embedding rows 8 (wave - 1) .. + 7 of stage s_g: lane = piece * 8 + row -> slot [half][piece][row] x 16 B
+            const bool ok = s_g < nst;
+            int p = 0;
+            if (ok) {
+                p = reinterpret_cast<const int4 *>(smem_x + WX_OFF_RM + (s_g % WX_RM_SLOTS) * 16)[8 * (wave - 1) + (lane & 7)].y;
+                p = p < 0 ? 0 : (p >= g.n_points ? g.n_points - 1 : p);
+            }
+            const float *src = g.emb + (long long)p * PN_F + (lane >> 3) * 4;
+            const uint4 *dst = smem_x + (ok ? WX_OFF_G + (s_g % WX_G_SLOTS) * 128 + (wave - 1) * 64 : WX_OFF_PAD);
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        } else if (wave <= 6) {                        // the saved columns of stage s_t: piece (plane, rg) = 64 units
+            const bool ok = s_t < nst;
+            const int plane = (wave - 3) >> 1, rg = (wave - 3) & 1;
+            const uint4 *src = g.x0t + (ok ? ((long long)plane * g.rg_total + stage_rg(s_t) + rg) * 64 : 0) + lane;
+            const uint4 *dst = smem_x + (ok ? WX_OFF_T + (s_t % WX_NST) * WX_TU + (wave - 3) * 64 : WX_OFF_PAD);
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        } else {                                       // wave 7: a pad piece, so that every wave counts two loads per iteration
+            __builtin_amdgcn_global_load_lds(A + lane, (__attribute__((address_space(3))) void *)(smem_x + WX_OFF_PAD), 16, 0, 0);
         }
     };
-    // ---- X0 of local stage s -> buffer s & 1
+    // ---- columns 0 .. 223 of local stage s -> buffer s & 1
     auto build = [&](int s) {
         char *buf = lds + (size_t)(WX_OFF_B + (s & 1) * 2 * WX_BU) * 16;
-        const char *slot = lds + (size_t)(WX_OFF_G + (s % WX_G_SLOTS) * WX_G_UNITS) * 16;
-        {
-            const int rg = tid >> 8, d = (tid >> 3) & 31, rlow = tid & 7;
-            const float e = *reinterpret_cast<const float *>(slot + rg * 1024 + ((d >> 2) * 8 + rlow) * 16 + (d & 3) * 4);
-            float sn[3], cs[3];
-            pn_pe_octaves<3>(e, sn, cs);
-            const int f = PN_F + d * 6;
-            wx_put2(buf, rg, rlow, d, f, e, sn[0]);
-            wx_put2(buf, rg, rlow, f + 1, f + 2, cs[0], sn[1]);
-            wx_put2(buf, rg, rlow, f + 3, f + 4, cs[1], sn[2]);
-            unsigned h, m;
-            pn_split2(cs[2], 0.f, h, m);
-            wx_store_h16(buf, 0, rg, f + 5, rlow, (unsigned short)h); wx_store_h16(buf, 1, rg, f + 5, rlow, (unsigned short)m);
-        }
-        if (tid < 96) {                            // PE5 of one distance component of one row (f_build of the forward, non-perspective-input form)
-            const int rlow = tid & 7, comp = (tid >> 3) % 6, rg = tid / 48, r = 8 * rg + rlow;
-            const float *px = reinterpret_cast<const float *>(slot + 2048) + 3 * r, *lx = reinterpret_cast<const float *>(slot + 2048 + 256) + 3 * r;
-            const float p0 = px[0], p1 = px[1], p2 = px[2], l0 = lx[0], l1 = lx[1], l2 = lx[2];
-            const float dwx = p0 - l0, dwy = p1 - l1, dwz = p2 - l2;
-            float pcx, pcy, pcz, scx, scy, scz, d0, d1, d2;
-            rot3b(g.cam.camrot, p0 - g.cam.campos[0], p1 - g.cam.campos[1], p2 - g.cam.campos[2], false, pcx, pcy, pcz);
-            rot3b(g.cam.camrot, l0 - g.cam.campos[0], l1 - g.cam.campos[1], l2 - g.cam.campos[2], false, scx, scy, scz);
-            const float ppx = pcx / pcz, ppy = pcy / pcz, spx = scx / scz, spy = scy / scz;
-            rot3b(g.cam.rw2c, dwx, dwy, dwz, true, d0, d1, d2);
-            const float d3 = ppx * pcz - spx * scz, d4 = ppy * pcz - spy * scz, d5 = pcz - scz;
-            const float dv = comp == 0 ? d0 : comp == 1 ? d1 : comp == 2 ? d2 : comp == 3 ? d3 : comp == 4 ? d4 : d5;
-            float sn[5], cs[5];
-            pn_pe_octaves<5>(dv, sn, cs);
-#pragma unroll
-            for (int f = 0; f < 5; ++f) { const int c0 = PN_F * 7 + (comp * 5 + f) * 2; wx_put2(buf, rg, rlow, c0, c0 + 1, sn[f], cs[f]); }
-        }
+        const char *slot = lds + (size_t)(WX_OFF_G + (s % WX_G_SLOTS) * 128) * 16;
+        const int rg = tid >> 8, d = (tid >> 3) & 31, rlow = tid & 7;
+        const float e = *reinterpret_cast<const float *>(slot + rg * 1024 + ((d >> 2) * 8 + rlow) * 16 + (d & 3) * 4);
+        float sn[3], cs[3];
+        pn_pe_octaves<3>(e, sn, cs);
+        const int f = PN_F + d * 6;
+        wx_put2(buf, rg, rlow, d, f, e, sn[0]);
+        wx_put2(buf, rg, rlow, f + 1, f + 2, cs[0], sn[1]);
+        wx_put2(buf, rg, rlow, f + 3, f + 4, cs[1], sn[2]);
+        unsigned h, m;
+        pn_split2(cs[2], 0.f, h, m);
+        wx_store_h16(buf, 0, rg, f + 5, rlow, (unsigned short)h); wx_store_h16(buf, 1, rg, f + 5, rlow, (unsigned short)m);
     };
-    // ---- constant columns of both X0 buffers: the ones column (its weight-gradient column is the bias gradient) and the three zero columns
-    if (tid < 2 * 2 * 2 * 4) {
-        const int b = tid >> 4, plane = (tid >> 3) & 1, rg = (tid >> 2) & 1, c = tid & 3;
-        const unsigned v = (plane == 0 && c == 0) ? 0x3C003C00u : 0u;           // 1.0 in f16
-        smem_x[WX_OFF_B + b * 2 * WX_BU + plane * WX_BU + rg * NFB + PN_ONES1 + c] = make_uint4(v, v, v, v);
-    }
-    pn_h8 ones = {0, 0, 0, 0, 0, 0, 0, 0};
-    (void)ones;
     if (nst > 0) {
-        // ---- prologue: metadata of stages 0 .. 6, then dY1 of stages 0 .. 2 and the gathers of stages 0 .. 3; drained once
+        // ---- prologue: metadata of stages 0 .. 6, then dY1 / saved columns of stages 0 .. 2 and the embedding rows of stages 0 .. 3; drained once
         if (wave == 0)
-            for (int s = 0; s < WX_RMD; ++s) issue_rm(s);
+            for (int s = 0; s < WX_RMD; ++s) issue_second(s, 0, 0);
         PN_WAIT_VMCNT(0);
         __syncthreads();
         for (int s = 0; s < WX_NST - 1; ++s) issue_a(s);
-        if (wave >= 1 && wave <= 4)
-            for (int s = 0; s < WX_GD; ++s) issue_gather(s);
+        if (wave >= 1 && wave <= 2)
+            for (int s = 0; s < WX_GD; ++s) issue_second(0, s, 0);
+        if (wave >= 3 && wave <= 6)
+            for (int s = 0; s < WX_NST - 1; ++s) issue_second(0, 0, s);
         PN_WAIT_VMCNT(0);
         __syncthreads();
         build(0);
         for (int s = 0; s < nst; ++s) {
-            // everything issued up to iteration s - 3 has landed for this wave (two iterations' worth may be outstanding: 2 wave-instructions
-            // per iteration for waves 0 .. 4, one for waves 5 .. 7), this wave's X0 writes of iteration s - 1 are done; then everybody's
-            if (wave < 5) PN_WAIT_VMCNT(4); else PN_WAIT_VMCNT(2);
+            // everything this wave issued up to iteration s - 3 has landed (two iterations' worth = 4 wave-instructions may be outstanding),
+            // its X0 writes of iteration s - 1 are done; then everybody's
+            PN_WAIT_VMCNT(4);
             PN_LDS_BARRIER();
             issue_a(s + WX_NST - 1);
-            if (wave == 0) issue_rm(s + WX_RMD);
-            else if (wave <= 4) issue_gather(s + WX_GD);
-            const uint4 *st = smem_x + (s % WX_NST) * WX_AU;
-            const uint4 *bb = smem_x + WX_OFF_B + (s & 1) * 2 * WX_BU;
-            const uint4 *fa = st + (lane >> 5) * MF + (lane & 31);
-            const uint4 *fb = bb + (lane >> 5) * NFB + (lane & 31);
-            pn_h8 ah[MTW], bh[NTW], bm[NTW];
+            issue_second(s + WX_RMD, s + WX_GD, s + WX_NST - 1);
+            const uint4 *fa = smem_x + (s % WX_NST) * WX_AU + (lane >> 5) * MF + (lane & 31);
+            const uint4 *fb = smem_x + WX_OFF_B + (s & 1) * 2 * WX_BU + (lane >> 5) * WX_NB + (lane & 31);            // built columns, high plane
+            const uint4 *ft = smem_x + WX_OFF_T + (s % WX_NST) * WX_TU + (lane >> 5) * 64 + (lane & 31);               // saved columns, high plane
+            pn_h8 ah[MTW], bh[2], bm[2];
 #pragma unroll
             for (int i = 0; i < MTW; ++i) ah[i] = __builtin_bit_cast(pn_h8, fa[(MTW * wm + i) * 32]);
-#pragma unroll
-            for (int i = 0; i < NTW; ++i) { bh[i] = __builtin_bit_cast(pn_h8, fb[(NTW * wn + i) * 32]); bm[i] = __builtin_bit_cast(pn_h8, fb[WX_BU + (NTW * wn + i) * 32]); }
+            const pn_h8 tah = __builtin_bit_cast(pn_h8, fa[(MTW * wm + wn) * 32]);
+            // n-tiles 2 wn, 2 wn + 1 of the 9: tiles 0 .. 6 = built columns, tile 7 = saved columns 224 .. 255, tile 8 (the tail, one m-tile per wave) = 256 .. 287
+            bh[0] = __builtin_bit_cast(pn_h8, fb[(2 * wn) * 32]); bm[0] = __builtin_bit_cast(pn_h8, fb[WX_BU + (2 * wn) * 32]);
+            if (wn < 3) { bh[1] = __builtin_bit_cast(pn_h8, fb[(2 * wn + 1) * 32]); bm[1] = __builtin_bit_cast(pn_h8, fb[WX_BU + (2 * wn + 1) * 32]); }
+            else { bh[1] = __builtin_bit_cast(pn_h8, ft[0]); bm[1] = __builtin_bit_cast(pn_h8, ft[2 * 64]); }
+            const pn_h8 tbh = __builtin_bit_cast(pn_h8, ft[32]), tbm = __builtin_bit_cast(pn_h8, ft[2 * 64 + 32]);
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
                 for (int i = 0; i < MTW; ++i)
 #pragma unroll
-                    for (int j = 0; j < NTW; ++j)
+                    for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], p == 1 ? bm[j] : bh[j], acc[i][j], 0, 0, 0);
-            {
-                const pn_h8 tah = wn == 0 ? ah[0] : wn == 1 ? ah[1] : wn == 2 ? ah[2] : ah[3];
-                const pn_h8 tbh = __builtin_bit_cast(pn_h8, fb[NMAIN]), tbm = __builtin_bit_cast(pn_h8, fb[WX_BU + NMAIN]);
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbh, acct, 0, 0, 0);
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbm, acct, 0, 0, 0);
-            }
-            if (s + 1 < nst) build(s + 1);
+            acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbh, acct, 0, 0, 0);
+            acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbm, acct, 0, 0, 0);
+            // (unconditional: past the last stage it rebuilds from a stale -- finite -- slot into the buffer nobody reads; no branch, so the
+            //  X0 arithmetic can be scheduled between the MFMAs instead of behind them)
+            build(s + 1);
         }
     }
     float *out = partial + (size_t)blockIdx.x * 256 * 288;
 #pragma unroll
     for (int i = 0; i < MTW; ++i)
 #pragma unroll
-        for (int j = 0; j < NTW; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (MTW * wm + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                out[(size_t)m * 288 + (NTW * wn + j) * 32 + (lane & 31)] = acc[i][j][r];
+                out[(size_t)m * 288 + (2 * wn + j) * 32 + (lane & 31)] = acc[i][j][r];
             }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1131,9 +1104,9 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     if (x0_saved) {        // the stand-alone aggregator (perspective coordinates from its caller): X0 planes saved by the forward
         if ((rc = launch_wgrad_f16<PN_NF1, PN_H>(sv.dy1k, sv.x0k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W1, PN_IN1, PN_IN1, PN_ONES1, PO_B1, s))) return rc;
     } else {               // the fused path: X0 rebuilt from the gather
+        (void)d_sample_loc; (void)R;
         WgX0Args wa;
-        wa.cam = *cam; wa.rmeta = sv.rmeta; wa.emb = pts->embedding; wa.xyz = pts->xyz; wa.loc = d_sample_loc;
-        wa.n_points = pts->n; wa.n_samples = (long long)R * SR;
+        wa.rmeta = sv.rmeta; wa.emb = pts->embedding; wa.x0t = sv.x0k; wa.rg_total = rgt; wa.n_points = pts->n;
         if ((rc = launch_wgrad_x0(sv.dy1k, wa, dt, rows, d_partials, sv.gscale, g, s))) return rc;
     }
     if ((rc = launch_wgrad_f16<PN_H, PN_H>(sv.dy2k, sv.h1k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W2, PN_H, PN_H, PN_H, PO_B2, s))) return rc;

@@ -333,3 +333,20 @@ __device__ __forceinline__ void pn_copy_out_kmajor(const char *X, uint4 *__restr
         }
     }
 }
+
+// the tile's columns C0 .. C0 + 63 -> k-major planes of 64 features ([2][rg_total][64] units): the saved part of X0 on the fused path
+// (the weight-gradient kernel rebuilds the rest from the embedding: backward.hip k_wgrad_x0)
+template <int C0>
+__device__ __forceinline__ void pn_copy_out_kmajor_cols64(const char *X, uint4 *__restrict__ dst, long long rg_total, long long rg0, int tid) {
+    static_assert(C0 % 16 == 0, "a 16-column group boundary");
+    const int lane = tid & 63, wave = tid >> 6;
+    const int blk = ((lane >> 2) & 3) * PN_XRS + ((lane >> 4) * 16 + (lane & 3) * 4) * 2 + C0 * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int combo = wave * 4 + i, plane = combo >> 3, rg = combo & 7;
+        const char *src = X + plane * PN_XPLANE + rg * 8 * PN_XRS + blk;
+        const uint2 lo = pn_lds_read_tr16(src), hi = pn_lds_read_tr16(src + 4 * PN_XRS);
+        pn_f4 t = {__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y)};
+        PN_STREAM_STORE(t, reinterpret_cast<pn_f4 *>(dst + ((long long)plane * rg_total + rg0 + rg) * 64 + lane));
+    }
+}

@@ -45,6 +45,7 @@ template <int N, class F> __device__ __forceinline__ void pn_static_for(F &&f) {
 struct PnSaved {
     // per neighbor row (rows = row tiles * 64), f16 plane pairs (f16x3.h):
     uint4 *x0k, *h1k, *h2k, *h3k;       // k-major [2][rows / 8][NF] inputs of the four layers (NF = 288, 256, 288, 256): what the weight-gradient GEMM streams
+                                        // (x0k on the fused path: only X0's last 64 columns, [2][rows / 8][64] -- k_wgrad_x0 rebuilds the other 224)
     uint4 *dy1k, *dy2k, *dy3k, *dy4k;   // k-major [rows / 8][256] output gradients of the four layers (ONE f16 plane, round to nearest), SCALED by the backward's power-of-two scale
     uint4 *h4r;                         // row-major [2][rows][32] last activation (alpha head / K-weighted sums of the backward)
     float *arow;                        // per row: pre-activation of the alpha head
@@ -65,7 +66,7 @@ struct PnSaved {
 // cls_info words: per class c (< PN_NCLS): number of samples, first position in cls_list, first tile; then totals
 enum : int { PN_NCLS = 3, PN_CI_COUNT = 0, PN_CI_VBASE = 4, PN_CI_TBASE = 8, PN_CI_TILES = 12, PN_CI_CTILES = 13 /* colour tiles of the step */, PN_CI_WORDS = 16 };
 int pn_class_slots(int K, int kc[3]);
-int pn_classify(const PnSaved &sv, const int32_t *d_valid_list, const int32_t *d_counters, const int32_t *d_pidx, int K, long long n_valid, bool train, hipStream_t s);
+int pn_classify(const PnSaved &sv, const int32_t *d_valid_list, const int32_t *d_counters, const int32_t *d_pidx, int K, long long n_valid, bool train, bool save_x0, hipStream_t s);
 size_t pn_cls_bytes(long long samples);
 void pn_cls_carve(void *base, long long samples, PnSaved &s);
 size_t pn_saved_bytes(long long n_valid, int K, long long *rows_out, long long *samples_out);
