@@ -419,6 +419,9 @@ def main():
                 out["roofline_mfma"] = mfma_entry(max([k for k in heavy if k != "wgrad"], key=lambda k: per[k]["ms_per_step"])) if len(heavy) > 1 or dom != "wgrad" else None
                 out["roofline_hbm"] = {k: hbm_entry(k) for k in heavy}
             out["kernels"] = per
+            # everything of a step that is NOT a libpnerf_hip.so kernel (HIP events around every library launch): the ATen glue of the loss /
+            # output dict, memsets, launch gaps and the one host synchronisation
+            out["ms_outside_library_kernels"] = dt / args.steps * 1e3 - sum(v["ms_per_step"] for v in per.values())
             for k in alg_flop:
                 if k in per:
                     out["kernels"][k]["tflops"] = alg_flop[k] / (per[k]["ms_per_step"] * 1e-3) / 1e12

@@ -110,6 +110,13 @@ int pnerf_zero_one_forward(const float *d_conf, int n_points, const int32_t *d_i
                            float *d_partial, void *stream);
 int pnerf_zero_one_backward(const float *d_conf, int n_points, const int32_t *d_idx, int64_t n_idx, float eps,
                             const float *d_gscale, float *d_grad_conf, void *stream);
+/* the same over the DENSE neighbor table d_idx [R][slots_per_ray] of a query, restricted to the rays with d_ray_hit[r] > 0 (the reference's
+ * conf_coefficient exists for the hit rays only): no [R'', SR, K] copy of the table is made.  d_partial holds pnerf_zero_one_blocks(R * 256)
+ * floats; the caller divides by (hit rays) x slots_per_ray. */
+int pnerf_zero_one_forward_rays(const float *d_conf, int n_points, const int32_t *d_idx, const int32_t *d_ray_hit, int R, int slots_per_ray, float eps,
+                                float *d_partial, void *stream);
+int pnerf_zero_one_backward_rays(const float *d_conf, int n_points, const int32_t *d_idx, const int32_t *d_ray_hit, int R, int slots_per_ray, float eps,
+                                 const float *d_gscale, float *d_grad_conf, void *stream);
 
 /* ---- aggregator MLP + renderer (PointAggregator.forward/viewmlp,
  * models/aggregators/point_aggregators.py:488-644,727-814; ray-dist,

@@ -282,7 +282,76 @@ __global__ __launch_bounds__(TPB) void k_zero_one_backward(const float *__restri
     __syncthreads();
     if (threadIdx.x == 0 && row0 != 0.f) atomicAdd(&grad_conf[0], row0);
 }
+// the same two passes over the DENSE neighbor table [R][slots] with the per-ray hit flags: only rays that hit the cloud count (the reference
+// forms conf_coefficient for the R'' hit rays only).  One workgroup per ray at a time: no [R'', SR, K] copy of the table is ever made.
+__global__ __launch_bounds__(TPB) void k_zero_one_forward_rays(const float *__restrict__ conf, int n, const int *__restrict__ idx, const int *__restrict__ hit, int R, int slots,
+                                                               float eps, float *__restrict__ partial) {
+    __shared__ float red[TPB / 64];
+    float acc = 0.f;
+    for (int r = blockIdx.x; r < R; r += gridDim.x) {
+        if (hit[r] <= 0) continue;
+        const int *row = idx + (long long)r * slots;
+        for (int e = threadIdx.x; e < slots; e += TPB) {
+            bool inside;
+            const float v = pn_zero_one_value(conf, n, row[e], eps, inside);
+            acc += logf(v) + logf(1.f - v);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < TPB / 64; ++w) t += red[w];
+        partial[blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(TPB) void k_zero_one_backward_rays(const float *__restrict__ conf, int n, const int *__restrict__ idx, const int *__restrict__ hit, int R, int slots,
+                                                                float eps, const float *__restrict__ gscale, float *__restrict__ grad_conf) {
+    __shared__ float row0;
+    if (threadIdx.x == 0) row0 = 0.f;
+    __syncthreads();
+    const float gs = gscale[0];
+    float mine0 = 0.f;
+    for (int r = blockIdx.x; r < R; r += gridDim.x) {
+        if (hit[r] <= 0) continue;
+        const int *row = idx + (long long)r * slots;
+        for (int e = threadIdx.x; e < slots; e += TPB) {
+            const int p = row[e];
+            bool inside;
+            const float v = pn_zero_one_value(conf, n, p, eps, inside);
+            if (!inside) continue;
+            const float g = gs * (1.f / v - 1.f / (1.f - v));
+            if (p <= 0) mine0 += g;
+            else atomicAdd(&grad_conf[p >= n ? n - 1 : p], g);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine0 += __shfl_xor(mine0, off, 64);
+    if ((threadIdx.x & 63) == 0 && mine0 != 0.f) atomicAdd(&row0, mine0);
+    __syncthreads();
+    if (threadIdx.x == 0 && row0 != 0.f) atomicAdd(&grad_conf[0], row0);
+}
 }  // namespace
+
+extern "C" int pnerf_zero_one_forward_rays(const float *d_conf, int n_points, const int32_t *d_idx, const int32_t *d_ray_hit, int R, int slots_per_ray, float eps,
+                                           float *d_partial, void *stream) {
+    if (!d_conf || !d_partial || !d_idx || !d_ray_hit || n_points <= 0 || R < 0 || slots_per_ray <= 0) return PNERF_E_INVAL;
+    PnProfScope prof(PNK_GATHER, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_zero_one_forward_rays, dim3(pnerf_zero_one_blocks((int64_t)R * TPB)), dim3(TPB), 0, (hipStream_t)stream, d_conf, n_points, d_idx, d_ray_hit, R, slots_per_ray, eps, d_partial);
+    PN_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pnerf_zero_one_backward_rays(const float *d_conf, int n_points, const int32_t *d_idx, const int32_t *d_ray_hit, int R, int slots_per_ray, float eps,
+                                            const float *d_gscale, float *d_grad_conf, void *stream) {
+    if (R == 0) return 0;
+    if (!d_conf || !d_idx || !d_ray_hit || !d_gscale || !d_grad_conf || n_points <= 0 || R < 0 || slots_per_ray <= 0) return PNERF_E_INVAL;
+    PnProfScope prof(PNK_GATHER, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_zero_one_backward_rays, dim3(pnerf_zero_one_blocks((int64_t)R * TPB)), dim3(TPB), 0, (hipStream_t)stream, d_conf, n_points, d_idx, d_ray_hit, R, slots_per_ray, eps, d_gscale, d_grad_conf);
+    PN_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int pnerf_zero_one_blocks(int64_t n_idx) {
     const long long b = (n_idx + TPB - 1) / TPB;

@@ -53,13 +53,13 @@ def hot_path_loss(opt, out, gt_image, zero_epsilon=1e-3):
     pred = out["coarse_raycolor"][0]
     gt = gt_image[0].index_select(0, out["_hit_index"]) if "_hit_index" in out else gt_image[0][out["ray_mask"][0] > 0]
     cc, zo = out.get("conf_coefficient"), out.get("_zero_one")
-    n_cc = cc.numel() if cc is not None else (zo[1].numel() if zo is not None else 0)
+    n_cc = cc.numel() if cc is not None else (zo[3] if zo is not None else 0)
     n = global_counts(pred.numel(), n_cc, device=pred.device)
     loss = ((pred - gt) ** 2).sum() / n[0].clamp(min=1.0) + 1e-6 / world()
     if "conf_coefficient" in opt.zero_one_loss_items:
         if zo is not None:            # the renderer handed out (points_conf, neighbor table) instead of the tensor: one fused pass
             from . import ops
-            loss = loss + ops.zero_one_conf_sum(zo[0], zo[1], zero_epsilon) / n[1].clamp(min=1.0) * opt.zero_one_loss_weights[0]
+            loss = loss + ops.zero_one_conf_sum_rays(zo[0], zo[1], zo[2], zero_epsilon) / n[1].clamp(min=1.0) * opt.zero_one_loss_weights[0]
         elif cc is not None:
             v = cc.clamp(zero_epsilon, 1 - zero_epsilon)
             loss = loss + (torch.log(v) + torch.log(1 - v)).sum() / n[1].clamp(min=1.0) * opt.zero_one_loss_weights[0]

@@ -292,9 +292,9 @@ class MvsPointsVolumetricModel:
         for i, name in enumerate(opt.zero_one_loss_items):
             if name == "conf_coefficient" and "_zero_one" in out:      # fused form (NeuralPointsRayMarching.fused_zero_one)
                 from . import ops
-                conf, pidx_hit = out["_zero_one"]
-                n = pdist.global_counts(pidx_hit.numel(), device=dev)[0]
-                loss = ops.zero_one_conf_sum(conf, pidx_hit, opt.zero_epsilon) / n.clamp(min=1.0)
+                conf, pidx_dense, ray_hit, count = out["_zero_one"]
+                n = pdist.global_counts(count, device=dev)[0]
+                loss = ops.zero_one_conf_sum_rays(conf, pidx_dense, ray_hit, opt.zero_epsilon) / n.clamp(min=1.0)
                 self.loss_total = self.loss_total + loss * opt.zero_one_loss_weights[i]
                 setattr(self, "loss_" + name, loss)
                 continue

@@ -100,8 +100,9 @@ class NeuralPointsRayMarching(nn.Module):
         idx = torch.argsort(dense["ray_hit"], descending=True, stable=True)[:n_hit]
         take = lambda t: t.index_select(0, idx)
         output = {"_hit_index": idx}
-        nn_hit = take(dense["sample_nn"])
-        output["queried_shading"] = torch.logical_not(torch.any(nn_hit > 0, dim=-1, keepdim=True)).repeat(1, 3).to(torch.float32)[None]
+        # queried_shading = not any(ray_valid) per ray (:322 of the reference): the R'' rays ARE the rays with a valid sample (ray_mask comes from
+        # the same neighbor table, query_worldcoords.cu:425-429), so it is identically zero -- no pass over the [R'', SR] counts
+        output["queried_shading"] = torch.zeros(1, n_hit, 3, dtype=torch.float32, device=ray_color.device)
         output["coarse_raycolor"] = take(ray_color)[None]
         output["coarse_point_opacity"] = take(opacity)[None]
         output["coarse_is_background"] = take(bg_trans)[None, :, None]
@@ -112,7 +113,9 @@ class NeuralPointsRayMarching(nn.Module):
         # neighbor table) under "_zero_one" -- instead of materialising weight / conf_coefficient [1, R'', SR, K] (ops.ZeroOneConf)
         only_zero_one = getattr(self, "fused_zero_one", False) and opt.sparse_loss_weight <= 0 and getattr(opt, "prob", 0) == 0
         if want_w and only_zero_one:
-            output["_zero_one"] = (self.neural_points.points_conf, take(dense["sample_pidx"]))
+            # (points_conf, the DENSE neighbor table, the rays' hit flags, number of conf_coefficient elements): the loss runs over the hit rays
+            # of the dense table in place (ops.ZeroOneConfRays) -- no [R'', SR, K] copy of it
+            output["_zero_one"] = (self.neural_points.points_conf, dense["sample_pidx"], dense["ray_hit"], n_hit * SR * K)
         elif want_w:
             output["weight"] = take(weight)[None].detach()
             output["blend_weight"] = take(blend_w)[None, ..., None].detach()

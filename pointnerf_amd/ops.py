@@ -369,6 +369,39 @@ def zero_one_conf_sum(conf, pidx, eps):
     return ZeroOneConf.apply(conf, pidx.contiguous(), eps)
 
 
+class ZeroOneConfRays(torch.autograd.Function):
+    """ZeroOneConf over the DENSE neighbor table [R, SR, K] of a query restricted to the rays that hit (ray_hit [R] int32 > 0): the
+    reference's conf_coefficient exists for the hit rays only; this form never copies the table to [R'', SR, K]
+    (pnerf_zero_one_forward_rays / _backward_rays)."""
+
+    @staticmethod
+    def forward(ctx, conf, pidx, ray_hit, eps):
+        lib = L.lib()
+        c = conf.detach().reshape(-1)
+        _need_cuda(c, "points_conf")
+        R = int(pidx.shape[0])
+        slots = int(pidx.numel() // max(R, 1))
+        nb = lib.pnerf_zero_one_blocks(R * 256)
+        part = torch.empty(nb, dtype=torch.float32, device=c.device)
+        L.check(lib.pnerf_zero_one_forward_rays(_ptr(c), c.numel(), _ptr(pidx), _ptr(ray_hit), R, slots, float(eps), _ptr(part), _stream()), "pnerf_zero_one_forward_rays")
+        ctx.save_for_backward(c, pidx, ray_hit)
+        ctx.eps, ctx.shape, ctx.dims = float(eps), conf.shape, (R, slots)
+        return part.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        c, pidx, ray_hit = ctx.saved_tensors
+        grad = torch.zeros_like(c)
+        gs = g.detach().reshape(1).to(torch.float32).contiguous()
+        L.check(L.lib().pnerf_zero_one_backward_rays(_ptr(c), c.numel(), _ptr(pidx), _ptr(ray_hit), ctx.dims[0], ctx.dims[1], ctx.eps, _ptr(gs), _ptr(grad), _stream()),
+                "pnerf_zero_one_backward_rays")
+        return grad.view(ctx.shape), None, None, None
+
+
+def zero_one_conf_sum_rays(conf, pidx_dense, ray_hit, eps):
+    return ZeroOneConfRays.apply(conf, pidx_dense.contiguous(), ray_hit.contiguous(), eps)
+
+
 def set_inference_products(n):
     """Products per multiply-add of the inference forward: 3 (default, fp32-class accuracy, what the training forward always runs) or
     2 (render / evaluation option: ~1.5x less matrix work, ray colour within ~2e-5 of fp32).  Returns the previous setting."""
