@@ -700,8 +700,11 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
 #else
 #define PN_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #endif
-#ifndef PN_WG_STAGES
-#define PN_WG_STAGES 4          // (measured: 3, 4 and 5 stages give 9.02 / 9.09 / 9.05 ms -- the HBM stream is what limits)
+#ifndef PN_WG_RS
+#define PN_WG_RS 32             // rows per stage of the aggregator layers' weight-gradient GEMMs (dev A/B: -DPN_WG_RS=16 -DPN_WG_NST=4 is round 2's)
+#endif
+#ifndef PN_WG_NST
+#define PN_WG_NST 3
 #endif
 template <int N> __device__ __forceinline__ void pn_wait_vm_stages(int stages) {       // wait until at most `stages` x N of this wave's loads are outstanding
     if (stages >= 3) PN_WAIT_VMCNT(3 * N);
@@ -713,13 +716,18 @@ template <int N> __device__ __forceinline__ void pn_wait_vm_stages(int stages) {
 // NFB = 288, 2 x 1 for NFB = 128).  Tail tile (one per wave, m-tile by wave): NFB == 288 -> the operand's columns 256..287; MF == 256 and
 // NFB == 256 -> the constant ones fragment (bias gradient); MF == 128 and NFB == 128 -> none (those bias sums come from k_color_backward).
 // tiles_per = rows per tile of *d_tiles / 16 (the aggregator counts 64-row tiles, and so does the colour MLP).
-template <int NFB, int MF>
+// RS = rows per stage (16 or 32), NST = ring depth.  A stage is one barrier, one LDS round trip for the fragments and RS / 16 x 18 MFMAs per wave,
+// and the two waves of a SIMD run it in lockstep: with 16-row stages a stage took ~1.1 us whatever it streamed (0.58 us of it the SIMD's
+// 36 MFMAs) -- the kernel was bound by the per-stage rendezvous, not by HBM (round 3: k_wgrad_x0 streamed 40 % fewer bytes in the same
+// time).  32-row stages halve the rendezvous per row; three ring slots of 48 .. 53 KB keep ~100 KB per CU in flight.
+template <int NFB, int MF, int RS, int NST>
 __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, const uint4 *__restrict__ B, long long rg_total,
                                                    const int *__restrict__ d_tiles, float *__restrict__ partial) {
-    constexpr int AU = 2 * MF, BU = 2 * NFB;                  // units (16 B) of one plane of a stage: 2 row groups = 16 rows
+    constexpr int RG = RS / 8;                                // row groups (8 rows) per stage
+    constexpr int AU = RG * MF, BU = RG * NFB;                // units (16 B) of one plane of a stage
     constexpr int STAGE = AU + 2 * BU;                        // [A h | B h | B m]
     constexpr int NI = STAGE / 64, NIW = (NI + 7) / 8;        // wave-instructions per stage, per wave (the last ones are padded)
-    constexpr int NST = PN_WG_STAGES;                         // ring depth: NST - 1 stages in flight
+    static_assert((NST - 2) * NIW <= 63 && NST >= 3 && NST <= 5, "vmcnt is a 6-bit count");
     constexpr int MTW = MF / 64, NTW = NFB >= 256 ? 2 : 1;    // m-tiles / main n-tiles per wave
     constexpr int NMAIN = 4 * NTW * 32;                       // columns covered by the main tiles
     constexpr bool TAIL_B = NFB > NMAIN, TAIL_ONES = !TAIL_B && MF == 256;
@@ -730,7 +738,7 @@ __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, 
     // 16-row stages are dealt to the workgroups round-robin (stage blockIdx.x + gridDim.x * i): at any moment the chip reads ONE contiguous
     // run of each plane instead of 256 runs that are a fixed, channel-aliasing distance apart.  The tiles actually used are known on the
     // device only.
-    const long long stages = (long long)(*d_tiles) * (PN_TILE / 16);
+    const long long stages = (long long)(*d_tiles) * (PN_TILE / RS);
     const int nst = stages > (long long)blockIdx.x ? (int)((stages - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
     f32x16 acc[MTW][NTW], acct;
 #pragma unroll
@@ -744,7 +752,7 @@ __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, 
     // stage s -> buffer: wave-instruction j copies units [64 j, 64 j + 64) of the stage's concatenated runs; every wave issues
     // exactly NIW instructions (a wave without a piece of its own re-reads the stage's first KB into the pad slot)
     auto issue = [&](int s, int buf) {
-        const long long rg = 2LL * ((long long)blockIdx.x + (long long)gridDim.x * s);
+        const long long rg = (long long)RG * ((long long)blockIdx.x + (long long)gridDim.x * s);
 #pragma unroll
         for (int i = 0; i < NIW; ++i) {
             const bool pad = wave + 8 * i >= NI;
@@ -769,30 +777,33 @@ __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, 
             __builtin_amdgcn_s_barrier();
             if (s + NST - 1 < nst) issue(s + NST - 1, (s + NST - 1) % NST);
             const uint4 *st = smem_w + (s % NST) * STAGE;
-            const uint4 *fa = st + (lane >> 5) * MF + (lane & 31);
-            const uint4 *fb = st + AU + (lane >> 5) * NFB + (lane & 31);
-            pn_h8 ah[MTW], bh[NTW], bm[NTW];
 #pragma unroll
-            for (int i = 0; i < MTW; ++i) ah[i] = __builtin_bit_cast(pn_h8, fa[(MTW * wm + i) * 32]);
+            for (int kk = 0; kk < RS / 16; ++kk) {            // 16 rows (two row groups) per MFMA k-step
+                const uint4 *fa = st + (2 * kk + (lane >> 5)) * MF + (lane & 31);
+                const uint4 *fb = st + AU + (2 * kk + (lane >> 5)) * NFB + (lane & 31);
+                pn_h8 ah[MTW], bh[NTW], bm[NTW];
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) { bh[i] = __builtin_bit_cast(pn_h8, fb[(NTW * wn + i) * 32]); bm[i] = __builtin_bit_cast(pn_h8, fb[BU + (NTW * wn + i) * 32]); }
+                for (int i = 0; i < MTW; ++i) ah[i] = __builtin_bit_cast(pn_h8, fa[(MTW * wm + i) * 32]);
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
+                for (int i = 0; i < NTW; ++i) { bh[i] = __builtin_bit_cast(pn_h8, fb[(NTW * wn + i) * 32]); bm[i] = __builtin_bit_cast(pn_h8, fb[BU + (NTW * wn + i) * 32]); }
 #pragma unroll
-                for (int i = 0; i < MTW; ++i)
+                for (int p = 0; p < 2; ++p)
 #pragma unroll
-                    for (int j = 0; j < NTW; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], p == 1 ? bm[j] : bh[j], acc[i][j], 0, 0, 0);
-            if (has_tail) {
-                pn_h8 tah;
-                if (MF == 256) tah = wn == 0 ? ah[0] : wn == 1 ? ah[1] : wn == 2 ? ah[MTW > 2 ? 2 : 0] : ah[MTW > 3 ? 3 : 0];
-                else tah = wn == 0 ? ah[0] : ah[MTW > 1 ? 1 : 0];
-                if (TAIL_B) {
-                    const pn_h8 tbh = __builtin_bit_cast(pn_h8, fb[NMAIN]), tbm = __builtin_bit_cast(pn_h8, fb[BU + NMAIN]);
-                    acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbh, acct, 0, 0, 0);
-                    acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbm, acct, 0, 0, 0);
-                } else {
-                    acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, ones, acct, 0, 0, 0);
+                    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], p == 1 ? bm[j] : bh[j], acc[i][j], 0, 0, 0);
+                if (has_tail) {
+                    pn_h8 tah;
+                    if (MF == 256) tah = wn == 0 ? ah[0] : wn == 1 ? ah[1] : wn == 2 ? ah[MTW > 2 ? 2 : 0] : ah[MTW > 3 ? 3 : 0];
+                    else tah = wn == 0 ? ah[0] : ah[MTW > 1 ? 1 : 0];
+                    if (TAIL_B) {
+                        const pn_h8 tbh = __builtin_bit_cast(pn_h8, fb[NMAIN]), tbm = __builtin_bit_cast(pn_h8, fb[BU + NMAIN]);
+                        acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbh, acct, 0, 0, 0);
+                        acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbm, acct, 0, 0, 0);
+                    } else {
+                        acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, ones, acct, 0, 0, 0);
+                    }
                 }
             }
         }
@@ -840,17 +851,18 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_f16(const float *__restric
     }
 }
 
-template <int NFB, int MF>
+template <int NFB, int MF, int RS, int NST>
 int launch_wgrad_f16(const uint4 *A, const uint4 *B, long long rg_total, const int *d_tiles, long long rows_max, float *partial, const unsigned *gscale,
                      float *grad, int dst_w, int ldc, int Nreal, int bias_col, int dst_b, hipStream_t s) {
     int chunks = WG_CHUNKS;
     const long long tiles = rows_max / PN_TILE;
     if (tiles < chunks) chunks = (int)(tiles > 0 ? tiles : 1);
     if ((size_t)chunks * 256 * 288 > PARTIAL_FLOATS) return PNERF_E_WS;
-    constexpr size_t lds = ((size_t)PN_WG_STAGES * (2 * MF + 2 * 2 * NFB) + 64) * 16;   // the stages [A h | B h | B m] + the pad slot
-    if (hipFuncSetAttribute((const void *)k_wgrad_f16<NFB, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PNERF_E_LAUNCH;
+    constexpr size_t lds = ((size_t)NST * (RS / 8) * (MF + 2 * NFB) + 64) * 16;   // the stages [A h | B h | B m] + the pad slot
+    static_assert(lds <= 160 * 1024, "wgrad ring");
+    if (hipFuncSetAttribute((const void *)k_wgrad_f16<NFB, MF, RS, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PNERF_E_LAUNCH;
     { PnProfScope prof(PNK_WGRAD, s);
-    hipLaunchKernelGGL((k_wgrad_f16<NFB, MF>), dim3(chunks), dim3(512), lds, s, A, B, rg_total, d_tiles, partial); }
+    hipLaunchKernelGGL((k_wgrad_f16<NFB, MF, RS, NST>), dim3(chunks), dim3(512), lds, s, A, B, rg_total, d_tiles, partial); }
     PnProfScope prof(PNK_WGRAD_REDUCE, s);
     hipLaunchKernelGGL(k_wgrad_reduce_f16, dim3(pn_cdiv((long long)MF * 288, 64)), dim3(256), 0, s, partial, chunks, MF, Nreal, bias_col, gscale, grad, dst_w, ldc, dst_b);
     PN_CHECK_LAUNCH();
@@ -1009,9 +1021,14 @@ __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, W
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], p == 1 ? bm[j] : bh[j], acc[i][j], 0, 0, 0);
             acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbh, acct, 0, 0, 0);
             acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbm, acct, 0, 0, 0);
+#ifdef PN_WX_NOMFMA
+            if (s >= 0) { for (int i = 0; i < MTW; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f; }
+#endif
             // (unconditional: past the last stage it rebuilds from a stale -- finite -- slot into the buffer nobody reads; no branch, so the
             //  X0 arithmetic can be scheduled between the MFMAs instead of behind them)
+#ifndef PN_WX_NOBUILD               // (dev variants, tools/_build only: where does the time of a stage go)
             build(s + 1);
+#endif
         }
     }
     float *out = partial + (size_t)blockIdx.x * 256 * 288;
@@ -1102,23 +1119,23 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     int rc;
     float *g = d_grad_params;
     if (x0_saved) {        // the stand-alone aggregator (perspective coordinates from its caller): X0 planes saved by the forward
-        if ((rc = launch_wgrad_f16<PN_NF1, PN_H>(sv.dy1k, sv.x0k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W1, PN_IN1, PN_IN1, PN_ONES1, PO_B1, s))) return rc;
+        if ((rc = launch_wgrad_f16<PN_NF1, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy1k, sv.x0k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W1, PN_IN1, PN_IN1, PN_ONES1, PO_B1, s))) return rc;
     } else {               // the fused path: X0 rebuilt from the gather
         (void)d_sample_loc; (void)R;
         WgX0Args wa;
         wa.rmeta = sv.rmeta; wa.emb = pts->embedding; wa.x0t = sv.x0k; wa.rg_total = rgt; wa.n_points = pts->n;
         if ((rc = launch_wgrad_x0(sv.dy1k, wa, dt, rows, d_partials, sv.gscale, g, s))) return rc;
     }
-    if ((rc = launch_wgrad_f16<PN_H, PN_H>(sv.dy2k, sv.h1k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W2, PN_H, PN_H, PN_H, PO_B2, s))) return rc;
-    if ((rc = launch_wgrad_f16<PN_NF1, PN_H>(sv.dy3k, sv.h2k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W3, PN_IN3, PN_IN3, PN_ONES3, PO_B3, s))) return rc;
-    if ((rc = launch_wgrad_f16<PN_H, PN_H>(sv.dy4k, sv.h3k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W4, PN_H, PN_H, PN_H, PO_B4, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_H, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy2k, sv.h1k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W2, PN_H, PN_H, PN_H, PO_B2, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_NF1, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy3k, sv.h2k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W3, PN_IN3, PN_IN3, PN_ONES3, PO_B3, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_H, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy4k, sv.h3k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W4, PN_H, PN_H, PN_H, PO_B4, s))) return rc;
     // the three colour layers: samples instead of neighbor rows, 128 output features; their bias gradients were summed by k_color_backward
     const long long rgc = sv.samples / 8;
     const int *ct = sv.cls_info + PN_CI_CTILES;
     (void)smp;
-    if ((rc = launch_wgrad_f16<PN_NF1, PN_HC>(sv.dc1k, sv.xck, rgc, ct, sv.samples, d_partials, sv.gscale, g, PO_WC1, PN_INC, PN_INC, -1, 0, s))) return rc;
-    if ((rc = launch_wgrad_f16<PN_HC, PN_HC>(sv.dc2k, sv.c1k, rgc, ct, sv.samples, d_partials, sv.gscale, g, PO_WC2, PN_HC, PN_HC, -1, 0, s))) return rc;
-    if ((rc = launch_wgrad_f16<PN_HC, PN_HC>(sv.dc3k, sv.c2k, rgc, ct, sv.samples, d_partials, sv.gscale, g, PO_WC3, PN_HC, PN_HC, -1, 0, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_NF1, PN_HC, 16, 4>(sv.dc1k, sv.xck, rgc, ct, sv.samples, d_partials, sv.gscale, g, PO_WC1, PN_INC, PN_INC, -1, 0, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_HC, PN_HC, 16, 4>(sv.dc2k, sv.c1k, rgc, ct, sv.samples, d_partials, sv.gscale, g, PO_WC2, PN_HC, PN_HC, -1, 0, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_HC, PN_HC, 16, 4>(sv.dc3k, sv.c2k, rgc, ct, sv.samples, d_partials, sv.gscale, g, PO_WC3, PN_HC, PN_HC, -1, 0, s))) return rc;
     return 0;
 }
 
