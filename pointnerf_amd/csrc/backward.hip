@@ -878,10 +878,10 @@ int launch_wgrad_f16(const uint4 *A, const uint4 *B, long long rg_total, const i
 // kernel rebuilds columns 0 .. 223 of every 16-row stage in LDS from the gathered embedding rows.
 // Everything that comes from memory arrives by LDS-DMA with per-lane source addresses, TWO wave-instructions per wave and iteration, so
 // that the hand-counted vmcnt waits of the rings stay exact:
-//   iteration i issues   dY1 of stage i + 3 (8 pieces of 1 KB, one per wave) | row metadata (sample, point) of stage i + 7 (wave 0) |
-//                        the 16 embedding rows of stage i + 4 (waves 1, 2), addressed with the metadata that landed three iterations
-//                        earlier | the saved last-64-column planes of stage i + 3 (waves 3 .. 6) | a pad piece (wave 7);
-//   iteration i waits for everything issued up to iteration i - 3, multiplies stage i (dY1 ring slot x [built columns | saved columns])
+//   iteration i issues   dY1 of a later stage (8 pieces of 1 KB, one per wave) | row metadata (sample, point) of a later stage (wave 0) |
+//                        the 16 embedding rows of a later stage (waves 1, 2), addressed with metadata that landed D iterations earlier |
+//                        the saved last-64-column planes of a later stage (waves 3 .. 6) | a pad piece (wave 7)   (distances: WX_D below);
+//   iteration i waits for everything issued up to iteration i - D, multiplies stage i (dY1 ring slot x [built columns | saved columns])
 //   and builds columns 0 .. 223 of stage i + 1 into the other X0 buffer: thread -> (row group, embedding dim, row in group); the 7 values
 //   are split into the two planes exactly as the forward splits them (pn_split2) and written as 2-byte elements of the k-major units.
 // Rows without a point (tile padding, the classes' gap tiles whose metadata is whatever memory held) are clamped to a valid point:
@@ -897,8 +897,18 @@ constexpr int WX_AU = 2 * PN_H;                     // dY1 units of a stage (one
 constexpr int WX_NB = 224;                          // columns rebuilt here
 constexpr int WX_BU = 2 * WX_NB;                    // their units of one plane of a stage
 constexpr int WX_TU = 2 * 2 * 64;                   // saved-column units of a stage: [plane][rg][64]
-constexpr int WX_NST = 4, WX_RMD = 7, WX_GD = 4;    // ring depth of dY1 / saved columns; metadata runs 7 stages ahead, embedding rows 4
-constexpr int WX_RM_SLOTS = 8, WX_G_SLOTS = 4;
+// Prefetch distance WX_D (iterations): what iteration i consumes was issued at iteration i - WX_D.  A stage is only 14 KB (dY1 8, saved
+// columns 4, embedding rows 2), so the distance has to be long for enough bytes to be in flight per CU (round 3: at a distance of 3, 42 KB
+// in flight, the kernel ran at 3.0 TB/s whatever it computed; Little's law with 2 - 4 us of loaded HBM latency asks for ~100 KB).
+//   iteration j issues   dY1 and saved columns of stage j + D | embedding rows of stage j + D + 1 (its X0 is built at iteration j + D) |
+//                        row metadata of stage j + 2 D + 1 (read when the embedding rows of that stage are addressed, D iterations later)
+#ifndef PN_WX_D
+#define PN_WX_D 7
+#endif
+constexpr int WX_D = PN_WX_D;
+constexpr int WX_NST = WX_D + 1, WX_RMD = 2 * WX_D + 1, WX_GD = WX_D + 1;    // ring depth of dY1 / saved columns; how far ahead metadata / embedding rows are issued
+constexpr int WX_RM_SLOTS = WX_D + 1, WX_G_SLOTS = WX_D + 1;
+static_assert(2 * (WX_D - 1) <= 63, "vmcnt is a 6-bit count");
 constexpr int WX_OFF_T = WX_NST * WX_AU, WX_OFF_B = WX_OFF_T + WX_NST * WX_TU, WX_OFF_RM = WX_OFF_B + 2 * 2 * WX_BU,
               WX_OFF_G = WX_OFF_RM + WX_RM_SLOTS * 16, WX_OFF_PAD = WX_OFF_G + WX_G_SLOTS * 128, WX_UNITS = WX_OFF_PAD + 64;
 static_assert(WX_UNITS * 16 <= 160 * 1024, "k_wgrad_x0 LDS");
@@ -980,26 +990,31 @@ __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, W
         wx_store_h16(buf, 0, rg, f + 5, rlow, (unsigned short)h); wx_store_h16(buf, 1, rg, f + 5, rlow, (unsigned short)m);
     };
     if (nst > 0) {
-        // ---- prologue: metadata of stages 0 .. 6, then dY1 / saved columns of stages 0 .. 2 and the embedding rows of stages 0 .. 3; drained once
+        // ---- prologue: the metadata the first embedding gathers need (stages 0 .. D: a ring's worth), drained; then dY1 / saved columns of
+        // stages 0 .. D - 1, the embedding rows of stages 0 .. D and the metadata of stages D + 1 .. 2 D, drained once more
         if (wave == 0)
-            for (int s = 0; s < WX_RMD; ++s) issue_second(s, 0, 0);
+            for (int s = 0; s < WX_RM_SLOTS; ++s) issue_second(s, 0, 0);
         PN_WAIT_VMCNT(0);
         __syncthreads();
-        for (int s = 0; s < WX_NST - 1; ++s) issue_a(s);
+        for (int s = 0; s < WX_D; ++s) issue_a(s);
         if (wave >= 1 && wave <= 2)
             for (int s = 0; s < WX_GD; ++s) issue_second(0, s, 0);
         if (wave >= 3 && wave <= 6)
-            for (int s = 0; s < WX_NST - 1; ++s) issue_second(0, 0, s);
+            for (int s = 0; s < WX_D; ++s) issue_second(0, 0, s);
+        PN_WAIT_VMCNT(0);
+        __syncthreads();                                  // (the metadata slots of stages 0 .. D have been read: they may be overwritten)
+        if (wave == 0)
+            for (int s = WX_RM_SLOTS; s < WX_RMD; ++s) issue_second(s, 0, 0);
         PN_WAIT_VMCNT(0);
         __syncthreads();
         build(0);
         for (int s = 0; s < nst; ++s) {
-            // everything this wave issued up to iteration s - 3 has landed (two iterations' worth = 4 wave-instructions may be outstanding),
-            // its X0 writes of iteration s - 1 are done; then everybody's
-            PN_WAIT_VMCNT(4);
+            // everything this wave issued up to iteration s - D has landed (D - 1 iterations' worth = 2 (D - 1) wave-instructions may be
+            // outstanding), its X0 writes of iteration s - 1 are done; then everybody's
+            PN_WAIT_VMCNT(2 * (WX_D - 1));
             PN_LDS_BARRIER();
-            issue_a(s + WX_NST - 1);
-            issue_second(s + WX_RMD, s + WX_GD, s + WX_NST - 1);
+            issue_a(s + WX_D);
+            issue_second(s + WX_RMD, s + WX_GD, s + WX_D);
             const uint4 *fa = smem_x + (s % WX_NST) * WX_AU + (lane >> 5) * MF + (lane & 31);
             const uint4 *fb = smem_x + WX_OFF_B + (s & 1) * 2 * WX_BU + (lane >> 5) * WX_NB + (lane & 31);            // built columns, high plane
             const uint4 *ft = smem_x + WX_OFF_T + (s % WX_NST) * WX_TU + (lane >> 5) * 64 + (lane & 31);               // saved columns, high plane
