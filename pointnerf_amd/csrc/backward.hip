@@ -901,13 +901,13 @@ constexpr int WX_TU = 2 * 2 * 64;                   // saved-column units of a s
 // columns 4, embedding rows 2), so the distance has to be long for enough bytes to be in flight per CU (round 3: at a distance of 3, 42 KB
 // in flight, the kernel ran at 3.0 TB/s whatever it computed; Little's law with 2 - 4 us of loaded HBM latency asks for ~100 KB).
 //   iteration j issues   dY1 and saved columns of stage j + D | embedding rows of stage j + D + 1 (its X0 is built at iteration j + D) |
-//                        row metadata of stage j + 2 D + 1 (read when the embedding rows of that stage are addressed, D iterations later)
+//                        row metadata of stage j + 2 D + 2 (read at the END of iteration j + D, for the gather that iteration j + D + 1 issues)
 #ifndef PN_WX_D
 #define PN_WX_D 7
 #endif
 constexpr int WX_D = PN_WX_D;
-constexpr int WX_NST = WX_D + 1, WX_RMD = 2 * WX_D + 1, WX_GD = WX_D + 1;    // ring depth of dY1 / saved columns; how far ahead metadata / embedding rows are issued
-constexpr int WX_RM_SLOTS = WX_D + 1, WX_G_SLOTS = WX_D + 1;
+constexpr int WX_NST = WX_D + 1, WX_RMD = 2 * WX_D + 2, WX_GD = WX_D + 1;    // ring depth of dY1 / saved columns; how far ahead metadata / embedding rows are issued
+constexpr int WX_RM_SLOTS = WX_D + 2, WX_G_SLOTS = WX_D + 1;
 static_assert(2 * (WX_D - 1) <= 63, "vmcnt is a 6-bit count");
 constexpr int WX_OFF_T = WX_NST * WX_AU, WX_OFF_B = WX_OFF_T + WX_NST * WX_TU, WX_OFF_RM = WX_OFF_B + 2 * 2 * WX_BU,
               WX_OFF_G = WX_OFF_RM + WX_RM_SLOTS * 16, WX_OFF_PAD = WX_OFF_G + WX_G_SLOTS * 128, WX_UNITS = WX_OFF_PAD + 64;
@@ -940,6 +940,7 @@ __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, W
         for (int i = 0; i < MTW; ++i) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; }
     }
     char *lds = reinterpret_cast<char *>(smem_x);
+    int p_gather = 0;
     // ---- issue helpers: each call is exactly ONE wave-instruction of the calling wave (a stage past the end re-reads a valid source into the pad)
     auto issue_a = [&](int s) {
         const bool ok = s < nst;
@@ -955,11 +956,7 @@ __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, W
             if (lane < 16) __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         } else if (wave <= 2) {                        // embedding rows 8 (wave - 1) .. + 7 of stage s_g: lane = piece * 8 + row -> slot [half][piece][row] x 16 B
             const bool ok = s_g < nst;
-            int p = 0;
-            if (ok) {
-                p = reinterpret_cast<const int4 *>(smem_x + WX_OFF_RM + (s_g % WX_RM_SLOTS) * 16)[8 * (wave - 1) + (lane & 7)].y;
-                p = p < 0 ? 0 : (p >= g.n_points ? g.n_points - 1 : p);
-            }
+            const int p = ok ? p_gather : 0;           // (read from the metadata ring and clamped one iteration ahead: next_point)
             const float *src = g.emb + (long long)p * PN_F + (lane >> 3) * 4;
             const uint4 *dst = smem_x + (ok ? WX_OFF_G + (s_g % WX_G_SLOTS) * 128 + (wave - 1) * 64 : WX_OFF_PAD);
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
@@ -971,6 +968,14 @@ __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, W
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         } else {                                       // wave 7: a pad piece, so that every wave counts two loads per iteration
             __builtin_amdgcn_global_load_lds(A + lane, (__attribute__((address_space(3))) void *)(smem_x + WX_OFF_PAD), 16, 0, 0);
+        }
+    };
+    // the point of this lane's embedding row of stage s_g (waves 1, 2), clamped: looked up at the END of an iteration for the gather the next
+    // one issues, so that the LDS round trip is not in front of the next stage's MFMAs
+    auto next_point = [&](int s_g) {
+        if (wave >= 1 && wave <= 2 && s_g < nst) {
+            const int p = reinterpret_cast<const int4 *>(smem_x + WX_OFF_RM + (s_g % WX_RM_SLOTS) * 16)[8 * (wave - 1) + (lane & 7)].y;
+            p_gather = p < 0 ? 0 : (p >= g.n_points ? g.n_points - 1 : p);
         }
     };
     // ---- columns 0 .. 223 of local stage s -> buffer s & 1
@@ -990,24 +995,25 @@ __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, W
         wx_store_h16(buf, 0, rg, f + 5, rlow, (unsigned short)h); wx_store_h16(buf, 1, rg, f + 5, rlow, (unsigned short)m);
     };
     if (nst > 0) {
-        // ---- prologue: the metadata the first embedding gathers need (stages 0 .. D: a ring's worth), drained; then dY1 / saved columns of
-        // stages 0 .. D - 1, the embedding rows of stages 0 .. D and the metadata of stages D + 1 .. 2 D, drained once more
+        // ---- prologue: the metadata the first embedding gathers need (stages 0 .. D + 1: a ring's worth), drained; then dY1 / saved columns
+        // of stages 0 .. D - 1 and the embedding rows of stages 0 .. D, drained; then the metadata of stages D + 2 .. 2 D + 1, drained
         if (wave == 0)
             for (int s = 0; s < WX_RM_SLOTS; ++s) issue_second(s, 0, 0);
         PN_WAIT_VMCNT(0);
         __syncthreads();
         for (int s = 0; s < WX_D; ++s) issue_a(s);
         if (wave >= 1 && wave <= 2)
-            for (int s = 0; s < WX_GD; ++s) issue_second(0, s, 0);
+            for (int s = 0; s < WX_GD; ++s) { next_point(s); issue_second(0, s, 0); }
         if (wave >= 3 && wave <= 6)
             for (int s = 0; s < WX_D; ++s) issue_second(0, 0, s);
         PN_WAIT_VMCNT(0);
-        __syncthreads();                                  // (the metadata slots of stages 0 .. D have been read: they may be overwritten)
+        __syncthreads();                                  // (the metadata slots of stages 0 .. D have been read: D of them may be overwritten)
         if (wave == 0)
             for (int s = WX_RM_SLOTS; s < WX_RMD; ++s) issue_second(s, 0, 0);
         PN_WAIT_VMCNT(0);
         __syncthreads();
         build(0);
+        next_point(WX_GD);                                // (its metadata was issued in the first prologue step or just now: landed)
         for (int s = 0; s < nst; ++s) {
             // everything this wave issued up to iteration s - D has landed (D - 1 iterations' worth = 2 (D - 1) wave-instructions may be
             // outstanding), its X0 writes of iteration s - 1 are done; then everybody's
@@ -1044,6 +1050,7 @@ __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, W
 #ifndef PN_WX_NOBUILD               // (dev variants, tools/_build only: where does the time of a stage go)
             build(s + 1);
 #endif
+            next_point(s + 1 + WX_GD);                    // for the gather the next iteration issues (its metadata was issued at iteration s - D: landed)
         }
     }
     float *out = partial + (size_t)blockIdx.x * 256 * 288;
