@@ -41,16 +41,16 @@ PEAK_HBM_GBS = 8000.0
 # roofline.traffic is NOT measured inside a bench run: it is read from the committed PMC summary (separate rocprofv3 --pmc passes of this
 # same command, FETCH x 2 + WRITE per the guide; tools/gpu_round_profile.sh regenerates it)
 TRAFFIC_SOURCE = "profiles/traffic.json (static: rocprofv3 --pmc passes of this command, not measured in this run)"
-# algorithmic HBM bytes of the weight-gradient GEMMs per neighbor row, read once: the inputs of the four layers as two f16 planes
-# (2 x 2 B x (288 + 256 + 288 + 256)) and their output gradients as one f16 plane (2 B x 4 x 256)
-BYTES_ROW_WGRAD = 2 * 2 * (288 + 256 + 288 + 256) + 2 * 4 * 256
+# algorithmic HBM bytes of the weight-gradient GEMMs per neighbor row, read once: the inputs of layers 2 .. 4 as two f16 planes
+# (2 x 2 B x (256 + 288 + 256)), layer 1's input as its saved last 64 columns (2 x 2 B x 64) + the 128-byte embedding row + 16 B of row
+# metadata it is rebuilt from (k_wgrad_x0), and the four output gradients as one f16 plane (2 B x 4 x 256)
+BYTES_ROW_WGRAD = 2 * 2 * (256 + 288 + 256) + (2 * 2 * 64 + 128 + 16) + 2 * 4 * 256
 # ... of the colour MLP's three weight-gradient GEMMs per valid sample ([f | view encoding] 288, c1, c2 as two planes; d c1..d c3 one plane)
 BYTES_SAMPLE_WGRAD = 2 * 2 * (288 + 128 + 128) + 2 * 3 * 128
-# ... of the training forward (gather 168 B + the saved planes x0 288, h1 256, [h2|extras] 288, h3 256, h4 256 columns + row metadata)
-BYTES_ROW_FWD = 168 + 2 * 2 * (288 + 256 + 288 + 256 + 256) + 16 + 4 + 96
-# ... of the backward (h4 planes + sign words + metadata read; four dY planes written)
-BYTES_ROW_BWD = 2 * 2 * 256 + 96 + 20 + 2 * 4 * 256
-
+# ... of the training forward (gather 168 B + the saved planes: X0's last 64 columns, h1 256, [h2|extras] 288, h3 256, h4 256 columns + row metadata)
+BYTES_ROW_FWD = 168 + 2 * 2 * (64 + 256 + 288 + 256 + 256) + 16 + 4 + 96
+# ... of the backward (h4 planes + sign words + metadata + d f and embedding rows read; four dY planes written)
+BYTES_ROW_BWD = 2 * 2 * 256 + 96 + 20 + 128 + 128 + 2 * 4 * 256
 
 def _cfg():
     from pointnerf_amd import config, scenes

@@ -55,6 +55,12 @@ with torch.no_grad():
         img, hit = eval_loop.render_image(model, cam["campos"], cam["camrotc2w"], intr, 800, 800, cam["near"], cam["far"], cam["bg_color"])
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
 full = dict(ms=dt * 1e3, rays=640000, rays_per_s=640000 / dt, rays_hit=int(hit.sum()))
+with torch.no_grad():        # the two-product inference option (ops.set_inference_products(2): weights' high plane only)
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        img2, hit2 = eval_loop.render_image(model, cam["campos"], cam["camrotc2w"], intr, 800, 800, cam["near"], cam["far"], cam["bg_color"], products=2)
+        torch.cuda.synchronize(); dt2 = time.perf_counter() - t0
+full["two_products"] = dict(ms=dt2 * 1e3, rays_per_s=640000 / dt2, max_abs_colour_difference=float((img2 - img).abs().max()))
 # point initialisation: voxel down-sampling of a raw cloud, lego script resolution
 from pointnerf_amd import point_init
 raw = torch.from_numpy(scenes.lego_points(2_000_000)).to(dev)

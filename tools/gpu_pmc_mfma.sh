@@ -15,7 +15,7 @@ for d in ('/tmp/pmc1','/tmp/pmc2'):
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(collections.Counter)
     for r in rows:
         k = r['Kernel_Name']
-        for pat in ('k_agg_backward','k_agg_forward','k_wgrad_f16','k_color_forward','k_color_backward'):
+        for pat in ('k_agg_backward','k_agg_forward','k_wgrad_f16','k_wgrad_x0','k_color_forward','k_color_backward'):
             if pat in k:
                 agg[pat][r['Counter_Name']] += float(r['Counter_Value']); n[pat][r['Counter_Name']] += 1
     for k,v in agg.items():

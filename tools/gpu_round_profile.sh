@@ -5,6 +5,7 @@ cd $GRAFT_REPO_ROOT
 T=$1; O=gpurun_out/$T; mkdir -p $O
 timeout 600 python bench.py --steps 20 --warmup 3 > $O/bench_lego.json 2>$O/bench_lego.err
 timeout 300 python bench.py --steps 10 --warmup 2 --render-only --cpu-rays 0 > $O/bench_render_only.json 2>$O/bench_render_only.err
+timeout 300 python bench.py --steps 10 --warmup 2 --render-only --inference-products 2 --cpu-rays 0 > $O/bench_render_only_2products.json 2>/dev/null
 for C in chair scannet barn; do
   timeout 600 python bench.py --config $C --steps 5 --warmup 2 --cpu-rays 0 > $O/bench_$C.json 2>$O/bench_$C.err
 done

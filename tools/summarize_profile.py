@@ -5,7 +5,7 @@ src, dst = os.path.join("gpurun_out", tag), "profiles"
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "stats", "run_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
 short = {"k_agg_backward": "agg_backward", "k_agg_forward": "agg_forward", "k_color_forward": "color_forward",
-         "k_color_backward": "color_backward", "k_wgrad_lds": "wgrad", "k_wgrad_f16": "wgrad", "k_wgrad<": "wgrad", "k_neighbors": "neighbors", "k_probe": "probe"}
+         "k_color_backward": "color_backward", "k_wgrad_lds": "wgrad", "k_wgrad_f16": "wgrad", "k_wgrad_x0": "wgrad", "k_wgrad<": "wgrad", "k_neighbors": "neighbors", "k_probe": "probe"}
 def agg(path):
     out = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(path)):
