@@ -53,14 +53,28 @@ enum : int {
     PKH_END = PKH_DC1 + PN_IMG(8, 8)
 };
 
-// streaming stores of the saved planes (dev A/B of the store policy: -DPN_PLAIN_STREAM_STORES, tools/_build only; -DPN_NO_STREAM_STORES drops
-// them altogether: results are garbage, the timing tells what the stores cost)
+// Streaming stores of the saved planes (whole 1 KB runs per wave-instruction, written once, read by another kernel much later):
+// global_store_dwordx4 ... nt sc1 -- non-temporal AND write-through, i.e. the line does not stay in the XCD's L2 (MI355X_MICROARCH.md: plain /
+// nt stores keep it there, sc1 forms drop it).  35 GB of saved planes per forward would otherwise pass through 4 MB of L2 per XCD as dirty
+// lines next to the 2 MB of weight images every GEMM chunk re-reads.  Measured on one box, whole step (round 3): plain 43.17 ms, nt 41.82,
+// sc1 41.28, sc0 sc1 41.42, nt sc1 40.99 (the backward gains most: 13.92 -> 13.29 ms).  The policy bits have no builtin: inline asm; the
+// compiler's waitcnt insertion sees the operands (the LDS reads that produce the value are waited for), the asm is not a memory barrier.
+// dev A/B: -DPN_STREAM_STORE_ASM='"sc1"' etc., -DPN_PLAIN_STREAM_STORES, -DPN_NT_STREAM_STORES (round 2's), -DPN_NO_STREAM_STORES (drops them:
+// results are garbage, the timing tells what the stores cost: forward -21 %, backward -10 %).
 #if defined(PN_NO_STREAM_STORES)
 #define PN_STREAM_STORE(val, ptr) ((void)(val), (void)(ptr))
-#elif defined(PN_PLAIN_STREAM_STORES)
+#elif defined(PN_PLAIN_STREAM_STORES) || defined(PN_EMU)
 #define PN_STREAM_STORE(val, ptr) (*(ptr) = (val))
-#else
+#elif defined(PN_NT_STREAM_STORES)
 #define PN_STREAM_STORE(val, ptr) __builtin_nontemporal_store((val), (ptr))
+#else
+#ifndef PN_STREAM_STORE_ASM
+#define PN_STREAM_STORE_ASM "nt sc1"
+#endif
+__device__ __forceinline__ void pn_stream_store_asm(pn_f4 v, pn_f4 *p) {
+    asm volatile("global_store_dwordx4 %0, %1, off " PN_STREAM_STORE_ASM : : "v"(p), "v"(v));
+}
+#define PN_STREAM_STORE(val, ptr) pn_stream_store_asm((val), (ptr))
 #endif
 
 // stores of fp32 rows straight from the accumulator layout (a lane pair writes 32 bytes, the wave's four stores of a row fill one
@@ -302,12 +316,15 @@ __device__ __forceinline__ void pn_copy_out_kmajor_h(const char *X, uint4 *__res
         const int rg = wave * 2 + i;
         const char *src = X + rg * 8 * PN_XRS + blk;
         uint4 *d = dst + (rg0 + rg) * NF;
+        // (all transposing reads of the run first, then its stores: the stores are inline asm, which the scheduler does not move loads across)
+        uint2 lo[(NF + 63) / 64], hi[(NF + 63) / 64];
+#pragma unroll
+        for (int j = 0; j < (NF + 63) / 64; ++j) { lo[j] = pn_lds_read_tr16(src + j * 128); hi[j] = pn_lds_read_tr16(src + 4 * PN_XRS + j * 128); }
 #pragma unroll
         for (int j = 0; j < (NF + 63) / 64; ++j) {
             const int f = lane + 64 * j;
-            const uint2 lo = pn_lds_read_tr16(src + j * 128), hi = pn_lds_read_tr16(src + 4 * PN_XRS + j * 128);
             if (f < NF) {
-                pn_f4 t = {__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y)};
+                pn_f4 t = {__uint_as_float(lo[j].x), __uint_as_float(lo[j].y), __uint_as_float(hi[j].x), __uint_as_float(hi[j].y)};
                 PN_STREAM_STORE(t, reinterpret_cast<pn_f4 *>(d + f));
             }
         }
@@ -322,12 +339,14 @@ __device__ __forceinline__ void pn_copy_out_kmajor(const char *X, uint4 *__restr
         const int combo = wave * 4 + i, plane = combo >> 3, rg = combo & 7;
         const char *src = X + plane * PN_XPLANE + rg * 8 * PN_XRS + blk;
         uint4 *d = dst + ((long long)plane * rg_total + rg0 + rg) * NF;
+        uint2 lo[(NF + 63) / 64], hi[(NF + 63) / 64];
+#pragma unroll
+        for (int j = 0; j < (NF + 63) / 64; ++j) { lo[j] = pn_lds_read_tr16(src + j * 128); hi[j] = pn_lds_read_tr16(src + 4 * PN_XRS + j * 128); }
 #pragma unroll
         for (int j = 0; j < (NF + 63) / 64; ++j) {
             const int f = lane + 64 * j;
-            const uint2 lo = pn_lds_read_tr16(src + j * 128), hi = pn_lds_read_tr16(src + 4 * PN_XRS + j * 128);
             if (f < NF) {
-                pn_f4 t = {__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y)};
+                pn_f4 t = {__uint_as_float(lo[j].x), __uint_as_float(lo[j].y), __uint_as_float(hi[j].x), __uint_as_float(hi[j].y)};
                 PN_STREAM_STORE(t, reinterpret_cast<pn_f4 *>(d + f));
             }
         }
