@@ -54,27 +54,25 @@ enum : int {
 };
 
 // Streaming stores of the saved planes (whole 1 KB runs per wave-instruction, written once, read by another kernel much later):
-// global_store_dwordx4 ... nt sc1 -- non-temporal AND write-through, i.e. the line does not stay in the XCD's L2 (MI355X_MICROARCH.md: plain /
-// nt stores keep it there, sc1 forms drop it).  35 GB of saved planes per forward would otherwise pass through 4 MB of L2 per XCD as dirty
-// lines next to the 2 MB of weight images every GEMM chunk re-reads.  Measured on one box, whole step (round 3): plain 43.17 ms, nt 41.82,
-// sc1 41.28, sc0 sc1 41.42, nt sc1 40.99 (the backward gains most: 13.92 -> 13.29 ms).  The policy bits have no builtin: inline asm; the
-// compiler's waitcnt insertion sees the operands (the LDS reads that produce the value are waited for), the asm is not a memory barrier.
-// dev A/B: -DPN_STREAM_STORE_ASM='"sc1"' etc., -DPN_PLAIN_STREAM_STORES, -DPN_NT_STREAM_STORES (round 2's), -DPN_NO_STREAM_STORES (drops them:
-// results are garbage, the timing tells what the stores cost: forward -21 %, backward -10 %).
+// non-temporal stores.  Round 3 compared the cache-policy bits on one box, whole step: plain 42.1 ms, nt 41.3 (shipped), sc1 (write-through,
+// line dropped from L2) 41.8, nt sc1 41.0 -- inside the box-to-box noise, so the builtin stays (the sc bits have no builtin; the dev variants
+// below go through inline asm, which needs its own s_nop against the store-data hazard: without it the data registers are overwritten
+// while the 16-byte store still reads them -- the NaN-poisoned parity tests caught exactly that).
+// dev A/B (tools/_build only): -DPN_STREAM_STORE_ASM='"nt sc1"' etc., -DPN_PLAIN_STREAM_STORES, -DPN_NO_STREAM_STORES (drops the stores:
+// results are garbage, the timing tells what they cost: forward -21 %, backward -10 %).
 #if defined(PN_NO_STREAM_STORES)
 #define PN_STREAM_STORE(val, ptr) ((void)(val), (void)(ptr))
 #elif defined(PN_PLAIN_STREAM_STORES) || defined(PN_EMU)
 #define PN_STREAM_STORE(val, ptr) (*(ptr) = (val))
-#elif defined(PN_NT_STREAM_STORES)
-#define PN_STREAM_STORE(val, ptr) __builtin_nontemporal_store((val), (ptr))
-#else
-#ifndef PN_STREAM_STORE_ASM
-#define PN_STREAM_STORE_ASM "nt sc1"
-#endif
+#elif defined(PN_STREAM_STORE_ASM)
 __device__ __forceinline__ void pn_stream_store_asm(pn_f4 v, pn_f4 *p) {
-    asm volatile("global_store_dwordx4 %0, %1, off " PN_STREAM_STORE_ASM : : "v"(p), "v"(v));
+    // (s_nop 1: a 16-byte store reads its data registers over several cycles; the compiler pads its own stores against a following write of
+    //  those registers, but it does not know that this asm is one)
+    asm volatile("global_store_dwordx4 %0, %1, off " PN_STREAM_STORE_ASM "\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 #define PN_STREAM_STORE(val, ptr) pn_stream_store_asm((val), (ptr))
+#else
+#define PN_STREAM_STORE(val, ptr) __builtin_nontemporal_store((val), (ptr))
 #endif
 
 // stores of fp32 rows straight from the accumulator layout (a lane pair writes 32 bytes, the wave's four stores of a row fill one
