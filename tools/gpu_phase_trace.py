@@ -39,13 +39,13 @@ def read(name):
 
 FWD_GEMM = [(2, 3), (5, 6), (8, 9), (11, 12)]
 BWD_GEMM = [(4, 5), (7, 8), (10, 11), (13, 14)]
-FWD_NAMES = {(0, 1): "build X0 + weights", (1, 2): "copy-out X0, acc zero", (2, 3): "GEMM1 + barrier", (3, 4): "E1 + barrier", (4, 5): "copy-out h1",
-             (5, 6): "GEMM2 + barrier", (6, 7): "E2 + extras + barrier", (7, 8): "copy-out h2x", (8, 9): "GEMM3 + barrier", (9, 10): "E3 + barrier",
-             (10, 11): "copy-out h3", (11, 12): "GEMM4", (12, 13): "next gather issue + barrier", (13, 14): "E4 + barrier", (14, 15): "alpha + h4 copy + barrier",
-             (15, 16): "K-sums"}
-BWD_NAMES = {(0, 1): "load h4 / meta + barrier", (1, 2): "alpha backward + barrier", (2, 3): "dY4 pass + barrier", (3, 4): "copy-out dY4", (4, 5): "GEMM4 + barrier",
-             (5, 6): "E(m3) + barrier", (6, 7): "copy-out dY3", (7, 8): "GEMM3 + extras + barrier", (8, 9): "E(m2) + extras finish + barrier", (9, 10): "copy-out dY2",
-             (10, 11): "GEMM2 + barrier", (11, 12): "E(m1) + barrier", (12, 13): "copy-out dY1", (13, 14): "GEMM1 + barrier", (14, 15): "dX0 -> LDS + barrier",
+FWD_NAMES = {(0, 1): "build X0 + weights", (1, 2): "acc = bias", (2, 3): "GEMM1 + copy-out X0 cols 224..287 + barrier", (3, 4): "E1 + barrier", (4, 5): "acc = bias",
+             (5, 6): "GEMM2 + copy-out h1 + barrier", (6, 7): "E2 + extras + barrier", (7, 8): "acc = bias", (8, 9): "GEMM3 + copy-out h2x + barrier", (9, 10): "E3 + barrier",
+             (10, 11): "acc = bias", (11, 12): "GEMM4 + copy-out h3", (12, 13): "next gather issue + barrier", (13, 14): "E4 + barrier",
+             (14, 15): "tail in one pass: alpha + h4 copy + K-sums + sigma", (15, 16): "-"}
+BWD_NAMES = {(0, 1): "load h4 / meta / d f + barrier", (1, 2): "front in one pass: alpha backward + dY4", (2, 3): "barrier", (3, 4): "acc zero", (4, 5): "GEMM4 + copy-out dY4 + barrier",
+             (5, 6): "E(m3) + barrier", (6, 7): "acc zero", (7, 8): "GEMM3 + extras + copy-out dY3 + barrier", (8, 9): "E(m2) + extras finish + barrier", (9, 10): "acc zero",
+             (10, 11): "GEMM2 + copy-out dY2 + barrier", (11, 12): "E(m1) + barrier", (12, 13): "acc zero", (13, 14): "GEMM1 + copy-out dY1 + barrier", (14, 15): "dX0 -> LDS + barrier",
              (15, 16): "embedding gradient"}
 
 def analyse(tr, names, gemm, last):
