@@ -267,6 +267,11 @@ def main():
         step_all([opt_mlp, opt_pts])          # both Adam instances in one launch (ShardedAdam, when --zero1, steps on its own)
         return loss, model.last_stats
 
+    # the 15 camera numbers per batch the host passes to the library by value (position, rotation, background, near / far): their host
+    # copies are made here, once per input tensor (ops.host_array caches them on the tensor object), not as synchronisations inside steps
+    for inp in inputs:
+        for k in ("campos", "camrotc2w", "bg_color", "near", "far"):
+            ops.host_array(inp[k])
     if not args.render_only:
         # size the activation arena for the largest of the batches that will be run (their neighbor tables differ: up to 2x between
         # poses of the Barn-scale configuration); the query alone tells the number of valid samples

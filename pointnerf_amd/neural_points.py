@@ -128,8 +128,8 @@ class NeuralPoints(nn.Module):
 
     def query_dense(self, inputs):
         """Fused-path query: dense [R,...] device tensors + the work list; no host synchronisation."""
-        near = float(torch.min(inputs["near"]).item()) if isinstance(inputs["near"], torch.Tensor) else float(inputs["near"])
-        far = float(torch.max(inputs["far"]).item()) if isinstance(inputs["far"], torch.Tensor) else float(inputs["far"])
+        from . import ops
+        near, far = float(ops.host_array(inputs["near"]).min()), float(ops.host_array(inputs["far"]).max())
         return self.querier.query_dense(self.xyz[None, ...], self.xyz.shape[0], near, far, inputs["raydir"], inputs["campos"])
 
     def get_point_indices(self, inputs, cam_rot_tensor, cam_pos_tensor, pixel_idx_tensor, near_plane, far_plane, h, w, intrinsic,

@@ -73,10 +73,10 @@ class NeuralPointsRayMarching(nn.Module):
         self.last_stats = dict(n_valid_samples=n_valid, rays_hit=int(counters[1]), n_selected=int(counters[2]),
                                n_neighbor_rows=int(counters[3]), rays=R)
         st = agg.mlp_state()
-        rw = npnt.Rw2c.detach().cpu().numpy() if isinstance(npnt.Rw2c, torch.Tensor) else None
-        cam = ops.make_camera(campos.detach().reshape(-1)[:3].cpu().numpy(), camrotc2w.detach().reshape(-1)[:9].cpu().numpy(),
+        rw = ops.host_array(npnt.Rw2c) if isinstance(npnt.Rw2c, torch.Tensor) else None
+        cam = ops.make_camera(ops.host_array(campos).reshape(-1)[:3], ops.host_array(camrotc2w).reshape(-1)[:9],
                               opt.vsize[2], opt.raydist_mode_unit,
-                              bg=None if bg_color is None else bg_color.detach().reshape(-1)[:3].cpu().numpy(), rw2c=rw)
+                              bg=None if bg_color is None else ops.host_array(bg_color).reshape(-1)[:3], rw2c=rw)
         mlp_params, layout = agg.ordered_params()
         env = dict(cam=cam, xyz=npnt.xyz.detach().reshape(-1, 3).contiguous(), raydir=raydir.detach().reshape(-1, 3).contiguous().float(),
                    dense=dense, R=R, SR=int(opt.SR), K=int(opt.K), n_valid=n_valid, flat=st.flat, packed=st.packed_image(),

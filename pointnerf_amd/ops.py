@@ -23,6 +23,27 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def host_array(t):
+    """The small tensors of a step that the host needs as numbers (camera position / rotation, background, near / far, Rw2c: 3 .. 9 floats)
+    as a numpy array.  A device tensor is read back ONCE per (tensor object, version): the copy is cached on the tensor object itself and is
+    valid as long as the tensor's in-place version counter has not moved (a new tensor -- the reference's ``set_input`` makes one per batch --
+    is read back again).  Every read-back is a host synchronisation with the device idle behind it: a step made eight of them (near, far,
+    camera position twice, rotation, background, Rw2c, counters) where one is needed."""
+    if not isinstance(t, torch.Tensor):
+        return np.asarray(t)
+    if not t.is_cuda:
+        return t.detach().numpy()
+    c = getattr(t, "_pnerf_host", None)
+    if c is not None and c[0] == t._version:
+        return c[1]
+    arr = t.detach().cpu().numpy()
+    try:
+        t._pnerf_host = (t._version, arr)
+    except Exception:
+        pass
+    return arr
+
+
 def _need_cuda(t, name):
     if not (isinstance(t, torch.Tensor) and t.is_cuda):
         raise RuntimeError("pointnerf_amd: %s must be a device tensor (this path has no CPU implementation)" % name)

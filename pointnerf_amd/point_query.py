@@ -137,7 +137,7 @@ class lighting_fast_querier():
             jitter = float(opt.ray_jitter)
         raydir = ray_dirs_tensor.detach().reshape(-1, 3).contiguous().float()
         R = raydir.shape[0]
-        campos = cam_pos_tensor.detach().reshape(-1)[:3].cpu().tolist() if isinstance(cam_pos_tensor, torch.Tensor) else list(cam_pos_tensor)
+        campos = ops.host_array(cam_pos_tensor).reshape(-1)[:3].tolist() if isinstance(cam_pos_tensor, torch.Tensor) else list(cam_pos_tensor)
         self.count += 1
         self.last_seed = self.count * 0x9E3779B1       # the jitter uniforms of this call are pnerf_debug_uniform(last_seed, ray * D + d)
         dense = ops.query_dense(grid, R, D, int(opt.SR), int(opt.K), campos=campos, raydir=raydir,
