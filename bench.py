@@ -79,7 +79,6 @@ def parse():
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--render-only", action="store_true", help="supplementary: inference (render, no backward) rays/s")
     ap.add_argument("--inference-products", type=int, default=3, choices=(2, 3), help="--render-only: MFMA products per multiply-add of the inference forward (3 = fp32-class, default; 2 = weights' high plane only)")
-    ap.add_argument("--no-prefetch-query", dest="prefetch_query", action="store_false", help="A/B: run every batch's query inside its own step (one host synchronisation stall per step) instead of one step ahead on a side stream")
     ap.add_argument("--no-overlap-comm", action="store_true", help="N > 1: all-reduce the point gradients after the whole backward instead of behind the weight-gradient GEMMs")
     ap.add_argument("--point-grads", default="auto", choices=("auto", "dense", "sparse"),
                     help="N > 1: exchange of the per-point gradients: dense all-reduce (one bucket, overlapped), sparse touched-row exchange, auto = sparse from 6 M points")
@@ -238,12 +237,8 @@ def main():
     total = args.warmup + args.steps
     inputs = [step_inputs(i, rank, world, args.rays, dev, rays_fn) for i in range(total)]   # resident in HBM before timing
 
-    def one_step(inp, nxt=None):
+    def one_step(inp):
         nonlocal comm_marks
-        # the NEXT batch's query (it depends on the rays and the point positions only) is issued now on a side stream: it executes in the
-        # idle moments of this step, and the next step starts without waiting for its counters (NeuralPointsRayMarching.prefetch_query)
-        if nxt is not None and args.prefetch_query:
-            model.prefetch_query(**nxt)
         if args.render_only:
             with torch.no_grad():
                 out = model(**inp)
@@ -297,7 +292,7 @@ def main():
     for _ in range(2):
         one_step(inputs[0])
     for i in range(args.warmup):
-        one_step(inputs[i], inputs[(i + 1) % total])
+        one_step(inputs[i])
     torch.cuda.synchronize()
     if not args.no_prof:
         ops.prof_enable(True)
@@ -311,8 +306,7 @@ def main():
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.warmup, total):
-        # (every timed step issues exactly one query: the next batch's, the last step's for the batch after the run -- wrapped around)
-        loss, st = one_step(inputs[i], inputs[(i + 1) % total])
+        loss, st = one_step(inputs[i])
         marks[i - args.warmup + 1].record()
         stats.append(st)
     torch.cuda.synchronize()
@@ -384,7 +378,6 @@ def main():
                           "valid_samples_per_step": smp, "neighbor_rows_per_step": rows,
                           "rays_hit_per_step": float(np.mean([s["rays_hit"] for s in stats])), "final_loss": float(loss.item()),
                           "device_allocs_in_timed_region": int(extra_allocs), "setup_steps": 2,
-                          "query_prefetch": bool(args.prefetch_query) and not sparse,
                           "saved_activation_bytes_per_step": int(ops.L.lib().pnerf_agg_saved_bytes(int(smp), int(opt.K))),
                           "arena_budget_bytes": ops.arena_budget_bytes(),
                           "backward_ray_chunks": None if getattr(FusedRender, "last_chunks", None) is None else

@@ -48,53 +48,6 @@ class NeuralPointsRayMarching(nn.Module):
         self.last_stats = None
         self._pool_rays = 0
 
-    # ---- the query of a LATER batch, one step ahead on a side stream -----------------------------------------------------------------
-    # The query (ray probe, neighbor search, work lists: ~0.85 ms of small kernels at the bench configuration) depends on the point positions
-    # and the batch's rays only -- not on anything the optimisation step changes -- and its result sizes the step's buffers, i.e. the host
-    # has to read 32 bytes of counters back before it can enqueue the forward.  A caller that knows its next batch (a data loader does) calls
-    # ``prefetch_query`` with it: the query then runs on a side stream while the current step is still executing, the counters travel to pinned
-    # host memory behind it, and the next ``forward`` finds both ready: no synchronisation stall, and the small query kernels fill the
-    # device's idle moments between the big ones.  Results are identical (same kernels, same jitter seed sequence).
-    _side_streams = {}
-
-    def prefetch_query(self, campos, raydir, near, far, **unused):
-        npnt = self.neural_points
-        if not (isinstance(raydir, torch.Tensor) and raydir.is_cuda) or getattr(self, "plan_sparse", None) is not None:
-            return False
-        if npnt.querier.last_grid is None:                     # the first query builds the grid: on the main stream
-            return False
-        dev = raydir.device
-        main = torch.cuda.current_stream(dev)
-        side = NeuralPointsRayMarching._side_streams.setdefault(dev, torch.cuda.Stream(device=dev))
-        side.wait_stream(main)                                 # inputs and point positions are whatever the main stream has produced so far
-        with torch.cuda.stream(side):
-            dense = npnt.query_dense(dict(campos=campos, raydir=raydir, near=near, far=far))
-            host = torch.empty(8, dtype=torch.int32, pin_memory=True)
-            host.copy_(dense["counters"], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(side)
-        self._prefetched = dict(key=(raydir.data_ptr(), raydir._version, tuple(raydir.shape), campos.data_ptr(), campos._version,
-                                     npnt.xyz.data_ptr(), npnt.xyz._version), raydir=raydir, dense=dense, host=host, event=ev)
-        return True
-
-    def _take_prefetched(self, campos, raydir, near, far):
-        pre = getattr(self, "_prefetched", None)
-        self._prefetched = None
-        npnt = self.neural_points
-        if pre is None or not isinstance(raydir, torch.Tensor):
-            return None
-        key = (raydir.data_ptr(), raydir._version, tuple(raydir.shape), campos.data_ptr(), campos._version, npnt.xyz.data_ptr(), npnt.xyz._version)
-        if key != pre["key"] or pre["raydir"] is not raydir:
-            return None                                        # a different batch (or the cloud changed): the prefetched result is dropped
-        main = torch.cuda.current_stream(raydir.device)
-        main.wait_event(pre["event"])                          # device side: the main stream's kernels see the query's outputs
-        pre["event"].synchronize()                             # host side: the counters have arrived (long ago, normally)
-        for t in pre["dense"].values():                        # allocated on the side stream, used on the main one from here on
-            if isinstance(t, torch.Tensor):
-                t.record_stream(main)
-        npnt.querier.last_dense = pre["dense"]
-        return pre["dense"], pre["host"].clone()
-
     def render_dense(self, campos, raydir, camrotc2w, near, far, bg_color=None, train=None):
         """The fused step on all R rays.  Returns (ray_color [R,3], opacity, bg_trans, blend_w, decoded, weight, dense)."""
         opt, npnt, agg = self.opt, self.neural_points, self.aggregator
@@ -106,21 +59,15 @@ class NeuralPointsRayMarching(nn.Module):
         if train and self._pool_rays < R:              # worst case (every ray hits): ~16 live [R,SR,K] fp32 tensors around the loss
             ops.reserve_pool(16 * R * int(opt.SR) * int(opt.K) * 4, raydir.device)
             self._pool_rays = R
-        pre = self._take_prefetched(campos, raydir, near, far)
-        if pre is not None:
-            # the query of this batch already ran on the side stream (prefetch_query): its counters are on the host, nothing to wait for
-            dense, counters = pre
-            plan = None
-        else:
-            dense = npnt.query_dense(dict(campos=campos, raydir=raydir, near=near, far=far))
-            # data-parallel callers that exchange touched rows only (dist.plan_sparse_exchange) prepare the row list here, so that its two
-            # counts travel with the one host read below instead of synchronising a second time after the backward
-            plan = getattr(self, "plan_sparse", None)
-            plan = plan(dense) if (plan is not None and train) else None
+        dense = npnt.query_dense(dict(campos=campos, raydir=raydir, near=near, far=far))
+        # data-parallel callers that exchange touched rows only (dist.plan_sparse_exchange) prepare the row list here, so that its two
+        # counts travel with the one host read below instead of synchronising a second time after the backward
+        plan = getattr(self, "plan_sparse", None)
+        plan = plan(dense) if (plan is not None and train) else None
         if plan is not None:
             both = torch.cat([dense["counters"].to(torch.int64), plan[1]]).cpu()
             counters, self.sparse_plan = both[:8], (plan[0], int(both[8]), int(both[9]))
-        elif pre is None:
+        else:
             counters = dense["counters"].cpu()                # the one sync: sizes the activation arena
         n_valid = int(counters[0])
         self.last_stats = dict(n_valid_samples=n_valid, rays_hit=int(counters[1]), n_selected=int(counters[2]),
