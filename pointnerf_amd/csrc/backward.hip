@@ -893,24 +893,33 @@ struct WgX0Args {
     long long rg_total;
     int n_points;
 };
-constexpr int WX_AU = 2 * PN_H;                     // dY1 units of a stage (one plane, 16 rows)
-constexpr int WX_NB = 224;                          // columns rebuilt here
-constexpr int WX_BU = 2 * WX_NB;                    // their units of one plane of a stage
-constexpr int WX_TU = 2 * 2 * 64;                   // saved-column units of a stage: [plane][rg][64]
-// Prefetch distance WX_D (iterations): what iteration i consumes was issued at iteration i - WX_D.  A stage is only 14 KB (dY1 8, saved
-// columns 4, embedding rows 2), so the distance has to be long for enough bytes to be in flight per CU (round 3: at a distance of 3, 42 KB
-// in flight, the kernel ran at 3.0 TB/s whatever it computed; Little's law with 2 - 4 us of loaded HBM latency asks for ~100 KB).
+// Rows per stage WX_RS (16 or 32) and prefetch distance WX_D (iterations): what iteration i consumes was issued at iteration i - WX_D.
 //   iteration j issues   dY1 and saved columns of stage j + D | embedding rows of stage j + D + 1 (its X0 is built at iteration j + D) |
 //                        row metadata of stage j + 2 D + 2 (read at the END of iteration j + D, for the gather that iteration j + D + 1 issues)
-#ifndef PN_WX_D
-#define PN_WX_D 7
+// A stage is one barrier and one LDS round trip in front of its MFMAs, and the two waves of a SIMD run it in lockstep: with 16-row stages the
+// kernel spent as long on that rendezvous as on the 36 MFMAs per SIMD (1.83 ms with the X0 arithmetic removed, prefetch distances of 3 and 7
+// stages the same).  32-row stages halve the rendezvous per row; LDS then holds a distance of 2 (= 64 rows ahead, as before).
+#ifndef PN_WX_RS
+#define PN_WX_RS 32
 #endif
+#ifndef PN_WX_D
+#define PN_WX_D (PN_WX_RS == 32 ? 2 : 7)
+#endif
+constexpr int WX_RS = PN_WX_RS, WX_RG = WX_RS / 8;  // rows / row groups per stage
+constexpr int WX_AU = WX_RG * PN_H;                 // dY1 units of a stage (one plane)
+constexpr int WX_NB = 224;                          // columns rebuilt here
+constexpr int WX_BU = WX_RG * WX_NB;                // their units of one plane of a stage
+constexpr int WX_TU = 2 * WX_RG * 64;               // saved-column units of a stage: [plane][rg][64]
+constexpr int WX_GU = WX_RS * 8;                    // embedding units of a stage: [rg][piece 8][row 8] x 16 B
+constexpr int WX_NA = WX_AU / 512;                  // dY1 pieces (1 KB) per wave and stage
+constexpr int WX_L = WX_NA + 2;                     // wave-instructions per wave and iteration: dY1 | a saved-column piece or pad | metadata / embedding rows / pad
 constexpr int WX_D = PN_WX_D;
 constexpr int WX_NST = WX_D + 1, WX_RMD = 2 * WX_D + 2, WX_GD = WX_D + 1;    // ring depth of dY1 / saved columns; how far ahead metadata / embedding rows are issued
 constexpr int WX_RM_SLOTS = WX_D + 2, WX_G_SLOTS = WX_D + 1;
-static_assert(2 * (WX_D - 1) <= 63, "vmcnt is a 6-bit count");
+static_assert(WX_L * (WX_D - 1) <= 63 && WX_D >= 2, "vmcnt is a 6-bit count");
+static_assert(WX_RS == 16 || WX_RS == 32, "rows per stage");
 constexpr int WX_OFF_T = WX_NST * WX_AU, WX_OFF_B = WX_OFF_T + WX_NST * WX_TU, WX_OFF_RM = WX_OFF_B + 2 * 2 * WX_BU,
-              WX_OFF_G = WX_OFF_RM + WX_RM_SLOTS * 16, WX_OFF_PAD = WX_OFF_G + WX_G_SLOTS * 128, WX_UNITS = WX_OFF_PAD + 64;
+              WX_OFF_G = WX_OFF_RM + WX_RM_SLOTS * WX_RS, WX_OFF_PAD = WX_OFF_G + WX_G_SLOTS * WX_GU, WX_UNITS = WX_OFF_PAD + 64;
 static_assert(WX_UNITS * 16 <= 160 * 1024, "k_wgrad_x0 LDS");
 
 __device__ __forceinline__ void wx_store_h16(char *buf, int plane, int rg, int f, int rlow, unsigned short v) {
@@ -929,9 +938,9 @@ __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, W
     extern __shared__ __attribute__((aligned(16))) uint4 smem_x[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const long long stages = (long long)(*d_tiles) * (PN_TILE / 16);
+    const long long stages = (long long)(*d_tiles) * (PN_TILE / WX_RS);
     const int nst = stages > (long long)blockIdx.x ? (int)((stages - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
-    auto stage_rg = [&](int s) { return 2LL * ((long long)blockIdx.x + (long long)gridDim.x * s); };       // first row group (8 rows) of local stage s
+    auto stage_rg = [&](int s) { return (long long)WX_RG * ((long long)blockIdx.x + (long long)gridDim.x * s); };       // first row group (8 rows) of local stage s
     f32x16 acc[MTW][2], acct;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -941,110 +950,114 @@ __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, W
     }
     char *lds = reinterpret_cast<char *>(smem_x);
     int p_gather = 0;
-    // ---- issue helpers: each call is exactly ONE wave-instruction of the calling wave (a stage past the end re-reads a valid source into the pad)
-    auto issue_a = [&](int s) {
+    // ---- issue helpers: a call is a fixed number of wave-instructions of the calling wave (a stage past the end re-reads a valid source into the pad)
+    auto issue_a = [&](int s) {                         // WX_NA + 1 instructions: the wave's dY1 pieces, then its saved-column piece (or a pad piece)
         const bool ok = s < nst;
-        const uint4 *src = A + (ok ? stage_rg(s) * MF + 64 * wave : 0) + lane;
-        const uint4 *dst = smem_x + (ok ? (s % WX_NST) * WX_AU + 64 * wave : WX_OFF_PAD);
+#pragma unroll
+        for (int i = 0; i < WX_NA; ++i) {
+            const int piece = wave + 8 * i;
+            const uint4 *src = A + (ok ? stage_rg(s) * MF + 64 * piece : 0) + lane;
+            const uint4 *dst = smem_x + (ok ? (s % WX_NST) * WX_AU + 64 * piece : WX_OFF_PAD);
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+        const bool okt = ok && wave < 2 * WX_RG;        // piece (plane, rg) = 64 units of the saved last-64-column planes
+        const int plane = wave / WX_RG, rg = wave - plane * WX_RG;
+        const uint4 *src = g.x0t + (okt ? ((long long)plane * g.rg_total + stage_rg(s) + rg) * 64 : 0) + lane;
+        const uint4 *dst = smem_x + (okt ? WX_OFF_T + (s % WX_NST) * WX_TU + wave * 64 : WX_OFF_PAD);
         __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     };
-    auto issue_second = [&](int s_rm, int s_g, int s_t) {
-        if (wave == 0) {                               // the 16 rows' (sample, point, ., .) records of stage s_rm
+    auto issue_second = [&](int s_rm, int s_g) {        // ONE instruction: metadata (wave 0), embedding rows (waves 1 .. RG), pad (the rest)
+        if (wave == 0) {                                // the stage's (sample, point, ., .) records, one per row
             const bool ok = s_rm < nst;
-            const int4 *src = g.rmeta + (ok ? stage_rg(s_rm) * 8 : 0) + (lane & 15);
-            const uint4 *dst = smem_x + (ok ? WX_OFF_RM + (s_rm % WX_RM_SLOTS) * 16 : WX_OFF_PAD);
-            if (lane < 16) __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-        } else if (wave <= 2) {                        // embedding rows 8 (wave - 1) .. + 7 of stage s_g: lane = piece * 8 + row -> slot [half][piece][row] x 16 B
+            const int4 *src = g.rmeta + (ok ? stage_rg(s_rm) * 8 : 0) + (lane & (WX_RS - 1));
+            const uint4 *dst = smem_x + (ok ? WX_OFF_RM + (s_rm % WX_RM_SLOTS) * WX_RS : WX_OFF_PAD);
+            if (lane < WX_RS) __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        } else if (wave <= WX_RG) {                     // embedding rows of row group wave - 1 of stage s_g: lane = piece * 8 + row -> slot [rg][piece][row] x 16 B
             const bool ok = s_g < nst;
-            const int p = ok ? p_gather : 0;           // (read from the metadata ring and clamped one iteration ahead: next_point)
+            const int p = ok ? p_gather : 0;            // (read from the metadata ring and clamped one iteration ahead: next_point)
             const float *src = g.emb + (long long)p * PN_F + (lane >> 3) * 4;
-            const uint4 *dst = smem_x + (ok ? WX_OFF_G + (s_g % WX_G_SLOTS) * 128 + (wave - 1) * 64 : WX_OFF_PAD);
+            const uint4 *dst = smem_x + (ok ? WX_OFF_G + (s_g % WX_G_SLOTS) * WX_GU + (wave - 1) * 64 : WX_OFF_PAD);
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-        } else if (wave <= 6) {                        // the saved columns of stage s_t: piece (plane, rg) = 64 units
-            const bool ok = s_t < nst;
-            const int plane = (wave - 3) >> 1, rg = (wave - 3) & 1;
-            const uint4 *src = g.x0t + (ok ? ((long long)plane * g.rg_total + stage_rg(s_t) + rg) * 64 : 0) + lane;
-            const uint4 *dst = smem_x + (ok ? WX_OFF_T + (s_t % WX_NST) * WX_TU + (wave - 3) * 64 : WX_OFF_PAD);
-            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-        } else {                                       // wave 7: a pad piece, so that every wave counts two loads per iteration
+        } else {                                        // a pad piece, so that every wave counts the same number of loads per iteration
             __builtin_amdgcn_global_load_lds(A + lane, (__attribute__((address_space(3))) void *)(smem_x + WX_OFF_PAD), 16, 0, 0);
         }
     };
-    // the point of this lane's embedding row of stage s_g (waves 1, 2), clamped: looked up at the END of an iteration for the gather the next
-    // one issues, so that the LDS round trip is not in front of the next stage's MFMAs
+    // the point of this lane's embedding row of stage s_g (waves 1 .. RG), clamped: looked up at the END of an iteration for the gather the
+    // next one issues, so that the LDS round trip is not in front of the next stage's MFMAs
     auto next_point = [&](int s_g) {
-        if (wave >= 1 && wave <= 2 && s_g < nst) {
-            const int p = reinterpret_cast<const int4 *>(smem_x + WX_OFF_RM + (s_g % WX_RM_SLOTS) * 16)[8 * (wave - 1) + (lane & 7)].y;
+        if (wave >= 1 && wave <= WX_RG && s_g < nst) {
+            const int p = reinterpret_cast<const int4 *>(smem_x + WX_OFF_RM + (s_g % WX_RM_SLOTS) * WX_RS)[8 * (wave - 1) + (lane & 7)].y;
             p_gather = p < 0 ? 0 : (p >= g.n_points ? g.n_points - 1 : p);
         }
     };
-    // ---- columns 0 .. 223 of local stage s -> buffer s & 1
+    // ---- columns 0 .. 223 of local stage s -> buffer s & 1: thread -> (row group, embedding dim, row in group), WX_RS / 16 items each
     auto build = [&](int s) {
         char *buf = lds + (size_t)(WX_OFF_B + (s & 1) * 2 * WX_BU) * 16;
-        const char *slot = lds + (size_t)(WX_OFF_G + (s % WX_G_SLOTS) * 128) * 16;
-        const int rg = tid >> 8, d = (tid >> 3) & 31, rlow = tid & 7;
-        const float e = *reinterpret_cast<const float *>(slot + rg * 1024 + ((d >> 2) * 8 + rlow) * 16 + (d & 3) * 4);
-        float sn[3], cs[3];
-        pn_pe_octaves<3>(e, sn, cs);
-        const int f = PN_F + d * 6;
-        wx_put2(buf, rg, rlow, d, f, e, sn[0]);
-        wx_put2(buf, rg, rlow, f + 1, f + 2, cs[0], sn[1]);
-        wx_put2(buf, rg, rlow, f + 3, f + 4, cs[1], sn[2]);
-        unsigned h, m;
-        pn_split2(cs[2], 0.f, h, m);
-        wx_store_h16(buf, 0, rg, f + 5, rlow, (unsigned short)h); wx_store_h16(buf, 1, rg, f + 5, rlow, (unsigned short)m);
+        const char *slot = lds + (size_t)(WX_OFF_G + (s % WX_G_SLOTS) * WX_GU) * 16;
+#pragma unroll
+        for (int it = 0; it < WX_RS / 16; ++it) {
+            const int item = tid + 512 * it, rg = item >> 8, d = (item >> 3) & 31, rlow = item & 7;
+            const float e = *reinterpret_cast<const float *>(slot + rg * 1024 + ((d >> 2) * 8 + rlow) * 16 + (d & 3) * 4);
+            float sn[3], cs[3];
+            pn_pe_octaves<3>(e, sn, cs);
+            const int f = PN_F + d * 6;
+            wx_put2(buf, rg, rlow, d, f, e, sn[0]);
+            wx_put2(buf, rg, rlow, f + 1, f + 2, cs[0], sn[1]);
+            wx_put2(buf, rg, rlow, f + 3, f + 4, cs[1], sn[2]);
+            unsigned h, m;
+            pn_split2(cs[2], 0.f, h, m);
+            wx_store_h16(buf, 0, rg, f + 5, rlow, (unsigned short)h); wx_store_h16(buf, 1, rg, f + 5, rlow, (unsigned short)m);
+        }
     };
     if (nst > 0) {
         // ---- prologue: the metadata the first embedding gathers need (stages 0 .. D + 1: a ring's worth), drained; then dY1 / saved columns
         // of stages 0 .. D - 1 and the embedding rows of stages 0 .. D, drained; then the metadata of stages D + 2 .. 2 D + 1, drained
         if (wave == 0)
-            for (int s = 0; s < WX_RM_SLOTS; ++s) issue_second(s, 0, 0);
+            for (int s = 0; s < WX_RM_SLOTS; ++s) issue_second(s, 0);
         PN_WAIT_VMCNT(0);
         __syncthreads();
         for (int s = 0; s < WX_D; ++s) issue_a(s);
-        if (wave >= 1 && wave <= 2)
-            for (int s = 0; s < WX_GD; ++s) { next_point(s); issue_second(0, s, 0); }
-        if (wave >= 3 && wave <= 6)
-            for (int s = 0; s < WX_D; ++s) issue_second(0, 0, s);
+        if (wave >= 1 && wave <= WX_RG)
+            for (int s = 0; s < WX_GD; ++s) { next_point(s); issue_second(0, s); }
         PN_WAIT_VMCNT(0);
         __syncthreads();                                  // (the metadata slots of stages 0 .. D have been read: D of them may be overwritten)
         if (wave == 0)
-            for (int s = WX_RM_SLOTS; s < WX_RMD; ++s) issue_second(s, 0, 0);
+            for (int s = WX_RM_SLOTS; s < WX_RMD; ++s) issue_second(s, 0);
         PN_WAIT_VMCNT(0);
         __syncthreads();
         build(0);
-        next_point(WX_GD);                                // (its metadata was issued in the first prologue step or just now: landed)
+        next_point(WX_GD);                                // (its metadata was issued in the first prologue step: landed)
         for (int s = 0; s < nst; ++s) {
-            // everything this wave issued up to iteration s - D has landed (D - 1 iterations' worth = 2 (D - 1) wave-instructions may be
-            // outstanding), its X0 writes of iteration s - 1 are done; then everybody's
-            PN_WAIT_VMCNT(2 * (WX_D - 1));
+            // everything this wave issued up to iteration s - D has landed (D - 1 iterations' worth of wave-instructions may be outstanding),
+            // its X0 writes of iteration s - 1 are done; then everybody's
+            PN_WAIT_VMCNT(WX_L * (WX_D - 1));
             PN_LDS_BARRIER();
             issue_a(s + WX_D);
-            issue_second(s + WX_RMD, s + WX_GD, s + WX_D);
-            const uint4 *fa = smem_x + (s % WX_NST) * WX_AU + (lane >> 5) * MF + (lane & 31);
-            const uint4 *fb = smem_x + WX_OFF_B + (s & 1) * 2 * WX_BU + (lane >> 5) * WX_NB + (lane & 31);            // built columns, high plane
-            const uint4 *ft = smem_x + WX_OFF_T + (s % WX_NST) * WX_TU + (lane >> 5) * 64 + (lane & 31);               // saved columns, high plane
-            pn_h8 ah[MTW], bh[2], bm[2];
+            issue_second(s + WX_RMD, s + WX_GD);
 #pragma unroll
-            for (int i = 0; i < MTW; ++i) ah[i] = __builtin_bit_cast(pn_h8, fa[(MTW * wm + i) * 32]);
-            const pn_h8 tah = __builtin_bit_cast(pn_h8, fa[(MTW * wm + wn) * 32]);
-            // n-tiles 2 wn, 2 wn + 1 of the 9: tiles 0 .. 6 = built columns, tile 7 = saved columns 224 .. 255, tile 8 (the tail, one m-tile per wave) = 256 .. 287
-            bh[0] = __builtin_bit_cast(pn_h8, fb[(2 * wn) * 32]); bm[0] = __builtin_bit_cast(pn_h8, fb[WX_BU + (2 * wn) * 32]);
-            if (wn < 3) { bh[1] = __builtin_bit_cast(pn_h8, fb[(2 * wn + 1) * 32]); bm[1] = __builtin_bit_cast(pn_h8, fb[WX_BU + (2 * wn + 1) * 32]); }
-            else { bh[1] = __builtin_bit_cast(pn_h8, ft[0]); bm[1] = __builtin_bit_cast(pn_h8, ft[2 * 64]); }
-            const pn_h8 tbh = __builtin_bit_cast(pn_h8, ft[32]), tbm = __builtin_bit_cast(pn_h8, ft[2 * 64 + 32]);
+            for (int kk = 0; kk < WX_RS / 16; ++kk) {         // 16 rows (two row groups) per MFMA k-step
+                const uint4 *fa = smem_x + (s % WX_NST) * WX_AU + (2 * kk + (lane >> 5)) * MF + (lane & 31);
+                const uint4 *fb = smem_x + WX_OFF_B + (s & 1) * 2 * WX_BU + (2 * kk + (lane >> 5)) * WX_NB + (lane & 31);            // built columns, high plane
+                const uint4 *ft = smem_x + WX_OFF_T + (s % WX_NST) * WX_TU + (2 * kk + (lane >> 5)) * 64 + (lane & 31);               // saved columns, high plane
+                pn_h8 ah[MTW], bh[2], bm[2];
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
+                for (int i = 0; i < MTW; ++i) ah[i] = __builtin_bit_cast(pn_h8, fa[(MTW * wm + i) * 32]);
+                const pn_h8 tah = __builtin_bit_cast(pn_h8, fa[(MTW * wm + wn) * 32]);
+                // n-tiles 2 wn, 2 wn + 1 of the 9: tiles 0 .. 6 = built columns, tile 7 = saved columns 224 .. 255, tile 8 (the tail, one m-tile per wave) = 256 .. 287
+                bh[0] = __builtin_bit_cast(pn_h8, fb[(2 * wn) * 32]); bm[0] = __builtin_bit_cast(pn_h8, fb[WX_BU + (2 * wn) * 32]);
+                if (wn < 3) { bh[1] = __builtin_bit_cast(pn_h8, fb[(2 * wn + 1) * 32]); bm[1] = __builtin_bit_cast(pn_h8, fb[WX_BU + (2 * wn + 1) * 32]); }
+                else { bh[1] = __builtin_bit_cast(pn_h8, ft[0]); bm[1] = __builtin_bit_cast(pn_h8, ft[WX_RG * 64]); }
+                const pn_h8 tbh = __builtin_bit_cast(pn_h8, ft[32]), tbm = __builtin_bit_cast(pn_h8, ft[WX_RG * 64 + 32]);
 #pragma unroll
-                for (int i = 0; i < MTW; ++i)
+                for (int p = 0; p < 2; ++p)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], p == 1 ? bm[j] : bh[j], acc[i][j], 0, 0, 0);
-            acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbh, acct, 0, 0, 0);
-            acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbm, acct, 0, 0, 0);
-#ifdef PN_WX_NOMFMA
-            if (s >= 0) { for (int i = 0; i < MTW; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f; }
-#endif
+                    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], p == 1 ? bm[j] : bh[j], acc[i][j], 0, 0, 0);
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbh, acct, 0, 0, 0);
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbm, acct, 0, 0, 0);
+            }
             // (unconditional: past the last stage it rebuilds from a stale -- finite -- slot into the buffer nobody reads; no branch, so the
             //  X0 arithmetic can be scheduled between the MFMAs instead of behind them)
 #ifndef PN_WX_NOBUILD               // (dev variants, tools/_build only: where does the time of a stage go)
