@@ -896,11 +896,11 @@ struct WgX0Args {
 // Rows per stage WX_RS (16 or 32) and prefetch distance WX_D (iterations): what iteration i consumes was issued at iteration i - WX_D.
 //   iteration j issues   dY1 and saved columns of stage j + D | embedding rows of stage j + D + 1 (its X0 is built at iteration j + D) |
 //                        row metadata of stage j + 2 D + 2 (read at the END of iteration j + D, for the gather that iteration j + D + 1 issues)
-// A stage is one barrier and one LDS round trip in front of its MFMAs, and the two waves of a SIMD run it in lockstep: with 16-row stages the
-// kernel spent as long on that rendezvous as on the 36 MFMAs per SIMD (1.83 ms with the X0 arithmetic removed, prefetch distances of 3 and 7
-// stages the same).  32-row stages halve the rendezvous per row; LDS then holds a distance of 2 (= 64 rows ahead, as before).
+// Measured (round 3, one box, 7.1 M rows): 16-row stages 2.1-2.2 ms with distances of 3 and 7 alike (42 vs 98 KB in flight per CU), 1.83 ms with
+// the X0 arithmetic removed; 32-row stages (half the barriers per row; LDS then holds a distance of 2) 2.56 ms -- SLOWER.  Neither bytes in
+// flight nor the per-stage rendezvous is what bounds it; 16 rows / distance 7 ships.
 #ifndef PN_WX_RS
-#define PN_WX_RS 32
+#define PN_WX_RS 16
 #endif
 #ifndef PN_WX_D
 #define PN_WX_D (PN_WX_RS == 32 ? 2 : 7)
