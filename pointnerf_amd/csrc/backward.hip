@@ -1027,18 +1027,48 @@ __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, W
         __syncthreads();
         build(0);
         next_point(WX_GD);                                // (its metadata was issued in the first prologue step: landed)
+        // ---- main loop.  The scalar unit is shared by the CU's eight waves: ring slots and source addresses are carried as counters and
+        // running pointers (one add per iteration) instead of being recomputed from the stage index (a 64-bit multiply, a modulo and a bounds
+        // select each: the loop body had 137 scalar instructions per wave for 18 MFMAs), and the bounds checks exist only in the last
+        // 2 D + 2 iterations, which go through the checked issue helpers.
+        const long long stride_a = (long long)WX_RG * gridDim.x * MF, stride_t = (long long)WX_RG * gridDim.x * 64, stride_rm = (long long)WX_RG * gridDim.x * 8;
+        const int t_plane = wave / WX_RG, t_rg = wave - t_plane * WX_RG;
+        const uint4 *pa = A + stage_rg(WX_D) * MF + 64 * wave + lane;
+        const uint4 *pt = g.x0t + ((long long)t_plane * g.rg_total + stage_rg(WX_D) + t_rg) * 64 + lane;
+        const int4 *prm = g.rmeta + stage_rg(WX_RMD) * 8 + (lane & (WX_RS - 1));
+        int ia = WX_D % WX_NST, ig = WX_GD % WX_G_SLOTS, irm = WX_RMD % WX_RM_SLOTS;      // slots the issues of iteration 0 write
+        int ra = 0, rgs = 1 % WX_G_SLOTS, rrm = (1 + WX_GD) % WX_RM_SLOTS;                  // slots iteration 0 reads: dY1 / saved columns, embedding rows of stage 1, metadata of stage 1 + GD
+        const int n_main = nst - WX_RMD > 0 ? nst - WX_RMD : 0;                             // iterations whose every issue is inside the run
+        auto bump = [](int &c, int n) { c = c + 1 == n ? 0 : c + 1; };
         for (int s = 0; s < nst; ++s) {
             // everything this wave issued up to iteration s - D has landed (D - 1 iterations' worth of wave-instructions may be outstanding),
             // its X0 writes of iteration s - 1 are done; then everybody's
             PN_WAIT_VMCNT(WX_L * (WX_D - 1));
             PN_LDS_BARRIER();
-            issue_a(s + WX_D);
-            issue_second(s + WX_RMD, s + WX_GD);
+            if (s < n_main) {
+#pragma unroll
+                for (int i = 0; i < WX_NA; ++i)
+                    __builtin_amdgcn_global_load_lds(pa + 512 * i, (__attribute__((address_space(3))) void *)(smem_x + ia * WX_AU + 64 * (wave + 8 * i)), 16, 0, 0);
+                if (wave < 2 * WX_RG) __builtin_amdgcn_global_load_lds(pt, (__attribute__((address_space(3))) void *)(smem_x + WX_OFF_T + ia * WX_TU + wave * 64), 16, 0, 0);
+                else __builtin_amdgcn_global_load_lds(A + lane, (__attribute__((address_space(3))) void *)(smem_x + WX_OFF_PAD), 16, 0, 0);
+                if (wave == 0) {
+                    if (lane < WX_RS) __builtin_amdgcn_global_load_lds(prm, (__attribute__((address_space(3))) void *)(smem_x + WX_OFF_RM + irm * WX_RS), 16, 0, 0);
+                } else if (wave <= WX_RG) {
+                    __builtin_amdgcn_global_load_lds(g.emb + (long long)p_gather * PN_F + (lane >> 3) * 4,
+                                                     (__attribute__((address_space(3))) void *)(smem_x + WX_OFF_G + ig * WX_GU + (wave - 1) * 64), 16, 0, 0);
+                } else {
+                    __builtin_amdgcn_global_load_lds(A + lane, (__attribute__((address_space(3))) void *)(smem_x + WX_OFF_PAD), 16, 0, 0);
+                }
+            } else {
+                issue_a(s + WX_D);
+                issue_second(s + WX_RMD, s + WX_GD);
+            }
+            pa += stride_a; pt += stride_t; prm += stride_rm;
 #pragma unroll
             for (int kk = 0; kk < WX_RS / 16; ++kk) {         // 16 rows (two row groups) per MFMA k-step
-                const uint4 *fa = smem_x + (s % WX_NST) * WX_AU + (2 * kk + (lane >> 5)) * MF + (lane & 31);
+                const uint4 *fa = smem_x + ra * WX_AU + (2 * kk + (lane >> 5)) * MF + (lane & 31);
                 const uint4 *fb = smem_x + WX_OFF_B + (s & 1) * 2 * WX_BU + (2 * kk + (lane >> 5)) * WX_NB + (lane & 31);            // built columns, high plane
-                const uint4 *ft = smem_x + WX_OFF_T + (s % WX_NST) * WX_TU + (2 * kk + (lane >> 5)) * 64 + (lane & 31);               // saved columns, high plane
+                const uint4 *ft = smem_x + WX_OFF_T + ra * WX_TU + (2 * kk + (lane >> 5)) * 64 + (lane & 31);                         // saved columns, high plane
                 pn_h8 ah[MTW], bh[2], bm[2];
 #pragma unroll
                 for (int i = 0; i < MTW; ++i) ah[i] = __builtin_bit_cast(pn_h8, fa[(MTW * wm + i) * 32]);
@@ -1058,12 +1088,34 @@ __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, W
                 acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbh, acct, 0, 0, 0);
                 acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbm, acct, 0, 0, 0);
             }
-            // (unconditional: past the last stage it rebuilds from a stale -- finite -- slot into the buffer nobody reads; no branch, so the
-            //  X0 arithmetic can be scheduled between the MFMAs instead of behind them)
+            // columns 0 .. 223 of stage s + 1 -> the other X0 buffer (unconditional: past the last stage it rebuilds from a stale -- finite --
+            // slot into the buffer nobody reads; no branch, so the arithmetic can be scheduled between the MFMAs instead of behind them)
 #ifndef PN_WX_NOBUILD               // (dev variants, tools/_build only: where does the time of a stage go)
-            build(s + 1);
+            {
+                char *buf = lds + (size_t)(WX_OFF_B + ((s + 1) & 1) * 2 * WX_BU) * 16;
+                const char *slot = lds + (size_t)(WX_OFF_G + rgs * WX_GU) * 16;
+#pragma unroll
+                for (int it = 0; it < WX_RS / 16; ++it) {
+                    const int item = tid + 512 * it, rg = item >> 8, d = (item >> 3) & 31, rlow = item & 7;
+                    const float e = *reinterpret_cast<const float *>(slot + rg * 1024 + ((d >> 2) * 8 + rlow) * 16 + (d & 3) * 4);
+                    float sn[3], cs[3];
+                    pn_pe_octaves<3>(e, sn, cs);
+                    const int f = PN_F + d * 6;
+                    wx_put2(buf, rg, rlow, d, f, e, sn[0]);
+                    wx_put2(buf, rg, rlow, f + 1, f + 2, cs[0], sn[1]);
+                    wx_put2(buf, rg, rlow, f + 3, f + 4, cs[1], sn[2]);
+                    unsigned h, m;
+                    pn_split2(cs[2], 0.f, h, m);
+                    wx_store_h16(buf, 0, rg, f + 5, rlow, (unsigned short)h); wx_store_h16(buf, 1, rg, f + 5, rlow, (unsigned short)m);
+                }
+            }
 #endif
-            next_point(s + 1 + WX_GD);                    // for the gather the next iteration issues (its metadata was issued at iteration s - D: landed)
+            // the point of the embedding row the NEXT iteration gathers (stage s + 1 + GD; its metadata was issued at iteration s - D: landed)
+            if (wave >= 1 && wave <= WX_RG && s + 1 + WX_GD < nst) {
+                const int p = reinterpret_cast<const int4 *>(smem_x + WX_OFF_RM + rrm * WX_RS)[8 * (wave - 1) + (lane & 7)].y;
+                p_gather = p < 0 ? 0 : (p >= g.n_points ? g.n_points - 1 : p);
+            }
+            bump(ia, WX_NST); bump(ig, WX_G_SLOTS); bump(irm, WX_RM_SLOTS); bump(ra, WX_NST); bump(rgs, WX_G_SLOTS); bump(rrm, WX_RM_SLOTS);
         }
     }
     float *out = partial + (size_t)blockIdx.x * 256 * 288;
