@@ -154,12 +154,12 @@ size_t pn_saved_bytes(long long n_valid, int K, long long *rows_out, long long *
     if (rows_out) *rows_out = rows;
     if (samples_out) *samples_out = samples;
     size_t b = 0;
-    b += 2 * pn_align((size_t)rows / 8 * PN_NF1 * 32) + 2 * pn_align((size_t)rows / 8 * PN_H * 32);      // x0k, h2k | h1k, h3k
+    b += 2 * pn_align((size_t)rows / 8 * PN_NF1 * 16) + 2 * pn_align((size_t)rows / 8 * PN_H * 16);      // x0k, h2k | h1k, h3k (one plane)
     b += 4 * pn_align((size_t)rows / 8 * PN_H * 16) + pn_align((size_t)rows * 32 * 32);                // dy1k..dy4k (one plane) | h4r
     b += pn_align((size_t)rows * 4) + pn_align((size_t)rows * 16) + pn_align((size_t)tiles * 3 * PN_NTHR * 8) + pn_align(16);
     b += pn_cls_bytes(samples);
     b += 2 * pn_align((size_t)samples * PN_H * 4) + pn_align((size_t)samples * PN_HC * 4);                         // fs, dfs | c3
-    b += pn_align((size_t)samples / 8 * PN_NF1 * 32) + 2 * pn_align((size_t)samples / 8 * PN_HC * 32);              // xck | c1k, c2k
+    b += pn_align((size_t)samples / 8 * PN_NF1 * 16) + 2 * pn_align((size_t)samples / 8 * PN_HC * 16);              // xck | c1k, c2k (one plane)
     b += 3 * pn_align((size_t)samples / 8 * PN_HC * 16) + pn_align((size_t)samples / PN_CTILE * 2 * 256 * 4);       // dc1k..dc3k | cmask
     return b;
 }
@@ -169,8 +169,8 @@ PnSaved pn_saved_carve(void *base, long long n_valid, int K) {
     size_t total = pn_saved_bytes(n_valid, K, &s.rows, &s.samples);
     PnCarver cv(base, total);
     const size_t rg = (size_t)s.rows / 8;
-    s.x0k = cv.take<uint4>(rg * PN_NF1 * 2); s.h2k = cv.take<uint4>(rg * PN_NF1 * 2);
-    s.h1k = cv.take<uint4>(rg * PN_H * 2); s.h3k = cv.take<uint4>(rg * PN_H * 2);
+    s.x0k = cv.take<uint4>(rg * PN_NF1); s.h2k = cv.take<uint4>(rg * PN_NF1);
+    s.h1k = cv.take<uint4>(rg * PN_H); s.h3k = cv.take<uint4>(rg * PN_H);
     s.dy1k = cv.take<uint4>(rg * PN_H); s.dy2k = cv.take<uint4>(rg * PN_H);
     s.dy3k = cv.take<uint4>(rg * PN_H); s.dy4k = cv.take<uint4>(rg * PN_H);
     s.h4r = cv.take<uint4>((size_t)s.rows * 32 * 2);
@@ -180,7 +180,7 @@ PnSaved pn_saved_carve(void *base, long long n_valid, int K) {
     s.fs = cv.take<float>((size_t)s.samples * PN_H); s.dfs = cv.take<float>((size_t)s.samples * PN_H);
     s.c3 = cv.take<float>((size_t)s.samples * PN_HC);
     const size_t rgc = (size_t)s.samples / 8;
-    s.xck = cv.take<uint4>(rgc * PN_NF1 * 2); s.c1k = cv.take<uint4>(rgc * PN_HC * 2); s.c2k = cv.take<uint4>(rgc * PN_HC * 2);
+    s.xck = cv.take<uint4>(rgc * PN_NF1); s.c1k = cv.take<uint4>(rgc * PN_HC); s.c2k = cv.take<uint4>(rgc * PN_HC);
     s.dc1k = cv.take<uint4>(rgc * PN_HC); s.dc2k = cv.take<uint4>(rgc * PN_HC); s.dc3k = cv.take<uint4>(rgc * PN_HC);
     s.cmask = cv.take<unsigned>((size_t)s.samples / PN_CTILE * 2 * 256);
     pn_cls_carve(cv.take<char>(pn_cls_bytes(s.samples)), s.samples, s);
@@ -287,13 +287,10 @@ __global__ void k_cls_zero_gaps(PnSaved sv, int ncls, int save_x0) {
     if ((blockIdx.x == 0 && !save_x0) || (blockIdx.x == 8 && save_x0)) return;
     const long long gap = (c + 1 < PN_NCLS ? sv.cls_info[PN_CI_TBASE + c + 1] : sv.cls_info[PN_CI_TILES]) - 1;
     uint4 *arrs[9] = {sv.x0k, sv.h2k, sv.h1k, sv.h3k, sv.dy1k, sv.dy2k, sv.dy3k, sv.dy4k, sv.x0k};
-    const int which = blockIdx.x;                      // 8 arrays (two planes or one) + x0k in its 64-column layout (the fused path: k_wgrad_x0)
+    const int which = blockIdx.x;                      // 8 arrays (one k-major plane each) + x0k in its 64-column layout (the fused path: k_wgrad_x0)
     const int nf = which == 8 ? 64 : which < 2 ? PN_NF1 : PN_H;
-    const long long rg_total = sv.rows / 8;
-    for (int plane = 0; plane < ((which < 4 || which == 8) ? 2 : 1); ++plane) {      // (the dY arrays hold one plane)
-        uint4 *p = arrs[which] + ((long long)plane * rg_total + gap * 8) * nf;
-        for (int i = threadIdx.x; i < 8 * nf; i += blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
-    }
+    uint4 *p = arrs[which] + gap * 8 * nf;
+    for (int i = threadIdx.x; i < 8 * nf; i += blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 }  // namespace
 
@@ -579,7 +576,6 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
     a.valid_list = a.cls_list + vb; a.cap_samples = Ns;
     a.sv.fs += vb * PN_H;
     const long long ntiles = ((long long)Ns + TS - 1) / TS;
-    const long long rg_total = a.sv.rows / 8;
     const float *P = a.params;
     const char *img = reinterpret_cast<const char *>(a.packed);
     if (tid0 < PN_H) w5s[tid0] = P[PO_W5 + tid0];
@@ -636,8 +632,8 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         PN_TR(pn_trace_fwd, 2);
         pn_gemm_f16x3<18, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F1), 2 * wave, lane, acc);
         if (TRAIN) {           // (behind the GEMM: see above)
-            if (a.save_x0) pn_copy_out_kmajor<PN_NF1>(X, a.sv.x0k, rg_total, gtile * 8, tid);
-            else pn_copy_out_kmajor_cols64<224>(X, a.sv.x0k, rg_total, gtile * 8, tid);       // the fused path: only the last 64 columns (k_wgrad_x0)
+            if (a.save_x0) pn_copy_out_kmajor<PN_NF1>(X, a.sv.x0k, gtile * 8, tid);
+            else pn_copy_out_kmajor_cols64<224>(X, a.sv.x0k, gtile * 8, tid);       // the fused path: only the last 64 columns (k_wgrad_x0)
         }
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 3);
@@ -649,7 +645,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         f_acc_bias(P + PO_B2, wave, lane, acc);
         PN_TR(pn_trace_fwd, 5);
         pn_gemm_f16x3<16, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F2), 2 * wave, lane, acc);
-        if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h1k, rg_total, gtile * 8, tid);      // (behind the GEMM: see below)
+        if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h1k, gtile * 8, tid);      // (behind the GEMM: see below)
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 6);
         f_epilogue<TRAIN>(acc, X, wave, lane, mask);
@@ -667,7 +663,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         f_acc_bias(P + PO_B3, wave, lane, acc);
         PN_TR(pn_trace_fwd, 8);
         pn_gemm_f16x3<17, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F3), 2 * wave, lane, acc);
-        if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.h2k, rg_total, gtile * 8, tid);      // (behind the GEMM: see below)
+        if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.h2k, gtile * 8, tid);      // (behind the GEMM: see below)
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 9);
         f_epilogue<TRAIN>(acc, X, wave, lane, mask);
@@ -678,7 +674,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         f_acc_bias(P + PO_B4, wave, lane, acc);
         PN_TR(pn_trace_fwd, 11);
         pn_gemm_f16x3<16, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F4), 2 * wave, lane, acc);
-        if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h3k, rg_total, gtile * 8, tid);
+        if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h3k, gtile * 8, tid);
         PN_TR(pn_trace_fwd, 12);
         // the next tile's point data and the indices of the two after it: requested here, consumed at the top of the next
         // iteration -- their HBM latency passes under the element-wise tail of this tile (nothing of this tile waits for memory any more)
@@ -844,9 +840,8 @@ __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
         }
         PN_LDS_BARRIER();
         float4 bias[4];
-        const long long rgc_total = a.sv.samples / 8;
         // ---- layer 1: 280 (288) -> 128.  Training: every layer's input tile leaves k-major for the weight-gradient GEMM
-        if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.xck, rgc_total, tile * 8, tid);
+        if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.xck, tile * 8, tid);
         c_acc_zero(acc);
         pn_gemm_f16x3<18, 4, 1, 7, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_FC1), wave, lane, acc);
         c_load_bias(P + PO_BC1, wave, lane, bias);
@@ -855,7 +850,7 @@ __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
         if (TRAIN) a.sv.cmask[(tile * 2 + 0) * 256 + tid] = mw;
         PN_LDS_BARRIER();
         // ---- layer 2
-        if (TRAIN) pn_copy_out_kmajor<PN_HC>(X, a.sv.c1k, rgc_total, tile * 8, tid);
+        if (TRAIN) pn_copy_out_kmajor<PN_HC>(X, a.sv.c1k, tile * 8, tid);
         c_acc_zero(acc);
         pn_gemm_f16x3<8, 4, 1, 7, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_FC2), wave, lane, acc);
         c_load_bias(P + PO_BC2, wave, lane, bias);
@@ -864,7 +859,7 @@ __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
         if (TRAIN) a.sv.cmask[(tile * 2 + 1) * 256 + tid] = mw;
         PN_LDS_BARRIER();
         // ---- layer 3
-        if (TRAIN) pn_copy_out_kmajor<PN_HC>(X, a.sv.c2k, rgc_total, tile * 8, tid);
+        if (TRAIN) pn_copy_out_kmajor<PN_HC>(X, a.sv.c2k, tile * 8, tid);
         c_acc_zero(acc);
         pn_gemm_f16x3<8, 4, 1, 7, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_FC3), wave, lane, acc);
         c_load_bias(P + PO_BC3, wave, lane, bias);

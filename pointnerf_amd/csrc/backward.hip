@@ -685,14 +685,20 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------ weight gradients (aggregator and colour layers)
-// dW[m][n] = sum_rows dY[row][m] X[row][n] on the f16 pipe: both operands arrive as ready-made two-plane fragments (the
-// producers wrote them k-major: f16x3.h), so the kernel is glds -> LDS -> ds_read_b128 -> MFMA with no conversion work:
+// dW[m][n] = sum_rows dY[row][m] X[row][n] on the f16 pipe: both operands arrive as ready-made k-major fragments of ONE f16 plane each,
+// rounded to nearest by their producers (f16x3.h), so the kernel is glds -> LDS -> ds_read_b128 -> MFMA with no conversion work:
 //   256 x (256 + 32) block (all of dW plus a 32-column tail) in the accumulators of 8 waves (2 (M) x 4 (N), 4 x 2 tiles each +
-//   one tail tile), split-K over the rows (one workgroup per CU), 16 rows per stage, a ring of four LDS stages filled by
-//   global_load_lds_dwordx4 (every (operand, plane) of a stage is one contiguous run in HBM and in LDS) THREE stages ahead:
-//   the kernel is HBM-bound by design (2 KB per row and layer against ~0.35 us of MFMA work per 16 rows), so what matters is
-//   that ~100 KB per CU are in flight at all times -- with two stages the queue drained at every barrier (4.1 TB/s measured).
+//   one tail tile), split-K over the rows (one workgroup per CU), a ring of LDS stages filled by global_load_lds_dwordx4 (every operand
+//   of a stage is one contiguous run in HBM and in LDS) NST - 1 stages ahead: the kernel is HBM-bound by design (1 KB per row and layer
+//   against ~0.17 us of MFMA work per 16 rows), so what matters is that ~100 KB per CU are in flight at all times.
 //   The LDS-DMA count is tracked by hand (s_waitcnt vmcnt(N) + raw s_barrier: __syncthreads() would drain the queue).
+// Error budget of the one-plane operands: every term dY[r][m] X[r][n] carries two independent, unbiased relative roundings of
+// <= 2^-12 (rms 1.1e-4 each); a dW element sums 10^5 .. 10^7 of them, so its error is 1.6e-4 x sqrt(sum t^2) -- for the elements that
+// matter (|sum t| of the order of the tensor's largest) 1e-6 .. 1e-5 of their value.  Until round 3 X came as two planes (22 bits) and
+// dY as one: the second plane of X doubled the X stream of this kernel and of the forward's stores without changing what the sum's error
+// is made of (measured on the benchmark configuration before / after: tests/test_gpu_bench_config.py prints both).  The forward values
+// and the input-gradient chain keep 22-bit operands: there every element is ONE dot product of 256 terms, here it is a sum over millions
+// of rows.
 // Tail: NFB == 288: the operand's own columns 256..287 (distance encoding of X0 / layer-3 extras, and the ONES column whose
 // "weight gradient" is the bias gradient); NFB == 256: a constant ones fragment (bias gradient of layers 2 and 4).
 #ifdef PN_EMU
@@ -704,7 +710,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
 #define PN_WG_RS 32             // rows per stage of the aggregator layers' weight-gradient GEMMs (dev A/B: -DPN_WG_RS=16 -DPN_WG_NST=4 is round 2's)
 #endif
 #ifndef PN_WG_NST
-#define PN_WG_NST 3
+#define PN_WG_NST 4
 #endif
 template <int N> __device__ __forceinline__ void pn_wait_vm_stages(int stages) {       // wait until at most `stages` x N of this wave's loads are outstanding
     if (stages >= 3) PN_WAIT_VMCNT(3 * N);
@@ -716,16 +722,15 @@ template <int N> __device__ __forceinline__ void pn_wait_vm_stages(int stages) {
 // NFB = 288, 2 x 1 for NFB = 128).  Tail tile (one per wave, m-tile by wave): NFB == 288 -> the operand's columns 256..287; MF == 256 and
 // NFB == 256 -> the constant ones fragment (bias gradient); MF == 128 and NFB == 128 -> none (those bias sums come from k_color_backward).
 // tiles_per = rows per tile of *d_tiles / 16 (the aggregator counts 64-row tiles, and so does the colour MLP).
-// RS = rows per stage (16 or 32), NST = ring depth.  A stage is one barrier, one LDS round trip for the fragments and RS / 16 x 18 MFMAs per wave,
-// and the two waves of a SIMD run it in lockstep: with 16-row stages a stage took ~1.1 us whatever it streamed (0.58 us of it the SIMD's
-// 36 MFMAs) -- the kernel was bound by the per-stage rendezvous, not by HBM (round 3: k_wgrad_x0 streamed 40 % fewer bytes in the same
-// time).  32-row stages halve the rendezvous per row; three ring slots of 48 .. 53 KB keep ~100 KB per CU in flight.
+// RS = rows per stage (16 or 32), NST = ring depth.  A stage is one barrier, one LDS round trip for the fragments and RS / 16 x 9 MFMAs per wave,
+// and the two waves of a SIMD run it in lockstep: with 16-row stages a stage took ~1.1 us whatever it streamed -- the kernel was bound by
+// the per-stage rendezvous, not by HBM.  32-row stages halve the rendezvous per row; four ring slots of 32 .. 34 KB keep ~100 KB per CU in flight.
 template <int NFB, int MF, int RS, int NST>
-__global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, const uint4 *__restrict__ B, long long rg_total,
+__global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, const uint4 *__restrict__ B,
                                                    const int *__restrict__ d_tiles, float *__restrict__ partial) {
     constexpr int RG = RS / 8;                                // row groups (8 rows) per stage
     constexpr int AU = RG * MF, BU = RG * NFB;                // units (16 B) of one plane of a stage
-    constexpr int STAGE = AU + 2 * BU;                        // [A h | B h | B m]
+    constexpr int STAGE = AU + BU;                            // [dY | X]
     constexpr int NI = STAGE / 64, NIW = (NI + 7) / 8;        // wave-instructions per stage, per wave (the last ones are padded)
     static_assert((NST - 2) * NIW <= 63 && NST >= 3 && NST <= 5, "vmcnt is a 6-bit count");
     constexpr int MTW = MF / 64, NTW = NFB >= 256 ? 2 : 1;    // m-tiles / main n-tiles per wave
@@ -760,7 +765,7 @@ __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, 
             const uint4 *dst = smem_w + (pad ? NST * STAGE : buf * STAGE + u0);
             const uint4 *src;
             if (u0 < AU) src = A + rg * MF + u0;
-            else { const int v = u0 - AU, p = v / BU, u = v - p * BU; src = B + ((long long)p * rg_total + rg) * NFB + u; }
+            else src = B + rg * NFB + (u0 - AU);
             __builtin_amdgcn_global_load_lds(src + lane, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
     };
@@ -781,26 +786,22 @@ __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, 
             for (int kk = 0; kk < RS / 16; ++kk) {            // 16 rows (two row groups) per MFMA k-step
                 const uint4 *fa = st + (2 * kk + (lane >> 5)) * MF + (lane & 31);
                 const uint4 *fb = st + AU + (2 * kk + (lane >> 5)) * NFB + (lane & 31);
-                pn_h8 ah[MTW], bh[NTW], bm[NTW];
+                pn_h8 ah[MTW], bh[NTW];
 #pragma unroll
                 for (int i = 0; i < MTW; ++i) ah[i] = __builtin_bit_cast(pn_h8, fa[(MTW * wm + i) * 32]);
 #pragma unroll
-                for (int i = 0; i < NTW; ++i) { bh[i] = __builtin_bit_cast(pn_h8, fb[(NTW * wn + i) * 32]); bm[i] = __builtin_bit_cast(pn_h8, fb[BU + (NTW * wn + i) * 32]); }
+                for (int i = 0; i < NTW; ++i) bh[i] = __builtin_bit_cast(pn_h8, fb[(NTW * wn + i) * 32]);
 #pragma unroll
-                for (int p = 0; p < 2; ++p)
+                for (int i = 0; i < MTW; ++i)
 #pragma unroll
-                    for (int i = 0; i < MTW; ++i)
-#pragma unroll
-                        for (int j = 0; j < NTW; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], p == 1 ? bm[j] : bh[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NTW; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 if (has_tail) {
                     pn_h8 tah;
                     if (MF == 256) tah = wn == 0 ? ah[0] : wn == 1 ? ah[1] : wn == 2 ? ah[MTW > 2 ? 2 : 0] : ah[MTW > 3 ? 3 : 0];
                     else tah = wn == 0 ? ah[0] : ah[MTW > 1 ? 1 : 0];
                     if (TAIL_B) {
-                        const pn_h8 tbh = __builtin_bit_cast(pn_h8, fb[NMAIN]), tbm = __builtin_bit_cast(pn_h8, fb[BU + NMAIN]);
-                        acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbh, acct, 0, 0, 0);
-                        acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbm, acct, 0, 0, 0);
+                        acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, __builtin_bit_cast(pn_h8, fb[NMAIN]), acct, 0, 0, 0);
                     } else {
                         acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, ones, acct, 0, 0, 0);
                     }
@@ -852,17 +853,17 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_f16(const float *__restric
 }
 
 template <int NFB, int MF, int RS, int NST>
-int launch_wgrad_f16(const uint4 *A, const uint4 *B, long long rg_total, const int *d_tiles, long long rows_max, float *partial, const unsigned *gscale,
+int launch_wgrad_f16(const uint4 *A, const uint4 *B, const int *d_tiles, long long rows_max, float *partial, const unsigned *gscale,
                      float *grad, int dst_w, int ldc, int Nreal, int bias_col, int dst_b, hipStream_t s) {
     int chunks = WG_CHUNKS;
     const long long tiles = rows_max / PN_TILE;
     if (tiles < chunks) chunks = (int)(tiles > 0 ? tiles : 1);
     if ((size_t)chunks * 256 * 288 > PARTIAL_FLOATS) return PNERF_E_WS;
-    constexpr size_t lds = ((size_t)NST * (RS / 8) * (MF + 2 * NFB) + 64) * 16;   // the stages [A h | B h | B m] + the pad slot
+    constexpr size_t lds = ((size_t)NST * (RS / 8) * (MF + NFB) + 64) * 16;   // the stages [dY | X] + the pad slot
     static_assert(lds <= 160 * 1024, "wgrad ring");
     if (hipFuncSetAttribute((const void *)k_wgrad_f16<NFB, MF, RS, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PNERF_E_LAUNCH;
     { PnProfScope prof(PNK_WGRAD, s);
-    hipLaunchKernelGGL((k_wgrad_f16<NFB, MF, RS, NST>), dim3(chunks), dim3(512), lds, s, A, B, rg_total, d_tiles, partial); }
+    hipLaunchKernelGGL((k_wgrad_f16<NFB, MF, RS, NST>), dim3(chunks), dim3(512), lds, s, A, B, d_tiles, partial); }
     PnProfScope prof(PNK_WGRAD_REDUCE, s);
     hipLaunchKernelGGL(k_wgrad_reduce_f16, dim3(pn_cdiv((long long)MF * 288, 64)), dim3(256), 0, s, partial, chunks, MF, Nreal, bias_col, gscale, grad, dst_w, ldc, dst_b);
     PN_CHECK_LAUNCH();
@@ -871,26 +872,25 @@ int launch_wgrad_f16(const uint4 *A, const uint4 *B, long long rg_total, const i
 
 
 // ------------------------------------------------------------------------------ layer-1 weight gradients with X0 REBUILT from the embedding
-// dW1 = dY1^T X0,  X0 = [e (32) | PE3(e) (192) | PE5(dists) (60) | 1 | 0 0 0].  As two saved f16 planes X0 is 1152 bytes per row written by
-// the forward and read back here -- a fifth of the forward's HBM writes and of this kernel's reads, and both kernels pay for every byte
-// (dropping the forward's saves altogether makes it 21 % faster).  224 of the 288 columns are a function of the point's 32 embedding
-// values (128 bytes): the fused path therefore saves only the LAST 64 columns (distance encoding, ones column: x0t, 256 B/row) and this
+// dW1 = dY1^T X0,  X0 = [e (32) | PE3(e) (192) | PE5(dists) (60) | 1 | 0 0 0].  As a saved f16 plane X0 is 576 bytes per row written by
+// the forward and read back here, and both kernels pay for every byte (dropping the forward's saves altogether makes it 21 % faster).  224 of the 288 columns are a function of the point's 32 embedding
+// values (128 bytes): the fused path therefore saves only the LAST 64 columns (distance encoding, ones column: x0t, 128 B/row) and this
 // kernel rebuilds columns 0 .. 223 of every 16-row stage in LDS from the gathered embedding rows.
 // Everything that comes from memory arrives by LDS-DMA with per-lane source addresses, TWO wave-instructions per wave and iteration, so
 // that the hand-counted vmcnt waits of the rings stay exact:
 //   iteration i issues   dY1 of a later stage (8 pieces of 1 KB, one per wave) | row metadata (sample, point) of a later stage (wave 0) |
 //                        the 16 embedding rows of a later stage (waves 1, 2), addressed with metadata that landed D iterations earlier |
-//                        the saved last-64-column planes of a later stage (waves 3 .. 6) | a pad piece (wave 7)   (distances: WX_D below);
+//                        the saved last 64 columns of a later stage (waves 0, 1) | a pad piece (the rest)   (distances: WX_D below);
 //   iteration i waits for everything issued up to iteration i - D, multiplies stage i (dY1 ring slot x [built columns | saved columns])
 //   and builds columns 0 .. 223 of stage i + 1 into the other X0 buffer: thread -> (row group, embedding dim, row in group); the 7 values
-//   are split into the two planes exactly as the forward splits them (pn_split2) and written as 2-byte elements of the k-major units.
+//   are rounded to nearest f16 (the forward's saved plane is the nearest f16 of its 22-bit value: the same number except where the
+//   22-bit rounding crosses a tie) and written as 2-byte elements of the k-major units.
 // Rows without a point (tile padding, the classes' gap tiles whose metadata is whatever memory held) are clamped to a valid point:
 // their dY rows are zero, X0 only has to be finite (the gap tiles of x0t are zeroed by k_cls_zero_gaps).
 struct WgX0Args {
     const int4 *rmeta;
     const float *emb;
-    const uint4 *x0t;                 // [2 planes][rows / 8][64] units: columns 224 .. 287 of X0
-    long long rg_total;
+    const uint4 *x0t;                 // [rows / 8][64] units (one plane): columns 224 .. 287 of X0
     int n_points;
 };
 // Rows per stage WX_RS (16 or 32) and prefetch distance WX_D (iterations): what iteration i consumes was issued at iteration i - WX_D.
@@ -908,8 +908,8 @@ struct WgX0Args {
 constexpr int WX_RS = PN_WX_RS, WX_RG = WX_RS / 8;  // rows / row groups per stage
 constexpr int WX_AU = WX_RG * PN_H;                 // dY1 units of a stage (one plane)
 constexpr int WX_NB = 224;                          // columns rebuilt here
-constexpr int WX_BU = WX_RG * WX_NB;                // their units of one plane of a stage
-constexpr int WX_TU = 2 * WX_RG * 64;               // saved-column units of a stage: [plane][rg][64]
+constexpr int WX_BU = WX_RG * WX_NB;                // their units of a stage
+constexpr int WX_TU = WX_RG * 64;                   // saved-column units of a stage: [rg][64]
 constexpr int WX_GU = WX_RS * 8;                    // embedding units of a stage: [rg][piece 8][row 8] x 16 B
 constexpr int WX_NA = WX_AU / 512;                  // dY1 pieces (1 KB) per wave and stage
 constexpr int WX_L = WX_NA + 2;                     // wave-instructions per wave and iteration: dY1 | a saved-column piece or pad | metadata / embedding rows / pad
@@ -918,19 +918,12 @@ constexpr int WX_NST = WX_D + 1, WX_RMD = 2 * WX_D + 2, WX_GD = WX_D + 1;    // 
 constexpr int WX_RM_SLOTS = WX_D + 2, WX_G_SLOTS = WX_D + 1;
 static_assert(WX_L * (WX_D - 1) <= 63 && WX_D >= 2, "vmcnt is a 6-bit count");
 static_assert(WX_RS == 16 || WX_RS == 32, "rows per stage");
-constexpr int WX_OFF_T = WX_NST * WX_AU, WX_OFF_B = WX_OFF_T + WX_NST * WX_TU, WX_OFF_RM = WX_OFF_B + 2 * 2 * WX_BU,
+constexpr int WX_OFF_T = WX_NST * WX_AU, WX_OFF_B = WX_OFF_T + WX_NST * WX_TU, WX_OFF_RM = WX_OFF_B + 2 * WX_BU,
               WX_OFF_G = WX_OFF_RM + WX_RM_SLOTS * WX_RS, WX_OFF_PAD = WX_OFF_G + WX_G_SLOTS * WX_GU, WX_UNITS = WX_OFF_PAD + 64;
 static_assert(WX_UNITS * 16 <= 160 * 1024, "k_wgrad_x0 LDS");
 
-__device__ __forceinline__ void wx_store_h16(char *buf, int plane, int rg, int f, int rlow, unsigned short v) {
-    *reinterpret_cast<unsigned short *>(buf + ((plane * WX_BU + rg * WX_NB + f) * 16) + rlow * 2) = v;
-}
-// two values -> both planes of features f0, f1 (row rlow of row group rg)
-__device__ __forceinline__ void wx_put2(char *buf, int rg, int rlow, int f0, int f1, float v0, float v1) {
-    unsigned h, m;
-    pn_split2(v0, v1, h, m);
-    wx_store_h16(buf, 0, rg, f0, rlow, (unsigned short)h); wx_store_h16(buf, 1, rg, f0, rlow, (unsigned short)m);
-    wx_store_h16(buf, 0, rg, f1, rlow, (unsigned short)(h >> 16)); wx_store_h16(buf, 1, rg, f1, rlow, (unsigned short)(m >> 16));
+__device__ __forceinline__ void wx_store_h16(char *buf, int rg, int f, int rlow, _Float16 v) {
+    *reinterpret_cast<_Float16 *>(buf + ((rg * WX_NB + f) * 16) + rlow * 2) = v;
 }
 
 __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, WgX0Args g, const int *__restrict__ d_tiles, float *__restrict__ partial) {
@@ -960,9 +953,8 @@ __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, W
             const uint4 *dst = smem_x + (ok ? (s % WX_NST) * WX_AU + 64 * piece : WX_OFF_PAD);
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
-        const bool okt = ok && wave < 2 * WX_RG;        // piece (plane, rg) = 64 units of the saved last-64-column planes
-        const int plane = wave / WX_RG, rg = wave - plane * WX_RG;
-        const uint4 *src = g.x0t + (okt ? ((long long)plane * g.rg_total + stage_rg(s) + rg) * 64 : 0) + lane;
+        const bool okt = ok && wave < WX_RG;            // piece rg = 64 units of the saved last-64-column plane
+        const uint4 *src = g.x0t + (okt ? (stage_rg(s) + wave) * 64 : 0) + lane;
         const uint4 *dst = smem_x + (okt ? WX_OFF_T + (s % WX_NST) * WX_TU + wave * 64 : WX_OFF_PAD);
         __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     };
@@ -991,9 +983,7 @@ __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, W
         }
     };
     // ---- columns 0 .. 223 of local stage s -> buffer s & 1: thread -> (row group, embedding dim, row in group), WX_RS / 16 items each
-    auto build = [&](int s) {
-        char *buf = lds + (size_t)(WX_OFF_B + (s & 1) * 2 * WX_BU) * 16;
-        const char *slot = lds + (size_t)(WX_OFF_G + (s % WX_G_SLOTS) * WX_GU) * 16;
+    auto build_into = [&](char *buf, const char *slot) {
 #pragma unroll
         for (int it = 0; it < WX_RS / 16; ++it) {
             const int item = tid + 512 * it, rg = item >> 8, d = (item >> 3) & 31, rlow = item & 7;
@@ -1001,13 +991,13 @@ __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, W
             float sn[3], cs[3];
             pn_pe_octaves<3>(e, sn, cs);
             const int f = PN_F + d * 6;
-            wx_put2(buf, rg, rlow, d, f, e, sn[0]);
-            wx_put2(buf, rg, rlow, f + 1, f + 2, cs[0], sn[1]);
-            wx_put2(buf, rg, rlow, f + 3, f + 4, cs[1], sn[2]);
-            unsigned h, m;
-            pn_split2(cs[2], 0.f, h, m);
-            wx_store_h16(buf, 0, rg, f + 5, rlow, (unsigned short)h); wx_store_h16(buf, 1, rg, f + 5, rlow, (unsigned short)m);
+            wx_store_h16(buf, rg, d, rlow, (_Float16)e);
+#pragma unroll
+            for (int o = 0; o < 3; ++o) { wx_store_h16(buf, rg, f + 2 * o, rlow, (_Float16)sn[o]); wx_store_h16(buf, rg, f + 2 * o + 1, rlow, (_Float16)cs[o]); }
         }
+    };
+    auto build = [&](int s) {
+        build_into(lds + (size_t)(WX_OFF_B + (s & 1) * WX_BU) * 16, lds + (size_t)(WX_OFF_G + (s % WX_G_SLOTS) * WX_GU) * 16);
     };
     if (nst > 0) {
         // ---- prologue: the metadata the first embedding gathers need (stages 0 .. D + 1: a ring's worth), drained; then dY1 / saved columns
@@ -1032,9 +1022,8 @@ __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, W
         // select each: the loop body had 137 scalar instructions per wave for 18 MFMAs), and the bounds checks exist only in the last
         // 2 D + 2 iterations, which go through the checked issue helpers.
         const long long stride_a = (long long)WX_RG * gridDim.x * MF, stride_t = (long long)WX_RG * gridDim.x * 64, stride_rm = (long long)WX_RG * gridDim.x * 8;
-        const int t_plane = wave / WX_RG, t_rg = wave - t_plane * WX_RG;
         const uint4 *pa = A + stage_rg(WX_D) * MF + 64 * wave + lane;
-        const uint4 *pt = g.x0t + ((long long)t_plane * g.rg_total + stage_rg(WX_D) + t_rg) * 64 + lane;
+        const uint4 *pt = g.x0t + (stage_rg(WX_D) + wave) * 64 + lane;
         const int4 *prm = g.rmeta + stage_rg(WX_RMD) * 8 + (lane & (WX_RS - 1));
         int ia = WX_D % WX_NST, ig = WX_GD % WX_G_SLOTS, irm = WX_RMD % WX_RM_SLOTS;      // slots the issues of iteration 0 write
         int ra = 0, rgs = 1 % WX_G_SLOTS, rrm = (1 + WX_GD) % WX_RM_SLOTS;                  // slots iteration 0 reads: dY1 / saved columns, embedding rows of stage 1, metadata of stage 1 + GD
@@ -1049,7 +1038,7 @@ __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, W
 #pragma unroll
                 for (int i = 0; i < WX_NA; ++i)
                     __builtin_amdgcn_global_load_lds(pa + 512 * i, (__attribute__((address_space(3))) void *)(smem_x + ia * WX_AU + 64 * (wave + 8 * i)), 16, 0, 0);
-                if (wave < 2 * WX_RG) __builtin_amdgcn_global_load_lds(pt, (__attribute__((address_space(3))) void *)(smem_x + WX_OFF_T + ia * WX_TU + wave * 64), 16, 0, 0);
+                if (wave < WX_RG) __builtin_amdgcn_global_load_lds(pt, (__attribute__((address_space(3))) void *)(smem_x + WX_OFF_T + ia * WX_TU + wave * 64), 16, 0, 0);
                 else __builtin_amdgcn_global_load_lds(A + lane, (__attribute__((address_space(3))) void *)(smem_x + WX_OFF_PAD), 16, 0, 0);
                 if (wave == 0) {
                     if (lane < WX_RS) __builtin_amdgcn_global_load_lds(prm, (__attribute__((address_space(3))) void *)(smem_x + WX_OFF_RM + irm * WX_RS), 16, 0, 0);
@@ -1067,49 +1056,25 @@ __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, W
 #pragma unroll
             for (int kk = 0; kk < WX_RS / 16; ++kk) {         // 16 rows (two row groups) per MFMA k-step
                 const uint4 *fa = smem_x + ra * WX_AU + (2 * kk + (lane >> 5)) * MF + (lane & 31);
-                const uint4 *fb = smem_x + WX_OFF_B + (s & 1) * 2 * WX_BU + (2 * kk + (lane >> 5)) * WX_NB + (lane & 31);            // built columns, high plane
-                const uint4 *ft = smem_x + WX_OFF_T + ra * WX_TU + (2 * kk + (lane >> 5)) * 64 + (lane & 31);                         // saved columns, high plane
-                pn_h8 ah[MTW], bh[2], bm[2];
+                const uint4 *fb = smem_x + WX_OFF_B + (s & 1) * WX_BU + (2 * kk + (lane >> 5)) * WX_NB + (lane & 31);                // built columns
+                const uint4 *ft = smem_x + WX_OFF_T + ra * WX_TU + (2 * kk + (lane >> 5)) * 64 + (lane & 31);                         // saved columns
+                pn_h8 ah[MTW], bh[2];
 #pragma unroll
                 for (int i = 0; i < MTW; ++i) ah[i] = __builtin_bit_cast(pn_h8, fa[(MTW * wm + i) * 32]);
                 const pn_h8 tah = __builtin_bit_cast(pn_h8, fa[(MTW * wm + wn) * 32]);
                 // n-tiles 2 wn, 2 wn + 1 of the 9: tiles 0 .. 6 = built columns, tile 7 = saved columns 224 .. 255, tile 8 (the tail, one m-tile per wave) = 256 .. 287
-                bh[0] = __builtin_bit_cast(pn_h8, fb[(2 * wn) * 32]); bm[0] = __builtin_bit_cast(pn_h8, fb[WX_BU + (2 * wn) * 32]);
-                if (wn < 3) { bh[1] = __builtin_bit_cast(pn_h8, fb[(2 * wn + 1) * 32]); bm[1] = __builtin_bit_cast(pn_h8, fb[WX_BU + (2 * wn + 1) * 32]); }
-                else { bh[1] = __builtin_bit_cast(pn_h8, ft[0]); bm[1] = __builtin_bit_cast(pn_h8, ft[WX_RG * 64]); }
-                const pn_h8 tbh = __builtin_bit_cast(pn_h8, ft[32]), tbm = __builtin_bit_cast(pn_h8, ft[WX_RG * 64 + 32]);
+                bh[0] = __builtin_bit_cast(pn_h8, fb[(2 * wn) * 32]);
+                bh[1] = __builtin_bit_cast(pn_h8, wn < 3 ? fb[(2 * wn + 1) * 32] : ft[0]);
 #pragma unroll
-                for (int p = 0; p < 2; ++p)
+                for (int i = 0; i < MTW; ++i)
 #pragma unroll
-                    for (int i = 0; i < MTW; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], p == 1 ? bm[j] : bh[j], acc[i][j], 0, 0, 0);
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbh, acct, 0, 0, 0);
-                acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, tbm, acct, 0, 0, 0);
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, __builtin_bit_cast(pn_h8, ft[32]), acct, 0, 0, 0);
             }
             // columns 0 .. 223 of stage s + 1 -> the other X0 buffer (unconditional: past the last stage it rebuilds from a stale -- finite --
             // slot into the buffer nobody reads; no branch, so the arithmetic can be scheduled between the MFMAs instead of behind them)
-#ifndef PN_WX_NOBUILD               // (dev variants, tools/_build only: where does the time of a stage go)
-            {
-                char *buf = lds + (size_t)(WX_OFF_B + ((s + 1) & 1) * 2 * WX_BU) * 16;
-                const char *slot = lds + (size_t)(WX_OFF_G + rgs * WX_GU) * 16;
-#pragma unroll
-                for (int it = 0; it < WX_RS / 16; ++it) {
-                    const int item = tid + 512 * it, rg = item >> 8, d = (item >> 3) & 31, rlow = item & 7;
-                    const float e = *reinterpret_cast<const float *>(slot + rg * 1024 + ((d >> 2) * 8 + rlow) * 16 + (d & 3) * 4);
-                    float sn[3], cs[3];
-                    pn_pe_octaves<3>(e, sn, cs);
-                    const int f = PN_F + d * 6;
-                    wx_put2(buf, rg, rlow, d, f, e, sn[0]);
-                    wx_put2(buf, rg, rlow, f + 1, f + 2, cs[0], sn[1]);
-                    wx_put2(buf, rg, rlow, f + 3, f + 4, cs[1], sn[2]);
-                    unsigned h, m;
-                    pn_split2(cs[2], 0.f, h, m);
-                    wx_store_h16(buf, 0, rg, f + 5, rlow, (unsigned short)h); wx_store_h16(buf, 1, rg, f + 5, rlow, (unsigned short)m);
-                }
-            }
-#endif
+            build_into(lds + (size_t)(WX_OFF_B + ((s + 1) & 1) * WX_BU) * 16, lds + (size_t)(WX_OFF_G + rgs * WX_GU) * 16);
             // the point of the embedding row the NEXT iteration gathers (stage s + 1 + GD; its metadata was issued at iteration s - D: landed)
             if (wave >= 1 && wave <= WX_RG && s + 1 + WX_GD < nst) {
                 const int p = reinterpret_cast<const int4 *>(smem_x + WX_OFF_RM + rrm * WX_RS)[8 * (wave - 1) + (lane & 7)].y;
@@ -1201,28 +1166,27 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     // weight gradients over every tile of every class (+ their zero padding tiles): the tile count lives on the device, the host
     // bound is the allocation.  samples: only the first n_valid rows of fs / pe / c1.. exist -- the GEMM masks the rest of the
     // last colour tile (0 * stale bits could be NaN)
-    const long long rows = sv.rows, smp = n_valid, rgt = sv.rows / 8;
+    const long long rows = sv.rows, smp = n_valid;
     const int *dt = sv.cls_info + PN_CI_TILES;
     int rc;
     float *g = d_grad_params;
     if (x0_saved) {        // the stand-alone aggregator (perspective coordinates from its caller): X0 planes saved by the forward
-        if ((rc = launch_wgrad_f16<PN_NF1, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy1k, sv.x0k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W1, PN_IN1, PN_IN1, PN_ONES1, PO_B1, s))) return rc;
+        if ((rc = launch_wgrad_f16<PN_NF1, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy1k, sv.x0k, dt, rows, d_partials, sv.gscale, g, PO_W1, PN_IN1, PN_IN1, PN_ONES1, PO_B1, s))) return rc;
     } else {               // the fused path: X0 rebuilt from the gather
         (void)d_sample_loc; (void)R;
         WgX0Args wa;
-        wa.rmeta = sv.rmeta; wa.emb = pts->embedding; wa.x0t = sv.x0k; wa.rg_total = rgt; wa.n_points = pts->n;
+        wa.rmeta = sv.rmeta; wa.emb = pts->embedding; wa.x0t = sv.x0k; wa.n_points = pts->n;
         if ((rc = launch_wgrad_x0(sv.dy1k, wa, dt, rows, d_partials, sv.gscale, g, s))) return rc;
     }
-    if ((rc = launch_wgrad_f16<PN_H, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy2k, sv.h1k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W2, PN_H, PN_H, PN_H, PO_B2, s))) return rc;
-    if ((rc = launch_wgrad_f16<PN_NF1, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy3k, sv.h2k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W3, PN_IN3, PN_IN3, PN_ONES3, PO_B3, s))) return rc;
-    if ((rc = launch_wgrad_f16<PN_H, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy4k, sv.h3k, rgt, dt, rows, d_partials, sv.gscale, g, PO_W4, PN_H, PN_H, PN_H, PO_B4, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_H, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy2k, sv.h1k, dt, rows, d_partials, sv.gscale, g, PO_W2, PN_H, PN_H, PN_H, PO_B2, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_NF1, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy3k, sv.h2k, dt, rows, d_partials, sv.gscale, g, PO_W3, PN_IN3, PN_IN3, PN_ONES3, PO_B3, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_H, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy4k, sv.h3k, dt, rows, d_partials, sv.gscale, g, PO_W4, PN_H, PN_H, PN_H, PO_B4, s))) return rc;
     // the three colour layers: samples instead of neighbor rows, 128 output features; their bias gradients were summed by k_color_backward
-    const long long rgc = sv.samples / 8;
     const int *ct = sv.cls_info + PN_CI_CTILES;
     (void)smp;
-    if ((rc = launch_wgrad_f16<PN_NF1, PN_HC, 16, 4>(sv.dc1k, sv.xck, rgc, ct, sv.samples, d_partials, sv.gscale, g, PO_WC1, PN_INC, PN_INC, -1, 0, s))) return rc;
-    if ((rc = launch_wgrad_f16<PN_HC, PN_HC, 16, 4>(sv.dc2k, sv.c1k, rgc, ct, sv.samples, d_partials, sv.gscale, g, PO_WC2, PN_HC, PN_HC, -1, 0, s))) return rc;
-    if ((rc = launch_wgrad_f16<PN_HC, PN_HC, 16, 4>(sv.dc3k, sv.c2k, rgc, ct, sv.samples, d_partials, sv.gscale, g, PO_WC3, PN_HC, PN_HC, -1, 0, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_NF1, PN_HC, 16, 4>(sv.dc1k, sv.xck, ct, sv.samples, d_partials, sv.gscale, g, PO_WC1, PN_INC, PN_INC, -1, 0, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_HC, PN_HC, 16, 4>(sv.dc2k, sv.c1k, ct, sv.samples, d_partials, sv.gscale, g, PO_WC2, PN_HC, PN_HC, -1, 0, s))) return rc;
+    if ((rc = launch_wgrad_f16<PN_HC, PN_HC, 16, 4>(sv.dc3k, sv.c2k, ct, sv.samples, d_partials, sv.gscale, g, PO_WC3, PN_HC, PN_HC, -1, 0, s))) return rc;
     return 0;
 }
 

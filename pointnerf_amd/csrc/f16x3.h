@@ -328,42 +328,55 @@ __device__ __forceinline__ void pn_copy_out_kmajor_h(const char *X, uint4 *__res
         }
     }
 }
+// the tile's value planes -> ONE k-major plane ([rg_total][NF] units): what the weight-gradient GEMM streams for its X operand.  The two
+// LDS planes are read transposed and summed by v_pk_add_f16: h + m is exact in 22 bits and the packed add rounds it ONCE to the nearest
+// f16 -- the best single f16 for the value (|x - f16| <= 2^-12 |x|, unbiased; h alone is rounded toward zero).  See k_wgrad_f16 for the
+// error budget of the one-plane operands.
+typedef _Float16 pn_h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 pn_rne_sum(uint2 h, uint2 m) { return __builtin_bit_cast(uint2, __builtin_bit_cast(pn_h4, h) + __builtin_bit_cast(pn_h4, m)); }
 template <int NF>
-__device__ __forceinline__ void pn_copy_out_kmajor(const char *X, uint4 *__restrict__ dst, long long rg_total, long long rg0, int tid) {
+__device__ __forceinline__ void pn_copy_out_kmajor(const char *X, uint4 *__restrict__ dst, long long rg0, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const int blk = ((lane >> 2) & 3) * PN_XRS + ((lane >> 4) * 16 + (lane & 3) * 4) * 2;      // this lane's slot inside a [4][64-column] block
+    constexpr int NJ = (NF + 63) / 64;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int combo = wave * 4 + i, plane = combo >> 3, rg = combo & 7;
-        const char *src = X + plane * PN_XPLANE + rg * 8 * PN_XRS + blk;
-        uint4 *d = dst + ((long long)plane * rg_total + rg0 + rg) * NF;
-        uint2 lo[(NF + 63) / 64], hi[(NF + 63) / 64];
+    for (int i = 0; i < 2; ++i) {
+        const int rg = wave * 2 + i;
+        const char *src = X + rg * 8 * PN_XRS + blk;
+        uint4 *d = dst + (rg0 + rg) * NF;
+        uint2 lo[NJ], hi[NJ], lom[NJ], him[NJ];
 #pragma unroll
-        for (int j = 0; j < (NF + 63) / 64; ++j) { lo[j] = pn_lds_read_tr16(src + j * 128); hi[j] = pn_lds_read_tr16(src + 4 * PN_XRS + j * 128); }
+        for (int j = 0; j < NJ; ++j) {
+            lo[j] = pn_lds_read_tr16(src + j * 128); hi[j] = pn_lds_read_tr16(src + 4 * PN_XRS + j * 128);
+            lom[j] = pn_lds_read_tr16(src + PN_XPLANE + j * 128); him[j] = pn_lds_read_tr16(src + PN_XPLANE + 4 * PN_XRS + j * 128);
+        }
 #pragma unroll
-        for (int j = 0; j < (NF + 63) / 64; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int f = lane + 64 * j;
             if (f < NF) {
-                pn_f4 t = {__uint_as_float(lo[j].x), __uint_as_float(lo[j].y), __uint_as_float(hi[j].x), __uint_as_float(hi[j].y)};
+                const uint2 a = pn_rne_sum(lo[j], lom[j]), b = pn_rne_sum(hi[j], him[j]);
+                pn_f4 t = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(b.x), __uint_as_float(b.y)};
                 PN_STREAM_STORE(t, reinterpret_cast<pn_f4 *>(d + f));
             }
         }
     }
 }
 
-// the tile's columns C0 .. C0 + 63 -> k-major planes of 64 features ([2][rg_total][64] units): the saved part of X0 on the fused path
+// the tile's columns C0 .. C0 + 63 -> one k-major plane of 64 features ([rg_total][64] units): the saved part of X0 on the fused path
 // (the weight-gradient kernel rebuilds the rest from the embedding: backward.hip k_wgrad_x0)
 template <int C0>
-__device__ __forceinline__ void pn_copy_out_kmajor_cols64(const char *X, uint4 *__restrict__ dst, long long rg_total, long long rg0, int tid) {
+__device__ __forceinline__ void pn_copy_out_kmajor_cols64(const char *X, uint4 *__restrict__ dst, long long rg0, int tid) {
     static_assert(C0 % 16 == 0, "a 16-column group boundary");
     const int lane = tid & 63, wave = tid >> 6;
     const int blk = ((lane >> 2) & 3) * PN_XRS + ((lane >> 4) * 16 + (lane & 3) * 4) * 2 + C0 * 2;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int combo = wave * 4 + i, plane = combo >> 3, rg = combo & 7;
-        const char *src = X + plane * PN_XPLANE + rg * 8 * PN_XRS + blk;
+    for (int i = 0; i < 2; ++i) {
+        const int rg = wave * 2 + i;
+        const char *src = X + rg * 8 * PN_XRS + blk;
         const uint2 lo = pn_lds_read_tr16(src), hi = pn_lds_read_tr16(src + 4 * PN_XRS);
-        pn_f4 t = {__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y)};
-        PN_STREAM_STORE(t, reinterpret_cast<pn_f4 *>(dst + ((long long)plane * rg_total + rg0 + rg) * 64 + lane));
+        const uint2 lom = pn_lds_read_tr16(src + PN_XPLANE), him = pn_lds_read_tr16(src + PN_XPLANE + 4 * PN_XRS);
+        const uint2 a = pn_rne_sum(lo, lom), b = pn_rne_sum(hi, him);
+        pn_f4 t = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(b.x), __uint_as_float(b.y)};
+        PN_STREAM_STORE(t, reinterpret_cast<pn_f4 *>(dst + (rg0 + rg) * 64 + lane));
     }
 }

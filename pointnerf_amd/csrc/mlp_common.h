@@ -43,18 +43,19 @@ template <int N, class F> __device__ __forceinline__ void pn_static_for(F &&f) {
 
 // ---- saved-activation area (training) -------------------------------------------------------
 struct PnSaved {
-    // per neighbor row (rows = row tiles * 64), f16 plane pairs (f16x3.h):
-    uint4 *x0k, *h1k, *h2k, *h3k;       // k-major [2][rows / 8][NF] inputs of the four layers (NF = 288, 256, 288, 256): what the weight-gradient GEMM streams
-                                        // (x0k on the fused path: only X0's last 64 columns, [2][rows / 8][64] -- k_wgrad_x0 rebuilds the other 224)
+    // per neighbor row (rows = row tiles * 64):
+    uint4 *x0k, *h1k, *h2k, *h3k;       // k-major [rows / 8][NF] inputs of the four layers (NF = 288, 256, 288, 256) as ONE f16 plane (round to nearest):
+                                        // what the weight-gradient GEMM streams (x0k on the fused path: only X0's last 64 columns, [rows / 8][64] --
+                                        // k_wgrad_x0 rebuilds the other 224)
     uint4 *dy1k, *dy2k, *dy3k, *dy4k;   // k-major [rows / 8][256] output gradients of the four layers (ONE f16 plane, round to nearest), SCALED by the backward's power-of-two scale
-    uint4 *h4r;                         // row-major [2][rows][32] last activation (alpha head / K-weighted sums of the backward)
+    uint4 *h4r;                         // row-major [2][rows][32] last activation, both planes (alpha head / K-weighted sums of the backward)
     float *arow;                        // per row: pre-activation of the alpha head
     int4 *rmeta;                        // per row: {sample id or -1, point id or -1, bits(normalised weight), bits(final weight)}
     unsigned long long *lmask;          // [row tiles][3 layers h1..h3][PN_NTHR]: LeakyReLU sign bits in the accumulator layout
     unsigned *gscale;                   // [4]: bits of max |d decoded| over the valid samples (the backward derives its scale from it)
     // per valid sample (padded to colour tiles * 64)
     float *fs, *dfs, *c3;               // fp32 rows: aggregated feature [256] and its gradient, last colour post-activation [128]
-    uint4 *xck, *c1k, *c2k;             // k-major [2][samples / 8][288 | 128 | 128] inputs of the three colour layers ([f | view encoding | 0], c1, c2)
+    uint4 *xck, *c1k, *c2k;             // k-major [samples / 8][288 | 128 | 128] inputs of the three colour layers ([f | view encoding | 0], c1, c2), one plane
     uint4 *dc1k, *dc2k, *dc3k;          // k-major [samples / 8][128] their output gradients (one plane, scaled)
     unsigned *cmask;                    // [colour tiles][2 layers c1, c2][256]: LeakyReLU sign bits in the accumulator layout
     // sample classes (aggregate.hip: pn_classify): the valid samples re-listed class by class, and where each class lives
