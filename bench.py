@@ -41,14 +41,15 @@ PEAK_HBM_GBS = 8000.0
 # roofline.traffic is NOT measured inside a bench run: it is read from the committed PMC summary (separate rocprofv3 --pmc passes of this
 # same command, FETCH x 2 + WRITE per the guide; tools/gpu_round_profile.sh regenerates it)
 TRAFFIC_SOURCE = "profiles/traffic.json (static: rocprofv3 --pmc passes of this command, not measured in this run)"
-# algorithmic HBM bytes of the weight-gradient GEMMs per neighbor row, read once: the inputs of layers 2 .. 4 as two f16 planes
-# (2 x 2 B x (256 + 288 + 256)), layer 1's input as its saved last 64 columns (2 x 2 B x 64) + the 128-byte embedding row + 16 B of row
+# algorithmic HBM bytes of the weight-gradient GEMMs per neighbor row, read once: the inputs of layers 2 .. 4 as ONE f16 plane
+# (2 B x (256 + 288 + 256)), layer 1's input as its saved last 64 columns (2 B x 64) + the 128-byte embedding row + 16 B of row
 # metadata it is rebuilt from (k_wgrad_x0), and the four output gradients as one f16 plane (2 B x 4 x 256)
-BYTES_ROW_WGRAD = 2 * 2 * (256 + 288 + 256) + (2 * 2 * 64 + 128 + 16) + 2 * 4 * 256
-# ... of the colour MLP's three weight-gradient GEMMs per valid sample ([f | view encoding] 288, c1, c2 as two planes; d c1..d c3 one plane)
-BYTES_SAMPLE_WGRAD = 2 * 2 * (288 + 128 + 128) + 2 * 3 * 128
-# ... of the training forward (gather 168 B + the saved planes: X0's last 64 columns, h1 256, [h2|extras] 288, h3 256, h4 256 columns + row metadata)
-BYTES_ROW_FWD = 168 + 2 * 2 * (64 + 256 + 288 + 256 + 256) + 16 + 4 + 96
+BYTES_ROW_WGRAD = 2 * (256 + 288 + 256) + (2 * 64 + 128 + 16) + 2 * 4 * 256
+# ... of the colour MLP's three weight-gradient GEMMs per valid sample ([f | view encoding] 288, c1, c2 and d c1..d c3, one plane each)
+BYTES_SAMPLE_WGRAD = 2 * (288 + 128 + 128) + 2 * 3 * 128
+# ... of the training forward (gather 168 B + the saved planes: X0's last 64 columns, h1 256, [h2|extras] 288, h3 256 as one plane, h4 256
+# columns as two + row metadata)
+BYTES_ROW_FWD = 168 + 2 * (64 + 256 + 288 + 256) + 2 * 2 * 256 + 16 + 4 + 96
 # ... of the backward (h4 planes + sign words + metadata + d f and embedding rows read; four dY planes written)
 BYTES_ROW_BWD = 2 * 2 * 256 + 96 + 20 + 128 + 128 + 2 * 4 * 256
 
@@ -370,7 +371,7 @@ def main():
                "value": rays_total / dt, "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "median_ms_per_step": median_ms,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32 in / out / accumulate; GEMM operands as 2 x f16 planes (22-bit) on the f16 MFMA, 3 products per multiply-add", "data": "synthetic",
+               "dtype": "f32 in / out / accumulate; forward and input-gradient GEMM operands as 2 x f16 planes (22-bit) on the f16 MFMA, 3 products per multiply-add; weight-gradient GEMM operands as one f16 plane each", "data": "synthetic",
                "neighbor_rows_per_s": rows * world * args.steps / dt, "valid_samples_per_s": smp * world * args.steps / dt,
                "config": {"workload": "BASELINE.json %s, %d neural points, K=%d, SR=%d, D=%d, %d rays/GPU/step, fwd+loss+bwd+Adam, grid cached"
                                       % (cfg_name, n_points, opt.K, opt.SR, opt.z_depth_dim, args.rays),
@@ -386,8 +387,9 @@ def main():
                                         "(aggregator and colour MLP) runs on v_mfma_f32_32x32x16_f16 with every f32 operand carried as two f16 planes "
                                         "(x = h + m to 2^-22) and three products per multiply-add (h*h + h*m + m*h), f32 accumulate: sigma/RGB within "
                                         "1.1e-6 of the f32 oracle at this configuration (bar 1e-4); the weight-gradient GEMMs (aggregator and colour layers) "
-                                        "stream the inputs as two planes and the output gradients as ONE f16 plane rounded to nearest (two products; "
-                                        "error budget: tests/test_split_f16_cpu.py)", **extra}}
+                                        "(sums over millions of rows) stream the saved inputs and the output gradients as ONE f16 plane each, rounded to nearest "
+                                        "(one product, f32 accumulate; error budget: csrc/backward.hip k_wgrad_f16, tests/test_split_f16_cpu.py; measured "
+                                        "against float64: tests/test_gpu_bench_config.py)", **extra}}
         if prof is not None:
             per = {k: {"ms_per_launch": ms / max(n, 1), "launches": n, "ms_per_step": ms / args.steps} for k, (ms, n) in prof.items() if n > 0}
             # algorithmic work per step of the three dominant kernels

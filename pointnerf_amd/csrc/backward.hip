@@ -693,7 +693,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
 //   against ~0.17 us of MFMA work per 16 rows), so what matters is that ~100 KB per CU are in flight at all times.
 //   The LDS-DMA count is tracked by hand (s_waitcnt vmcnt(N) + raw s_barrier: __syncthreads() would drain the queue).
 // Error budget of the one-plane operands: every term dY[r][m] X[r][n] carries two independent, unbiased relative roundings of
-// <= 2^-12 (rms 1.1e-4 each); a dW element sums 10^5 .. 10^7 of them, so its error is 1.6e-4 x sqrt(sum t^2) -- for the elements that
+// <= 2^-11 (rms 1.1e-4 each); a dW element sums 10^5 .. 10^7 of them, so its error is 1.6e-4 x sqrt(sum t^2) -- for the elements that
 // matter (|sum t| of the order of the tensor's largest) 1e-6 .. 1e-5 of their value.  Until round 3 X came as two planes (22 bits) and
 // dY as one: the second plane of X doubled the X stream of this kernel and of the forward's stores without changing what the sum's error
 // is made of (measured on the benchmark configuration before / after: tests/test_gpu_bench_config.py prints both).  The forward values
@@ -896,14 +896,15 @@ struct WgX0Args {
 // Rows per stage WX_RS (16 or 32) and prefetch distance WX_D (iterations): what iteration i consumes was issued at iteration i - WX_D.
 //   iteration j issues   dY1 and saved columns of stage j + D | embedding rows of stage j + D + 1 (its X0 is built at iteration j + D) |
 //                        row metadata of stage j + 2 D + 2 (read at the END of iteration j + D, for the gather that iteration j + D + 1 issues)
-// Measured (round 3, one box, 7.1 M rows): 16-row stages 2.1-2.2 ms with distances of 3 and 7 alike (42 vs 98 KB in flight per CU), 1.83 ms with
-// the X0 arithmetic removed; 32-row stages (half the barriers per row; LDS then holds a distance of 2) 2.56 ms -- SLOWER.  Neither bytes in
-// flight nor the per-stage rendezvous is what bounds it; 16 rows / distance 7 ships.
+// Measured (round 3, one box, 7.1 M rows).  With two-plane operands: 16-row stages 2.1-2.2 ms with distances of 3 and 7 alike (42 vs 98 KB in
+// flight per CU), 1.83 ms with the X0 arithmetic removed; 32-row stages (LDS then held a distance of 2) 2.56 ms.  With one-plane operands
+// (half the MFMAs, half the LDS per stage): 16 rows / distance 7 1.42 ms, distance 10 1.45; 32 rows / distance 3 1.28, distance 4 1.29 --
+// the per-stage rendezvous is what is left (849 stages of 1.5 us per workgroup; the HBM floor of its 5.4 GB is 1.0 ms).
 #ifndef PN_WX_RS
-#define PN_WX_RS 16
+#define PN_WX_RS 32
 #endif
 #ifndef PN_WX_D
-#define PN_WX_D (PN_WX_RS == 32 ? 2 : 7)
+#define PN_WX_D (PN_WX_RS == 32 ? 3 : 7)
 #endif
 constexpr int WX_RS = PN_WX_RS, WX_RG = WX_RS / 8;  // rows / row groups per stage
 constexpr int WX_AU = WX_RG * PN_H;                 // dY1 units of a stage (one plane)

@@ -135,7 +135,7 @@ __device__ __forceinline__ void pn_split2(float x0, float x1, unsigned &h, unsig
 }
 // Gradients: the value is clamped to the f16 range first (their scale is chosen per call, an outlier must saturate, not poison) and
 // the high plane is rounded to NEAREST (v_cvt_pk_f16_f32, new on gfx950), the residual as before.  h + m is the same 22-bit number
-// for the dgrad GEMMs; h ALONE is then the best single f16 for the value (|x - h| <= 2^-12 |x|, unbiased), which is what the
+// for the dgrad GEMMs; h ALONE is then the best single f16 for the value (|x - h| <= 2^-11 |x|, unbiased), which is what the
 // weight-gradient GEMM streams for its dY operand (one plane instead of two: see k_wgrad_f16 for the error budget).
 __device__ __forceinline__ void pn_split2_sat(float x0, float x1, unsigned &h, unsigned &m) {
     x0 = __builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f);
@@ -330,7 +330,7 @@ __device__ __forceinline__ void pn_copy_out_kmajor_h(const char *X, uint4 *__res
 }
 // the tile's value planes -> ONE k-major plane ([rg_total][NF] units): what the weight-gradient GEMM streams for its X operand.  The two
 // LDS planes are read transposed and summed by v_pk_add_f16: h + m is exact in 22 bits and the packed add rounds it ONCE to the nearest
-// f16 -- the best single f16 for the value (|x - f16| <= 2^-12 |x|, unbiased; h alone is rounded toward zero).  See k_wgrad_f16 for the
+// f16 -- the best single f16 for the value (|x - f16| <= 2^-11 |x|, unbiased; h alone is rounded toward zero).  See k_wgrad_f16 for the
 // error budget of the one-plane operands.
 typedef _Float16 pn_h4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint2 pn_rne_sum(uint2 h, uint2 m) { return __builtin_bit_cast(uint2, __builtin_bit_cast(pn_h4, h) + __builtin_bit_cast(pn_h4, m)); }
