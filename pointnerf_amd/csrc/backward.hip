@@ -133,7 +133,28 @@ __global__ __launch_bounds__(256, 2) void k_color_backward(BwdArgs a) {
     if (blockIdx.x == 0 && threadIdx.x == 0) a.sv.cls_info[PN_CI_CTILES] = (Ns + PN_CTILE - 1) / PN_CTILE;       // for the weight-gradient GEMMs
     float *gacc = reinterpret_cast<float *>(smem_cb + CB_GACC);          // [3][128] d Wc4 | d bc3 | d bc2 (x S) | d bc1 (x S)
     for (int i = threadIdx.x; i < 6 * PN_HC; i += 256) gacc[i] = 0.f;
-    float gb4 = 0.f;
+    float gb4x = 0.f, gb4y = 0.f, gb4z = 0.f;
+    // d(pre-sigmoid colour) of this thread's row (threads 0 .. 63) is formed from two dependent gathers (sample id -> decoded / its gradient):
+    // requested one tile ahead (the id at the top of the previous tile, the six values behind its first GEMM), so that no tile starts with two
+    // HBM round trips; d bc4 = the column sums of d raw accumulate per row thread and are reduced once at the end
+    auto row_sample = [&](long long t) -> long long {
+        const long long vs = t * PN_CTILE + threadIdx.x;
+        return (threadIdx.x < PN_CTILE && vs < Ns) ? (long long)a.valid_list[vs] : -1;
+    };
+    float po[3] = {0.f, 0.f, 0.f}, pg[3] = {0.f, 0.f, 0.f};
+    auto row_values = [&](long long si) {
+        if (si >= 0) {
+            const float *o = a.decoded + si * 4, *g = a.grad_decoded + si * 4;
+            po[0] = o[1]; po[1] = o[2]; po[2] = o[3]; pg[0] = g[1]; pg[1] = g[2]; pg[2] = g[3];
+        }
+    };
+    long long si_cur = row_sample(blockIdx.x);
+    row_values(si_cur);
+    float w4[3][4];                                                     // the thread's 4 columns of Wc4 (the colour tensors sit at odd float offsets)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w4[k][i] = P[PO_WC4 + k * PN_HC + 4 * (threadIdx.x & 31) + i];
 
     f32x16 acc[2][2];
     for (long long tile = blockIdx.x; tile * PN_CTILE < Ns; tile += gridDim.x) {
@@ -143,28 +164,26 @@ __global__ __launch_bounds__(256, 2) void k_color_backward(BwdArgs a) {
         const long long grow0 = tile * PN_CTILE;
         PN_LDS_BARRIER();
         if (tid < PN_CTILE) {
-            const long long vs = grow0 + tid;
             float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-            if (vs < Ns) {
-                const long long si = a.valid_list[vs];
-                const float *o = a.decoded + si * 4, *g = a.grad_decoded + si * 4;
+            if (si_cur >= 0) {
                 // rgb = sigmoid(raw) * 1.002 - 0.001  ->  d raw = d rgb * 1.002 * s (1 - s)
-                const float s0 = (o[1] + 0.001f) / 1.002f, s1 = (o[2] + 0.001f) / 1.002f, s2 = (o[3] + 0.001f) / 1.002f;
-                d0 = g[1] * 1.002f * s0 * (1.f - s0); d1 = g[2] * 1.002f * s1 * (1.f - s1); d2 = g[3] * 1.002f * s2 * (1.f - s2);
+                const float s0 = (po[0] + 0.001f) / 1.002f, s1 = (po[1] + 0.001f) / 1.002f, s2 = (po[2] + 0.001f) / 1.002f;
+                d0 = pg[0] * 1.002f * s0 * (1.f - s0); d1 = pg[1] * 1.002f * s1 * (1.f - s1); d2 = pg[2] * 1.002f * s2 * (1.f - s2);
             }
             *reinterpret_cast<float4 *>(draw + tid * 4) = make_float4(d0, d1, d2, 0.f);
+            gb4x += d0; gb4y += d1; gb4z += d2;
         }
+        const long long si_next = row_sample(tile + gridDim.x);
         PN_LDS_BARRIER();
         // ---- d c3 = (d raw @ Wc4) * lrelu'(c3); d Wc4, d bc4, d bc3 accumulate in registers
         {
             const int c4 = tid & 31, rg = tid >> 5;
             float4 c3v[8];
-            float w4[3][4], gw4[3][4], gb3[4] = {0.f, 0.f, 0.f, 0.f};
+            float gw4[3][4], gb3[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
+            for (int k = 0; k < 3; ++k)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { w4[k][i] = P[PO_WC4 + k * PN_HC + 4 * c4 + i]; gw4[k][i] = 0.f; }      // (the colour tensors sit at odd float offsets)
-            }
+                for (int i = 0; i < 4; ++i) gw4[k][i] = 0.f;
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) c3v[rr] = *reinterpret_cast<const float4 *>(a.sv.c3 + (grow0 + 8 * rg + rr) * PN_HC + 4 * c4);
 #pragma unroll
@@ -187,10 +206,6 @@ __global__ __launch_bounds__(256, 2) void k_color_backward(BwdArgs a) {
                 for (int k = 0; k < 3; ++k) atomicAdd(gacc + k * PN_HC + 4 * c4 + i, gw4[k][i]);
                 atomicAdd(gacc + 3 * PN_HC + 4 * c4 + i, gb3[i]);
             }
-            if (tid < 3) {
-#pragma unroll 4
-                for (int row = 0; row < PN_CTILE; ++row) gb4 += draw[row * 4 + tid];
-            }
         }
         PN_LDS_BARRIER();
         // ---- d c2 = (d c3 @ Wc3) * lrelu'(c2)
@@ -198,6 +213,8 @@ __global__ __launch_bounds__(256, 2) void k_color_backward(BwdArgs a) {
         const unsigned mw2 = a.sv.cmask[(tile * 2 + 1) * 256 + tid], mw1 = a.sv.cmask[(tile * 2 + 0) * 256 + tid];
         cb_acc_zero(acc);
         pn_gemm_f16x3<8, 4, 1, 7>(X, reinterpret_cast<const uint4 *>(img + PKH_DC3), wave, lane, acc);
+        row_values(si_next);                              // (the next tile's six values: consumed at the top of the next iteration)
+        si_cur = si_next;
         PN_LDS_BARRIER();
         cb_epilogue(acc, mw2, X, wave, lane);
         PN_LDS_BARRIER();
@@ -233,7 +250,11 @@ __global__ __launch_bounds__(256, 2) void k_color_backward(BwdArgs a) {
             atomicAdd(&a.gparams[PO_BC2 + tid], gacc[4 * PN_HC + tid] * invS);
             atomicAdd(&a.gparams[PO_BC1 + tid], gacc[5 * PN_HC + tid] * invS);
         }
-        if (tid < 3) atomicAdd(&a.gparams[PO_BC4 + tid], gb4);
+        if (tid < PN_CTILE) {                              // d bc4: the row threads' partial column sums (wave 0)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { gb4x += __shfl_xor(gb4x, off, 64); gb4y += __shfl_xor(gb4y, off, 64); gb4z += __shfl_xor(gb4z, off, 64); }
+            if (tid == 0) { atomicAdd(&a.gparams[PO_BC4], gb4x); atomicAdd(&a.gparams[PO_BC4 + 1], gb4y); atomicAdd(&a.gparams[PO_BC4 + 2], gb4z); }
+        }
     }
 }
 
