@@ -78,8 +78,12 @@ __device__ __forceinline__ void pn_scale_from_bits(unsigned mb, float &S, float 
 // k-major as one f16 plane (scaled) for the weight-gradient GEMMs of these layers, d f as fp32 rows (x 1/S) for k_agg_backward.
 // LDS: the tile, d raw [64][4], and the workgroup's running sums of d Wc4 [3][128], d bc3, d bc2, d bc1 [128] (LDS float adds:
 // kept in registers they are 45 loop-carried values per thread next to the GEMM's working set)
-constexpr int CB_DRAW = PN_XBYTES, CB_GACC = CB_DRAW + PN_CTILE * 4 * 4, CB_BYTES = CB_GACC + 6 * PN_HC * 4;
-static_assert(2 * CB_BYTES <= 160 * 1024, "two colour workgroups must fit the 160 KB LDS");
+// The tile holds 128 columns at most (d c3, d c2, d c1): its rows are 272 bytes apart (68 dwords = 4 mod 64 banks: the GEMM's 16-byte fragment
+// reads of 16 consecutive rows are conflict-free), 35 KB for both planes instead of the 76 KB of the 296-column tile -- THREE workgroups per
+// CU instead of two (the kernel is a chain of short phases with 3.5 us of MFMA work per tile: what it lacks is waves to overlap them).
+constexpr int CB_XRS = 2 * PN_HC + 16, CB_XPL = PN_CTILE * CB_XRS, CB_XBYTES = 2 * CB_XPL;
+constexpr int CB_DRAW = CB_XBYTES, CB_GACC = CB_DRAW + PN_CTILE * 4 * 4, CB_W4 = CB_GACC + 6 * PN_HC * 4, CB_BYTES = CB_W4 + 3 * PN_HC * 4;
+static_assert(3 * CB_BYTES <= 160 * 1024, "three colour workgroups must fit the 160 KB LDS");
 
 __device__ __forceinline__ void cb_acc_zero(f32x16 (&acc)[2][2]) {
 #pragma unroll
@@ -100,7 +104,7 @@ __device__ __forceinline__ void cb_epilogue(const f32x16 (&acc)[2][2], unsigned 
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = acc[0][rb][4 * g + i] * ((int)(mw << (e + i)) < 0 ? 0.01f : 1.f);
-            pn_x_store4<true>(X, row, f0, v[0], v[1], v[2], v[3]);
+            pn_x_store4<true, CB_XRS, CB_XPL>(X, row, f0, v[0], v[1], v[2], v[3]);
         }
 }
 // column sums of the tile's first 128 columns (the bias gradient of the layer whose d(pre-activation) the tile holds): thread ->
@@ -110,8 +114,8 @@ __device__ __forceinline__ void cb_bias_sums(const char *X, int tid, float *__re
     float gb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-        const uint4 h = *reinterpret_cast<const uint4 *>(X + (r0 + rr) * PN_XRS + c0 * 2);
-        const uint4 m = *reinterpret_cast<const uint4 *>(X + PN_XPLANE + (r0 + rr) * PN_XRS + c0 * 2);
+        const uint4 h = *reinterpret_cast<const uint4 *>(X + (r0 + rr) * CB_XRS + c0 * 2);
+        const uint4 m = *reinterpret_cast<const uint4 *>(X + CB_XPL + (r0 + rr) * CB_XRS + c0 * 2);
         gb[0] = pn_fma2_lo(h.x, m.x, 1.f, gb[0]); gb[1] = pn_fma2_hi(h.x, m.x, 1.f, gb[1]);
         gb[2] = pn_fma2_lo(h.y, m.y, 1.f, gb[2]); gb[3] = pn_fma2_hi(h.y, m.y, 1.f, gb[3]);
         gb[4] = pn_fma2_lo(h.z, m.z, 1.f, gb[4]); gb[5] = pn_fma2_hi(h.z, m.z, 1.f, gb[5]);
@@ -121,7 +125,7 @@ __device__ __forceinline__ void cb_bias_sums(const char *X, int tid, float *__re
     for (int i = 0; i < 8; ++i) atomicAdd(gsum + c0 + i, gb[i]);
 }
 
-__global__ __launch_bounds__(256, 2) void k_color_backward(BwdArgs a) {
+__global__ __launch_bounds__(256, 3) void k_color_backward(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_cb[];
     char *X = smem_cb;
     float *draw = reinterpret_cast<float *>(smem_cb + CB_DRAW);          // [64][4] d(pre-sigmoid colour)
@@ -150,11 +154,8 @@ __global__ __launch_bounds__(256, 2) void k_color_backward(BwdArgs a) {
     };
     long long si_cur = row_sample(blockIdx.x);
     row_values(si_cur);
-    float w4[3][4];                                                     // the thread's 4 columns of Wc4 (the colour tensors sit at odd float offsets)
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w4[k][i] = P[PO_WC4 + k * PN_HC + 4 * (threadIdx.x & 31) + i];
+    float *w4s = reinterpret_cast<float *>(smem_cb + CB_W4);             // Wc4 [3][128] (the colour tensors sit at odd float offsets in the flat vector)
+    for (int i = threadIdx.x; i < 3 * PN_HC; i += 256) w4s[i] = P[PO_WC4 + i];
 
     f32x16 acc[2][2];
     for (long long tile = blockIdx.x; tile * PN_CTILE < Ns; tile += gridDim.x) {
@@ -179,11 +180,14 @@ __global__ __launch_bounds__(256, 2) void k_color_backward(BwdArgs a) {
         {
             const int c4 = tid & 31, rg = tid >> 5;
             float4 c3v[8];
-            float gw4[3][4], gb3[4] = {0.f, 0.f, 0.f, 0.f};
+            float w4[3][4], gw4[3][4], gb3[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
+            for (int k = 0; k < 3; ++k) {
+                const float4 w = *reinterpret_cast<const float4 *>(w4s + k * PN_HC + 4 * c4);
+                w4[k][0] = w.x; w4[k][1] = w.y; w4[k][2] = w.z; w4[k][3] = w.w;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) gw4[k][i] = 0.f;
+            }
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) c3v[rr] = *reinterpret_cast<const float4 *>(a.sv.c3 + (grow0 + 8 * rg + rr) * PN_HC + 4 * c4);
 #pragma unroll
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void k_color_backward(BwdArgs a) {
                     gw4[0][i] += d.x * c[i]; gw4[1][i] += d.y * c[i]; gw4[2][i] += d.z * c[i];
                     gb3[i] += u[i];
                 }
-                pn_x_store4<true>(X, row, 4 * c4, u[0] * S, u[1] * S, u[2] * S, u[3] * S);
+                pn_x_store4<true, CB_XRS, CB_XPL>(X, row, 4 * c4, u[0] * S, u[1] * S, u[2] * S, u[3] * S);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -209,10 +213,10 @@ __global__ __launch_bounds__(256, 2) void k_color_backward(BwdArgs a) {
         }
         PN_LDS_BARRIER();
         // ---- d c2 = (d c3 @ Wc3) * lrelu'(c2)
-        pn_copy_out_kmajor_h<PN_HC>(X, a.sv.dc3k, tile * 8, tid);
+        pn_copy_out_kmajor_h<PN_HC, CB_XRS>(X, a.sv.dc3k, tile * 8, tid);
         const unsigned mw2 = a.sv.cmask[(tile * 2 + 1) * 256 + tid], mw1 = a.sv.cmask[(tile * 2 + 0) * 256 + tid];
         cb_acc_zero(acc);
-        pn_gemm_f16x3<8, 4, 1, 7>(X, reinterpret_cast<const uint4 *>(img + PKH_DC3), wave, lane, acc);
+        pn_gemm_f16x3<8, 4, 1, 4, 3, CB_XRS, CB_XPL>(X, reinterpret_cast<const uint4 *>(img + PKH_DC3), wave, lane, acc);
         row_values(si_next);                              // (the next tile's six values: consumed at the top of the next iteration)
         si_cur = si_next;
         PN_LDS_BARRIER();
@@ -220,17 +224,17 @@ __global__ __launch_bounds__(256, 2) void k_color_backward(BwdArgs a) {
         PN_LDS_BARRIER();
         cb_bias_sums(X, tid, gacc + 4 * PN_HC);
         // ---- d c1 = (d c2 @ Wc2) * lrelu'(c1)
-        pn_copy_out_kmajor_h<PN_HC>(X, a.sv.dc2k, tile * 8, tid);
+        pn_copy_out_kmajor_h<PN_HC, CB_XRS>(X, a.sv.dc2k, tile * 8, tid);
         cb_acc_zero(acc);
-        pn_gemm_f16x3<8, 4, 1, 7>(X, reinterpret_cast<const uint4 *>(img + PKH_DC2), wave, lane, acc);
+        pn_gemm_f16x3<8, 4, 1, 4, 3, CB_XRS, CB_XPL>(X, reinterpret_cast<const uint4 *>(img + PKH_DC2), wave, lane, acc);
         PN_LDS_BARRIER();
         cb_epilogue(acc, mw1, X, wave, lane);
         PN_LDS_BARRIER();
         cb_bias_sums(X, tid, gacc + 5 * PN_HC);
-        pn_copy_out_kmajor_h<PN_HC>(X, a.sv.dc1k, tile * 8, tid);
+        pn_copy_out_kmajor_h<PN_HC, CB_XRS>(X, a.sv.dc1k, tile * 8, tid);
         // ---- d f = d c1 @ Wc1[:, :256]
         cb_acc_zero(acc);
-        pn_gemm_f16x3<8, 8, 2, 4>(X, reinterpret_cast<const uint4 *>(img + PKH_DC1), 2 * wave, lane, acc);
+        pn_gemm_f16x3<8, 8, 2, 1, 3, CB_XRS, CB_XPL>(X, reinterpret_cast<const uint4 *>(img + PKH_DC1), 2 * wave, lane, acc);
 #pragma unroll
         for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
@@ -1159,7 +1163,7 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     if (hipGetDevice(&dev) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
     const long long ctiles = (n_valid + PN_CTILE - 1) / PN_CTILE;
-    const int grid_c = (int)(ctiles < 2 * ncu ? (ctiles > 0 ? ctiles : 1) : 2 * ncu);       // 69 KB of LDS: two workgroups per CU
+    const int grid_c = (int)(ctiles < 3 * ncu ? (ctiles > 0 ? ctiles : 1) : 3 * ncu);       // 40 KB of LDS: three workgroups per CU
     const size_t lds_c = CB_BYTES, lds_a = BL_BYTES;
     if (hipFuncSetAttribute((const void *)k_color_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipFuncSetAttribute((const void *)k_agg_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;

@@ -170,14 +170,15 @@ __device__ __forceinline__ void pn_x_store2(char *X, int row, int col, float v0,
     *reinterpret_cast<unsigned *>(X + row * PN_XRS + col * 2) = h;
     *reinterpret_cast<unsigned *>(X + PN_XPLANE + row * PN_XRS + col * 2) = m;
 }
-// four values at (row, col .. col + 3), col % 4 == 0
-template <bool SAT>
+// four values at (row, col .. col + 3), col % 4 == 0.  XRS / XPL: row stride and plane distance of the tile (the colour backward keeps a
+// narrower one)
+template <bool SAT, int XRS = PN_XRS, int XPL = PN_XPLANE>
 __device__ __forceinline__ void pn_x_store4(char *X, int row, int col, float v0, float v1, float v2, float v3) {
     unsigned h0, m0, h1, m1;
     if (SAT) { pn_split2_sat(v0, v1, h0, m0); pn_split2_sat(v2, v3, h1, m1); }
     else { pn_split2(v0, v1, h0, m0); pn_split2(v2, v3, h1, m1); }
-    *reinterpret_cast<uint2 *>(X + row * PN_XRS + col * 2) = make_uint2(h0, h1);
-    *reinterpret_cast<uint2 *>(X + PN_XPLANE + row * PN_XRS + col * 2) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2 *>(X + row * XRS + col * 2) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2 *>(X + XPL + row * XRS + col * 2) = make_uint2(m0, m1);
 }
 // four values back: h + m
 __device__ __forceinline__ float4 pn_x_load4(const char *X, int row, int col) {
@@ -244,11 +245,11 @@ __device__ __forceinline__ void pn_x_axpy4(const char *X, int row, int col, floa
 // plane dropped: an inference OPTION (pnerf_set_inference_products) -- rendered ray colour within 2e-5 of fp32, per-sample sigma / RGB only
 // within 4e-4 (outside the 1e-4 bar: not the default); rejected for training because a systematic
 // perturbation of the weights flips LeakyReLU sides between forward and backward; a third of the MFMAs and half of the weight stream less).
-template <int NC, int MB, int NFB, int WPF = PN_WPF, int NP = 3>
+template <int NC, int MB, int NFB, int WPF = PN_WPF, int NP = 3, int XRS = PN_XRS, int XPL = PN_XPLANE>
 __device__ __forceinline__ void pn_gemm_f16x3(const char *X, const uint4 *__restrict__ img, int fb0, int lane, f32x16 (&acc)[2][2], int c0 = 0) {
     static_assert(NP == 2 || NP == 3, "two or three products");
     constexpr int PF = WPF < NC ? WPF : NC - 1, NS = PF + 1;
-    const char *xb = X + (lane & 31) * PN_XRS + (lane >> 5) * 16 + c0 * 32;
+    const char *xb = X + (lane & 31) * XRS + (lane >> 5) * 16 + c0 * 32;
     const uint4 *wp = img + ((size_t)c0 * MB + fb0) * 128 + lane;
     uint4 wh[NS][2], wm[NS][2], xh[2][2], xm[2][2];
     auto load_w = [&](auto cc) {
@@ -260,8 +261,8 @@ __device__ __forceinline__ void pn_gemm_f16x3(const char *X, const uint4 *__rest
         constexpr int c = decltype(cc)::value, s = c & 1;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-            xh[s][rb] = *reinterpret_cast<const uint4 *>(xb + rb * 32 * PN_XRS + c * 32);
-            xm[s][rb] = *reinterpret_cast<const uint4 *>(xb + PN_XPLANE + rb * 32 * PN_XRS + c * 32);
+            xh[s][rb] = *reinterpret_cast<const uint4 *>(xb + rb * 32 * XRS + c * 32);
+            xm[s][rb] = *reinterpret_cast<const uint4 *>(xb + XPL + rb * 32 * XRS + c * 32);
         }
     };
     pn_static_for<PF>([&](auto cc) { load_w(cc); });
@@ -305,19 +306,19 @@ __device__ __forceinline__ uint2 pn_lds_read_tr16(const char *p) {
     return __builtin_bit_cast(uint2, r);
 }
 // the high plane only ([rg_total][NF] units): the dY operand of the weight-gradient GEMM
-template <int NF>
+template <int NF, int XRS = PN_XRS>
 __device__ __forceinline__ void pn_copy_out_kmajor_h(const char *X, uint4 *__restrict__ dst, long long rg0, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
-    const int blk = ((lane >> 2) & 3) * PN_XRS + ((lane >> 4) * 16 + (lane & 3) * 4) * 2;
+    const int blk = ((lane >> 2) & 3) * XRS + ((lane >> 4) * 16 + (lane & 3) * 4) * 2;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int rg = wave * 2 + i;
-        const char *src = X + rg * 8 * PN_XRS + blk;
+        const char *src = X + rg * 8 * XRS + blk;
         uint4 *d = dst + (rg0 + rg) * NF;
         // (all transposing reads of the run first, then its stores: the stores are inline asm, which the scheduler does not move loads across)
         uint2 lo[(NF + 63) / 64], hi[(NF + 63) / 64];
 #pragma unroll
-        for (int j = 0; j < (NF + 63) / 64; ++j) { lo[j] = pn_lds_read_tr16(src + j * 128); hi[j] = pn_lds_read_tr16(src + 4 * PN_XRS + j * 128); }
+        for (int j = 0; j < (NF + 63) / 64; ++j) { lo[j] = pn_lds_read_tr16(src + j * 128); hi[j] = pn_lds_read_tr16(src + 4 * XRS + j * 128); }
 #pragma unroll
         for (int j = 0; j < (NF + 63) / 64; ++j) {
             const int f = lane + 64 * j;
