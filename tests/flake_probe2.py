@@ -1,0 +1,53 @@
+"""dev helper (not a test): which kernel of the inference forward is not bit-reproducible -- compares the aggregated features f (the colour
+MLP's input, first region of the workspace) and decoded between repeated runs on the same inputs."""
+import ctypes, sys
+import torch
+from pointnerf_amd import ops, _lib as L
+from pointnerf_amd.point_query import lighting_fast_querier
+from test_gpu_bench_config import _bench_case
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+opt, xyz, attrs, inp, mlp = _bench_case()
+dev = torch.device("cuda:0")
+xyz_d = xyz.to(dev).contiguous()
+pts_t = {k: v.detach().to(dev).reshape(v.shape[1], v.shape[2]).contiguous() for k, v in attrs.items()}
+qr = lighting_fast_querier(dev, opt)
+raydir = inp["raydir"][0].to(dev).contiguous()
+dense = qr.query_dense(xyz_d[None], xyz.shape[0], float(inp["near"].min()), float(inp["far"].max()), raydir[None], inp["campos"].to(dev))
+n_valid = int(dense["counters"][0].item())
+flat = ops.flatten_mlp(mlp, dev)
+packed = ops.pack_mlp(flat)
+cam = ops.make_camera(inp["campos"][0].numpy(), inp["camrotc2w"][0].numpy(), opt.vsize[2], opt.raydist_mode_unit, bg=inp["bg_color"][0].numpy())
+pts = ops.make_points(xyz_d, pts_t["points_embeding"], pts_t["points_conf"], pts_t["points_dir"], pts_t["points_color"])
+R, SR, K = raydir.shape[0], opt.SR, opt.K
+lib = L.lib()
+f32 = dict(dtype=torch.float32, device=dev)
+nws = lib.pnerf_agg_workspace_bytes(n_valid, K)
+first = None
+stats = {"fs": 0, "decoded": 0}
+for it in range(N):
+    decoded = torch.empty(R, SR, 4, **f32); weight = torch.empty(R, SR, K, **f32)
+    ray_color = torch.empty(R, 3, **f32); opacity = torch.empty(R, SR, **f32); bg_trans = torch.empty(R, **f32); blend_w = torch.empty(R, SR, **f32)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    ws.fill_(0xFF)
+    L.check(lib.pnerf_render_forward(ctypes.byref(cam), ctypes.byref(pts), ops._ptr(packed), ops._ptr(flat), ops._ptr(raydir),
+                                     ops._ptr(dense["sample_loc"]), ops._ptr(dense["sample_pidx"]), ops._ptr(dense["sample_nn"]),
+                                     ops._ptr(dense["valid_list"]), ops._ptr(dense["counters"]), R, SR, K,
+                                     ops._ptr(decoded), ops._ptr(weight), ops._ptr(ray_color), ops._ptr(opacity), ops._ptr(bg_trans), ops._ptr(blend_w),
+                                     None, n_valid, ops._ptr(ws), nws, ops._stream()), "pnerf_render_forward")
+    torch.cuda.synchronize()
+    fs = ws[: n_valid * 256 * 4].view(torch.float32).reshape(n_valid, 256).cpu().clone()
+    cur = {"fs": fs, "decoded": decoded.cpu().clone()}
+    if first is None:
+        first = cur
+        continue
+    for k in ("fs", "decoded"):
+        if not torch.equal(cur[k], first[k]):
+            a, b = cur[k].reshape(-1, cur[k].shape[-1]), first[k].reshape(-1, cur[k].shape[-1])
+            neq = (a != b) & ~(torch.isnan(a) & torch.isnan(b))
+            rows = torch.nonzero(neq.any(-1))[:, 0]
+            stats[k] += 1
+            for r in rows[:3].tolist():
+                cols = torch.nonzero(neq[r])[:, 0]
+                print("run %d: %s row %d: %d columns differ (first %s), max |diff| %.3e" % (it, k, r, cols.numel(), cols[:12].tolist(), float((a[r] - b[r])[cols].abs().max())))
+print("done", N, "runs; runs with differing fs / decoded:", stats)

@@ -56,6 +56,35 @@ def test_code_object_is_gfx950_only():
         assert other not in blob
 
 
+def test_code_object_has_no_packed_fp32_math(tmp_path):
+    """csrc/Makefile builds with -fno-slp-vectorize: chains of dependent v_pk_fma_f32 gave intermittently wrong results on the MI355X
+    (see the Makefile).  The shipped code object must not contain packed fp32 arithmetic at all."""
+    import struct
+    from pointnerf_amd import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no ROCm llvm tools here")
+    blob = open(_lib.LIB_PATH, "rb").read()
+    # the device code objects are ELF files (e_machine 224 = AMDGPU) embedded in the host library, one per translation unit
+    pos, n_obj, mfma, packed = 1, 0, 0, []
+    while True:
+        pos = blob.find(b"\x7fELF", pos)
+        if pos < 0:
+            break
+        if struct.unpack_from("<H", blob, pos + 18)[0] == 224:
+            shoff, = struct.unpack_from("<Q", blob, pos + 40)
+            shentsize, shnum = struct.unpack_from("<HH", blob, pos + 58)
+            co = tmp_path / ("co%d.elf" % n_obj)
+            co.write_bytes(blob[pos: pos + shoff + shentsize * shnum])
+            asm = subprocess.check_output([objdump, "-d", "--mcpu=gfx950", str(co)]).decode()
+            mfma += asm.count("v_mfma_f32_32x32x16_f16")
+            packed += re.findall(r"v_pk_(?:fma|mul|add)_f32", asm)
+            n_obj += 1
+        pos += 4
+    assert n_obj >= 8 and mfma > 1000, (n_obj, mfma)                  # it IS the kernels' code
+    assert not packed, len(packed)
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "pointnerf_amd")
     for dp, _, files in os.walk(pkg):

@@ -44,7 +44,26 @@ def test_bench_config_forward_and_gradients():
         a = fwd[ours].cpu()[hit]
         errs[ours] = float((a - ref[theirs][0].detach().reshape(a.shape)).abs().max())
     print("configs[1] forward max abs errors:", errs, "rays hit", int(hit.sum()), "valid samples", ctx["n_valid"])
-    assert max(errs.values()) <= 1e-4, errs
+    if max(errs.values()) > 1e-4:          # say WHERE: sample, channel, its neighbor count (sample class), both values
+        a = fwd["decoded"].cpu()[hit].reshape(-1, 4)
+        b = ref["decoded_features"][0].detach().reshape(-1, 4)
+        nn = (dense["sample_pidx"].cpu()[hit].reshape(-1, opt.K) >= 0).sum(-1)
+        bad = torch.nonzero((a - b).abs().amax(-1) > 1e-4)[:, 0]
+        errs["where"] = [(int(i), int(i) // opt.SR, int(i) % opt.SR, int(nn[i]), a[i].tolist(), b[i].tolist()) for i in bad[:6]]
+        errs["n_bad"] = int(bad.numel())
+        # which side moved?  run both again on the same inputs
+        ref2 = pyref.render(opt, op, om, inp, nthreads=8)
+        _, fwd2, _ = hip_render(opt, xyz, attrs, inp, mlp, train=True)
+        a2 = fwd2["decoded"].cpu()[hit].reshape(-1, 4)
+        b2 = ref2["decoded_features"][0].detach().reshape(-1, 4)
+        errs["second_run"] = [(int(i), a2[i].tolist(), b2[i].tolist()) for i in bad[:6]]
+        errs["hip_runs_equal"] = bool(torch.equal(a, a2))
+        errs["oracle_runs_equal"] = bool(torch.equal(b, b2))
+        import json, os
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/forward_mismatch.jsonl", "a") as fh:
+            fh.write(json.dumps(errs) + "\n")
+    assert max(v for k, v in errs.items() if k not in ("where", "n_bad", "second_run", "hip_runs_equal", "oracle_runs_equal")) <= 1e-4, errs
 
     # gradients of a fixed random functional of the ray colours: fp32 oracle, float64 yardstick, HIP path
     probe = torch.rand(ref["coarse_raycolor"].shape, generator=torch.Generator().manual_seed(123))
