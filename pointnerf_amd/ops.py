@@ -249,7 +249,7 @@ ARENA = Arena()
 
 
 def arena_budget_bytes():
-    """Upper bound for the saved-activation arena of ONE render step (9.6 KB per neighbor row: 68 GB at the bench configuration).
+    """Upper bound for the saved-activation arena of ONE render step (5.9 KB per neighbor row incl. the per-sample areas: 44 GB at the bench configuration).
     A training step whose rows would need more (Barn-scale clouds at K = 12, large ray batches) does not fail or swap: its forward runs
     in inference mode and its backward re-runs the forward chunk of rays by chunk of rays, each chunk within the budget
     (fused.FusedRender).  PNERF_ARENA_BUDGET_GB overrides the default of 160 GB (of the 288 GB of an MI355X)."""
