@@ -52,3 +52,22 @@ def test_inference_forward_is_bit_reproducible():
         elif not all(torch.equal(a, b) for a, b in zip(cur, first)):
             differing.append(it)
     assert not differing, "launches whose forward differs from the first one's: %s" % differing[:10]
+
+
+def test_training_forward_and_its_saved_activations_are_bit_reproducible():
+    """the same for the training forward: outputs AND every byte it saves for the backward (k-major planes written through the LDS transpose
+    read and v_pk_add_f16, sign words, row metadata, h4 rows, class lists) -- the arena is pre-filled with 0xFF, so bytes the launch does
+    not write compare equal too"""
+    from gpu_util import hip_render
+    opt, xyz, attrs, inp, mlp = _bench_case()
+    first, differing = None, []
+    for it in range(150):
+        dense, fwd, ctx = hip_render(opt, xyz, attrs, inp, mlp, train=True)          # (conftest: Arena.take fills the block with 0xFF)
+        need = L.lib().pnerf_agg_saved_bytes(ctx["n_valid"], opt.K)
+        cur = (fwd["saved"][:need].clone(), fwd["decoded"].clone(), fwd["ray_color"].clone())
+        ops.ARENA.give(fwd["saved"])
+        if first is None:
+            first = cur
+        elif not all(torch.equal(a, b) for a, b in zip(cur, first)):
+            differing.append(it)
+    assert not differing, "launches whose training forward differs from the first one's: %s" % differing[:10]
