@@ -71,3 +71,38 @@ def test_training_forward_and_its_saved_activations_are_bit_reproducible():
         elif not all(torch.equal(a, b) for a, b in zip(cur, first)):
             differing.append(it)
     assert not differing, "launches whose training forward differs from the first one's: %s" % differing[:10]
+
+
+def test_backward_chain_and_weight_gradient_gemms_are_bit_reproducible():
+    """the backward adds the POINT gradients (and the small head / bias sums) with atomics -- those differ in the last bits from run to run --
+    but its dgrad chain and the split-K weight-gradient GEMMs are deterministic: the output-gradient planes it saves and d W of the seven MFMA
+    layers (and the four aggregator bias gradients, the GEMMs' ones column) must be the same bits, launch after launch"""
+    import numpy as np
+    from gpu_util import hip_render, DEV
+    opt, xyz, attrs, inp, mlp = _bench_case()
+    dev = torch.device(DEV)
+    lay, _ = ops.mlp_layout()
+    det = [k for k in lay if k in ("block1.0.weight", "block1.0.bias", "block1.2.weight", "block1.2.bias", "block3.0.weight", "block3.0.bias",
+                                   "block3.2.weight", "block3.2.bias", "color_branch.0.weight", "color_branch.2.weight", "color_branch.4.weight")]
+    assert len(det) == 11
+    probe = torch.rand(768, 3, generator=torch.Generator().manual_seed(123)).to(dev)
+    first, differing = None, []
+    for it in range(80):
+        dense, fwd, ctx = hip_render(opt, xyz, attrs, inp, mlp, train=True)
+        hit = dense["ray_hit"] > 0
+        g = torch.zeros(ctx["R"], 3, device=dev)
+        g[hit] = probe[: int(hit.sum())]
+        gflat = torch.zeros_like(ctx["flat"])
+        grads = {k: torch.zeros_like(v) for k, v in ctx["pts_t"].items()}
+        ops.render_backward(ctx["cam"], ctx["pts"], ctx["packed"], ctx["flat"], ctx["raydir"], dense, ctx["R"], opt.SR, opt.K, ctx["n_valid"], fwd, g, gflat, grads)
+        need = L.lib().pnerf_agg_saved_bytes(ctx["n_valid"], opt.K)
+        cur = [fwd["saved"][:need].clone()] + [gflat[lay[k][0]: lay[k][0] + int(np.prod(lay[k][1]))].clone() for k in det]
+        ops.ARENA.give(fwd["saved"])
+        if first is None:
+            first = cur
+            assert all(bool(torch.isfinite(t).all()) and float(t.abs().max()) > 0 for t in cur[1:])
+        else:
+            bad = [(["saved area"] + det)[i] for i, (a, b) in enumerate(zip(cur, first)) if not torch.equal(a, b)]
+            if bad:
+                differing.append((it, bad))
+    assert not differing, differing[:5]
