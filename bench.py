@@ -85,6 +85,10 @@ def parse():
                     help="N > 1: exchange of the per-point gradients: dense all-reduce (one bucket, overlapped), sparse touched-row exchange, auto = sparse from 6 M points")
     ap.add_argument("--unfused-zero-one", action="store_true", help="A/B: the zero-one regulariser as the reference's chain of ATen ops on a materialised conf_coefficient")
     ap.add_argument("--zero1", action="store_true", help="N > 1: shard the point-parameter Adam (reduce-scatter + all-gather) instead of all-reducing the gradients")
+    ap.add_argument("--wgrad-planes", type=int, default=1, choices=(1, 2),
+                    help="f16 planes per operand of the weight-gradient GEMMs: 1 = shipped (one plane rounded to nearest, one product); 2 = both operands "
+                         "as two planes, three products (fp32-class weight gradients).  The default run times 1 and ALSO reports 2 as config.fp32_class_variant")
+    ap.add_argument("--no-fp32-class-variant", action="store_true", help="skip the supplementary --wgrad-planes 2 measurement of the default run")
     return ap.parse_args()
 
 
@@ -192,6 +196,7 @@ def rccl_selftest(dev, rank, world):
     if rank == 0:
         print("rccl_selftest: ok  backend=%s world=%d HSA_ENABLE_IPC_MODE_LEGACY=%s" % (backend, world, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")),
               file=sys.stderr, flush=True)
+    return "ok backend=%s world=%d" % (backend, world)
 
 
 def main():
@@ -199,6 +204,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # --gpus N without N ranks would print an N = 1 number under an N-GPU label, with no collective ever exercised
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with python -m torch.distributed.run --nproc-per-node %d ... bench.py --gpus %d"
+                         % (args.gpus, world, args.gpus, args.gpus))
     if world > 1:
         # "nccl" IS RCCL on ROCm.  PNERF_DIST_BACKEND=gloo exists only so that tests can run 2 ranks on a 1-GPU box.
         torch.distributed.init_process_group(backend=os.environ.get("PNERF_DIST_BACKEND", "nccl"))
@@ -209,8 +218,12 @@ def main():
     dev = torch.device("cuda", local)
     from pointnerf_amd import ops, dist as pdist
     from pointnerf_amd.fused import FusedRender
+    selftest = None
     if world > 1:
-        rccl_selftest(dev, rank, world)
+        selftest = rccl_selftest(dev, rank, world)       # raises on a wrong sum
+        if not selftest:
+            raise SystemExit("bench.py: the collective self-test did not run: refusing to time a multi-GPU step")
+    ops.set_wgrad_planes(args.wgrad_planes)
 
     # is_train=1: the reference trains with 30 % segment jitter (point_query.py:81); the in-kernel RNG path is what a
     # training step runs, so it is what is timed (parity runs -- tests/ -- use jitter off, where results are bit-defined)
@@ -343,6 +356,29 @@ def main():
             opt_mlp.zero_grad(set_to_none=True); opt_pts.zero_grad(set_to_none=True)
             loss_fn(opt, model(**inputs[-1]), inputs[-1], world).backward()
         extra = {"ms_step_cold_grid": timed(cold), "ms_step_without_optimizer": timed(no_adam)}
+        # the SAME step with fp32-class weight gradients (both operands of every weight-gradient GEMM as two f16 planes, three products:
+        # pnerf_set_wgrad_planes(2)) -- the headline's arithmetic caveat priced in the same run, outside the timed region
+        if args.wgrad_planes == 1 and world == 1 and not args.no_fp32_class_variant:
+            ops.set_wgrad_planes(2)
+            try:
+                need2 = int(L.lib().pnerf_agg_saved_bytes(biggest, int(opt.K)))
+                if need2 <= ops.arena_budget_bytes():
+                    ops.ARENA.reserve(int(need2 * 1.05), dev)
+                for _ in range(2):
+                    one_step(inputs[0])
+                nv = min(args.steps, 10)
+                torch.cuda.synchronize(); tv0 = time.perf_counter()
+                for i in range(nv):
+                    lv, _ = one_step(inputs[args.warmup + i])
+                torch.cuda.synchronize()
+                msv = (time.perf_counter() - tv0) / nv * 1e3
+                extra["fp32_class_variant"] = {"ms_per_step": msv, "value": args.rays / (msv * 1e-3), "unit": "rays/s", "steps": nv,
+                                               "final_loss": float(lv.item()),
+                                               "what": "the same step with --wgrad-planes 2: weight-gradient GEMM operands as 2 x f16 planes (22 bits), three "
+                                                       "products per multiply-add -- the arithmetic of the forward and of the input-gradient chain; "
+                                                       "tests/test_gpu_convergence.py, tests/test_gpu_bench_config.py compare the two"}
+            finally:
+                ops.set_wgrad_planes(1)
     if not np.isfinite(float(loss.item())) and not os.environ.get("PNERF_BENCH_ALLOW_NAN"):      # (the env switch exists for dev variants that drop work on purpose)
         raise SystemExit("bench.py: non-finite loss after %d steps -- the timed path produced NaN/Inf, the number would be meaningless" % total)
     per_rank_ms = [dt / args.steps * 1e3]
@@ -371,10 +407,15 @@ def main():
                "value": rays_total / dt, "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "median_ms_per_step": median_ms,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32 in / out / accumulate; forward and input-gradient GEMM operands as 2 x f16 planes (22-bit) on the f16 MFMA, 3 products per multiply-add; weight-gradient GEMM operands as one f16 plane each", "data": "synthetic",
+               "dtype": "f32 in / out / accumulate; forward and input-gradient GEMM operands as 2 x f16 planes (22-bit) on the f16 MFMA, 3 products per multiply-add; weight-gradient GEMM operands as "
+                        + ("one f16 plane each" if args.wgrad_planes == 1 else "2 x f16 planes each, 3 products (--wgrad-planes 2: fp32-class)"), "data": "synthetic",
                "neighbor_rows_per_s": rows * world * args.steps / dt, "valid_samples_per_s": smp * world * args.steps / dt,
                "config": {"workload": "BASELINE.json %s, %d neural points, K=%d, SR=%d, D=%d, %d rays/GPU/step, fwd+loss+bwd+Adam, grid cached"
                                       % (cfg_name, n_points, opt.K, opt.SR, opt.z_depth_dim, args.rays),
+                          "wgrad_planes": args.wgrad_planes, "collective_selftest": selftest,
+                          "parity_note": ("the synthetic Barn shell puts up to ~70 points in a 0.009 cell, beyond P = 11: the reference switches to a wall-clock-seeded "
+                                          "reservoir there (parity undefined); the HIP path and the oracle both keep the first P by index, so parity on this "
+                                          "configuration is HIP-vs-oracle truncation only (pointnerf_amd/config.py barn_opt)") if args.config == "barn" else None,
                           "parallelism": "ray-shard dp%d, point cloud + MLP replicated" % world, "point_grad_exchange": ("none" if world == 1 else ("zero1 reduce-scatter" if zero1 else ("sparse touched rows" if sparse else "dense all-reduce, one bucket, overlapped"))), "world_size": world, "ms_per_step_by_rank": per_rank_ms, "ms_allreduce_exposed_by_rank": exposed_ms, "replica_param_checksum_spread": replica_spread,
                           "valid_samples_per_step": smp, "neighbor_rows_per_step": rows,
                           "rays_hit_per_step": float(np.mean([s["rays_hit"] for s in stats])), "final_loss": float(loss.item()),
@@ -396,6 +437,13 @@ def main():
             alg_flop = {"agg_forward": rows * FLOP_ROW_FWD, "agg_backward": rows * FLOP_ROW_DGRAD, "wgrad": rows * FLOP_ROW_WGRAD + smp * FLOP_SAMPLE_WGRAD,
                         "color_forward": smp * FLOP_SAMPLE_FWD}
             alg_byte = {"agg_forward": rows * BYTES_ROW_FWD, "agg_backward": rows * BYTES_ROW_BWD, "wgrad": rows * BYTES_ROW_WGRAD + smp * BYTES_SAMPLE_WGRAD}
+            if args.wgrad_planes == 2:
+                # --wgrad-planes 2: every saved operand leaves as two planes (X0 whole: 288 columns), the output gradients as two, and the
+                # weight-gradient GEMMs stream each (dY plane, X plane) pair of their three products
+                xcols = 288 + 256 + 288 + 256
+                alg_byte = {"agg_forward": rows * (168 + 2 * 2 * xcols + 2 * 2 * 256 + 16 + 4 + 96),
+                            "agg_backward": rows * (2 * 2 * 256 + 96 + 20 + 128 + 128 + 2 * 2 * 4 * 256),
+                            "wgrad": 3 * (rows * (2 * xcols + 2 * 4 * 256) + smp * BYTES_SAMPLE_WGRAD)}
             traffic = {}
             tf = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-derived HBM bytes per step (separate rocprofv3 --pmc passes)
             if os.path.exists(tf):

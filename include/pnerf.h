@@ -189,6 +189,15 @@ int pnerf_render_forward(const pnerf_camera *cam, const pnerf_points *pts, const
  * previous setting, or PNERF_E_INVAL for n not in {2, 3}.  Process-wide. */
 int pnerf_set_inference_products(int n);
 
+/* Arithmetic of the WEIGHT-GRADIENT GEMMs of the training backward (dW = dY^T X summed over all neighbor rows / samples of the step; the
+ * reference: cuBLAS SGEMMs under loss.backward(), models/mvs_points_volumetric_model.py:98-118).  1 (default): each operand is streamed as
+ * ONE f16 plane rounded to nearest, one MFMA product (11-bit significands, fp32 accumulation; the rounding errors are unbiased and add up
+ * like a random walk over the rows: DESIGN.md 4.1).  2: both operands as TWO f16 planes (22 bits), three products -- the arithmetic of the
+ * forward and of the input-gradient chain, i.e. fp32-class weight gradients; the forward then saves, and the weight-gradient GEMMs stream,
+ * twice the bytes (pnerf_agg_saved_bytes grows accordingly: size the arena AFTER choosing the mode, and keep the mode fixed between a
+ * training forward and its backward).  Returns the previous setting, or PNERF_E_INVAL for n not in {1, 2}.  Process-wide. */
+int pnerf_set_wgrad_planes(int n);
+
 /* Backward of pnerf_render_forward for dL/d(ray_color) = d_grad_ray_color [R,3]:
  * accumulates dL/d(MLP params) into d_grad_params (flat, pnerf_mlp_layout order) and
  * dL/d(point tensors) into pg.  n_valid = the n_valid_max given to the forward call;
@@ -208,6 +217,11 @@ int pnerf_render_backward(const pnerf_camera *cam, const pnerf_points *pts, cons
 /* work list from a caller-supplied per-sample neighbor count (ray_valid = any_K(sample_pnt_mask),
  * models/aggregators/point_aggregators.py:741): d_list = ascending i with d_nn[i] > 0, d_counters[0] = count */
 size_t pnerf_compact_workspace_bytes(int64_t n);
+/* d_flags [n_points] int32 := 1 for every point index that occurs in d_pidx [n] (>= 0), 0 elsewhere; d_flags[0] := 1 as well if any entry
+ * is negative (an empty neighbor slot reads point 0: models/neural_points/neural_points.py:709).  The rows of the per-point gradients a
+ * rank can have touched: the sparse gradient exchange of the data-parallel step (no reference counterpart: its DataParallel is batch 1,
+ * models/neural_points_volumetric_model.py:165-168). */
+int pnerf_touched_flags(const int32_t *d_pidx, int64_t n, int32_t n_points, int32_t *d_flags, void *stream);
 int pnerf_compact_valid(const int32_t *d_nn, int64_t n, int32_t *d_list, int32_t *d_counters, void *d_ws, size_t ws_bytes, void *stream);
 
 /* PointAggregator.forward (point_aggregators.py:727-814) on its own: -> d_decoded [R,SR,4], d_weight [R,SR,K].

@@ -161,6 +161,10 @@ size_t pn_saved_bytes(long long n_valid, int K, long long *rows_out, long long *
     b += 2 * pn_align((size_t)samples * PN_H * 4) + pn_align((size_t)samples * PN_HC * 4);                         // fs, dfs | c3
     b += pn_align((size_t)samples / 8 * PN_NF1 * 16) + 2 * pn_align((size_t)samples / 8 * PN_HC * 16);              // xck | c1k, c2k (one plane)
     b += 3 * pn_align((size_t)samples / 8 * PN_HC * 16) + pn_align((size_t)samples / PN_CTILE * 2 * 256 * 4);       // dc1k..dc3k | cmask
+    if (pn_wgrad_planes() == 2) {       // the residual planes of the fourteen streamed arrays
+        b += 2 * pn_align((size_t)rows / 8 * PN_NF1 * 16) + 6 * pn_align((size_t)rows / 8 * PN_H * 16);
+        b += pn_align((size_t)samples / 8 * PN_NF1 * 16) + 5 * pn_align((size_t)samples / 8 * PN_HC * 16);
+    }
     return b;
 }
 
@@ -183,6 +187,17 @@ PnSaved pn_saved_carve(void *base, long long n_valid, int K) {
     s.xck = cv.take<uint4>(rgc * PN_NF1); s.c1k = cv.take<uint4>(rgc * PN_HC); s.c2k = cv.take<uint4>(rgc * PN_HC);
     s.dc1k = cv.take<uint4>(rgc * PN_HC); s.dc2k = cv.take<uint4>(rgc * PN_HC); s.dc3k = cv.take<uint4>(rgc * PN_HC);
     s.cmask = cv.take<unsigned>((size_t)s.samples / PN_CTILE * 2 * 256);
+    s.wg2 = pn_wgrad_planes() == 2 ? 1 : 0;
+    s.x0m = s.h1m = s.h2m = s.h3m = s.dy1m = s.dy2m = s.dy3m = s.dy4m = nullptr;
+    s.xcm = s.c1m = s.c2m = s.dc1m = s.dc2m = s.dc3m = nullptr;
+    if (s.wg2) {
+        s.x0m = cv.take<uint4>(rg * PN_NF1); s.h2m = cv.take<uint4>(rg * PN_NF1);
+        s.h1m = cv.take<uint4>(rg * PN_H); s.h3m = cv.take<uint4>(rg * PN_H);
+        s.dy1m = cv.take<uint4>(rg * PN_H); s.dy2m = cv.take<uint4>(rg * PN_H);
+        s.dy3m = cv.take<uint4>(rg * PN_H); s.dy4m = cv.take<uint4>(rg * PN_H);
+        s.xcm = cv.take<uint4>(rgc * PN_NF1); s.c1m = cv.take<uint4>(rgc * PN_HC); s.c2m = cv.take<uint4>(rgc * PN_HC);
+        s.dc1m = cv.take<uint4>(rgc * PN_HC); s.dc2m = cv.take<uint4>(rgc * PN_HC); s.dc3m = cv.take<uint4>(rgc * PN_HC);
+    }
     pn_cls_carve(cv.take<char>(pn_cls_bytes(s.samples)), s.samples, s);
     return s;
 }
@@ -287,10 +302,15 @@ __global__ void k_cls_zero_gaps(PnSaved sv, int ncls, int save_x0) {
     if ((blockIdx.x == 0 && !save_x0) || (blockIdx.x == 8 && save_x0)) return;
     const long long gap = (c + 1 < PN_NCLS ? sv.cls_info[PN_CI_TBASE + c + 1] : sv.cls_info[PN_CI_TILES]) - 1;
     uint4 *arrs[9] = {sv.x0k, sv.h2k, sv.h1k, sv.h3k, sv.dy1k, sv.dy2k, sv.dy3k, sv.dy4k, sv.x0k};
+    uint4 *arrm[9] = {sv.x0m, sv.h2m, sv.h1m, sv.h3m, sv.dy1m, sv.dy2m, sv.dy3m, sv.dy4m, nullptr};
     const int which = blockIdx.x;                      // 8 arrays (one k-major plane each) + x0k in its 64-column layout (the fused path: k_wgrad_x0)
     const int nf = which == 8 ? 64 : which < 2 ? PN_NF1 : PN_H;
     uint4 *p = arrs[which] + gap * 8 * nf;
     for (int i = threadIdx.x; i < 8 * nf; i += blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (sv.wg2 && arrm[which]) {                       // two-plane weight-gradient mode: the residual planes too
+        uint4 *pm = arrm[which] + gap * 8 * nf;
+        for (int i = threadIdx.x; i < 8 * nf; i += blockDim.x) pm[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
 }
 }  // namespace
 
@@ -526,6 +546,22 @@ __device__ __forceinline__ void f_tail(const FwdArgs &a, const char *X, const fl
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
         const long long vs = tile * (PN_TILE / KC) + (r0 / KC) + j;
+#if defined(PN_TAIL_GUARD) && !defined(PN_EMU)
+        // dev A/B of round 3's packed-fp32 fault (tools/gpu_pkfma_ab.sh): the eight sums pass through an asm statement as two
+        // 4-register tuples (the vectoriser keeps its packed chains), so every instruction that writes them is in front of it and the stores read
+        // its outputs.  PN_TAIL_GUARD = 1: s_nop 4 (wait states between the last VALU write and the stores' data read); 2: an empty statement
+        // (the same scheduling constraint without wait states)
+#if PN_TAIL_GUARD == 1
+#define PN_TAIL_GUARD_ASM "s_nop 4"
+#else
+#define PN_TAIL_GUARD_ASM ""
+#endif
+        {
+            pn_f4 va = {fa[j].x, fa[j].y, fa[j].z, fa[j].w}, vb = {fb[j].x, fb[j].y, fb[j].z, fb[j].w};
+            asm volatile(PN_TAIL_GUARD_ASM : "+v"(va), "+v"(vb));
+            fa[j] = make_float4(va[0], va[1], va[2], va[3]); fb[j] = make_float4(vb[0], vb[1], vb[2], vb[3]);
+        }
+#endif
         if (vs < a.cap_samples) {
             *reinterpret_cast<float4 *>(a.sv.fs + vs * PN_H + 8 * cg) = fa[j];
             *reinterpret_cast<float4 *>(a.sv.fs + vs * PN_H + 8 * cg + 4) = fb[j];
@@ -560,7 +596,8 @@ __device__ __forceinline__ void f_tail(const FwdArgs &a, const char *X, const fl
 #ifdef PN_PHASE_TRACE
 PN_TR_DECL(pn_trace_fwd);
 #endif
-template <bool TRAIN, bool PERS, int NP>
+// WG2: the two-plane weight-gradient mode (pnerf_set_wgrad_planes(2)): every saved GEMM operand also leaves its residual plane, X0 whole
+template <bool TRAIN, bool PERS, int NP, bool WG2 = false>
 __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_f[];
     char *X = smem_f;
@@ -632,7 +669,8 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         PN_TR(pn_trace_fwd, 2);
         pn_gemm_f16x3<18, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F1), 2 * wave, lane, acc);
         if (TRAIN) {           // (behind the GEMM: see above)
-            if (a.save_x0) pn_copy_out_kmajor<PN_NF1>(X, a.sv.x0k, gtile * 8, tid);
+            if (WG2) pn_copy_out_kmajor<PN_NF1, true>(X, a.sv.x0k, gtile * 8, tid, a.sv.x0m);
+            else if (a.save_x0) pn_copy_out_kmajor<PN_NF1>(X, a.sv.x0k, gtile * 8, tid);
             else pn_copy_out_kmajor_cols64<224>(X, a.sv.x0k, gtile * 8, tid);       // the fused path: only the last 64 columns (k_wgrad_x0)
         }
         PN_LDS_BARRIER();
@@ -645,7 +683,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         f_acc_bias(P + PO_B2, wave, lane, acc);
         PN_TR(pn_trace_fwd, 5);
         pn_gemm_f16x3<16, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F2), 2 * wave, lane, acc);
-        if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h1k, gtile * 8, tid);      // (behind the GEMM: see below)
+        if (TRAIN) pn_copy_out_kmajor<PN_H, WG2>(X, a.sv.h1k, gtile * 8, tid, a.sv.h1m);      // (behind the GEMM: see below)
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 6);
         f_epilogue<TRAIN>(acc, X, wave, lane, mask);
@@ -663,7 +701,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         f_acc_bias(P + PO_B3, wave, lane, acc);
         PN_TR(pn_trace_fwd, 8);
         pn_gemm_f16x3<17, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F3), 2 * wave, lane, acc);
-        if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.h2k, gtile * 8, tid);      // (behind the GEMM: see below)
+        if (TRAIN) pn_copy_out_kmajor<PN_NF1, WG2>(X, a.sv.h2k, gtile * 8, tid, a.sv.h2m);      // (behind the GEMM: see below)
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 9);
         f_epilogue<TRAIN>(acc, X, wave, lane, mask);
@@ -674,7 +712,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         f_acc_bias(P + PO_B4, wave, lane, acc);
         PN_TR(pn_trace_fwd, 11);
         pn_gemm_f16x3<16, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F4), 2 * wave, lane, acc);
-        if (TRAIN) pn_copy_out_kmajor<PN_H>(X, a.sv.h3k, gtile * 8, tid);
+        if (TRAIN) pn_copy_out_kmajor<PN_H, WG2>(X, a.sv.h3k, gtile * 8, tid, a.sv.h3m);
         PN_TR(pn_trace_fwd, 12);
         // the next tile's point data and the indices of the two after it: requested here, consumed at the top of the next
         // iteration -- their HBM latency passes under the element-wise tail of this tile (nothing of this tile waits for memory any more)
@@ -793,7 +831,7 @@ __device__ __forceinline__ void c_acc_zero(f32x16 (&acc)[2][2]) {
         for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
 }
 
-template <bool TRAIN, int NP>
+template <bool TRAIN, int NP, bool WG2 = false>
 __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     char *X = smem_c;
@@ -841,7 +879,7 @@ __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
         PN_LDS_BARRIER();
         float4 bias[4];
         // ---- layer 1: 280 (288) -> 128.  Training: every layer's input tile leaves k-major for the weight-gradient GEMM
-        if (TRAIN) pn_copy_out_kmajor<PN_NF1>(X, a.sv.xck, tile * 8, tid);
+        if (TRAIN) pn_copy_out_kmajor<PN_NF1, WG2>(X, a.sv.xck, tile * 8, tid, a.sv.xcm);
         c_acc_zero(acc);
         pn_gemm_f16x3<18, 4, 1, 7, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_FC1), wave, lane, acc);
         c_load_bias(P + PO_BC1, wave, lane, bias);
@@ -850,7 +888,7 @@ __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
         if (TRAIN) a.sv.cmask[(tile * 2 + 0) * 256 + tid] = mw;
         PN_LDS_BARRIER();
         // ---- layer 2
-        if (TRAIN) pn_copy_out_kmajor<PN_HC>(X, a.sv.c1k, tile * 8, tid);
+        if (TRAIN) pn_copy_out_kmajor<PN_HC, WG2>(X, a.sv.c1k, tile * 8, tid, a.sv.c1m);
         c_acc_zero(acc);
         pn_gemm_f16x3<8, 4, 1, 7, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_FC2), wave, lane, acc);
         c_load_bias(P + PO_BC2, wave, lane, bias);
@@ -859,7 +897,7 @@ __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
         if (TRAIN) a.sv.cmask[(tile * 2 + 1) * 256 + tid] = mw;
         PN_LDS_BARRIER();
         // ---- layer 3
-        if (TRAIN) pn_copy_out_kmajor<PN_HC>(X, a.sv.c2k, tile * 8, tid);
+        if (TRAIN) pn_copy_out_kmajor<PN_HC, WG2>(X, a.sv.c2k, tile * 8, tid, a.sv.c2m);
         c_acc_zero(acc);
         pn_gemm_f16x3<8, 4, 1, 7, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_FC3), wave, lane, acc);
         c_load_bias(P + PO_BC3, wave, lane, bias);
@@ -897,6 +935,16 @@ extern "C" int pnerf_set_inference_products(int n) {
     return old;
 }
 
+// planes per operand of the weight-gradient GEMMs (include/pnerf.h: pnerf_set_wgrad_planes)
+static int pn_wgrad_planes_ = 1;
+int pn_wgrad_planes() { return pn_wgrad_planes_; }
+extern "C" int pnerf_set_wgrad_planes(int n) {
+    if (n != 1 && n != 2) return PNERF_E_INVAL;
+    const int old = pn_wgrad_planes_;
+    pn_wgrad_planes_ = n;
+    return old;
+}
+
 // shared with render.hip
 int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, const float *d_params, const void *d_packed,
                           const float *d_raydir, const float *d_sample_loc, const float *d_xyz_pers, const float *d_loc_pers,
@@ -905,6 +953,8 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
                           float *d_decoded, float *d_weight, const PnSaved &sv, long long cap_samples, bool train, bool save_x0,
                           hipStream_t s) {
     FwdArgs a;
+    const bool wg2 = train && sv.wg2;                  // two-plane weight-gradient mode: residual planes, X0 saved whole
+    if (wg2) save_x0 = true;
     a.save_x0 = save_x0 ? 1 : 0;
     a.cam = *cam;
     a.xyz = pts->xyz; a.emb = pts->embedding; a.conf = pts->conf; a.dir = pts->dir; a.color = pts->color;
@@ -921,10 +971,11 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     const size_t lds_a = FL_BYTES, lds_c = CL_BYTES;
     const bool pers = d_xyz_pers != nullptr;
     const bool np2 = !train && pn_inference_products == 2;      // inference with the weights' high plane only (f16x3.h: NP)
-    const void *kfn = train ? (pers ? (const void *)k_agg_forward<true, true, 3> : (const void *)k_agg_forward<true, false, 3>)
+    const void *kfn = wg2   ? (pers ? (const void *)k_agg_forward<true, true, 3, true> : (const void *)k_agg_forward<true, false, 3, true>)
+                    : train ? (pers ? (const void *)k_agg_forward<true, true, 3> : (const void *)k_agg_forward<true, false, 3>)
                     : np2   ? (pers ? (const void *)k_agg_forward<false, true, 2> : (const void *)k_agg_forward<false, false, 2>)
                             : (pers ? (const void *)k_agg_forward<false, true, 3> : (const void *)k_agg_forward<false, false, 3>);
-    const void *cfn = train ? (const void *)k_color_forward<true, 3> : np2 ? (const void *)k_color_forward<false, 2> : (const void *)k_color_forward<false, 3>;
+    const void *cfn = wg2 ? (const void *)k_color_forward<true, 3, true> : train ? (const void *)k_color_forward<true, 3> : np2 ? (const void *)k_color_forward<false, 2> : (const void *)k_color_forward<false, 3>;
     if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipFuncSetAttribute(cfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
     int rc = pn_classify(sv, d_valid_list, d_counters, d_sample_pidx, K, cap_samples, train, save_x0, s);
@@ -938,7 +989,9 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
             a.cls = j; a.K = kc[j]; a.TS = pn_tile_samples(kc[j]);
             const long long tiles = (cap_samples + a.TS - 1) / a.TS;
             const int grid_a = (int)(tiles < 2LL * ncu ? (tiles > 0 ? tiles : 1) : 2LL * ncu);     // two workgroups per CU
-            if (train && pers) hipLaunchKernelGGL((k_agg_forward<true, true, 3>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            if (wg2 && pers) hipLaunchKernelGGL((k_agg_forward<true, true, 3, true>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            else if (wg2) hipLaunchKernelGGL((k_agg_forward<true, false, 3, true>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            else if (train && pers) hipLaunchKernelGGL((k_agg_forward<true, true, 3>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
             else if (train) hipLaunchKernelGGL((k_agg_forward<true, false, 3>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
             else if (np2 && pers) hipLaunchKernelGGL((k_agg_forward<false, true, 2>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
             else if (np2) hipLaunchKernelGGL((k_agg_forward<false, false, 2>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
@@ -949,7 +1002,8 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     a.K = K; a.TS = pn_tile_samples(K); a.valid_list = sv.cls_list;      // the colour MLP walks the class-ordered list: f rows are in that order
     {
         PnProfScope prof(PNK_COLOR_FWD, s);
-        if (train) hipLaunchKernelGGL((k_color_forward<true, 3>), dim3(grid_c), dim3(256), lds_c, s, a);
+        if (wg2) hipLaunchKernelGGL((k_color_forward<true, 3, true>), dim3(grid_c), dim3(256), lds_c, s, a);
+        else if (train) hipLaunchKernelGGL((k_color_forward<true, 3>), dim3(grid_c), dim3(256), lds_c, s, a);
         else if (np2) hipLaunchKernelGGL((k_color_forward<false, 2>), dim3(grid_c), dim3(256), lds_c, s, a);
         else hipLaunchKernelGGL((k_color_forward<false, 3>), dim3(grid_c), dim3(256), lds_c, s, a);
     }

@@ -125,6 +125,8 @@ __device__ __forceinline__ void cb_bias_sums(const char *X, int tid, float *__re
     for (int i = 0; i < 8; ++i) atomicAdd(gsum + c0 + i, gb[i]);
 }
 
+// WG2: the two-plane weight-gradient mode (pnerf_set_wgrad_planes(2)): the residual plane of every d c tile leaves as well
+template <bool WG2>
 __global__ __launch_bounds__(256, 3) void k_color_backward(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_cb[];
     char *X = smem_cb;
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(256, 3) void k_color_backward(BwdArgs a) {
         PN_LDS_BARRIER();
         // ---- d c2 = (d c3 @ Wc3) * lrelu'(c2)
         pn_copy_out_kmajor_h<PN_HC, CB_XRS>(X, a.sv.dc3k, tile * 8, tid);
+        if (WG2) pn_copy_out_kmajor_h<PN_HC, CB_XRS>(X + CB_XPL, a.sv.dc3m, tile * 8, tid);
         const unsigned mw2 = a.sv.cmask[(tile * 2 + 1) * 256 + tid], mw1 = a.sv.cmask[(tile * 2 + 0) * 256 + tid];
         cb_acc_zero(acc);
         pn_gemm_f16x3<8, 4, 1, 4, 3, CB_XRS, CB_XPL>(X, reinterpret_cast<const uint4 *>(img + PKH_DC3), wave, lane, acc);
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(256, 3) void k_color_backward(BwdArgs a) {
         cb_bias_sums(X, tid, gacc + 4 * PN_HC);
         // ---- d c1 = (d c2 @ Wc2) * lrelu'(c1)
         pn_copy_out_kmajor_h<PN_HC, CB_XRS>(X, a.sv.dc2k, tile * 8, tid);
+        if (WG2) pn_copy_out_kmajor_h<PN_HC, CB_XRS>(X + CB_XPL, a.sv.dc2m, tile * 8, tid);
         cb_acc_zero(acc);
         pn_gemm_f16x3<8, 4, 1, 4, 3, CB_XRS, CB_XPL>(X, reinterpret_cast<const uint4 *>(img + PKH_DC2), wave, lane, acc);
         PN_LDS_BARRIER();
@@ -232,6 +236,7 @@ __global__ __launch_bounds__(256, 3) void k_color_backward(BwdArgs a) {
         PN_LDS_BARRIER();
         cb_bias_sums(X, tid, gacc + 5 * PN_HC);
         pn_copy_out_kmajor_h<PN_HC, CB_XRS>(X, a.sv.dc1k, tile * 8, tid);
+        if (WG2) pn_copy_out_kmajor_h<PN_HC, CB_XRS>(X + CB_XPL, a.sv.dc1m, tile * 8, tid);
         // ---- d f = d c1 @ Wc1[:, :256]
         cb_acc_zero(acc);
         pn_gemm_f16x3<8, 8, 2, 1, 3, CB_XRS, CB_XPL>(X, reinterpret_cast<const uint4 *>(img + PKH_DC1), 2 * wave, lane, acc);
@@ -420,6 +425,7 @@ __device__ __forceinline__ void b_front(const BwdArgs &a, char *X, const float *
 #ifdef PN_PHASE_TRACE
 PN_TR_DECL(pn_trace_bwd);
 #endif
+template <bool WG2>
 __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     char *X = smem_b;
@@ -583,6 +589,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         PN_TR(pn_trace_bwd, 4);
         pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D4), 2 * wave, lane, acc);
         pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy4k, gtile * 8, tid);
+        if (WG2) pn_copy_out_kmajor_h<PN_H>(X + PN_XPLANE, a.sv.dy4m, gtile * 8, tid);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 5);
         b_epilogue(acc, m3, X, wave, lane);
@@ -596,6 +603,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         b_acc_zero(acce);
         pn_gemm_f16x3<4, 9, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D3), 8, lane, acce, 4 * wave);
         pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy3k, gtile * 8, tid);
+        if (WG2) pn_copy_out_kmajor_h<PN_H>(X + PN_XPLANE, a.sv.dy3m, gtile * 8, tid);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 8);
         b_epilogue(acc, m2, X, wave, lane);
@@ -634,6 +642,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         PN_TR(pn_trace_bwd, 10);
         pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D2), 2 * wave, lane, acc);
         pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy2k, gtile * 8, tid);
+        if (WG2) pn_copy_out_kmajor_h<PN_H>(X + PN_XPLANE, a.sv.dy2m, gtile * 8, tid);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 11);
         b_epilogue(acc, m1, X, wave, lane);
@@ -645,6 +654,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         if (wave < 3) pn_gemm_f16x3<16, PN_MB_D1, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D1), 2 * wave, lane, acc);
         else pn_gemm_f16x3<16, PN_MB_D1, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D1), 6, lane, acc);
         pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy1k, gtile * 8, tid);
+        if (WG2) pn_copy_out_kmajor_h<PN_H>(X + PN_XPLANE, a.sv.dy1m, gtile * 8, tid);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 14);
 #pragma unroll
@@ -1013,7 +1023,9 @@ __global__ __launch_bounds__(512) void k_wgrad_x0(const uint4 *__restrict__ A, W
 #pragma unroll
         for (int it = 0; it < WX_RS / 16; ++it) {
             const int item = tid + 512 * it, rg = item >> 8, d = (item >> 3) & 31, rlow = item & 7;
-            const float e = *reinterpret_cast<const float *>(slot + rg * 1024 + ((d >> 2) * 8 + rlow) * 16 + (d & 3) * 4);
+            // (clamped like every other producer of an f16 plane, pn_split2_sat: a plain cast turns |e| > 65504 into inf, and inf x the zero
+            //  dY of a padded row is NaN in dW1)
+            const float e = __builtin_amdgcn_fmed3f(*reinterpret_cast<const float *>(slot + rg * 1024 + ((d >> 2) * 8 + rlow) * 16 + (d & 3) * 4), -65504.f, 65504.f);
             float sn[3], cs[3];
             pn_pe_octaves<3>(e, sn, cs);
             const int f = PN_F + d * 6;
@@ -1165,8 +1177,12 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     const long long ctiles = (n_valid + PN_CTILE - 1) / PN_CTILE;
     const int grid_c = (int)(ctiles < 3 * ncu ? (ctiles > 0 ? ctiles : 1) : 3 * ncu);       // 40 KB of LDS: three workgroups per CU
     const size_t lds_c = CB_BYTES, lds_a = BL_BYTES;
-    if (hipFuncSetAttribute((const void *)k_color_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
-    if (hipFuncSetAttribute((const void *)k_agg_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
+    const bool wg2 = sv.wg2 != 0;                      // two-plane weight-gradient mode (the forward of this step ran in it: same process-wide setting)
+    if (wg2) x0_saved = true;
+    const void *kcb = wg2 ? (const void *)k_color_backward<true> : (const void *)k_color_backward<false>;
+    const void *kab = wg2 ? (const void *)k_agg_backward<true> : (const void *)k_agg_backward<false>;
+    if (hipFuncSetAttribute(kcb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
+    if (hipFuncSetAttribute(kab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
     // the forward left the class partition of the valid samples in the saved area (aggregate.hip: pn_classify)
     a.cls_list = sv.cls_list; a.cls_info = sv.cls_info; a.valid_list = sv.cls_list;
     // the scale of this call's gradients (a power of two derived on the device from max |d decoded| over the valid samples)
@@ -1175,7 +1191,9 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
         const long long blocks = (n_valid + 255) / 256;
         hipLaunchKernelGGL(k_grad_max, dim3((unsigned)(blocks < 1024 ? (blocks > 0 ? blocks : 1) : 1024)), dim3(256), 0, s, sv.cls_list, d_counters, (long long)n_valid, d_grad_decoded, sv.gscale);
     }
-    { PnProfScope prof(PNK_COLOR_BWD, s); hipLaunchKernelGGL(k_color_backward, dim3(grid_c), dim3(256), lds_c, s, a); }
+    { PnProfScope prof(PNK_COLOR_BWD, s);
+      if (wg2) hipLaunchKernelGGL(k_color_backward<true>, dim3(grid_c), dim3(256), lds_c, s, a);
+      else hipLaunchKernelGGL(k_color_backward<false>, dim3(grid_c), dim3(256), lds_c, s, a); }
     int kc[PN_NCLS];
     const int ncls = pn_class_slots(K, kc);
     { PnProfScope prof(PNK_AGG_BWD, s);
@@ -1183,7 +1201,8 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
           a.cls = j; a.K = kc[j]; a.TS = pn_tile_samples(kc[j]);
           const long long tiles = (n_valid + a.TS - 1) / a.TS;                    // worst-case grid, two workgroups per CU
           const int grid_a = (int)(tiles < 2LL * ncu ? (tiles > 0 ? tiles : 1) : 2LL * ncu);
-          hipLaunchKernelGGL(k_agg_backward, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+          if (wg2) hipLaunchKernelGGL(k_agg_backward<true>, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+          else hipLaunchKernelGGL(k_agg_backward<false>, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
       } }
     PN_CHECK_LAUNCH();
     // the point gradients are final here: let a data-parallel caller start their all-reduce behind this event while the
@@ -1207,8 +1226,27 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     if ((rc = launch_wgrad_f16<PN_H, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy2k, sv.h1k, dt, rows, d_partials, sv.gscale, g, PO_W2, PN_H, PN_H, PN_H, PO_B2, s))) return rc;
     if ((rc = launch_wgrad_f16<PN_NF1, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy3k, sv.h2k, dt, rows, d_partials, sv.gscale, g, PO_W3, PN_IN3, PN_IN3, PN_ONES3, PO_B3, s))) return rc;
     if ((rc = launch_wgrad_f16<PN_H, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy4k, sv.h3k, dt, rows, d_partials, sv.gscale, g, PO_W4, PN_H, PN_H, PN_H, PO_B4, s))) return rc;
-    // the three colour layers: samples instead of neighbor rows, 128 output features; their bias gradients were summed by k_color_backward
     const int *ct = sv.cls_info + PN_CI_CTILES;
+    if (wg2) {
+        // two-plane weight-gradient mode: dW = dYh^T Xh (above) + dYh^T Xm + dYm^T Xh -- the same kernel on the residual planes, its reduction
+        // ADDS to the gradient.  The constant-ones tail (bias gradient of layers 2 and 4) must not be counted with dYh twice: bias column -1
+        // for the dYh^T Xm launches; the operands' own ones column (layers 1 and 3) has a zero residual.
+        if ((rc = launch_wgrad_f16<PN_NF1, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy1k, sv.x0m, dt, rows, d_partials, sv.gscale, g, PO_W1, PN_IN1, PN_IN1, PN_ONES1, PO_B1, s))) return rc;
+        if ((rc = launch_wgrad_f16<PN_NF1, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy1m, sv.x0k, dt, rows, d_partials, sv.gscale, g, PO_W1, PN_IN1, PN_IN1, PN_ONES1, PO_B1, s))) return rc;
+        if ((rc = launch_wgrad_f16<PN_H, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy2k, sv.h1m, dt, rows, d_partials, sv.gscale, g, PO_W2, PN_H, PN_H, -1, PO_B2, s))) return rc;
+        if ((rc = launch_wgrad_f16<PN_H, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy2m, sv.h1k, dt, rows, d_partials, sv.gscale, g, PO_W2, PN_H, PN_H, PN_H, PO_B2, s))) return rc;
+        if ((rc = launch_wgrad_f16<PN_NF1, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy3k, sv.h2m, dt, rows, d_partials, sv.gscale, g, PO_W3, PN_IN3, PN_IN3, PN_ONES3, PO_B3, s))) return rc;
+        if ((rc = launch_wgrad_f16<PN_NF1, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy3m, sv.h2k, dt, rows, d_partials, sv.gscale, g, PO_W3, PN_IN3, PN_IN3, PN_ONES3, PO_B3, s))) return rc;
+        if ((rc = launch_wgrad_f16<PN_H, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy4k, sv.h3m, dt, rows, d_partials, sv.gscale, g, PO_W4, PN_H, PN_H, -1, PO_B4, s))) return rc;
+        if ((rc = launch_wgrad_f16<PN_H, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy4m, sv.h3k, dt, rows, d_partials, sv.gscale, g, PO_W4, PN_H, PN_H, PN_H, PO_B4, s))) return rc;
+        if ((rc = launch_wgrad_f16<PN_NF1, PN_HC, 16, 4>(sv.dc1k, sv.xcm, ct, sv.samples, d_partials, sv.gscale, g, PO_WC1, PN_INC, PN_INC, -1, 0, s))) return rc;
+        if ((rc = launch_wgrad_f16<PN_NF1, PN_HC, 16, 4>(sv.dc1m, sv.xck, ct, sv.samples, d_partials, sv.gscale, g, PO_WC1, PN_INC, PN_INC, -1, 0, s))) return rc;
+        if ((rc = launch_wgrad_f16<PN_HC, PN_HC, 16, 4>(sv.dc2k, sv.c1m, ct, sv.samples, d_partials, sv.gscale, g, PO_WC2, PN_HC, PN_HC, -1, 0, s))) return rc;
+        if ((rc = launch_wgrad_f16<PN_HC, PN_HC, 16, 4>(sv.dc2m, sv.c1k, ct, sv.samples, d_partials, sv.gscale, g, PO_WC2, PN_HC, PN_HC, -1, 0, s))) return rc;
+        if ((rc = launch_wgrad_f16<PN_HC, PN_HC, 16, 4>(sv.dc3k, sv.c2m, ct, sv.samples, d_partials, sv.gscale, g, PO_WC3, PN_HC, PN_HC, -1, 0, s))) return rc;
+        if ((rc = launch_wgrad_f16<PN_HC, PN_HC, 16, 4>(sv.dc3m, sv.c2k, ct, sv.samples, d_partials, sv.gscale, g, PO_WC3, PN_HC, PN_HC, -1, 0, s))) return rc;
+    }
+    // the three colour layers: samples instead of neighbor rows, 128 output features; their bias gradients were summed by k_color_backward
     (void)smp;
     if ((rc = launch_wgrad_f16<PN_NF1, PN_HC, 16, 4>(sv.dc1k, sv.xck, ct, sv.samples, d_partials, sv.gscale, g, PO_WC1, PN_INC, PN_INC, -1, 0, s))) return rc;
     if ((rc = launch_wgrad_f16<PN_HC, PN_HC, 16, 4>(sv.dc2k, sv.c1k, ct, sv.samples, d_partials, sv.gscale, g, PO_WC2, PN_HC, PN_HC, -1, 0, s))) return rc;

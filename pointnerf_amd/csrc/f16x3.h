@@ -335,8 +335,15 @@ __device__ __forceinline__ void pn_copy_out_kmajor_h(const char *X, uint4 *__res
 // error budget of the one-plane operands.
 typedef _Float16 pn_h4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint2 pn_rne_sum(uint2 h, uint2 m) { return __builtin_bit_cast(uint2, __builtin_bit_cast(pn_h4, h) + __builtin_bit_cast(pn_h4, m)); }
-template <int NF>
-__device__ __forceinline__ void pn_copy_out_kmajor(const char *X, uint4 *__restrict__ dst, long long rg0, int tid) {
+// what the nearest f16 s = rne(h + m) leaves of h + m: r = m - (s - h).  Both subtractions are exact in f16 (|h| >= |m|: Fast2Sum), so
+// s + r == h + m, the tile's 22-bit value: the second plane of the two-plane weight-gradient mode (pnerf_set_wgrad_planes(2))
+__device__ __forceinline__ uint2 pn_rne_rest(uint2 h, uint2 m, uint2 s) {
+    const pn_h4 hh = __builtin_bit_cast(pn_h4, h), mm = __builtin_bit_cast(pn_h4, m), ss = __builtin_bit_cast(pn_h4, s);
+    return __builtin_bit_cast(uint2, mm - (ss - hh));
+}
+// TWO: also write the residual plane to dstm (same layout) -- the fp32-class weight-gradient mode
+template <int NF, bool TWO = false>
+__device__ __forceinline__ void pn_copy_out_kmajor(const char *X, uint4 *__restrict__ dst, long long rg0, int tid, uint4 *__restrict__ dstm = nullptr) {
     const int lane = tid & 63, wave = tid >> 6;
     const int blk = ((lane >> 2) & 3) * PN_XRS + ((lane >> 4) * 16 + (lane & 3) * 4) * 2;      // this lane's slot inside a [4][64-column] block
     constexpr int NJ = (NF + 63) / 64;
@@ -358,6 +365,11 @@ __device__ __forceinline__ void pn_copy_out_kmajor(const char *X, uint4 *__restr
                 const uint2 a = pn_rne_sum(lo[j], lom[j]), b = pn_rne_sum(hi[j], him[j]);
                 pn_f4 t = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(b.x), __uint_as_float(b.y)};
                 PN_STREAM_STORE(t, reinterpret_cast<pn_f4 *>(d + f));
+                if (TWO) {
+                    const uint2 ra = pn_rne_rest(lo[j], lom[j], a), rb = pn_rne_rest(hi[j], him[j], b);
+                    pn_f4 u = {__uint_as_float(ra.x), __uint_as_float(ra.y), __uint_as_float(rb.x), __uint_as_float(rb.y)};
+                    PN_STREAM_STORE(u, reinterpret_cast<pn_f4 *>(dstm + (rg0 + rg) * NF + f));
+                }
             }
         }
     }

@@ -58,6 +58,11 @@ struct PnSaved {
     uint4 *xck, *c1k, *c2k;             // k-major [samples / 8][288 | 128 | 128] inputs of the three colour layers ([f | view encoding | 0], c1, c2), one plane
     uint4 *dc1k, *dc2k, *dc3k;          // k-major [samples / 8][128] their output gradients (one plane, scaled)
     unsigned *cmask;                    // [colour tiles][2 layers c1, c2][256]: LeakyReLU sign bits in the accumulator layout
+    // two-plane weight-gradient mode only (pnerf_set_wgrad_planes(2); null otherwise): the RESIDUAL plane of every array above that the
+    // weight-gradient GEMMs stream (value = plane + residual to 22 bits), same layouts; x0k then always holds all 288 columns
+    uint4 *x0m, *h1m, *h2m, *h3m, *dy1m, *dy2m, *dy3m, *dy4m;
+    uint4 *xcm, *c1m, *c2m, *dc1m, *dc2m, *dc3m;
+    int wg2;                            // 1 in that mode
     // sample classes (aggregate.hip: pn_classify): the valid samples re-listed class by class, and where each class lives
     int *cls_list;                      // [samples] sample ids, class 0 first
     int *cls_info;                      // PN_CI_* words
@@ -71,6 +76,7 @@ int pn_classify(const PnSaved &sv, const int32_t *d_valid_list, const int32_t *d
 size_t pn_cls_bytes(long long samples);
 void pn_cls_carve(void *base, long long samples, PnSaved &s);
 size_t pn_saved_bytes(long long n_valid, int K, long long *rows_out, long long *samples_out);
+int pn_wgrad_planes();                  // 1 (default: one f16 plane per weight-gradient operand) or 2 (both operands as two planes, three products)
 PnSaved pn_saved_carve(void *base, long long n_valid, int K);
 
 __host__ __device__ inline int pn_tile_samples(int K) { return PN_TILE / K; }

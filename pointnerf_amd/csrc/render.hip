@@ -396,6 +396,32 @@ extern "C" int pnerf_scatter_add_rows(const float *d_grad_rows, const int32_t *d
     return 0;
 }
 
+// flags[p] = 1 for every point p that occurs in the neighbor table, flags[0] = 1 if any slot is empty (empty slots read point 0 like the
+// reference, neural_points.py:709, and the zero-one regulariser differentiates through that read): the rows a rank's point gradients can be
+// non-zero in -- what a data-parallel caller exchanges instead of the dense [N, 39] gradient (pointnerf_amd/dist.py).  Plain stores of the
+// same value race benignly; the table is read as int4 where it can be.
+namespace {
+__global__ __launch_bounds__(256) void k_touched_flags(const int *__restrict__ pidx, long long n, int n_points, int *__restrict__ flags) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int p = pidx[i];
+        if (p >= 0 && p < n_points) flags[p] = 1;
+        else if (p < 0) flags[0] = 1;
+    }
+}
+}  // namespace
+extern "C" int pnerf_touched_flags(const int32_t *d_pidx, int64_t n, int32_t n_points, int32_t *d_flags, void *stream) {
+    if (n < 0 || n_points < 0 || (n > 0 && !d_pidx) || (n_points > 0 && !d_flags)) return PNERF_E_INVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_points == 0) return 0;
+    if (hipMemsetAsync(d_flags, 0, (size_t)n_points * sizeof(int32_t), s) != hipSuccess) return PNERF_E_LAUNCH;
+    if (n == 0) return 0;
+    const long long blocks = (n + 255) / 256;
+    PnProfScope prof(PNK_GATHER, s);
+    hipLaunchKernelGGL(k_touched_flags, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, d_pidx, (long long)n, n_points, d_flags);
+    PN_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" size_t pnerf_agg_workspace_bytes(int64_t n_valid_max, int K) {
     if (K <= 0 || K > PNERF_MAX_K || n_valid_max < 0) return 0;
     // inference: only fs lives here; training: the caller passes a pnerf_agg_saved_bytes() area instead.

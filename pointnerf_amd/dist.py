@@ -131,7 +131,13 @@ def allreduce_grads(mlp_params, point_params, ready_event=None, early_params=())
 def touched_flags(pidx, n_points):
     """[n_points] 0/1 int32 flags of the points a rank's gradients can be non-zero for (``pidx`` int tensor, -1 = empty slot).
     Row 0 is touched whenever ANY slot is empty: empty slots read point 0 like the reference (neural_points.py:709 clamps the index),
-    and the zero-one regulariser differentiates through that read into points_conf[0] (k_zero_one_backward / the unfused gather)."""
+    and the zero-one regulariser differentiates through that read into points_conf[0] (k_zero_one_backward / the unfused gather).
+    Device tables: one library pass over the int32 table (ops.touched_flags); CPU tensors (gloo tests): torch."""
+    if n_points <= 0:
+        return torch.zeros(0, dtype=torch.int32, device=pidx.device)
+    if pidx.is_cuda and pidx.dtype == torch.int32:
+        from . import ops
+        return ops.touched_flags(pidx.contiguous(), n_points)
     flag = torch.zeros(n_points + 1, dtype=torch.int32, device=pidx.device)
     flag[pidx.reshape(-1).long() + 1] = 1             # slot 0 collects the -1 entries
     flag[1] |= flag[0]
@@ -186,7 +192,9 @@ def sparse_allreduce_rows(grads, touched, group=None, cap=None):
         dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=group)
         cap = int(cap.item())
     cap = max(int(cap), 1)
-    ids = torch.full((cap,), -1, dtype=torch.int64, device=dev)
+    # padding: row id 0 with an all-zero row -- adding 0.0 to row 0 changes nothing, so no rank has to mask (a boolean-mask index is a
+    # device -> host read per rank block: W stalls inside the exchange) and every rank still performs the same additions in the same order
+    ids = torch.zeros(cap, dtype=torch.int64, device=dev)
     ids[:touched.numel()] = touched
     rows = torch.zeros(cap, sum(cols), dtype=torch.float32, device=dev)
     if touched.numel():
@@ -204,11 +212,7 @@ def sparse_allreduce_rows(grads, touched, group=None, cap=None):
             g.index_fill_(0, touched, 0.0)
     for r in range(W):
         i = all_ids[r * cap:(r + 1) * cap]
-        keep = i >= 0
-        i = i[keep]
-        if i.numel() == 0:
-            continue
-        blk = all_rows[r * cap:(r + 1) * cap][keep]
+        blk = all_rows[r * cap:(r + 1) * cap]
         o = 0
         for g, c in zip(flat, cols):
             g.index_add_(0, i, blk[:, o:o + c])

@@ -33,14 +33,26 @@ def host_array(t):
         return np.asarray(t)
     if not t.is_cuda:
         return t.detach().numpy()
-    c = getattr(t, "_pnerf_host", None)
-    if c is not None and c[0] == t._version:
-        return c[1]
+    # Only step INPUTS are cached: a Parameter (Rw2c, when it is learnable) is written through .data / optimizer kernels without a version
+    # bump, and an inference-mode tensor has no version counter at all (t._version raises): both are read back every time.
+    cacheable = not isinstance(t, torch.nn.Parameter) and not t.requires_grad
+    ver = None
+    if cacheable:
+        try:
+            ver = t._version
+        except Exception:
+            cacheable = False
+    if cacheable:
+        c = getattr(t, "_pnerf_host", None)
+        if c is not None and c[0] == ver and c[2] == t.data_ptr():      # (data_ptr: t.data = ... / set_() re-home a tensor without a version bump)
+            return c[1]
     arr = t.detach().cpu().numpy()
-    try:
-        t._pnerf_host = (t._version, arr)
-    except Exception:
-        pass
+    arr.setflags(write=False)                                            # callers share the cached copy
+    if cacheable:
+        try:
+            t._pnerf_host = (ver, arr, t.data_ptr())
+        except Exception:
+            pass
     return arr
 
 
@@ -270,6 +282,17 @@ def compact_valid(sample_nn):
     return vlist, counters
 
 
+def touched_flags(pidx, n_points):
+    """[n_points] int32 0/1 flags of the points that occur in the int32 neighbor table ``pidx`` (row 0 also when a slot is empty):
+    pnerf_touched_flags, one pass over the table, no int64 temporaries"""
+    _need_cuda(pidx, "pidx")
+    if pidx.dtype != torch.int32 or not pidx.is_contiguous():
+        raise ValueError("touched_flags: a contiguous int32 neighbor table is expected")
+    flags = torch.empty(max(int(n_points), 0), dtype=torch.int32, device=pidx.device)
+    L.check(L.lib().pnerf_touched_flags(_ptr(pidx), pidx.numel(), int(n_points), _ptr(flags), _stream()), "pnerf_touched_flags")
+    return flags
+
+
 def reserve_pool(nbytes, device):
     """Pre-size torch's caching allocator for the step's variable-size tensors (everything indexed by the number of rays
     that hit the cloud: compacted weights / indices / confidences, the loss temporaries and their gradients).  Their sizes
@@ -429,6 +452,17 @@ def set_inference_products(n):
     old = L.lib().pnerf_set_inference_products(int(n))
     if old < 0:
         raise ValueError("inference products must be 2 or 3")
+    return old
+
+
+def set_wgrad_planes(n):
+    """f16 planes per operand of the weight-gradient GEMMs of the training backward: 1 (default: one plane rounded to nearest, one MFMA
+    product) or 2 (both operands as two planes, three products: fp32-class weight gradients, the reference arithmetic of the convergence
+    A/B in tests/test_gpu_convergence.py; twice the saved / streamed bytes).  Process-wide; choose it between steps, never between a
+    training forward and its backward.  Returns the previous setting."""
+    old = L.lib().pnerf_set_wgrad_planes(int(n))
+    if old < 0:
+        raise ValueError("weight-gradient planes must be 1 or 2")
     return old
 
 

@@ -144,7 +144,25 @@ def _sparse_worker(rank, world, port, out_dir):
     ref = [g.clone() for g in dense]
     for g in ref:
         dist.all_reduce(g)
-    pdist.sparse_allreduce_rows(dense, touched, cap=cap)
+    # with the plan's cap the exchange itself must not read anything back to the host: no .item() / .tolist() / nonzero / boolean-mask
+    # index / masked_select (each is a device -> host synchronisation on a GPU: round 3's version made W of them per step)
+    banned = []
+    orig = {n: getattr(torch.Tensor, n) for n in ("item", "tolist", "nonzero", "masked_select", "__getitem__", "__bool__", "__int__")}
+
+    def ban(name):
+        def f(self, *a, **k):
+            if name != "__getitem__" or any(isinstance(x, torch.Tensor) and x.dtype in (torch.bool, torch.uint8) for x in (a[0] if isinstance(a[0], tuple) else (a[0],))):
+                banned.append(name)
+            return orig[name](self, *a, **k)
+        return f
+    for n in orig:
+        setattr(torch.Tensor, n, ban(n))
+    try:
+        pdist.sparse_allreduce_rows(dense, touched, cap=cap)
+    finally:
+        for n, fn in orig.items():
+            setattr(torch.Tensor, n, fn)
+    assert not banned, "host reads inside the sparse exchange: %s" % banned
     torch.save((dense, ref), os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()

@@ -146,3 +146,25 @@ def test_emulated_fused_zero_one_loss_matches_the_torch_chain():
     (got * 0.37).backward()
     assert abs(float(got) - float(ref)) <= 2e-5 * abs(float(ref))
     assert torch.allclose(b.grad, a.grad, rtol=2e-5, atol=1e-5 * float(a.grad.abs().max()))
+
+
+def test_emulated_two_plane_weight_gradients():
+    """pnerf_set_wgrad_planes(2): the saved operands' residual planes, the three-product weight-gradient launches and the whole-X0 path of the
+    fused step, on the emulator: same bars as the default mode, and the MLP gradients of the two modes agree to the one-plane rounding."""
+    from pointnerf_amd import ops
+    case = _tiny_case(8, 12, 5)
+    gm_o, gp_o, probe = TB._oracle_grads(*case)
+    one, _, _, _ = TB._hip_grads(*case, probe)
+    old = ops.set_wgrad_planes(2)
+    try:
+        assert old == 1
+        two, gp2, _, _ = TB._hip_grads(*case, probe)
+    finally:
+        assert ops.set_wgrad_planes(old) == 2
+    for k in gm_o:
+        TB._check(k, two[k], gm_o[k])
+    for k in gp_o:
+        TB._check(k, gp2[k], gp_o[k])
+    for k in gm_o:       # one plane against two planes: the 2^-11 roundings of a few hundred rows, far below the parity bar
+        scale = max(float(two[k].abs().max()), 1e-12)
+        assert float((one[k] - two[k]).abs().max()) <= 2e-4 * scale, k

@@ -17,13 +17,13 @@ pytestmark = pytest.mark.gpu
 NRAYS = 768
 
 
-def _bench_case():
+def _bench_case(nrays=NRAYS, first=0):
     opt = config.bench_lego_opt()                   # is_train = 0: no jitter, results are bit-defined
     xyz = torch.from_numpy(scenes.lego_points())
     attrs = {k: torch.from_numpy(v) for k, v in scenes.point_attributes(xyz.shape[0], 32, 1).items()}
     d = scenes.random_rays(0, 65536)
     # a contiguous run of the step-0 batch that contains hits
-    d["raydir"], d["gt_image"], d["pixel_idx"] = d["raydir"][:, :NRAYS], d["gt_image"][:, :NRAYS], d["pixel_idx"][:, :NRAYS]
+    d["raydir"], d["gt_image"], d["pixel_idx"] = d["raydir"][:, first:first + nrays], d["gt_image"][:, first:first + nrays], d["pixel_idx"][:, first:first + nrays]
     inp = pyref.to_torch_inputs(d)
     mlp = pyref.init_mlp_params(opt, seed=0, bias_scale=0.05)
     return opt, xyz, attrs, inp, mlp
@@ -44,26 +44,7 @@ def test_bench_config_forward_and_gradients():
         a = fwd[ours].cpu()[hit]
         errs[ours] = float((a - ref[theirs][0].detach().reshape(a.shape)).abs().max())
     print("configs[1] forward max abs errors:", errs, "rays hit", int(hit.sum()), "valid samples", ctx["n_valid"])
-    if max(errs.values()) > 1e-4:          # say WHERE: sample, channel, its neighbor count (sample class), both values
-        a = fwd["decoded"].cpu()[hit].reshape(-1, 4)
-        b = ref["decoded_features"][0].detach().reshape(-1, 4)
-        nn = (dense["sample_pidx"].cpu()[hit].reshape(-1, opt.K) >= 0).sum(-1)
-        bad = torch.nonzero((a - b).abs().amax(-1) > 1e-4)[:, 0]
-        errs["where"] = [(int(i), int(i) // opt.SR, int(i) % opt.SR, int(nn[i]), a[i].tolist(), b[i].tolist()) for i in bad[:6]]
-        errs["n_bad"] = int(bad.numel())
-        # which side moved?  run both again on the same inputs
-        ref2 = pyref.render(opt, op, om, inp, nthreads=8)
-        _, fwd2, _ = hip_render(opt, xyz, attrs, inp, mlp, train=True)
-        a2 = fwd2["decoded"].cpu()[hit].reshape(-1, 4)
-        b2 = ref2["decoded_features"][0].detach().reshape(-1, 4)
-        errs["second_run"] = [(int(i), a2[i].tolist(), b2[i].tolist()) for i in bad[:6]]
-        errs["hip_runs_equal"] = bool(torch.equal(a, a2))
-        errs["oracle_runs_equal"] = bool(torch.equal(b, b2))
-        import json, os
-        os.makedirs("gpurun_out", exist_ok=True)
-        with open("gpurun_out/forward_mismatch.jsonl", "a") as fh:
-            fh.write(json.dumps(errs) + "\n")
-    assert max(v for k, v in errs.items() if k not in ("where", "n_bad", "second_run", "hip_runs_equal", "oracle_runs_equal")) <= 1e-4, errs
+    assert max(errs.values()) <= 1e-4, errs
 
     # gradients of a fixed random functional of the ray colours: fp32 oracle, float64 yardstick, HIP path
     probe = torch.rand(ref["coarse_raycolor"].shape, generator=torch.Generator().manual_seed(123))
@@ -123,3 +104,74 @@ def test_bench_config_forward_and_gradients():
     touched = int((row_pts.unique() >= 0).sum())
     print("points touched %d, kink-affected %d, with an out-of-tolerance element %d" % (touched, int(kinked.sum()), n_bad_total))
     assert n_bad_total <= max(4, touched // 500)
+
+
+WG_RAYS, WG_CHUNK = 8192, 1024
+
+
+def test_bench_config_weight_gradients_8192_rays():
+    """The weight gradients of the timed configuration on 8 192 rays of the step-0 batch (round 3 measured 768), against FLOAT64, for the
+    three arithmetics that exist: the fp32 oracle (what the reference's cuBLAS SGEMMs compute, up to summation order), the shipped
+    one-f16-plane operands (ops.set_wgrad_planes(1)) and the two-plane / three-product mode (set_wgrad_planes(2): fp32-class).  The float64
+    and fp32 oracle gradients are accumulated over chunks of 1 024 rays (a gradient of a sum); the device runs the 8 192 rays as one step.
+    Bars (per MLP tensor, relative to the tensor's largest |dW| in float64):
+      * two planes: rms error <= 2 x the fp32 oracle's own (+1e-7: tensors the oracle gets exactly) -- the same class of arithmetic;
+      * one plane:  rms error <= 6e-6 -- the random-walk budget of DESIGN 4.1 (1.6e-4 sqrt(sum t^2) per element; 4.7e-6 rms for a structured
+        gradient in tests/test_split_f16_cpu.py), which does NOT depend on what the oracle's own error happens to be;
+      * max error of both <= max(3 x the oracle's, 1e-4): isolated LeakyReLU-kink flips, not rounding (the attribution is the 768-ray test's)."""
+    torch.set_num_threads(8)
+    opt, xyz, attrs, inp, mlp = _bench_case(WG_RAYS)
+    om = {k: v.clone().requires_grad_(True) for k, v in mlp.items()}
+    op = dict(xyz=xyz, **{k: v.clone().requires_grad_(True) for k, v in attrs.items()})
+    m64 = {k: torch.zeros(v.shape, dtype=torch.float64) for k, v in mlp.items()}
+    probes, hits = [], 0
+    gen = torch.Generator().manual_seed(123)
+    for c0 in range(0, WG_RAYS, WG_CHUNK):
+        ci = dict(inp)
+        for k in ("raydir", "gt_image", "pixel_idx"):
+            ci[k] = inp[k][:, c0:c0 + WG_CHUNK]
+        ref = pyref.render(opt, op, om, ci, nthreads=8)
+        probe = torch.rand(ref["coarse_raycolor"].shape, generator=gen)
+        probes.append(probe[0])
+        hits += probe.shape[1]
+        if probe.shape[1] == 0:
+            continue
+        (ref["coarse_raycolor"] * probe).sum().backward()                      # accumulates into om[k].grad
+        out64, _, mm = pyref.render_f64(opt, op, om, ci, ref["query"])
+        (out64["coarse_raycolor"] * probe.double()).sum().backward()
+        for k in m64:
+            m64[k] += mm[k].grad
+    probe_all = torch.cat(probes, 0)
+    dev = torch.device(DEV)
+    lay, _ = ops.mlp_layout()
+    res = {}
+    for planes in (1, 2):
+        old = ops.set_wgrad_planes(planes)
+        try:
+            dense, fwd, ctx = hip_render(opt, xyz, attrs, inp, mlp, train=True)
+            hit = dense["ray_hit"] > 0
+            assert int(hit.sum()) == hits
+            g = torch.zeros(ctx["R"], 3, device=dev)
+            g[hit] = probe_all.to(dev)
+            gflat = torch.zeros_like(ctx["flat"])
+            grads = {k: torch.zeros_like(v) for k, v in ctx["pts_t"].items()}
+            ops.render_backward(ctx["cam"], ctx["pts"], ctx["packed"], ctx["flat"], ctx["raydir"], dense, ctx["R"], opt.SR, opt.K,
+                                ctx["n_valid"], fwd, g, gflat, grads)
+            torch.cuda.synchronize()
+            res[planes] = {k: gflat[o:o + int(np.prod(shp))].view(shp).cpu().double() for k, (o, shp) in lay.items()}
+        finally:
+            ops.set_wgrad_planes(old)
+    print("rays %d, hit %d, valid samples %d; errors relative to max |dW| (float64)" % (WG_RAYS, hits, ctx["n_valid"]))
+    print("%-24s %-23s %-23s %-23s" % ("tensor", "fp32 oracle rms / max", "one plane rms / max", "two planes rms / max"))
+    failures = []
+    for k in lay:
+        g64 = m64[k]
+        scale = float(g64.abs().max())
+        st = {}
+        for name, t in (("o32", om[k].grad.double()), ("p1", res[1][k]), ("p2", res[2][k])):
+            d = (t - g64).abs()
+            st[name] = (float(d.pow(2).mean().sqrt()) / scale, float(d.max()) / scale)
+        print("%-24s %.2e / %.2e     %.2e / %.2e     %.2e / %.2e" % (k, *st["o32"], *st["p1"], *st["p2"]))
+        if not (st["p2"][0] <= 2.0 * st["o32"][0] + 1e-7 and st["p1"][0] <= 6e-6 and max(st["p1"][1], st["p2"][1]) <= max(3.0 * st["o32"][1], 1e-4)):
+            failures.append((k, st))
+    assert not failures, failures

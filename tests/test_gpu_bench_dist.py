@@ -32,6 +32,35 @@ def test_bench_json_contract_single_gpu():
     assert r["bound"] in ("hbm", "mfma") and r["peak"] > 0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    # the headline line carries the fp32-class weight-gradient variant of the same step (--wgrad-planes 2) next to the shipped arithmetic
+    v = d["config"]["fp32_class_variant"]
+    assert d["config"]["wgrad_planes"] == 1 and v["ms_per_step"] > 0 and v["value"] > 0 and abs(v["final_loss"]) < 1e3
+    # and the mode can be timed on its own
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--rays", "8192",
+                                   "--points", "300000", "--cpu-rays", "0", "--wgrad-planes", "2"], cwd=ROOT, timeout=900)
+    d2 = _last_json(out)
+    assert d2["config"]["wgrad_planes"] == 2 and "fp32_class_variant" not in d2["config"] and "3 products" in d2["dtype"]
+    assert abs(d2["config"]["final_loss"] - d["config"]["final_loss"]) <= 1e-4 * max(1.0, abs(d["config"]["final_loss"]))
+
+
+def test_bench_refuses_a_gpu_count_it_was_not_launched_with():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=ROOT, capture_output=True, timeout=300)
+    assert r.returncode != 0 and b"WORLD_SIZE=1" in r.stderr
+
+
+def test_touched_flags_kernel_equals_the_torch_form():
+    import torch
+    from pointnerf_amd import dist as pdist
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    for n, shape, frac_empty in ((5000, (300, 8), 0.3), (70, (4, 16, 8), 0.0), (1, (9,), 1.0), (1000, (0, 8), 0.0)):
+        pidx = torch.randint(0, n, shape, generator=g, dtype=torch.int32)
+        if frac_empty:
+            pidx[torch.rand(shape, generator=g) < frac_empty] = -1
+        want = pdist.touched_flags(pidx, n)                       # CPU tensors: the torch form
+        got = pdist.touched_flags(pidx.to(dev), n)                # device int32 table: pnerf_touched_flags
+        assert got.dtype == torch.int32 and torch.equal(got.cpu(), want), (n, shape)
+    assert pdist.touched_flags(torch.zeros(4, 8, dtype=torch.int32, device=dev), 0).numel() == 0
 
 
 def _two_ranks(extra, port_off):

@@ -18,24 +18,26 @@ pytestmark = pytest.mark.gpu
 STEPS = 3
 
 
-@pytest.mark.parametrize("name", ["small_k8", "small_k4"])
-def test_three_training_steps_match_the_oracle(name):
-    opt, xyz, attrs, inp, mlp = build_case(name)
-    dev = torch.device("cuda:0")
-    # ---- oracle side: torch-CPU restatement + torch.optim.Adam
+def oracle_steps(opt, xyz, attrs, inp, mlp, steps):
+    """`steps` optimisation steps of the CPU oracle with torch.optim.Adam: (losses, MLP tensors, point tensors)"""
     om = {k: v.clone().requires_grad_(True) for k, v in mlp.items()}
     oa = {k: v.clone().requires_grad_(True) for k, v in attrs.items()}
     o_mlp = torch.optim.Adam(list(om.values()), lr=opt.lr, betas=(0.9, 0.999))
     o_pts = torch.optim.Adam(list(oa.values()), lr=opt.plr, betas=(0.9, 0.999))
     ref_losses = []
-    for _ in range(STEPS):
+    for _ in range(steps):
         o_mlp.zero_grad(); o_pts.zero_grad()
         out = pyref.render(opt, dict(xyz=xyz, **oa), om, inp, nthreads=8)
         loss = pyref.training_loss(opt, out, inp)
         loss.backward()
         o_mlp.step(); o_pts.step()
         ref_losses.append(float(loss))
-    # ---- device side
+    return ref_losses, om, oa
+
+
+def device_steps(opt, xyz, attrs, inp, mlp, steps):
+    """the same steps on the device: (losses, aggregator, neural points)"""
+    dev = torch.device("cuda:0")
     agg = PointAggregator(opt).to(dev)
     agg.load_state_dict(mlp)
     agg.flatten_()
@@ -50,13 +52,21 @@ def test_three_training_steps_match_the_oracle(name):
     pt_params = [npnt.points_embeding, npnt.points_conf, npnt.points_dir, npnt.points_color]
     h_mlp, h_pts = FusedAdam(mlp_params, lr=opt.lr, betas=(0.9, 0.999)), FusedAdam(pt_params, lr=opt.plr, betas=(0.9, 0.999))
     losses = []
-    for _ in range(STEPS):
+    for _ in range(steps):
         h_mlp.zero_grad(set_to_none=True); h_pts.zero_grad(set_to_none=True)
         out = model(**d)
         loss = pdist.hot_path_loss(opt, out, d["gt_image"])
         loss.backward()
         h_mlp.step(); h_pts.step()
-        losses.append(float(loss))
+        losses.append(loss.detach())
+    return [float(v) for v in torch.stack(losses).cpu()], agg, npnt
+
+
+@pytest.mark.parametrize("name", ["small_k8", "small_k4"])
+def test_three_training_steps_match_the_oracle(name):
+    opt, xyz, attrs, inp, mlp = build_case(name)
+    ref_losses, om, oa = oracle_steps(opt, xyz, attrs, inp, mlp, STEPS)
+    losses, agg, npnt = device_steps(opt, xyz, attrs, inp, mlp, STEPS)
     print("losses  device", losses, " oracle", ref_losses)
     for a_, b_ in zip(losses, ref_losses):
         assert abs(a_ - b_) <= 1e-4 * max(1.0, abs(b_)), (losses, ref_losses)

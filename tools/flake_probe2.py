@@ -4,6 +4,8 @@ import ctypes, sys
 import torch
 from pointnerf_amd import ops, _lib as L
 from pointnerf_amd.point_query import lighting_fast_querier
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 from test_gpu_bench_config import _bench_case
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
@@ -36,14 +38,15 @@ for it in range(N):
                                      ops._ptr(decoded), ops._ptr(weight), ops._ptr(ray_color), ops._ptr(opacity), ops._ptr(bg_trans), ops._ptr(blend_w),
                                      None, n_valid, ops._ptr(ws), nws, ops._stream()), "pnerf_render_forward")
     torch.cuda.synchronize()
-    fs = ws[: n_valid * 256 * 4].view(torch.float32).reshape(n_valid, 256).cpu().clone()
-    cur = {"fs": fs, "decoded": decoded.cpu().clone()}
+    fs = ws[: n_valid * 256 * 4].view(torch.float32).reshape(n_valid, 256).clone()
+    cur = {"fs": fs, "decoded": decoded.clone()}
     if first is None:
         first = cur
         continue
     for k in ("fs", "decoded"):
-        if not torch.equal(cur[k], first[k]):
-            a, b = cur[k].reshape(-1, cur[k].shape[-1]), first[k].reshape(-1, cur[k].shape[-1])
+        # (compared on the device as bit patterns: a run is ~15 ms, a 950 MB copy to the host per run was 20x that)
+        if not torch.equal(cur[k].view(torch.int32), first[k].view(torch.int32)):
+            a, b = cur[k].reshape(-1, cur[k].shape[-1]).cpu(), first[k].reshape(-1, cur[k].shape[-1]).cpu()
             neq = (a != b) & ~(torch.isnan(a) & torch.isnan(b))
             rows = torch.nonzero(neq.any(-1))[:, 0]
             stats[k] += 1
