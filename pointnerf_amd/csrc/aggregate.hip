@@ -546,22 +546,6 @@ __device__ __forceinline__ void f_tail(const FwdArgs &a, const char *X, const fl
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
         const long long vs = tile * (PN_TILE / KC) + (r0 / KC) + j;
-#if defined(PN_TAIL_GUARD) && !defined(PN_EMU)
-        // dev A/B of round 3's packed-fp32 fault (tools/gpu_pkfma_ab.sh): the eight sums pass through an asm statement as two
-        // 4-register tuples (the vectoriser keeps its packed chains), so every instruction that writes them is in front of it and the stores read
-        // its outputs.  PN_TAIL_GUARD = 1: s_nop 4 (wait states between the last VALU write and the stores' data read); 2: an empty statement
-        // (the same scheduling constraint without wait states)
-#if PN_TAIL_GUARD == 1
-#define PN_TAIL_GUARD_ASM "s_nop 4"
-#else
-#define PN_TAIL_GUARD_ASM ""
-#endif
-        {
-            pn_f4 va = {fa[j].x, fa[j].y, fa[j].z, fa[j].w}, vb = {fb[j].x, fb[j].y, fb[j].z, fb[j].w};
-            asm volatile(PN_TAIL_GUARD_ASM : "+v"(va), "+v"(vb));
-            fa[j] = make_float4(va[0], va[1], va[2], va[3]); fb[j] = make_float4(vb[0], vb[1], vb[2], vb[3]);
-        }
-#endif
         if (vs < a.cap_samples) {
             *reinterpret_cast<float4 *>(a.sv.fs + vs * PN_H + 8 * cg) = fa[j];
             *reinterpret_cast<float4 *>(a.sv.fs + vs * PN_H + 8 * cg + 4) = fb[j];

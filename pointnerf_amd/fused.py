@@ -56,7 +56,10 @@ class FusedRender(torch.autograd.Function):
         ctx.recompute = bool(env["train"]) and L.lib().pnerf_agg_saved_bytes(env["n_valid"], env["K"]) > ops.arena_budget_bytes()
         fwd = ops.render_forward(env["cam"], pts, env["packed"], env["flat"], env["raydir"], env["dense"],
                                  env["R"], env["SR"], env["K"], env["n_valid"], env["train"] and not ctx.recompute)
-        ctx.env, ctx.pts, ctx.fwd = env, pts, fwd
+        # only what the backward reads: ray_color must NOT be kept -- the returned tensor's grad_fn is this node, and node -> fwd -> ray_color ->
+        # node is a reference cycle that only Python's cycle collector breaks: a training-mode forward that is never back-propagated (an evaluation
+        # under enabled gradients) then holds its activation arena (tens of GB) until some later collection
+        ctx.env, ctx.pts, ctx.fwd = env, pts, {k: fwd[k] for k in ("saved", "decoded", "weight", "opacity")}
         ctx.shapes = (tuple(emb.shape), tuple(conf.shape), tuple(pdir.shape), tuple(color.shape))
         ctx.n_mlp = len(mlp_params)
         ctx.mark_non_differentiable(fwd["opacity"], fwd["bg_trans"], fwd["blend_w"], fwd["decoded"], fwd["weight"])

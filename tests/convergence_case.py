@@ -97,6 +97,8 @@ def run(dev, steps, planes, rays_per_step=1024, seed=0, log_every=100, sc=None):
         Adam = FusedAdam if torch.device(dev).type == "cuda" else torch.optim.Adam          # (the emulator dry run of this harness steps with torch's)
         o_mlp, o_pts = Adam(mlp_params, lr=opt.lr, betas=(0.9, 0.999)), Adam(pt_params, lr=opt.plr, betas=(0.9, 0.999))
         psnr0 = float(np.mean([psnr(render_view(model, v, dev), g) for v, g in zip(held_views, held_gt)]))
+        mse_all = lambda: float(np.mean([float(((render_view(model, v, dev) - g) ** 2).mean()) for v, g in zip(train_views, gts)]))
+        mse0 = mse_all()
         g = torch.Generator().manual_seed(99 + seed)
         nray = train_views[0]["raydir"].shape[1]
         curve, acc, last = [], [], []
@@ -120,6 +122,8 @@ def run(dev, steps, planes, rays_per_step=1024, seed=0, log_every=100, sc=None):
                 last = vals[-100:] if vals.numel() >= 100 else vals
                 acc = []
         held = float(np.mean([psnr(render_view(model, v, dev), gt) for v, gt in zip(held_views, held_gt)]))
-        return dict(planes=planes, steps=steps, loss_curve=curve, final_loss=float(last.mean()), psnr_heldout=held, psnr_heldout_before=psnr0)
+        mse1 = mse_all()                  # all rays of all training views, after the last step
+        return dict(planes=planes, steps=steps, loss_curve=curve, final_loss=float(last.mean()), psnr_heldout=held, psnr_heldout_before=psnr0,
+                    train_mse=mse1, train_mse_before=mse0, psnr_train=float(-10.0 * np.log10(mse1)))
     finally:
         ops.set_wgrad_planes(old)

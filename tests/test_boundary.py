@@ -57,8 +57,10 @@ def test_code_object_is_gfx950_only():
 
 
 def test_code_object_has_no_packed_fp32_math(tmp_path):
-    """csrc/Makefile builds with -fno-slp-vectorize: chains of dependent v_pk_fma_f32 gave intermittently wrong results on the MI355X
-    (see the Makefile).  The shipped code object must not contain packed fp32 arithmetic at all."""
+    """csrc/Makefile builds without the vectorisers: on the MI355X a v_pk_fma_f32 can deliver a wrong low destination register for the
+    wave's last 16 lanes while another wave of the SIMD executes MFMA (isolated by tools/pkfma_probe.hip, profiles/r04_pkfma_probe.log;
+    tests/test_gpu_pkfma_probe.py runs the probe).  The shipped code object must not contain packed fp32 arithmetic at all -- whatever
+    compiler or flag change would bring it back fails here."""
     import struct
     from pointnerf_amd import _lib
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"

@@ -14,6 +14,7 @@ import pytest
 import torch
 
 import convergence_case as C
+from pointnerf_amd import ops
 from cases import build_case
 from test_gpu_train_steps import device_steps, oracle_steps
 
@@ -22,37 +23,64 @@ DEV = torch.device("cuda:0")
 
 
 def test_200_steps_against_the_fp32_oracle():
+    """Two fp32 evaluations of this optimisation do not stay within 1e-3 of each other for 200 steps: Adam normalises every gradient element
+    to ~lr, so a difference in the last bit of one gradient grows step by step (and a LeakyReLU-kink flip moves an element by 2 lr at once).
+    The yardstick is therefore measured, not assumed: the CPU oracle is run TWICE, the second time with every MLP weight moved by a relative
+    2^-23 (half an fp32 ulp: the smallest perturbation that exists), and the device trajectory must (i) match the oracle to 1e-4 while the two
+    oracle runs still agree to 1e-4 (measured: 1e-7 .. 1e-6 for the first 50 steps), and (ii) never be further from the oracle than
+    3 x the largest divergence the perturbed oracle has shown up to that step (floor 1e-3)."""
     case = build_case("small_k8")
+    opt, xyz, attrs, inp, mlp = case
     ref, _, _ = oracle_steps(*case, 200)
+    g = torch.Generator().manual_seed(7)
+    mlp2 = {k: v * (1.0 + (torch.randint(0, 2, v.shape, generator=g).float() * 2 - 1) * 2.0 ** -23) for k, v in mlp.items()}
+    ref2, _, _ = oracle_steps(opt, xyz, attrs, inp, mlp2, 200)
     ours, _, _ = device_steps(*case, 200)
-    rel = [abs(a - b) / max(abs(b), 1e-6) for a, b in zip(ours, ref)]
-    print("loss  step 1 %.6f / %.6f   step 50 %.6f / %.6f   step 200 %.6f / %.6f   (device / oracle);  worst relative difference %.2e at step %d"
-          % (ours[0], ref[0], ours[49], ref[49], ours[-1], ref[-1], max(rel), int(np.argmax(rel)) + 1))
+    old = ops.set_wgrad_planes(2)
+    try:
+        ours2, _, _ = device_steps(*case, 200)
+    finally:
+        ops.set_wgrad_planes(old)
+    rel = lambda a, b: np.array([abs(x - y) / max(abs(y), 1e-6) for x, y in zip(a, b)])
+    d_dev, d_dev2, d_orc = rel(ours, ref), rel(ours2, ref), rel(ref2, ref)
+    env = np.maximum.accumulate(d_orc)
+    for t in (1, 10, 25, 50, 75, 100, 125, 150, 175, 200):
+        print("step %3d  loss device %.6f (two-plane %.6f) oracle %.6f perturbed oracle %.6f   relative to the oracle: device %.1e, two-plane device %.1e, perturbed oracle %.1e"
+              % (t, ours[t - 1], ours2[t - 1], ref[t - 1], ref2[t - 1], d_dev[t - 1], d_dev2[t - 1], d_orc[t - 1]))
     assert ref[-1] < 0.5 * ref[0], "the case must actually optimise"
-    assert max(rel) <= 1e-3, (max(rel), int(np.argmax(rel)))
+    agree = env <= 1e-4
+    assert agree[:30].all(), "the oracle's own perturbed run left 1e-4 within 30 steps: the yardstick is broken"
+    for d in (d_dev, d_dev2):
+        assert (d[agree] <= 1e-4).all(), float(d[agree].max())
+        assert (d <= np.maximum(3.0 * env, 1e-3)).all(), (float(d.max()), int(np.argmax(d - np.maximum(3.0 * env, 1e-3))))
 
 
 STEPS = 2000
 
 
 def test_convergence_one_plane_vs_two_planes():
+    """4 + 4 runs of 2 000 steps.  Every run ends at a slightly different point (the backward's atomics order the point-gradient sums
+    differently from launch to launch, and the optimisation amplifies that), so the two arithmetics are compared as two samples: the
+    difference of their means against the standard error of that difference (Welch), for the held-out PSNR and for the loss over ALL
+    training rays evaluated after the last step (not the noisy mini-batch losses)."""
     sc = C.scene()
-    runs = {1: [C.run(DEV, STEPS, 1, sc=sc) for _ in range(3)], 2: [C.run(DEV, STEPS, 2, sc=sc) for _ in range(2)]}
+    runs = {1: [C.run(DEV, STEPS, 1, sc=sc) for _ in range(4)], 2: [C.run(DEV, STEPS, 2, sc=sc) for _ in range(4)]}
     stat = lambda key, planes: np.array([r[key] for r in runs[planes]])
-    out = {}
-    for key in ("final_loss", "psnr_heldout"):
+    out = {"steps": STEPS, "psnr_heldout_before": runs[1][0]["psnr_heldout_before"], "train_mse_before": runs[1][0]["train_mse_before"]}
+    for key in ("train_mse", "psnr_heldout", "psnr_train"):
         a, b = stat(key, 1), stat(key, 2)
-        spread = max(a.max() - a.min(), b.max() - b.min())
-        out[key] = dict(one_plane=a.tolist(), two_planes=b.tolist(), spread_within_an_arithmetic=float(spread), difference_of_means=float(abs(a.mean() - b.mean())))
+        se = float(np.sqrt(a.var(ddof=1) / a.size + b.var(ddof=1) / b.size))
+        out[key] = dict(one_plane=a.tolist(), two_planes=b.tolist(), mean_one_plane=float(a.mean()), mean_two_planes=float(b.mean()),
+                        difference_of_means=float(abs(a.mean() - b.mean())), standard_error_of_the_difference=se,
+                        run_to_run_std=[float(a.std(ddof=1)), float(b.std(ddof=1))])
         print(key, out[key])
-    out["psnr_heldout_before"] = runs[1][0]["psnr_heldout_before"]
     out["loss_curves"] = {"one_plane": runs[1][0]["loss_curve"], "two_planes": runs[2][0]["loss_curve"]}
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/convergence_ab.json", "w") as fh:
         json.dump(out, fh)
-    # the problem is a real one: the student gains > 6 dB on views it never trained on
-    assert min(stat("psnr_heldout", 1).min(), stat("psnr_heldout", 2).min()) > out["psnr_heldout_before"] + 6.0
-    # the two arithmetics end where repeated runs of one arithmetic end: within 2 x the larger within-arithmetic spread (floors: 0.1 dB, 2 % of the loss)
-    p, l = out["psnr_heldout"], out["final_loss"]
-    assert p["difference_of_means"] <= max(2.0 * p["spread_within_an_arithmetic"], 0.1), p
-    assert l["difference_of_means"] <= max(2.0 * l["spread_within_an_arithmetic"], 0.02 * abs(np.mean(l["one_plane"]))), l
+    # the problem is a real one: every run gains > 10 dB on views it never trained on
+    assert min(stat("psnr_heldout", 1).min(), stat("psnr_heldout", 2).min()) > out["psnr_heldout_before"] + 10.0
+    # the two arithmetics are one population: |difference of means| <= 3 standard errors (floors: 0.15 dB, 5 % of the loss)
+    for key, floor in (("psnr_heldout", 0.15), ("psnr_train", 0.15), ("train_mse", 0.05 * out["train_mse"]["mean_two_planes"])):
+        o = out[key]
+        assert o["difference_of_means"] <= max(3.0 * o["standard_error_of_the_difference"], floor), (key, o)
