@@ -59,12 +59,12 @@ STEPS = 2000
 
 
 def test_convergence_one_plane_vs_two_planes():
-    """4 + 4 runs of 2 000 steps.  Every run ends at a slightly different point (the backward's atomics order the point-gradient sums
+    """6 + 6 runs of 2 000 steps (profiles/r04_convergence_ab.json: 12 + 12).  Every run ends at a slightly different point (the backward's atomics order the point-gradient sums
     differently from launch to launch, and the optimisation amplifies that), so the two arithmetics are compared as two samples: the
     difference of their means against the standard error of that difference (Welch), for the held-out PSNR and for the loss over ALL
     training rays evaluated after the last step (not the noisy mini-batch losses)."""
     sc = C.scene()
-    runs = {1: [C.run(DEV, STEPS, 1, sc=sc) for _ in range(4)], 2: [C.run(DEV, STEPS, 2, sc=sc) for _ in range(4)]}
+    runs = {1: [C.run(DEV, STEPS, 1, sc=sc) for _ in range(6)], 2: [C.run(DEV, STEPS, 2, sc=sc) for _ in range(6)]}
     stat = lambda key, planes: np.array([r[key] for r in runs[planes]])
     out = {"steps": STEPS, "psnr_heldout_before": runs[1][0]["psnr_heldout_before"], "train_mse_before": runs[1][0]["train_mse_before"]}
     for key in ("train_mse", "psnr_heldout", "psnr_train"):
