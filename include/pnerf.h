@@ -270,6 +270,43 @@ int pnerf_voxel_downsample(const float *d_xyz, int64_t n_points, const float *sp
                            int rx, int ry, int rz, float *d_centroid, int32_t *d_grid_idx, int64_t *d_min_idx, int32_t *d_counts,
                            void *d_ws, size_t ws_bytes, void *stream);
 
+/* ---- point initialisation: appearance of candidate points from GIVEN 2-D maps (MvsPointsModel.extract_2d
+ * models/mvs/mvs_points_model.py:198-218 = homo_warp_nongrid / homo_warp_nongrid_occ models/mvs/mvs_utils.py:299-315,333-369 +
+ * extract_from_2d_grid :411-421; called from query_embedding :233-238).  The maps (the source images and the feature pyramid of the
+ * reference's FeatureNet) are INPUTS: the 2-D network itself is outside the hot-path scope.
+ * d_cam_xyz [n,3]: the points in the frame of the camera `cam_vid`.  A view = (c2w of cam_vid, w2c of the view, the view's 3x3 intrinsic,
+ * all row-major; has_w2c = 0 for the view that IS cam_vid: no transform, :302-305).  Pixel = ((p / p.z) @ K^T).xy; in-image test
+ * 0 <= pixel <= (WD-1, HD-1) (depth_occ == 0) or on ceil(pixel) (depth_occ != 0), then for depth_occ != 0 the z-buffer test
+ * z <= min(z over the in-image points of the same ceil-pixel) + tolerate.  Every map [C,H,W] of a view is sampled at the pixel scaled to
+ * [-1,1] by (WD-1, HD-1) (bilinear, zeros outside, align_corners) into columns [out_col, out_col + C) of d_feats [n,feat_cols] or, with
+ * is_color, of d_colors [n,color_cols]; rows of points that fail a view's test are zero in that view's columns.  d_mask [n_views,n]
+ * (optional): the views' final masks. */
+#define PNERF_EX2D_MAX_VIEWS 8
+#define PNERF_EX2D_MAX_MAPS 32
+typedef struct pnerf_view_desc {
+    float c2w[16];          /* c2ws[:, cam_vid] */
+    float w2c[16];          /* w2cs[:, vid] */
+    float intrinsic[9];     /* intrinsics[:, vid] */
+    int32_t has_w2c;
+} pnerf_view_desc;
+typedef struct pnerf_map_desc {
+    const float *d_map;     /* [C,H,W] device: img_feats[lid][vid] */
+    int32_t view;           /* index into the views array */
+    int32_t C, H, W;
+    int32_t out_col;        /* first column in d_feats (d_colors when is_color) */
+    int32_t is_color;       /* layer 0 of the reference's pyramid = the image itself (:209-210) */
+    int32_t first_of_view;  /* set by the library */
+} pnerf_map_desc;
+size_t pnerf_extract_2d_workspace_bytes(int64_t n_points, int n_views, int HD, int WD, int depth_occ);
+int pnerf_extract_2d(const float *d_cam_xyz, int64_t n_points, const pnerf_view_desc *views, int n_views, const pnerf_map_desc *maps,
+                     int n_maps, int HD, int WD, int depth_occ, float tolerate, float *d_feats, int feat_cols, float *d_colors,
+                     int color_cols, uint8_t *d_mask, void *d_ws, size_t ws_bytes, void *stream);
+/* the "dir" block of query_embedding (models/mvs/mvs_points_model.py:239-251): d_dirs [n, n_views, 3] = unit(p - cam_pos_cam[v]) (norm + 1e-6)
+ * @ rot1^T (@ rot2^T when rot2 != NULL); cam_pos_cam_host [n_views,3] = the views' centres in cam_vid's frame, rot1 = c2ws[cam_vid][:3,:3],
+ * rot2 = c2ws[ref_vid][:3,:3] unless pointdir_w. */
+int pnerf_point_dirs(const float *d_cam_xyz, int64_t n_points, const float *cam_pos_cam_host, int n_views, const float *rot1_host9,
+                     const float *rot2_host9, float *d_dirs, void *stream);
+
 /* ---- diagnostics: ONE v_mfma_f32_32x32x16_f16, D = A B with caller-built fragments: d_a / d_b [64 lanes][8] f16 (lane l holds
  * A[l & 31][8 (l >> 5) .. + 7] resp. B[8 (l >> 5) .. + 7][l & 31]), d_out [64 lanes][16] f32 (register r of lane l =
  * D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31]).  The tests pin with it the fragment layout and the un-flushed handling of f16

@@ -466,3 +466,97 @@ def test_view_losses(canvas, gt_rays, pixel_idx, ray_mask, height, width):
     masked = float(np.mean((pred.astype(np.float64) - gt_rays[ray_mask]) ** 2))
     ps = lambda x: -10.0 * math.log(x) / math.log(10.0)
     return dict(coarse_raycolor=full, coarse_raycolor_psnr=ps(full), ray_masked_coarse_raycolor=masked, ray_masked_coarse_raycolor_psnr=ps(masked))
+
+
+# ---- point initialisation from given 2-D maps --------------------------------------------------------------------------
+def project_to_view(cam_xyz, c2w, w2c, intrinsic, HD, WD, depth_occ, tolerate=0.1):
+    """models/mvs/mvs_utils.py homo_warp_nongrid :299-315 (depth_occ == 0) / homo_warp_nongrid_occ :333-369 in numpy fp32 WITHOUT the
+    compaction: -> (pixel [N,2], mask [N]).  cam_xyz [N,3] in the frame of the camera c2w belongs to; w2c None = that camera itself.
+    Pinned through query_embedding against the reference's functions exec'ed from source (tests/golden/refembed.npz)."""
+    f32 = np.float32
+    p = cam_xyz.astype(f32)
+    if w2c is not None:
+        h = np.concatenate([p, np.ones((len(p), 1), f32)], 1)
+        p = ((h @ c2w.T.astype(f32)).astype(f32) @ w2c.T.astype(f32)).astype(f32)[:, :3]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = (p / p[:, 2:3]).astype(f32)
+    pix = (q @ intrinsic.T.astype(f32)).astype(f32)[:, :2]
+    lim = np.array([WD - 1, HD - 1], f32)
+    if not depth_occ:
+        mask = np.all((pix >= 0) & (pix <= lim), axis=1)
+        return pix, mask
+    mask = np.all((pix >= 0) & (np.ceil(pix) <= lim), axis=1)
+    hard = np.ceil(pix[mask]).astype(np.int64)
+    cell = hard[:, 0] * HD + hard[:, 1]                                    # :355 (x * HD + y)
+    z = p[mask, 2]
+    zmin = np.full(int(cell.max()) + 1 if len(cell) else 0, np.inf, f32)
+    np.minimum.at(zmin, cell, z)
+    keep = z <= zmin[cell] + f32(tolerate)                                 # :361
+    out = np.zeros(len(p), bool)
+    out[np.nonzero(mask)[0][keep]] = True
+    return pix, out
+
+
+def grid_sample_bilinear(fmap, pix, HD, WD):
+    """extract_from_2d_grid (models/mvs/mvs_utils.py:411-415): F.grid_sample(bilinear, zeros, align_corners=True) of fmap [C,H,W] at the
+    pixel positions scaled to [-1, 1] by (WD-1, HD-1) (:313-314) -> [N,C]"""
+    f32 = np.float32
+    C, H, W = fmap.shape
+    gx = pix[:, 0] / f32((WD - 1.0) / 2.0) - f32(1)
+    gy = pix[:, 1] / f32((HD - 1.0) / 2.0) - f32(1)
+    x = (gx + f32(1)) * f32((W - 1) / 2.0)
+    y = (gy + f32(1)) * f32((H - 1) / 2.0)
+    x0, y0 = np.floor(x), np.floor(y)
+    w, n = x - x0, y - y0
+    e, s = f32(1) - w, f32(1) - n
+    x0, y0 = x0.astype(np.int64), y0.astype(np.int64)
+
+    def tex(ix, iy):
+        ok = (ix >= 0) & (ix < W) & (iy >= 0) & (iy < H)
+        v = fmap[:, np.clip(iy, 0, H - 1), np.clip(ix, 0, W - 1)].T
+        return np.where(ok[:, None], v, f32(0))
+    return (tex(x0, y0) * (s * e)[:, None] + tex(x0 + 1, y0) * (s * w)[:, None] + tex(x0, y0 + 1) * (n * e)[:, None]
+            + tex(x0 + 1, y0 + 1) * (n * w)[:, None]).astype(f32)
+
+
+def extract_2d(img_feats, view_ids, layer_ids, intrinsics, c2ws, w2cs, cam_xyz, HD, WD, cam_vid=0, depth_occ=0):
+    """MvsPointsModel.extract_2d (models/mvs/mvs_points_model.py:198-218), batch of one, numpy: img_feats = list over pyramid layers of
+    [V,C,H,W]; intrinsics [V,3,3], c2ws / w2cs [V,4,4], cam_xyz [N,3] -> (out_feats [N, sum], colors [N, 3 per view] or None)"""
+    feats, colors = [], []
+    for vid in view_ids:
+        pix, mask = project_to_view(cam_xyz, c2ws[cam_vid], None if vid == cam_vid else w2cs[vid], intrinsics[vid], HD, WD, depth_occ)
+        pix = np.where(mask[:, None], pix, np.float32(0))                                   # NaN / inf of rejected points
+        for lid in layer_ids:
+            v = grid_sample_bilinear(img_feats[lid][vid], pix, HD, WD) * mask[:, None]
+            (colors if lid == 0 else feats).append(v.astype(np.float32))
+    return np.concatenate(feats, -1), (np.concatenate(colors, -1) if colors else None)
+
+
+def point_dirs(cam_xyz, view_ids, c2ws, w2cs, cam_vid, ref_vid=0, pointdir_w=False):
+    """the "dir" block of query_embedding (models/mvs/mvs_points_model.py:239-251) -> [N, 3 per view]"""
+    f32 = np.float32
+    pos_w = c2ws[view_ids][:, :, 3]                                                            # [V,4]
+    pos_c = (pos_w @ w2cs[cam_vid].T).astype(f32)[:, :3]
+    d = cam_xyz[:, None, :] - pos_c[None]
+    d = d / (np.sqrt((d * d).sum(-1, keepdims=True)).astype(f32) + f32(1e-6))
+    d = (d.reshape(-1, 3) @ c2ws[cam_vid][:3, :3].T).astype(f32)
+    if not pointdir_w:
+        d = (d @ c2ws[ref_vid][:3, :3].T).astype(f32)
+    return d.reshape(len(cam_xyz), -1)
+
+
+def query_embedding(feat_strs, HDWD, cam_xyz, photometric_confidence, img_feats, c2ws, w2cs, intrinsics, cam_vid, pointdir_w=False,
+                    depth_occ=0, ref_vid=0):
+    """MvsPointsModel.query_embedding (models/mvs/mvs_points_model.py:225-259) with shading_feature_mlp_layer0 == 0, batch of one."""
+    emb, colors, dirs, conf = [], None, None, None
+    for s in feat_strs:
+        if s.startswith("imgfeat"):
+            _, v, l = s.split("_")
+            f, colors = extract_2d(img_feats, [int(a) for a in v], [int(a) for a in l], intrinsics, c2ws, w2cs, cam_xyz, HDWD[0], HDWD[1],
+                                   cam_vid=cam_vid, depth_occ=depth_occ)
+            emb.append(f)
+        elif s.startswith("dir"):
+            dirs = point_dirs(cam_xyz, np.array([int(a) for a in s.split("_")[1]]), c2ws, w2cs, cam_vid, ref_vid, pointdir_w)
+        elif s.startswith("point_conf"):
+            conf = np.ones_like(emb[0][:, :1]) if photometric_confidence is None else photometric_confidence
+    return np.concatenate(emb, -1), colors, dirs, conf

@@ -44,6 +44,15 @@ class AdamTensor(ctypes.Structure):
                 ("n", ctypes.c_int64), ("lr", ctypes.c_double), ("step", ctypes.c_int64)]
 
 
+class ViewDesc(ctypes.Structure):
+    _fields_ = [("c2w", c_f32 * 16), ("w2c", c_f32 * 16), ("intrinsic", c_f32 * 9), ("has_w2c", ctypes.c_int32)]
+
+
+class MapDesc(ctypes.Structure):
+    _fields_ = [("d_map", c_void_p), ("view", ctypes.c_int32), ("C", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("out_col", ctypes.c_int32), ("is_color", ctypes.c_int32), ("first_of_view", ctypes.c_int32)]
+
+
 class PointGrads(ctypes.Structure):
     _fields_ = [("embedding", c_void_p), ("conf", c_void_p), ("dir", c_void_p), ("color", c_void_p), ("ready_event", c_void_p)]
 
@@ -68,6 +77,10 @@ PROTOTYPES = {
     "pnerf_zero_one_backward_rays": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_f32, c_void_p, c_void_p, c_void_p]),
     "pnerf_voxel_downsample_workspace_bytes": (c_size_t, [c_i64, c_int, c_int, c_int]),
     "pnerf_voxel_downsample": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pnerf_extract_2d_workspace_bytes": (c_size_t, [c_i64, c_int, c_int, c_int, c_int]),
+    "pnerf_extract_2d": (c_int, [c_void_p, c_i64, ctypes.POINTER(ViewDesc), c_int, ctypes.POINTER(MapDesc), c_int, c_int, c_int, c_int, c_f32,
+                                 c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pnerf_point_dirs": (c_int, [c_void_p, c_i64, ctypes.POINTER(c_f32), c_int, ctypes.POINTER(c_f32), ctypes.POINTER(c_f32), c_void_p, c_void_p]),
     "pnerf_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_i64, c_void_p]),
     "pnerf_adam_step_multi": (c_int, [ctypes.POINTER(AdamTensor), c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_void_p]),
     "pnerf_mlp_layout": (c_int, [c_int, ctypes.POINTER(c_i64)]),

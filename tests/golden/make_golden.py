@@ -16,6 +16,9 @@ What is pinned (the reference has no tests or golden vectors of it
   * refshell.npz (python tests/golden/make_golden.py --shell): the opt.prob == 1 outputs of the forward (:331-362),
     construct_vox_points_closest (models/mvs/mvs_utils.py:537-561), probe_hole (run/train_ft.py:417-540) and test()
     (run/train_ft.py:252-414), all exec'ed from the reference's source text -- see ref_shell()
+  * refembed.npz (python tests/golden/make_golden.py --embed): MvsPointsModel.extract_2d / query_embedding
+    (models/mvs/mvs_points_model.py:198-259) with homo_warp_nongrid, homo_warp_nongrid_occ and extract_from_2d_grid
+    (models/mvs/mvs_utils.py:299-315, 333-369, 411-421), exec'ed from the reference's source text on seeded maps -- see ref_embed()
 Inputs are NOT stored: they are regenerated from seeds by pointnerf_amd/scenes.py,
 oracle/pyref.init_mlp_params and the C oracle query, all deterministic.
 """
@@ -248,8 +251,57 @@ def ref_shell():
 
 
 
+def scatter_min_rows(src, index, dim=1):
+    """torch_scatter.scatter_min(src [1,M], index [1,M], dim=1) -> (min [1,G], argmin [1,G]); groups nothing fell into read 0 like
+    torch_scatter's (the reference only reads groups that exist)"""
+    assert dim == 1 and src.dim() == 2 and src.shape[0] == 1
+    g = int(index.max()) + 1 if index.numel() else 0
+    mn = torch.full((g,), float("inf"), dtype=src.dtype).scatter_reduce(0, index[0], src[0], reduce="amin", include_self=True)
+    mn = torch.where(torch.isinf(mn), torch.zeros_like(mn), mn)
+    return mn[None], torch.zeros(1, g, dtype=torch.int64)
+
+
+def ref_embed():
+    """refembed.npz: MvsPointsModel.extract_2d and .query_embedding (models/mvs/mvs_points_model.py:198-218, 225-259) bound to a stand-in
+    object, on top of homo_warp_nongrid / homo_warp_nongrid_occ / extract_from_2d_grid (models/mvs/mvs_utils.py:299-315, 333-369, 411-421),
+    all exec'ed from the reference's source text (".cuda()" -> ".cpu()"; torch_scatter.scatter_min served by scatter_min_rows)."""
+    import types
+    import torch.nn.functional as F
+    env = dict(torch=torch, F=F, np=np, scatter_min=scatter_min_rows, feature_str_lst=["appr_feature_str0", "appr_feature_str1",
+                                                                                       "appr_feature_str2", "appr_feature_str3"])
+    U = "/root/reference/models/mvs/mvs_utils.py"
+    exec(_cpu_text(_ref_lines(U, 299, 315, "def homo_warp_nongrid(c2w, w2c, intrinsic, ref_cam_xyz, HD, WD, filter=True")), env)
+    exec(_cpu_text(_ref_lines(U, 333, 369, "def homo_warp_nongrid_occ(c2w, w2c, intrinsic, ref_cam_xyz, HD, WD, tolerate=0.1")), env)
+    exec(_cpu_text(_ref_lines(U, 411, 421, "def extract_from_2d_grid(src_feat, src_grid, mask):")), env)
+    M = "/root/reference/models/mvs/mvs_points_model.py"
+    body = _ref_lines(M, 198, 218, "def extract_2d(self, img_feats, view_ids, layer_ids") + "\n\n" + \
+        _ref_lines(M, 225, 259, "def query_embedding(self, HDWD, cam_xyz, photometric_confidence, img_feats")
+    exec("class _Model:\n" + "\n".join("    " + ln for ln in _cpu_text(body).split("\n")), env)
+    from shell_fakes import embed_inputs, EMBED_CASES
+    fix = {}
+    inp = embed_inputs()
+    for tag, (occ, cam_vid, strs, pointdir_w, with_conf) in EMBED_CASES.items():
+        m = env["_Model"]()
+        m.args = types.SimpleNamespace(depth_occ=occ, ref_vid=0, shading_feature_mlp_layer0=0, **{"appr_feature_str%d" % cam_vid: strs})
+        xyz = inp["cam_xyz"] if cam_vid == 0 else \
+            (torch.cat([inp["cam_xyz"], torch.ones_like(inp["cam_xyz"][..., :1])], -1) @ inp["c2ws"][:, 0].transpose(1, 2)
+             @ inp["w2cs"][:, cam_vid].transpose(1, 2))[..., :3].contiguous()
+        emb, col, dirs, conf = m.query_embedding((inp["HD"], inp["WD"]), xyz, inp["photometric_confidence"] if with_conf else None,
+                                                 inp["img_feats"], inp["c2ws"], inp["w2cs"], inp["intrinsics"], cam_vid, pointdir_w=pointdir_w)
+        fix[tag + "_embedding"], fix[tag + "_dirs"] = emb.numpy(), dirs.numpy()
+        if col is not None:
+            fix[tag + "_colors"] = col.numpy()
+        if conf is not None:
+            fix[tag + "_conf"] = conf.numpy()
+        assert float(emb.abs().sum()) > 0 and float((emb.abs().sum(-1) == 0).float().mean()) > 0.02, tag      # both branches of the mask occur
+    np.savez_compressed(os.path.join(HERE, "refembed.npz"), **fix)
+    print("refembed ok", {k: v.shape for k, v in fix.items()})
+
+
 if __name__ == "__main__":
-    if "--blocks" in sys.argv:
+    if "--embed" in sys.argv:
+        ref_embed()
+    elif "--blocks" in sys.argv:
         ref_blocks()
     elif "--shell" in sys.argv:
         ref_shell()
@@ -257,3 +309,4 @@ if __name__ == "__main__":
         main()
         ref_blocks()
         ref_shell()
+        ref_embed()

@@ -169,3 +169,34 @@ def shell_test_setup():
     model.visual_names = ["coarse_raycolor", "gt_image"]
     return o, model, data
 
+
+# ---- the extract_2d / query_embedding fixture (tests/golden/refembed.npz; tests/golden/make_golden.py --embed) ----
+def embed_inputs(seed=5, n=1000, HD=24, WD=32, n_views=3):
+    """seeded inputs of the extract_2d / query_embedding fixture (tests rebuild them with this function): points in the frame of camera
+    0 (some outside its image, a few behind it), three cameras on an arc looking at the cloud, an image + 3-level feature pyramid per view"""
+    g = torch.Generator().manual_seed(seed)
+    xyz = torch.rand(n, 3, generator=g) * torch.tensor([2.4, 1.8, 1.5]) + torch.tensor([-1.2, -0.9, 1.5])
+    xyz[: n // 50, 2] = -xyz[: n // 50, 2]                                            # behind the camera
+    xyz[n // 50: n // 25] = xyz[n // 25: n // 25 + (n // 25 - n // 50)] * torch.tensor([1.0, 1.0, 1.35])   # occluded twins on the same pixels
+    c2ws, w2cs, intr = [], [], []
+    for v in range(n_views):
+        ang = 0.22 * v
+        R = torch.tensor([[np.cos(ang), 0.0, np.sin(ang)], [0.0, 1.0, 0.0], [-np.sin(ang), 0.0, np.cos(ang)]], dtype=torch.float32)
+        c2w = torch.eye(4)
+        c2w[:3, :3] = R
+        c2w[:3, 3] = torch.tensor([0.35 * v, 0.05 * v, -0.1 * v])
+        c2ws.append(c2w); w2cs.append(torch.linalg.inv(c2w))
+        f = 26.0 + v
+        intr.append(torch.tensor([[f, 0.0, (WD - 1) / 2.0 + 0.3 * v], [0.0, f, (HD - 1) / 2.0], [0.0, 0.0, 1.0]]))
+    feats = [torch.rand(n_views, c, HD // d, WD // d, generator=g) for c, d in ((3, 1), (8, 1), (16, 2), (32, 4))]
+    conf = torch.rand(1, n, 1, generator=g)
+    return dict(cam_xyz=xyz[None].contiguous(), c2ws=torch.stack(c2ws)[None], w2cs=torch.stack(w2cs)[None], intrinsics=torch.stack(intr)[None],
+                img_feats=feats, photometric_confidence=conf, HD=HD, WD=WD)
+
+
+EMBED_CASES = {   # tag -> (depth_occ, cam_vid, feature strings of that camera, pointdir_w, pass the confidences)
+    "a": (0, 0, ["imgfeat_0_0123", "dir_0", "point_conf"], False, True),
+    "b": (1, 0, ["imgfeat_0_0123", "dir_0", "point_conf"], False, False),
+    "c": (0, 1, ["imgfeat_012_0123", "dir_012", "point_conf"], True, True),
+    "d": (1, 2, ["imgfeat_201_123", "dir_20"], False, True),
+}

@@ -152,3 +152,14 @@ def test_querier_reads_query_size_at_call_time(monkeypatch):
     q._grid(xyz, 10)
     assert seen == [(3, 3, 3), (5, 5, 5)], seen   # a new grid, dilated with the new size: not the cached one, not the constructor's value
     clear_grid_cache()
+
+
+def test_point_embedding_has_no_cpu_path():
+    import types
+    from pointnerf_amd.mvs_points_model import MvsPointsModel
+    m = MvsPointsModel(types.SimpleNamespace(depth_occ=0, ref_vid=0, shading_feature_mlp_layer0=0))
+    z = torch.zeros(1, 4, 3)
+    with pytest.raises(RuntimeError, match="device tensor"):
+        m.extract_2d([torch.zeros(1, 3, 8, 8)], [0], [0], torch.eye(3)[None, None], torch.eye(4)[None, None], torch.eye(4)[None, None], z, 8, 8)
+    with pytest.raises(NotImplementedError):
+        m.gen_points({})

@@ -168,3 +168,13 @@ def test_emulated_two_plane_weight_gradients():
     for k in gm_o:       # one plane against two planes: the 2^-11 roundings of a few hundred rows, far below the parity bar
         scale = max(float(two[k].abs().max()), 1e-12)
         assert float((one[k] - two[k]).abs().max()) <= 2e-4 * scale, k
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_emulated_extract_2d_and_query_embedding(tag):
+    """csrc/embed2d.hip on the emulator: MvsPointsModel.query_embedding (projection, in-image / z-buffer masks, bilinear sampling of the
+    image + feature pyramid, per-view directions) against the oracle and against the reference's own functions (refembed.npz)."""
+    from embed_case import run_case
+    with emu_backend():
+        err = run_case(tag, "cpu")
+    assert max(err.values()) <= 1e-5, err

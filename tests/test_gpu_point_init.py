@@ -39,3 +39,50 @@ def test_voxel_downsample_lego_scale_properties():
     cell = torch.floor((xyz - smin.cuda()[None]) / vox.cuda()[None]).to(torch.int32)
     assert torch.equal(cell[midx], gidx)
     assert len(torch.unique(cell, dim=0)) == len(gidx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_extract_2d_and_query_embedding(tag):
+    """MvsPointsModel.query_embedding on the device (csrc/embed2d.hip) = the oracle's restatement = the reference's own extract_2d /
+    query_embedding / homo_warp_nongrid(_occ) / extract_from_2d_grid exec'ed from source (tests/golden/refembed.npz): both mask variants,
+    one and three source views, the current camera among them or not, colours, per-view directions."""
+    from embed_case import run_case
+    err = run_case(tag, "cuda:0")
+    print(tag, err)
+    assert max(err.values()) <= 1e-5, err
+
+
+@pytest.mark.gpu
+def test_extract_2d_at_scale_properties():
+    """2 M points x 3 views x the full pyramid: size-independent properties -- rows outside every mask are zero, rows inside are a convex
+    combination of the map's values (min <= value <= max per channel), the colour columns of a constant image are that constant, and the call
+    is deterministic."""
+    import types
+    from shell_fakes import embed_inputs
+    from pointnerf_amd.mvs_points_model import MvsPointsModel
+    inp = embed_inputs(seed=9, n=2_000_000, HD=96, WD=128)
+    dev = "cuda:0"
+    for occ in (0, 1):
+        m = MvsPointsModel(types.SimpleNamespace(depth_occ=occ, ref_vid=0, shading_feature_mlp_layer0=0))
+        feats = [f.to(dev) for f in inp["img_feats"]]
+        feats[0] = torch.full_like(feats[0], 0.25)
+        args = (feats, [0, 1, 2], [0, 1, 2, 3], inp["intrinsics"].to(dev), inp["c2ws"].to(dev), inp["w2cs"].to(dev), inp["cam_xyz"].to(dev),
+                inp["HD"], inp["WD"])
+        f1, c1, mask = m.extract_2d(*args, cam_vid=0, return_mask=True)
+        f2, c2 = m.extract_2d(*args, cam_vid=0)
+        assert torch.equal(f1, f2) and torch.equal(c1, c2)
+        assert f1.shape == (1, 2_000_000, 168) and c1.shape == (1, 2_000_000, 9)
+        for v in range(3):
+            mv = mask[v]
+            assert 0.02 < float(mv.float().mean()) < 0.98
+            fv, cv = f1[0, :, 56 * v:56 * (v + 1)], c1[0, :, 3 * v:3 * (v + 1)]
+            assert float(fv[~mv].abs().max()) == 0.0 and float(cv[~mv].abs().max()) == 0.0
+            assert float((cv[mv] - 0.25).abs().max()) <= 1e-6
+            col = 0
+            for lid in (1, 2, 3):
+                fm = feats[lid][v]
+                lo, hi = fm.amin(dim=(1, 2)), fm.amax(dim=(1, 2))
+                blk = fv[mv][:, col:col + fm.shape[0]]
+                assert bool((blk >= lo - 1e-6).all()) and bool((blk <= hi + 1e-6).all())
+                col += fm.shape[0]

@@ -79,3 +79,27 @@ def test_ray_dist_and_fill_invalid_match_the_reference_source():
     full = pyref.fill_invalid(out, inp)
     for k in ("coarse_is_background", "coarse_mask", "coarse_raycolor", "coarse_point_opacity"):
         assert np.array_equal(full[k].numpy(), fix["fill_" + k]), k
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_query_embedding_restatement_equals_the_reference_functions(tag):
+    """oracle/pyref.query_embedding / extract_2d / project_to_view / grid_sample_bilinear / point_dirs against MvsPointsModel.query_embedding
+    + homo_warp_nongrid(_occ) + extract_from_2d_grid of the reference, exec'ed from its source text (tests/golden/make_golden.py --embed):
+    every mask decision identical, values to fp32 rounding."""
+    import os
+    import embed_case as E
+    from shell_fakes import embed_inputs, EMBED_CASES
+    occ, cam_vid, strs, pointdir_w, with_conf = EMBED_CASES[tag]
+    inp = embed_inputs()
+    xyz = E.cam_points(inp, cam_vid)[0].numpy()
+    got = pyref.query_embedding(strs, (inp["HD"], inp["WD"]), xyz, inp["photometric_confidence"][0].numpy() if with_conf else None,
+                                [f.numpy() for f in inp["img_feats"]], inp["c2ws"][0].numpy(), inp["w2cs"][0].numpy(),
+                                inp["intrinsics"][0].numpy(), cam_vid, pointdir_w, occ)
+    fx = np.load(E.FIX)
+    for name, g in zip(("embedding", "colors", "dirs", "conf"), got):
+        key = "%s_%s" % (tag, name)
+        if g is None:
+            assert key not in fx.files
+            continue
+        assert np.array_equal(np.abs(g).sum(-1) == 0, np.abs(fx[key][0]).sum(-1) == 0), key        # the same rows masked out
+        assert float(np.abs(g - fx[key][0]).max()) <= 5e-7, key

@@ -105,3 +105,17 @@ def test_reference_forward_body_runs_module_by_module_on_the_overlay():
     print(out)
     assert out["network"] == "models._reference_neural_points_volumetric_model" and out["updated"]
     assert abs(out["loss"] - out["oracle"]) <= 1e-5 * max(1.0, abs(out["oracle"]))
+
+
+def test_overlay_serves_extract_2d_and_query_embedding_of_the_reference_class():
+    """models/mvs/mvs_points_model.py through the overlay is the reference's module (gen_points, the networks: its own code) whose
+    extract_2d / query_embedding are the library's."""
+    U.install()
+    import models.mvs.mvs_points_model as M
+    from pointnerf_amd import mvs_points_model as A
+    assert M._ref.__file__.startswith(U.REF)
+    assert M.MvsPointsModel is M._ref.MvsPointsModel and M.MvsPointsModel.__module__ == "models.mvs._reference_mvs_points_model"
+    assert M.MvsPointsModel.extract_2d is A.MvsPointsModel.extract_2d and M.MvsPointsModel.query_embedding is A.MvsPointsModel.query_embedding
+    assert "gen_points" in vars(M._ref.MvsPointsModel) and M.MvsPointsModel.gen_points is not A.MvsPointsModel.gen_points
+    import models.mvs_points_volumetric_model as shell
+    assert shell.MvsPointsModel is M.MvsPointsModel

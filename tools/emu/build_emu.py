@@ -14,8 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 SRC = os.path.join(ROOT, "pointnerf_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "_build", "emu")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-FILES = ["scan", "grid", "query", "aggregate", "render", "backward", "optim", "pointinit", "prof"]
-EXACT = {"grid", "query", "pointinit"}
+FILES = ["scan", "grid", "query", "aggregate", "render", "backward", "optim", "pointinit", "embed2d", "prof"]
+EXACT = {"grid", "query", "pointinit", "embed2d"}
 OPT = {}
 
 
