@@ -171,7 +171,7 @@ def shell_test_setup():
 
 
 # ---- the extract_2d / query_embedding fixture (tests/golden/refembed.npz; tests/golden/make_golden.py --embed) ----
-def embed_inputs(seed=5, n=1000, HD=24, WD=32, n_views=3):
+def embed_inputs(seed=5, n=1000, HD=24, WD=32, n_views=3, focal=26.0):
     """seeded inputs of the extract_2d / query_embedding fixture (tests rebuild them with this function): points in the frame of camera
     0 (some outside its image, a few behind it), three cameras on an arc looking at the cloud, an image + 3-level feature pyramid per view"""
     g = torch.Generator().manual_seed(seed)
@@ -186,7 +186,7 @@ def embed_inputs(seed=5, n=1000, HD=24, WD=32, n_views=3):
         c2w[:3, :3] = R
         c2w[:3, 3] = torch.tensor([0.35 * v, 0.05 * v, -0.1 * v])
         c2ws.append(c2w); w2cs.append(torch.linalg.inv(c2w))
-        f = 26.0 + v
+        f = focal + v
         intr.append(torch.tensor([[f, 0.0, (WD - 1) / 2.0 + 0.3 * v], [0.0, f, (HD - 1) / 2.0], [0.0, 0.0, 1.0]]))
     feats = [torch.rand(n_views, c, HD // d, WD // d, generator=g) for c, d in ((3, 1), (8, 1), (16, 2), (32, 4))]
     conf = torch.rand(1, n, 1, generator=g)
