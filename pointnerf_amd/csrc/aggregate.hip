@@ -156,7 +156,7 @@ size_t pn_saved_bytes(long long n_valid, int K, long long *rows_out, long long *
     size_t b = 0;
     b += 2 * pn_align((size_t)rows / 8 * PN_NF1 * 16) + 2 * pn_align((size_t)rows / 8 * PN_H * 16);      // x0k, h2k | h1k, h3k (one plane)
     b += 4 * pn_align((size_t)rows / 8 * PN_H * 16) + pn_align((size_t)rows * 32 * 32);                // dy1k..dy4k (one plane) | h4r
-    b += pn_align((size_t)rows * 4) + pn_align((size_t)rows * 16) + pn_align((size_t)tiles * 3 * PN_NTHR * 8) + pn_align(16);
+    b += pn_align((size_t)rows * 4) + pn_align((size_t)rows * 16) + pn_align((size_t)tiles * 3 * 512 * 4) + pn_align(16);
     b += pn_cls_bytes(samples);
     b += 2 * pn_align((size_t)samples * PN_H * 4) + pn_align((size_t)samples * PN_HC * 4);                         // fs, dfs | c3
     b += pn_align((size_t)samples / 8 * PN_NF1 * 16) + 2 * pn_align((size_t)samples / 8 * PN_HC * 16);              // xck | c1k, c2k (one plane)
@@ -179,7 +179,7 @@ PnSaved pn_saved_carve(void *base, long long n_valid, int K) {
     s.dy3k = cv.take<uint4>(rg * PN_H); s.dy4k = cv.take<uint4>(rg * PN_H);
     s.h4r = cv.take<uint4>((size_t)s.rows * 32 * 2);
     s.arow = cv.take<float>((size_t)s.rows); s.rmeta = cv.take<int4>((size_t)s.rows);
-    s.lmask = cv.take<unsigned long long>((size_t)(s.rows / PN_TILE) * 3 * PN_NTHR);
+    s.lmask = cv.take<unsigned>((size_t)(s.rows / PN_TILE) * 3 * 512);
     s.gscale = cv.take<unsigned>(4);
     s.fs = cv.take<float>((size_t)s.samples * PN_H); s.dfs = cv.take<float>((size_t)s.samples * PN_H);
     s.c3 = cv.take<float>((size_t)s.samples * PN_HC);
@@ -421,6 +421,7 @@ __device__ __forceinline__ void f_build(const FwdArgs &a, const FGather &G, char
         pn_x_store2(X, row, PN_F + dd * 6, s[0], c[0]);
         pn_x_store2(X, row, PN_F + dd * 6 + 2, s[1], c[1]);
         pn_x_store2(X, row, PN_F + dd * 6 + 4, s[2], c[2]);
+        if (PN_NW == 8 && (i & 1)) __builtin_amdgcn_sched_barrier(0);      // (register budget of the 8-wave organisation)
     }
     // PE5 of distance components q and q + 4
 #pragma unroll
@@ -452,29 +453,31 @@ __device__ __forceinline__ void f_build(const FwdArgs &a, const FGather &G, char
 // The bias is the accumulators' INITIAL value (D = W X^T + b: a lane's element (fb, rb, g, i) belongs to feature pn_d_feat(..) + i, the
 // same for both row blocks): requested before the tile's copy-out, in the accumulators when the GEMM starts -- the epilogue then holds
 // no global data at all (round 2 loaded it behind the GEMM, and behind the next tile's gather in the in-order vmcnt queue).
-__device__ __forceinline__ void f_acc_bias(const float *__restrict__ bias, int wave, int lane, f32x16 (&acc)[2][2]) {
+__device__ __forceinline__ void f_acc_bias(const float *__restrict__ bias, int wave, int lane, f32x16 (&acc)[PN_NFB][2]) {
 #pragma unroll
-    for (int fb = 0; fb < 2; ++fb)
+    for (int fb = 0; fb < PN_NFB; ++fb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 b = *reinterpret_cast<const float4 *>(bias + pn_d_feat(2 * wave + fb, g, lane));
+            const float4 b = *reinterpret_cast<const float4 *>(bias + pn_d_feat(PN_NFB * wave + fb, g, lane));
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) { acc[fb][rb][4 * g] = b.x; acc[fb][rb][4 * g + 1] = b.y; acc[fb][rb][4 * g + 2] = b.z; acc[fb][rb][4 * g + 3] = b.w; }
         }
 }
 // epilogue of a layer: LeakyReLU of the accumulators (bias included), sign bits, both planes -> the tile (columns 0..255).
 // Sign word: one v_alignbit_b32 per element shifts the element's sign bit into a 32-bit accumulator (MSB first), element
-// e = ((fb * 2 + rb) * 4 + g) * 4 + i of a lane -> bit 31 - (e & 31) of half e >> 5; bit set = negative = slope 0.01 in the backward
+// e = (rb * 4 + g) * 4 + i of a lane's feature block -> bit 31 - e of the block's word; bit set = negative = slope 0.01 in the backward.
+// mw[fb] = the word of the wave's feature block fb (global block PN_NFB * wave + fb): stored as lmask[tile][layer][block][lane].
 template <bool BITS>
-__device__ __forceinline__ void f_epilogue(const f32x16 (&acc)[2][2], char *X, int wave, int lane, unsigned long long &mask) {
-    unsigned mw[2] = {0u, 0u};
+__device__ __forceinline__ void f_epilogue(const f32x16 (&acc)[PN_NFB][2], char *X, int wave, int lane, unsigned (&mw)[PN_NFB]) {
 #pragma unroll
-    for (int fb = 0; fb < 2; ++fb)
+    for (int fb = 0; fb < PN_NFB; ++fb) mw[fb] = 0u;
+#pragma unroll
+    for (int fb = 0; fb < PN_NFB; ++fb)
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int f0 = pn_d_feat(2 * wave + fb, g, lane);
+                const int f0 = pn_d_feat(PN_NFB * wave + fb, g, lane);
                 float v[4] = {acc[fb][rb][4 * g], acc[fb][rb][4 * g + 1], acc[fb][rb][4 * g + 2], acc[fb][rb][4 * g + 3]};
                 if (BITS) {
 #pragma unroll
@@ -484,12 +487,16 @@ __device__ __forceinline__ void f_epilogue(const f32x16 (&acc)[2][2], char *X, i
                 for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.01f * v[i]);
                 pn_x_store4<false>(X, 32 * rb + (lane & 31), f0, v[0], v[1], v[2], v[3]);
             }
-    mask = ((unsigned long long)mw[1] << 32) | mw[0];
+}
+// the sign words of a layer -> lmask[gtile][layer][block][lane]
+__device__ __forceinline__ void f_store_masks(unsigned *__restrict__ lmask, long long gtile, int layer, int wave, int lane, const unsigned (&mw)[PN_NFB]) {
+#pragma unroll
+    for (int fb = 0; fb < PN_NFB; ++fb) lmask[((gtile * 3 + layer) * 8 + PN_NFB * wave + fb) * 64 + lane] = mw[fb];
 }
 
-__device__ __forceinline__ void f_acc_zero(f32x16 (&acc)[2][2]) {
+__device__ __forceinline__ void f_acc_zero(f32x16 (&acc)[PN_NFB][2]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < PN_NFB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -541,6 +548,8 @@ __device__ __forceinline__ void f_tail(const FwdArgs &a, const char *X, const fl
         float4 &f0 = fa[i / KC], &f1 = fb[i / KC];
         f0.x = pn_fma2_lo(h.x, m.x, w, f0.x); f0.y = pn_fma2_hi(h.x, m.x, w, f0.y); f0.z = pn_fma2_lo(h.y, m.y, w, f0.z); f0.w = pn_fma2_hi(h.y, m.y, w, f0.w);
         f1.x = pn_fma2_lo(h.z, m.z, w, f1.x); f1.y = pn_fma2_hi(h.z, m.z, w, f1.y); f1.z = pn_fma2_lo(h.w, m.w, w, f1.z); f1.w = pn_fma2_hi(h.w, m.w, w, f1.w);
+        // 128 registers per wave in the 8-wave organisation: at most two rows' planes in flight (the scheduler otherwise hoists all 16 reads)
+        if (PN_NW == 8 && (i & 1)) __builtin_amdgcn_sched_barrier(0);
     }
     // f rows of the thread's samples (class-ordered list: the colour MLP reads them in that order)
 #pragma unroll
@@ -582,7 +591,7 @@ PN_TR_DECL(pn_trace_fwd);
 #endif
 // WG2: the two-plane weight-gradient mode (pnerf_set_wgrad_planes(2)): every saved GEMM operand also leaves its residual plane, X0 whole
 template <bool TRAIN, bool PERS, int NP, bool WG2 = false>
-__global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
+__global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_f[];
     char *X = smem_f;
     float *exb = reinterpret_cast<float *>(smem_f + FL_EX), *w5s = reinterpret_cast<float *>(smem_f + FL_W5);
@@ -608,15 +617,19 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
     long long tile = blockIdx.x;
     int si0, si1, si2, p0, p1;
     FGather G;
-    {
-        const int row = tid0 / TPR, q = tid0 % TPR, k = row - pn_row_div(row, kinv) * K;
+    // Roles in the 8-wave organisation: the LAST PN_ETHR threads (waves 4..7) own the gather + feature build + row weights (4 threads per
+    // tile row), the FIRST PN_ETHR threads (waves 0..3) own the tail.  The next tile's gathered point data is in flight across the tail:
+    // with both roles on the same waves it does not fit 128 registers beside the tail's rows (the compiler spilled it, i.e. waited for it).
+    si0 = si1 = si2 = p0 = p1 = -1;
+    if (tid0 >= PN_NTHR - PN_ETHR) {
+        const int bt = tid0 - (PN_NTHR - PN_ETHR), row = bt / TPR, q = bt % TPR, k = row - pn_row_div(row, kinv) * K;
         si0 = f_sample_of(a, tile, row, Ns, kinv); si1 = f_sample_of(a, tile + stride, row, Ns, kinv); si2 = f_sample_of(a, tile + 2 * stride, row, Ns, kinv);
         p0 = si0 >= 0 ? a.pidx[(long long)si0 * a.Kstride + k] : -1;
         p1 = si1 >= 0 ? a.pidx[(long long)si1 * a.Kstride + k] : -1;
         f_gather<PERS>(a, G, si0, p0, q);
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[PN_NFB][2];
     PN_TR_ITER_DECL;
     for (; tile < ntiles; tile += stride) {
         PN_TR_ITER_NEXT;
@@ -624,13 +637,22 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         // registers (every LDS / bias / image address of every unrolled store) and spill
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), row = tid / TPR, q = tid % TPR, k = row - pn_row_div(row, kinv) * K;
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const bool ew = PN_NTHR == PN_ETHR || tid < PN_ETHR;               // this thread works in the tail
+        const bool bw = PN_NTHR == PN_ETHR || tid >= PN_NTHR - PN_ETHR;    // this thread works in the gather / feature build
+        const int bt = bw ? tid - (PN_NTHR - PN_ETHR) : 0, row = bt / TPR, q = bt % TPR, k = row - pn_row_div(row, kinv) * K;
         const long long gtile = tb + tile;               // tile index inside the saved area
         PN_LDS_BARRIER();                                 // the previous tile's readers are done with X and the row arrays
         PN_TR(pn_trace_fwd, 0); PN_TR_HWID(pn_trace_fwd);
-        f_build<PERS>(a, G, X, exb, wraw, sidx, si0, p0, row, q);
+        if (bw) f_build<PERS>(a, G, X, exb, wraw, sidx, si0, p0, row, q);
+        // Round 4: what the next GEMM needs from GLOBAL memory -- its bias (the accumulators' initial value) and its first weight-fragment
+        // chunks -- is requested in front of the barrier that precedes it, not behind: neither depends on LDS, and the L2 round trip
+        // (0.6 .. 1.1 us per layer in profiles/r03_phase_trace.json: the "acc = bias" phases) passes under the barrier wait.
+        f_acc_bias(P + PO_B1, wave, lane, acc);
+        PnGemmW<18, 8, PN_NFB, PN_WPF, NP> W1;
+        W1.prefetch(reinterpret_cast<const uint4 *>(img + PKH_F1), PN_NFB * wave, lane);
         PN_LDS_BARRIER();
-        if (q == 0) {      // weights of the row: normalise over the K slots, multiply by the clamped confidence (:801-811)
+        if (bw && q == 0) {      // weights of the row: normalise over the K slots, multiply by the clamped confidence (:801-811)
             const int ls = pn_row_div(row, kinv);
             float wn = 0.f, w = 0.f;
             if (si0 >= 0) {
@@ -643,35 +665,36 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
             wnrm[row] = wn; wrow[row] = w;
             if (TRAIN) a.sv.rmeta[gtile * PN_TILE + row] = make_int4(si0, si0 >= 0 ? p0 : -1, __float_as_int(wn), __float_as_int(w));
         }
-        unsigned long long mask;
+        unsigned mask[PN_NFB];
         PN_TR(pn_trace_fwd, 1);
         // ---- layer 1: 288 -> 256.  Training: the layer's input tile is copied out (k-major planes for the weight-gradient GEMM) BEHIND the
         // layer's GEMM, not in front of it: vmcnt counts loads and stores of a wave in ONE in-order queue, so a GEMM that starts right
         // behind 20 stores waits for their acknowledgements from HBM before its first weight fragment counts as arrived (round 2 order:
         // every GEMM phase carried 1 .. 3 us of that).  Behind the GEMM the stores have the epilogue and two barriers to drain.
-        f_acc_bias(P + PO_B1, wave, lane, acc);
         PN_TR(pn_trace_fwd, 2);
-        pn_gemm_f16x3<18, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F1), 2 * wave, lane, acc);
+        pn_gemm_f16x3_run<18, 8, PN_NFB, PN_WPF, NP>(X, W1, lane, acc);
         if (TRAIN) {           // (behind the GEMM: see above)
-            if (WG2) pn_copy_out_kmajor<PN_NF1, true>(X, a.sv.x0k, gtile * 8, tid, a.sv.x0m);
-            else if (a.save_x0) pn_copy_out_kmajor<PN_NF1>(X, a.sv.x0k, gtile * 8, tid);
-            else pn_copy_out_kmajor_cols64<224>(X, a.sv.x0k, gtile * 8, tid);       // the fused path: only the last 64 columns (k_wgrad_x0)
+            if (WG2) pn_copy_out_kmajor<PN_NF1, true, PN_NW>(X, a.sv.x0k, gtile * 8, tid, a.sv.x0m);
+            else if (a.save_x0) pn_copy_out_kmajor<PN_NF1, false, PN_NW>(X, a.sv.x0k, gtile * 8, tid);
+            else pn_copy_out_kmajor_cols64<224, PN_NW>(X, a.sv.x0k, gtile * 8, tid);       // the fused path: only the last 64 columns (k_wgrad_x0)
         }
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 3);
         f_epilogue<TRAIN>(acc, X, wave, lane, mask);
-        if (TRAIN) a.sv.lmask[(gtile * 3 + 0) * PN_NTHR + tid] = mask;
+        if (TRAIN) f_store_masks(a.sv.lmask, gtile, 0, wave, lane, mask);
+        f_acc_bias(P + PO_B2, wave, lane, acc);
+        PnGemmW<16, 8, PN_NFB, PN_WPF, NP> W2;
+        W2.prefetch(reinterpret_cast<const uint4 *>(img + PKH_F2), PN_NFB * wave, lane);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 4);
         // ---- layer 2: 256 -> 256
-        f_acc_bias(P + PO_B2, wave, lane, acc);
         PN_TR(pn_trace_fwd, 5);
-        pn_gemm_f16x3<16, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F2), 2 * wave, lane, acc);
-        if (TRAIN) pn_copy_out_kmajor<PN_H, WG2>(X, a.sv.h1k, gtile * 8, tid, a.sv.h1m);      // (behind the GEMM: see below)
+        pn_gemm_f16x3_run<16, 8, PN_NFB, PN_WPF, NP>(X, W2, lane, acc);
+        if (TRAIN) pn_copy_out_kmajor<PN_H, WG2, PN_NW>(X, a.sv.h1k, gtile * 8, tid, a.sv.h1m);      // (behind the GEMM: see below)
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 6);
         f_epilogue<TRAIN>(acc, X, wave, lane, mask);
-        if (TRAIN) a.sv.lmask[(gtile * 3 + 1) * PN_NTHR + tid] = mask;
+        if (TRAIN) f_store_masks(a.sv.lmask, gtile, 1, wave, lane, mask);
         if (tid < PN_TILE) {     // the row's extras next to h2: columns 256..262, the ones column, zeros up to 271
             const float4 u = *reinterpret_cast<const float4 *>(exb + tid * 8), v = *reinterpret_cast<const float4 *>(exb + tid * 8 + 4);
             pn_x_store4<false>(X, tid, PN_H, u.x, u.y, u.z, u.w);
@@ -679,33 +702,39 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
             pn_x_store4<false>(X, tid, PN_H + 8, 0.f, 0.f, 0.f, 0.f);
             pn_x_store4<false>(X, tid, PN_H + 12, 0.f, 0.f, 0.f, 0.f);
         }
+        f_acc_bias(P + PO_B3, wave, lane, acc);
+        PnGemmW<17, 8, PN_NFB, PN_WPF, NP> W3;
+        W3.prefetch(reinterpret_cast<const uint4 *>(img + PKH_F3), PN_NFB * wave, lane);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 7);
         // ---- layer 3: 256 + 7 -> 256
-        f_acc_bias(P + PO_B3, wave, lane, acc);
         PN_TR(pn_trace_fwd, 8);
-        pn_gemm_f16x3<17, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F3), 2 * wave, lane, acc);
-        if (TRAIN) pn_copy_out_kmajor<PN_NF1, WG2>(X, a.sv.h2k, gtile * 8, tid, a.sv.h2m);      // (behind the GEMM: see below)
+        pn_gemm_f16x3_run<17, 8, PN_NFB, PN_WPF, NP>(X, W3, lane, acc);
+        if (TRAIN) pn_copy_out_kmajor<PN_NF1, WG2, PN_NW>(X, a.sv.h2k, gtile * 8, tid, a.sv.h2m);      // (behind the GEMM: see below)
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 9);
         f_epilogue<TRAIN>(acc, X, wave, lane, mask);
-        if (TRAIN) a.sv.lmask[(gtile * 3 + 2) * PN_NTHR + tid] = mask;
+        if (TRAIN) f_store_masks(a.sv.lmask, gtile, 2, wave, lane, mask);
+        f_acc_bias(P + PO_B4, wave, lane, acc);
+        PnGemmW<16, 8, PN_NFB, PN_WPF, NP> W4;
+        W4.prefetch(reinterpret_cast<const uint4 *>(img + PKH_F4), PN_NFB * wave, lane);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 10);
         // ---- layer 4: 256 -> 256
-        f_acc_bias(P + PO_B4, wave, lane, acc);
         PN_TR(pn_trace_fwd, 11);
-        pn_gemm_f16x3<16, 8, 2, PN_WPF, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_F4), 2 * wave, lane, acc);
-        if (TRAIN) pn_copy_out_kmajor<PN_H, WG2>(X, a.sv.h3k, gtile * 8, tid, a.sv.h3m);
+        pn_gemm_f16x3_run<16, 8, PN_NFB, PN_WPF, NP>(X, W4, lane, acc);
+        if (TRAIN) pn_copy_out_kmajor<PN_H, WG2, PN_NW>(X, a.sv.h3k, gtile * 8, tid, a.sv.h3m);
         PN_TR(pn_trace_fwd, 12);
         // the next tile's point data and the indices of the two after it: requested here, consumed at the top of the next
         // iteration -- their HBM latency passes under the element-wise tail of this tile (nothing of this tile waits for memory any more)
         const float cf_cur = G.cf;
         (void)cf_cur;
         const int si_next = si1, p_next = p1;
-        if (tile + stride < ntiles) f_gather<PERS>(a, G, si1, p1, q);
+        // (8 waves: the gather is issued by the build waves WHILE the tail waves run the tail, in the other arm of that branch -- then the
+        //  tail's code never holds the gathered registers)
+        if (PN_NW != 8 && tile + stride < ntiles) f_gather<PERS>(a, G, si1, p1, q);
         const int p2 = si2 >= 0 ? a.pidx[(long long)si2 * a.Kstride + k] : -1;
-        const int si3 = f_sample_of(a, tile + 3 * stride, row, Ns, kinv);
+        const int si3 = bw ? f_sample_of(a, tile + 3 * stride, row, Ns, kinv) : -1;
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 13);
         f_epilogue<false>(acc, X, wave, lane, mask);
@@ -713,30 +742,45 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_forward(FwdArgs a) {
         PN_TR(pn_trace_fwd, 14);
         if (K == 8 || K == 4 || K == 2 || K == 1) {
             // ---- alpha head + h4 copy + K-weighted sums + sigma in one pass (f_tail)
-            if (K == 8) f_tail<8, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
+#ifdef PN_EXP_NOTAIL
+            if (!ew) { if (PN_NW == 8 && tile + stride < ntiles) f_gather<PERS>(a, G, si1, p1, q); }
+#elif defined(PN_EXP_NOGATHER)
+            if (!ew) { }
+            else if (K == 8) f_tail<8, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
+#elif defined(PN_EXP_TAIL8)
+            if (!ew) { if (PN_NW == 8 && tile + stride < ntiles) f_gather<PERS>(a, G, si1, p1, q); }
+            else f_tail<8, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
+#else
+            if (!ew) { if (PN_NW == 8 && tile + stride < ntiles) f_gather<PERS>(a, G, si1, p1, q); }
+            else if (K == 8) f_tail<8, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
+#endif
+#if !defined(PN_EXP_NOTAIL) && !defined(PN_EXP_TAIL8)
             else if (K == 4) f_tail<4, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
             else if (K == 2) f_tail<2, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
             else f_tail<1, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
+#endif
             PN_TR(pn_trace_fwd, 15);
         } else {
         // ---- (any other K: three passes) alpha head (256 -> 1, softplus(x - 1), raw2out_density :262-265): 4 threads per row, 8-column groups interleaved
-        {
+        if (PN_NW == 8 && bw && tile + stride < ntiles) f_gather<PERS>(a, G, si1, p1, q);      // (8 waves: the build waves' prefetch, see above)
+        if (ew) {
+            const int trow = tid / TPR, tq = tid % TPR;
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int c0 = 8 * (q + 4 * j);
-                s = pn_x_dot8(X, row, c0, *reinterpret_cast<const float4 *>(w5s + c0), *reinterpret_cast<const float4 *>(w5s + c0 + 4), s);
+                const int c0 = 8 * (tq + 4 * j);
+                s = pn_x_dot8(X, trow, c0, *reinterpret_cast<const float4 *>(w5s + c0), *reinterpret_cast<const float4 *>(w5s + c0 + 4), s);
             }
             s = group_sum<TPR>(s);
-            if (q == 0) {
+            if (tq == 0) {
                 const float x = s + b5 - 1.0f;
-                wraw[row] = pn_softplus(x) * wrow[row];
-                if (TRAIN) a.sv.arow[gtile * PN_TILE + row] = x;
+                wraw[trow] = pn_softplus(x) * wrow[trow];
+                if (TRAIN) a.sv.arow[gtile * PN_TILE + trow] = x;
             }
         }
         if (TRAIN) {     // h4 planes, row-major, for the backward's alpha head
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 4096 / PN_NTHR; ++i) {
                 const int e = tid + PN_NTHR * i, plane = e >> 11, r = (e >> 5) & 63, u = e & 31;
                 const uint4 v = *reinterpret_cast<const uint4 *>(X + plane * PN_XPLANE + r * PN_XRS + u * 16);
                 pn_f4 t = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
@@ -833,6 +877,10 @@ __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), row = tid >> 2, q = tid & 3;
         const long long grow0 = tile * PN_CTILE, vs = grow0 + row;
         const int si = vs < Ns ? a.valid_list[vs] : -1;
+        // (round 4: the first weight-fragment chunks of a GEMM -- here 7 of a layer's 8 or 18 -- are requested in front of the barrier that
+        //  precedes it; a colour tile has 3.5 us of MFMA work in ~25 us, the L2 round trips at the start of its three GEMMs were exposed)
+        PnGemmW<18, 4, 1, 7, NP> WC1;
+        WC1.prefetch(reinterpret_cast<const uint4 *>(img + PKH_FC1), wave, lane);
         PN_LDS_BARRIER();                                 // the previous tile's readers are done with X
         if (si >= 0) {
             const float4 *f = reinterpret_cast<const float4 *>(a.sv.fs + vs * PN_H + q * 64);
@@ -865,25 +913,29 @@ __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
         // ---- layer 1: 280 (288) -> 128.  Training: every layer's input tile leaves k-major for the weight-gradient GEMM
         if (TRAIN) pn_copy_out_kmajor<PN_NF1, WG2>(X, a.sv.xck, tile * 8, tid, a.sv.xcm);
         c_acc_zero(acc);
-        pn_gemm_f16x3<18, 4, 1, 7, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_FC1), wave, lane, acc);
+        pn_gemm_f16x3_run<18, 4, 1, 7, NP>(X, WC1, lane, acc);
         c_load_bias(P + PO_BC1, wave, lane, bias);
         PN_LDS_BARRIER();                                 // every wave is done reading the input tile
         unsigned mw = c_epilogue<TRAIN, false>(acc, bias, X, wave, lane, nullptr, grow0);
         if (TRAIN) a.sv.cmask[(tile * 2 + 0) * 256 + tid] = mw;
+        PnGemmW<8, 4, 1, 7, NP> WC2;
+        WC2.prefetch(reinterpret_cast<const uint4 *>(img + PKH_FC2), wave, lane);
         PN_LDS_BARRIER();
         // ---- layer 2
         if (TRAIN) pn_copy_out_kmajor<PN_HC, WG2>(X, a.sv.c1k, tile * 8, tid, a.sv.c1m);
         c_acc_zero(acc);
-        pn_gemm_f16x3<8, 4, 1, 7, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_FC2), wave, lane, acc);
+        pn_gemm_f16x3_run<8, 4, 1, 7, NP>(X, WC2, lane, acc);
         c_load_bias(P + PO_BC2, wave, lane, bias);
         PN_LDS_BARRIER();
         mw = c_epilogue<TRAIN, false>(acc, bias, X, wave, lane, nullptr, grow0);
         if (TRAIN) a.sv.cmask[(tile * 2 + 1) * 256 + tid] = mw;
+        PnGemmW<8, 4, 1, 7, NP> WC3;
+        WC3.prefetch(reinterpret_cast<const uint4 *>(img + PKH_FC3), wave, lane);
         PN_LDS_BARRIER();
         // ---- layer 3
         if (TRAIN) pn_copy_out_kmajor<PN_HC, WG2>(X, a.sv.c2k, tile * 8, tid, a.sv.c2m);
         c_acc_zero(acc);
-        pn_gemm_f16x3<8, 4, 1, 7, NP>(X, reinterpret_cast<const uint4 *>(img + PKH_FC3), wave, lane, acc);
+        pn_gemm_f16x3_run<8, 4, 1, 7, NP>(X, WC3, lane, acc);
         c_load_bias(P + PO_BC3, wave, lane, bias);
         PN_LDS_BARRIER();
         c_epilogue<TRAIN, true>(acc, bias, X, wave, lane, a.sv.c3, grow0);

@@ -213,33 +213,40 @@ __global__ __launch_bounds__(256, 3) void k_color_backward(BwdArgs a) {
                 atomicAdd(gacc + 3 * PN_HC + 4 * c4 + i, gb3[i]);
             }
         }
+        // (round 4: the first weight chunks of each GEMM are requested in front of the barrier that precedes it: see k_color_forward)
+        PnGemmW<8, 4, 1, 4, 3> WD3;
+        WD3.prefetch(reinterpret_cast<const uint4 *>(img + PKH_DC3), wave, lane);
         PN_LDS_BARRIER();
         // ---- d c2 = (d c3 @ Wc3) * lrelu'(c2)
         pn_copy_out_kmajor_h<PN_HC, CB_XRS>(X, a.sv.dc3k, tile * 8, tid);
         if (WG2) pn_copy_out_kmajor_h<PN_HC, CB_XRS>(X + CB_XPL, a.sv.dc3m, tile * 8, tid);
         const unsigned mw2 = a.sv.cmask[(tile * 2 + 1) * 256 + tid], mw1 = a.sv.cmask[(tile * 2 + 0) * 256 + tid];
         cb_acc_zero(acc);
-        pn_gemm_f16x3<8, 4, 1, 4, 3, CB_XRS, CB_XPL>(X, reinterpret_cast<const uint4 *>(img + PKH_DC3), wave, lane, acc);
+        pn_gemm_f16x3_run<8, 4, 1, 4, 3, CB_XRS, CB_XPL>(X, WD3, lane, acc);
         row_values(si_next);                              // (the next tile's six values: consumed at the top of the next iteration)
         si_cur = si_next;
         PN_LDS_BARRIER();
         cb_epilogue(acc, mw2, X, wave, lane);
+        PnGemmW<8, 4, 1, 4, 3> WD2;
+        WD2.prefetch(reinterpret_cast<const uint4 *>(img + PKH_DC2), wave, lane);
         PN_LDS_BARRIER();
         cb_bias_sums(X, tid, gacc + 4 * PN_HC);
         // ---- d c1 = (d c2 @ Wc2) * lrelu'(c1)
         pn_copy_out_kmajor_h<PN_HC, CB_XRS>(X, a.sv.dc2k, tile * 8, tid);
         if (WG2) pn_copy_out_kmajor_h<PN_HC, CB_XRS>(X + CB_XPL, a.sv.dc2m, tile * 8, tid);
         cb_acc_zero(acc);
-        pn_gemm_f16x3<8, 4, 1, 4, 3, CB_XRS, CB_XPL>(X, reinterpret_cast<const uint4 *>(img + PKH_DC2), wave, lane, acc);
+        pn_gemm_f16x3_run<8, 4, 1, 4, 3, CB_XRS, CB_XPL>(X, WD2, lane, acc);
         PN_LDS_BARRIER();
         cb_epilogue(acc, mw1, X, wave, lane);
+        PnGemmW<8, 8, 2, 1, 3> WD1;
+        WD1.prefetch(reinterpret_cast<const uint4 *>(img + PKH_DC1), 2 * wave, lane);
         PN_LDS_BARRIER();
         cb_bias_sums(X, tid, gacc + 5 * PN_HC);
         pn_copy_out_kmajor_h<PN_HC, CB_XRS>(X, a.sv.dc1k, tile * 8, tid);
         if (WG2) pn_copy_out_kmajor_h<PN_HC, CB_XRS>(X + CB_XPL, a.sv.dc1m, tile * 8, tid);
         // ---- d f = d c1 @ Wc1[:, :256]
         cb_acc_zero(acc);
-        pn_gemm_f16x3<8, 8, 2, 1, 3, CB_XRS, CB_XPL>(X, reinterpret_cast<const uint4 *>(img + PKH_DC1), 2 * wave, lane, acc);
+        pn_gemm_f16x3_run<8, 8, 2, 1, 3, CB_XRS, CB_XPL>(X, WD1, lane, acc);
 #pragma unroll
         for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
@@ -287,20 +294,20 @@ template <int N> __device__ __forceinline__ float group_sum_b(float v) {
     for (int off = 1; off < N; off <<= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
-__device__ __forceinline__ void b_acc_zero(f32x16 (&acc)[2][2]) {
+template <int AF> __device__ __forceinline__ void b_acc_zero(f32x16 (&acc)[AF][2]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < AF; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
-// dgrad epilogue: accumulators x LeakyReLU' (sign bit of the forward's word: element e = ((fb * 2 + rb) * 4 + g) * 4 + i at bit
-// 31 - (e & 31) of half fb) -> both planes of the next dY tile
-__device__ __forceinline__ void b_epilogue(const f32x16 (&acc)[2][2], unsigned long long mask, char *X, int wave, int lane) {
+// dgrad epilogue: accumulators x LeakyReLU' (sign bit of the forward's word of the feature block: element e = (rb * 4 + g) * 4 + i at bit
+// 31 - e) -> both planes of the next dY tile
+__device__ __forceinline__ void b_epilogue(const f32x16 (&acc)[PN_NFB][2], const unsigned (&mask)[PN_NFB], char *X, int wave, int lane) {
 #pragma unroll
-    for (int fb = 0; fb < 2; ++fb) {
-        const unsigned mw = (unsigned)(mask >> (32 * fb));
+    for (int fb = 0; fb < PN_NFB; ++fb) {
+        const unsigned mw = mask[fb];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -311,7 +318,7 @@ __device__ __forceinline__ void b_epilogue(const f32x16 (&acc)[2][2], unsigned l
                     const int e = (rb * 4 + g) * 4 + i;
                     v[i] = acc[fb][rb][4 * g + i] * ((int)(mw << e) < 0 ? 0.01f : 1.f);
                 }
-                pn_x_store4<true>(X, 32 * rb + (lane & 31), pn_d_feat(2 * wave + fb, g, lane), v[0], v[1], v[2], v[3]);
+                pn_x_store4<true>(X, 32 * rb + (lane & 31), pn_d_feat(PN_NFB * wave + fb, g, lane), v[0], v[1], v[2], v[3]);
             }
     }
 }
@@ -320,8 +327,10 @@ __device__ __forceinline__ void b_epilogue(const f32x16 (&acc)[2][2], unsigned l
 // (The host emulation runs lanes as fibers: there it has to be a rendezvous.)
 #ifdef PN_EMU
 #define PN_WAVE_LDS_SYNC() __syncthreads()
+#define PN_EMU_MATCH_WAVE_SYNC() __syncthreads()      // for the threads of a workgroup that skip a phase with a PN_WAVE_LDS_SYNC in it
 #else
 #define PN_WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define PN_EMU_MATCH_WAVE_SYNC() ((void)0)
 #endif
 __device__ __forceinline__ float pn_softplus_b(float x) {
 #ifdef PN_EMU
@@ -426,7 +435,7 @@ __device__ __forceinline__ void b_front(const BwdArgs &a, char *X, const float *
 PN_TR_DECL(pn_trace_bwd);
 #endif
 template <bool WG2>
-__global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
+__global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_backward(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     char *X = smem_b;
     float *wrow = reinterpret_cast<float *>(smem_b + BL_ROW), *wnrm = wrow + PN_TILE, *draw = wnrm + PN_TILE, *dsg = draw + PN_TILE, *xrow = dsg + PN_TILE;
@@ -449,7 +458,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
     float4 gw5v = make_float4(0.f, 0.f, 0.f, 0.f);      // two-pass front: d W5 of columns 4 (tid & 63) .. + 3 (scaled)
     float gw5[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // one-pass front: d W5 of columns 8 (tid & 31) .. + 7 (scaled)
     float gb5t = 0.f;
-    f32x16 acc[2][2];
+    f32x16 acc[PN_NFB][2];
     // row metadata of the tile (threads 0..63: one row each), fetched ONE TILE AHEAD: the d sigma of a row hangs off its sample id, and
     // two dependent HBM round trips at the top of every tile were 4 of the 6 us of the load phase
     int4 rm_cur = make_int4(-1, -1, 0, 0);
@@ -463,18 +472,26 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         PN_TR_ITER_NEXT;
         int tid = threadIdx.x;                          // (recomputed per tile: see the forward)
         asm volatile("" : "+v"(tid));
-        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), row = tid / TPR, q = tid % TPR;
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        // roles in the 8-wave organisation (the forward's): the first PN_ETHR threads (waves 0..3) own the front (alpha head backward + dY4),
+        // the last PN_ETHR threads (waves 4..7) the rows' embedding gradients (4 threads per tile row: row, q)
+        const bool ew = PN_NTHR == PN_ETHR || tid < PN_ETHR, bw = PN_NTHR == PN_ETHR || tid >= PN_NTHR - PN_ETHR;
+        const int bt = bw ? tid - (PN_NTHR - PN_ETHR) : 0, row = bt / TPR, q = bt % TPR;
         const long long gtile = tb + tile;
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 0); PN_TR_HWID(pn_trace_bwd);
         // ---- load: sign words, d sigma of the rows, the h4 planes (-> LDS before the barrier), the next tile's row metadata: one burst
-        const unsigned long long m1 = a.sv.lmask[(gtile * 3 + 0) * PN_NTHR + tid], m2 = a.sv.lmask[(gtile * 3 + 1) * PN_NTHR + tid],
-                                 m3 = a.sv.lmask[(gtile * 3 + 2) * PN_NTHR + tid];
+        unsigned m1[PN_NFB], m2[PN_NFB], m3[PN_NFB];
+#pragma unroll
+        for (int fb = 0; fb < PN_NFB; ++fb) {
+            const long long o = (long long)(PN_NFB * wave + fb) * 64 + lane;
+            m1[fb] = a.sv.lmask[(gtile * 3 + 0) * 512 + o]; m2[fb] = a.sv.lmask[(gtile * 3 + 1) * 512 + o]; m3[fb] = a.sv.lmask[(gtile * 3 + 2) * 512 + o];
+        }
         float dsg_v = 0.f;
         if (tid < PN_TILE && rm_cur.x >= 0) dsg_v = a.grad_decoded[(long long)rm_cur.x * 4];
-        pn_f4 h4v[16];
+        pn_f4 h4v[4096 / PN_NTHR];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < 4096 / PN_NTHR; ++i) {
             const int e = tid + PN_NTHR * i, plane = e >> 11, r = (e >> 5) & 63, u = e & 31;
             h4v[i] = *reinterpret_cast<const pn_f4 *>(a.sv.h4r + ((long long)plane * a.sv.rows + gtile * PN_TILE + r) * 32 + u);
         }
@@ -492,7 +509,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
             dsg[tid] = dsg_v * S;
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < 4096 / PN_NTHR; ++i) {
             const int e = tid + PN_NTHR * i, plane = e >> 11, r = (e >> 5) & 63, u = e & 31;
             *reinterpret_cast<pn_f4 *>(X + plane * PN_XPLANE + r * PN_XRS + u * 16) = h4v[i];
         }
@@ -500,8 +517,8 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         // one-pass front: the d f rows of the thread's samples (they follow from the tile index alone; rows past the class's last sample
         // read allocated, unused memory and are ignored): requested before the barrier, consumed behind it
         float4 dfr[4];
-        const float *dfb0 = a.sv.dfs + (tile * TS + pn_row_div(8 * (tid >> 5), kinv)) * PN_H + 8 * (tid & 31);
-        if (K == 8 || K == 4) {
+        const float *dfb0 = a.sv.dfs + (tile * TS + pn_row_div(8 * ((tid >> 5) & 7), kinv)) * PN_H + 8 * (tid & 31);
+        if (ew && (K == 8 || K == 4)) {
             dfr[0] = *reinterpret_cast<const float4 *>(dfb0); dfr[1] = *reinterpret_cast<const float4 *>(dfb0 + 4);
             if (K == 4) { dfr[2] = *reinterpret_cast<const float4 *>(dfb0 + PN_H); dfr[3] = *reinterpret_cast<const float4 *>(dfb0 + PN_H + 4); }
         }
@@ -509,7 +526,7 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         rm_cur = rm_nxt; ar_cur = ar_nxt;
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 1);
-        const int rp = prow[row];
+        const int rp = bw ? prow[row] : -1;
         float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;       // the row's embedding values (for its gradient at the end of the tile)
         if (rp >= 0) {
             const float *ep = a.emb + (long long)rp * PN_F + EPT * q;
@@ -517,35 +534,36 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         }
         if (one_pass) {
             // ---- alpha head backward + dY4 in one pass (b_front)
-            if (K == 8) b_front<8>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
+            if (!ew) { PN_EMU_MATCH_WAVE_SYNC(); }
+            else if (K == 8) b_front<8>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
             else if (K == 4) b_front<4>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
             else if (K == 2) b_front<2>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
             else b_front<1>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
             PN_TR(pn_trace_bwd, 2);
         } else {
         // ---- (any other K: two passes) alpha head backward (4 threads per row): d w_k = d sigma alpha_k + d f . h4_k ; d x = d sigma w sigmoid(x)
-        const int rsi = sidx[row];
-        {
+        if (ew) {
+            const int trow = tid / TPR, tq = tid % TPR, rsi = sidx[trow], trp = prow[trow];
             float dotf = 0.f;
             if (rsi >= 0) {
-                const float *df = a.sv.dfs + (tile * TS + pn_row_div(row, kinv)) * PN_H;
+                const float *df = a.sv.dfs + (tile * TS + pn_row_div(trow, kinv)) * PN_H;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int c0 = 8 * (q + 4 * j);
-                    dotf = pn_x_dot8(X, row, c0, *reinterpret_cast<const float4 *>(df + c0), *reinterpret_cast<const float4 *>(df + c0 + 4), dotf);
+                    const int c0 = 8 * (tq + 4 * j);
+                    dotf = pn_x_dot8(X, trow, c0, *reinterpret_cast<const float4 *>(df + c0), *reinterpret_cast<const float4 *>(df + c0 + 4), dotf);
                 }
             }
             dotf = group_sum_b<TPR>(dotf) * S;
-            if (q == 0) {
+            if (tq == 0) {
                 float dr = 0.f;
                 if (rsi >= 0) {
-                    const float x = xrow[row];
+                    const float x = xrow[trow];
                     const float alpha = pn_softplus_b(x), sg = pn_sigmoid_b(x);
                     // w = wn * clamp(conf) with a straight-through clamp (gradiant_clamp, point_aggregators.py:722-724)
-                    if (rp >= 0) atomicAdd(&a.g_conf[rp], (dsg[row] * alpha + dotf) * wnrm[row] * invS);
-                    dr = dsg[row] * wrow[row] * sg;
+                    if (trp >= 0) atomicAdd(&a.g_conf[trp], (dsg[trow] * alpha + dotf) * wnrm[trow] * invS);
+                    dr = dsg[trow] * wrow[trow] * sg;
                 }
-                draw[row] = dr;
+                draw[trow] = dr;
             }
         }
         PN_LDS_BARRIER();
@@ -554,16 +572,16 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         {
             const int c4 = tid & 63;
             const float4 w5 = *reinterpret_cast<const float4 *>(w5s + c4 * 4);
-            float4 gq[16];                                   // the d f values of the 16 rows, requested in one burst (the accumulators are dead here)
+            float4 gq[64 / PN_NW];                           // the d f values of the thread's rows, requested in one burst (the accumulators are dead here)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int r = (tid >> 6) + 4 * i;
+            for (int i = 0; i < 64 / PN_NW; ++i) {
+                const int r = (tid >> 6) + PN_NW * i;
                 gq[i] = *reinterpret_cast<const float4 *>(a.sv.dfs + (tile * TS + pn_row_div(r, kinv)) * PN_H + c4 * 4);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int r = (tid >> 6) + 4 * i;
+            for (int i = 0; i < 64 / PN_NW; ++i) {
+                const int r = (tid >> 6) + PN_NW * i;
                 const int si = sidx[r];
                 float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (si >= 0) {
@@ -581,38 +599,47 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
             if (tid < PN_TILE) gb5t += draw[tid];
         }
         }
+        // (round 4: the first weight-fragment chunks of every GEMM are requested in FRONT of the barrier that precedes it -- see the forward)
+        PnGemmW<16, 8, PN_NFB> W4;
+        W4.prefetch(reinterpret_cast<const uint4 *>(img + PKH_D4), PN_NFB * wave, lane);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 3);
         // ---- layer 4: dY4 -> d h3
         // (every dY tile is copied out BEHIND its GEMM: stores and loads of a wave share one in-order vmcnt queue, see the forward)
         b_acc_zero(acc);
         PN_TR(pn_trace_bwd, 4);
-        pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D4), 2 * wave, lane, acc);
-        pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy4k, gtile * 8, tid);
-        if (WG2) pn_copy_out_kmajor_h<PN_H>(X + PN_XPLANE, a.sv.dy4m, gtile * 8, tid);
+        pn_gemm_f16x3_run<16, 8, PN_NFB>(X, W4, lane, acc);
+        pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X, a.sv.dy4k, gtile * 8, tid);
+        if (WG2) pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X + PN_XPLANE, a.sv.dy4m, gtile * 8, tid);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 5);
         b_epilogue(acc, m3, X, wave, lane);
+        PnGemmW<16, 9, PN_NFB> W3;
+        W3.prefetch(reinterpret_cast<const uint4 *>(img + PKH_D3), PN_NFB * wave, lane);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 6);
         // ---- layer 3: dY3 -> d h2, and the extras block (input columns 256..262 of W3), K split over the waves
         b_acc_zero(acc);
         PN_TR(pn_trace_bwd, 7);
-        pn_gemm_f16x3<16, 9, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D3), 2 * wave, lane, acc);
-        f32x16 acce[2][2];
-        b_acc_zero(acce);
-        pn_gemm_f16x3<4, 9, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D3), 8, lane, acce, 4 * wave);
-        pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy3k, gtile * 8, tid);
-        if (WG2) pn_copy_out_kmajor_h<PN_H>(X + PN_XPLANE, a.sv.dy3m, gtile * 8, tid);
+        // the extras block first, K split over the first four waves; their partial sums go straight to the tile's free bytes (80 per row and
+        // plane behind column 255, which no GEMM reads: no barrier needed) -- wave w -> plane w >> 1, 32-byte slot w & 1; a lane holds
+        // features 4 (l >> 5) .. + 3 of rows (l & 31), (l & 31) + 32.  Done before the main GEMM so that its accumulators are dead by then
+        // (an 8-wave workgroup has 128 registers per wave).
+        if (wave < 4) {
+            f32x16 acce[1][2];
+            b_acc_zero(acce);
+            pn_gemm_f16x3<4, 9, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D3), 8, lane, acce, 4 * wave);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+                *reinterpret_cast<float4 *>(X + (wave >> 1) * PN_XPLANE + (32 * rb + (lane & 31)) * PN_XRS + 512 + (wave & 1) * 32 + (lane >> 5) * 16) =
+                    make_float4(acce[0][rb][0], acce[0][rb][1], acce[0][rb][2], acce[0][rb][3]);
+        }
+        pn_gemm_f16x3_run<16, 9, PN_NFB>(X, W3, lane, acc);
+        pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X, a.sv.dy3k, gtile * 8, tid);
+        if (WG2) pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X + PN_XPLANE, a.sv.dy3m, gtile * 8, tid);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 8);
         b_epilogue(acc, m2, X, wave, lane);
-        // the waves' partial sums of the extras block go to the tile's free bytes (80 per row and plane behind column 255):
-        // wave w -> plane w >> 1, 32-byte slot w & 1; a lane holds features 4 (l >> 5) .. + 3 of rows (l & 31), (l & 31) + 32
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-            *reinterpret_cast<float4 *>(X + (wave >> 1) * PN_XPLANE + (32 * rb + (lane & 31)) * PN_XRS + 512 + (wave & 1) * 32 + (lane >> 5) * 16) =
-                make_float4(acce[0][rb][0], acce[0][rb][1], acce[0][rb][2], acce[0][rb][3]);
         PN_LDS_BARRIER();
         if (tid < PN_TILE) {        // d colour, d dir of the row's point from the extras' gradient
             const int p = prow[tid];
@@ -633,6 +660,8 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
                 atomicAdd(&a.g_dir[3 * p], gx * invS); atomicAdd(&a.g_dir[3 * p + 1], gy * invS); atomicAdd(&a.g_dir[3 * p + 2], gz * invS);
             }
         }
+        PnGemmW<16, 8, PN_NFB> W2;
+        W2.prefetch(reinterpret_cast<const uint4 *>(img + PKH_D2), PN_NFB * wave, lane);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 9);
         // ---- layer 2: dY2 -> d h1
@@ -640,9 +669,9 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         //  reads, one per 128-byte line: 16.65 ms against 16.19 ms -- the load phase is not waiting for HBM.)
         b_acc_zero(acc);
         PN_TR(pn_trace_bwd, 10);
-        pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D2), 2 * wave, lane, acc);
-        pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy2k, gtile * 8, tid);
-        if (WG2) pn_copy_out_kmajor_h<PN_H>(X + PN_XPLANE, a.sv.dy2m, gtile * 8, tid);
+        pn_gemm_f16x3_run<16, 8, PN_NFB>(X, W2, lane, acc);
+        pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X, a.sv.dy2k, gtile * 8, tid);
+        if (WG2) pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X + PN_XPLANE, a.sv.dy2m, gtile * 8, tid);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 11);
         b_epilogue(acc, m1, X, wave, lane);
@@ -651,20 +680,24 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         // ---- layer 1: dY1 -> d X0 (columns 0..223), fp32 into LDS
         b_acc_zero(acc);
         PN_TR(pn_trace_bwd, 13);
-        if (wave < 3) pn_gemm_f16x3<16, PN_MB_D1, 2>(X, reinterpret_cast<const uint4 *>(img + PKH_D1), 2 * wave, lane, acc);
-        else pn_gemm_f16x3<16, PN_MB_D1, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D1), 6, lane, acc);
-        pn_copy_out_kmajor_h<PN_H>(X, a.sv.dy1k, gtile * 8, tid);
-        if (WG2) pn_copy_out_kmajor_h<PN_H>(X + PN_XPLANE, a.sv.dy1m, gtile * 8, tid);
+        if (PN_NFB == 2) {       // seven feature blocks over four waves: 2 2 2 1
+            if (wave < 3) pn_gemm_f16x3<16, PN_MB_D1, PN_NFB>(X, reinterpret_cast<const uint4 *>(img + PKH_D1), 2 * wave, lane, acc);
+            else pn_gemm_f16x3<16, PN_MB_D1, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D1), 6, lane, acc);
+        } else if (wave < PN_MB_D1) {      // over eight waves: one each, the last wave idle
+            pn_gemm_f16x3<16, PN_MB_D1, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D1), wave, lane, acc);
+        }
+        pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X, a.sv.dy1k, gtile * 8, tid);
+        if (WG2) pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X + PN_XPLANE, a.sv.dy1m, gtile * 8, tid);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 14);
 #pragma unroll
-        for (int fb = 0; fb < 2; ++fb)
-            if (2 * wave + fb < PN_MB_D1) {
+        for (int fb = 0; fb < PN_NFB; ++fb)
+            if (PN_NFB * wave + fb < PN_MB_D1) {
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<float4 *>(dx + (32 * rb + (lane & 31)) * LDDX + pn_d_feat(2 * wave + fb, g, lane)) =
+                        *reinterpret_cast<float4 *>(dx + (32 * rb + (lane & 31)) * LDDX + pn_d_feat(PN_NFB * wave + fb, g, lane)) =
                             make_float4(acc[fb][rb][4 * g], acc[fb][rb][4 * g + 1], acc[fb][rb][4 * g + 2], acc[fb][rb][4 * g + 3]);
             }
         PN_LDS_BARRIER();
@@ -698,10 +731,13 @@ __global__ __launch_bounds__(PN_NTHR, 2) void k_agg_backward(BwdArgs a) {
         const int cg = tid0 & 31, rs = tid0 >> 5;
         float *red = reinterpret_cast<float *>(smem_b);            // [8 row sets][256 columns] over the tile's space
         PN_LDS_BARRIER();
+        if (tid0 < PN_ETHR) {                                      // (the front's threads hold the sums)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) red[rs * PN_H + 8 * cg + c] = gw5[c];
-        if (cg == 0) red[8 * PN_H + rs] = gb5t;
+            for (int c = 0; c < 8; ++c) red[rs * PN_H + 8 * cg + c] = gw5[c];
+            if (cg == 0) red[8 * PN_H + rs] = gb5t;
+        }
         PN_LDS_BARRIER();
+        if (tid0 >= PN_H) return;
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) t += red[r * PN_H + tid0];

@@ -187,13 +187,25 @@ __device__ __forceinline__ float4 pn_x_load4(const char *X, int row, int col) {
     return make_float4(pn_h_lo(h.x) + pn_h_lo(m.x), pn_h_hi(h.x) + pn_h_hi(m.x), pn_h_lo(h.y) + pn_h_lo(m.y), pn_h_hi(h.y) + pn_h_hi(m.y));
 }
 
-// acc + (h + m) * w for the two packed values of a plane pair: fmaf of a converted half is ONE v_fma_mix_f32 (no conversion, no add)
-__device__ __forceinline__ float pn_fma2_lo(unsigned h, unsigned m, float w, float acc) {
-    return __builtin_fmaf((float)__builtin_bit_cast(pn_h2, m)[0], w, __builtin_fmaf((float)__builtin_bit_cast(pn_h2, h)[0], w, acc));
+// acc + (h + m) * w for the two packed values of a plane pair: fmaf of a converted half is ONE v_fma_mix_f32 (no conversion, no add).
+// Written as inline asm since round 4: where a half feeds two sums (the tail's alpha dot product and K-weighted sum, the backward front's
+// two passes) hipcc converts it once (v_cvt_f32_f16) and keeps the fp32 copy -- 128 conversions and 128 more live registers per thread in
+// f_tail, which an 8-wave workgroup (128 registers per wave) spills.  Same arithmetic: fma(f32(half), w, acc), the conversion is exact.
+#ifdef PN_EMU
+__device__ __forceinline__ float pn_mix_lo(unsigned p, float w, float acc) { return __builtin_fmaf((float)__builtin_bit_cast(pn_h2, p)[0], w, acc); }
+__device__ __forceinline__ float pn_mix_hi(unsigned p, float w, float acc) { return __builtin_fmaf((float)__builtin_bit_cast(pn_h2, p)[1], w, acc); }
+#else
+__device__ __forceinline__ float pn_mix_lo(unsigned p, float w, float acc) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(p), "v"(w));
+    return acc;
 }
-__device__ __forceinline__ float pn_fma2_hi(unsigned h, unsigned m, float w, float acc) {
-    return __builtin_fmaf((float)__builtin_bit_cast(pn_h2, m)[1], w, __builtin_fmaf((float)__builtin_bit_cast(pn_h2, h)[1], w, acc));
+__device__ __forceinline__ float pn_mix_hi(unsigned p, float w, float acc) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(p), "v"(w));
+    return acc;
 }
+#endif
+__device__ __forceinline__ float pn_fma2_lo(unsigned h, unsigned m, float w, float acc) { return pn_mix_lo(m, w, pn_mix_lo(h, w, acc)); }
+__device__ __forceinline__ float pn_fma2_hi(unsigned h, unsigned m, float w, float acc) { return pn_mix_hi(m, w, pn_mix_hi(h, w, acc)); }
 // dot product of 8 tile columns (row, col .. col + 7, col % 8 == 0) with 8 floats
 __device__ __forceinline__ float pn_x_dot8(const char *X, int row, int col, const float4 &w0, const float4 &w1, float acc) {
     const uint4 h = *reinterpret_cast<const uint4 *>(X + row * PN_XRS + col * 2);
@@ -245,18 +257,33 @@ __device__ __forceinline__ void pn_x_axpy4(const char *X, int row, int col, floa
 // plane dropped: an inference OPTION (pnerf_set_inference_products) -- rendered ray colour within 2e-5 of fp32, per-sample sigma / RGB only
 // within 4e-4 (outside the 1e-4 bar: not the default); rejected for training because a systematic
 // perturbation of the weights flips LeakyReLU sides between forward and backward; a third of the MFMAs and half of the weight stream less).
-template <int NC, int MB, int NFB, int WPF = PN_WPF, int NP = 3, int XRS = PN_XRS, int XPL = PN_XPLANE>
-__device__ __forceinline__ void pn_gemm_f16x3(const char *X, const uint4 *__restrict__ img, int fb0, int lane, f32x16 (&acc)[2][2], int c0 = 0) {
-    static_assert(NP == 2 || NP == 3, "two or three products");
-    constexpr int PF = WPF < NC ? WPF : NC - 1, NS = PF + 1;
-    const char *xb = X + (lane & 31) * XRS + (lane >> 5) * 16 + c0 * 32;
-    const uint4 *wp = img + ((size_t)c0 * MB + fb0) * 128 + lane;
-    uint4 wh[NS][2], wm[NS][2], xh[2][2], xm[2][2];
-    auto load_w = [&](auto cc) {
-        constexpr int c = decltype(cc)::value, s = c % NS;
+// The ring of weight-fragment register sets of one tile GEMM.  prefetch() requests the first PF chunks; a caller may issue it BEFORE the
+// barrier in front of the GEMM (round 4): the fragments come from L2 and depend on nothing in LDS, so their round trip (0.6 .. 1 us under
+// load, paid at the start of every GEMM phase in rounds 2-3) passes under the barrier wait and the tail of the previous phase.
+template <int NC, int MB, int NFB, int WPF = PN_WPF, int NP = 3>
+struct PnGemmW {
+    static constexpr int PF = WPF < NC ? WPF : NC - 1, NS = PF + 1;
+    uint4 wh[NS][NFB], wm[NS][NFB];
+    const uint4 *wp;
+    template <int C> __device__ __forceinline__ void load() {
+        constexpr int s = C % NS;
 #pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) { wh[s][fb] = wp[(c * MB + fb) * 128]; if (NP == 3) wm[s][fb] = wp[(c * MB + fb) * 128 + 64]; }
-    };
+        for (int fb = 0; fb < NFB; ++fb) { wh[s][fb] = wp[(C * MB + fb) * 128]; if (NP == 3) wm[s][fb] = wp[(C * MB + fb) * 128 + 64]; }
+    }
+    __device__ __forceinline__ void prefetch(const uint4 *__restrict__ img, int fb0, int lane, int c0 = 0) {
+        wp = img + ((size_t)c0 * MB + fb0) * 128 + lane;
+        pn_static_for<PF>([&](auto cc) { load<decltype(cc)::value>(); });
+    }
+};
+
+// the GEMM proper, on a ring whose first PF chunks have been requested (W.prefetch with the same img / fb0 / lane / c0)
+template <int NC, int MB, int NFB, int WPF = PN_WPF, int NP = 3, int XRS = PN_XRS, int XPL = PN_XPLANE, int AF>
+__device__ __forceinline__ void pn_gemm_f16x3_run(const char *X, PnGemmW<NC, MB, NFB, WPF, NP> &W, int lane, f32x16 (&acc)[AF][2], int c0 = 0) {
+    static_assert(NP == 2 || NP == 3, "two or three products");
+    static_assert(NFB <= AF, "accumulator blocks");
+    constexpr int PF = PnGemmW<NC, MB, NFB, WPF, NP>::PF, NS = PF + 1;
+    const char *xb = X + (lane & 31) * XRS + (lane >> 5) * 16 + c0 * 32;
+    uint4 xh[2][2], xm[2][2];
     auto load_x = [&](auto cc) {
         constexpr int c = decltype(cc)::value, s = c & 1;
 #pragma unroll
@@ -265,12 +292,11 @@ __device__ __forceinline__ void pn_gemm_f16x3(const char *X, const uint4 *__rest
             xm[s][rb] = *reinterpret_cast<const uint4 *>(xb + XPL + rb * 32 * XRS + c * 32);
         }
     };
-    pn_static_for<PF>([&](auto cc) { load_w(cc); });
     load_x(std::integral_constant<int, 0>{});
     PN_GEMM_PRIO_BEGIN();
     pn_static_for<NC>([&](auto cc) {
         constexpr int c = decltype(cc)::value, sw = c % NS, sx = c & 1;
-        if constexpr (c + PF < NC) load_w(std::integral_constant<int, c + PF>{});
+        if constexpr (c + PF < NC) W.template load<c + PF>();
         if constexpr (c + 1 < NC) load_x(std::integral_constant<int, c + 1>{});
         // (without the fences hipcc sinks every load down to its first use to shorten live ranges: "load; s_waitcnt; mfma" --
         //  an exposed L2 round trip per chunk, measured 30 % of the MFMA rate)
@@ -281,7 +307,7 @@ __device__ __forceinline__ void pn_gemm_f16x3(const char *X, const uint4 *__rest
             for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) {
-                    const pn_h8 a = __builtin_bit_cast(pn_h8, p == 2 ? wm[sw][fb] : wh[sw][fb]);
+                    const pn_h8 a = __builtin_bit_cast(pn_h8, p == 2 ? W.wm[sw][fb] : W.wh[sw][fb]);
                     const pn_h8 b = __builtin_bit_cast(pn_h8, p == 1 ? xm[sx][rb] : xh[sx][rb]);
                     acc[fb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[fb][rb], 0, 0, 0);
                     PN_MFMA_GAP();
@@ -289,6 +315,13 @@ __device__ __forceinline__ void pn_gemm_f16x3(const char *X, const uint4 *__rest
         __builtin_amdgcn_sched_barrier(0);
     });
     PN_GEMM_PRIO_END();
+}
+
+template <int NC, int MB, int NFB, int WPF = PN_WPF, int NP = 3, int XRS = PN_XRS, int XPL = PN_XPLANE, int AF>
+__device__ __forceinline__ void pn_gemm_f16x3(const char *X, const uint4 *__restrict__ img, int fb0, int lane, f32x16 (&acc)[AF][2], int c0 = 0) {
+    PnGemmW<NC, MB, NFB, WPF, NP> W;
+    W.prefetch(img, fb0, lane, c0);
+    pn_gemm_f16x3_run<NC, MB, NFB, WPF, NP, XRS, XPL>(X, W, lane, acc, c0);
 }
 
 // accumulator element (fb, rb, g, i) of a lane: feature = 32 fbg + 8 g + 4 (l >> 5) + i (fbg = global block), row = 32 rb + (l & 31)
@@ -306,13 +339,14 @@ __device__ __forceinline__ uint2 pn_lds_read_tr16(const char *p) {
     return __builtin_bit_cast(uint2, r);
 }
 // the high plane only ([rg_total][NF] units): the dY operand of the weight-gradient GEMM
-template <int NF, int XRS = PN_XRS>
+// NW = waves of the calling workgroup: wave w copies the row groups 8 / NW * w .. (8 of them in a 64-row tile)
+template <int NF, int XRS = PN_XRS, int NW = 4>
 __device__ __forceinline__ void pn_copy_out_kmajor_h(const char *X, uint4 *__restrict__ dst, long long rg0, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const int blk = ((lane >> 2) & 3) * XRS + ((lane >> 4) * 16 + (lane & 3) * 4) * 2;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rg = wave * 2 + i;
+    for (int i = 0; i < 8 / NW; ++i) {
+        const int rg = wave * (8 / NW) + i;
         const char *src = X + rg * 8 * XRS + blk;
         uint4 *d = dst + (rg0 + rg) * NF;
         // (all transposing reads of the run first, then its stores: the stores are inline asm, which the scheduler does not move loads across)
@@ -342,14 +376,14 @@ __device__ __forceinline__ uint2 pn_rne_rest(uint2 h, uint2 m, uint2 s) {
     return __builtin_bit_cast(uint2, mm - (ss - hh));
 }
 // TWO: also write the residual plane to dstm (same layout) -- the fp32-class weight-gradient mode
-template <int NF, bool TWO = false>
+template <int NF, bool TWO = false, int NW = 4>
 __device__ __forceinline__ void pn_copy_out_kmajor(const char *X, uint4 *__restrict__ dst, long long rg0, int tid, uint4 *__restrict__ dstm = nullptr) {
     const int lane = tid & 63, wave = tid >> 6;
     const int blk = ((lane >> 2) & 3) * PN_XRS + ((lane >> 4) * 16 + (lane & 3) * 4) * 2;      // this lane's slot inside a [4][64-column] block
     constexpr int NJ = (NF + 63) / 64;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rg = wave * 2 + i;
+    for (int i = 0; i < 8 / NW; ++i) {
+        const int rg = wave * (8 / NW) + i;
         const char *src = X + rg * 8 * PN_XRS + blk;
         uint4 *d = dst + (rg0 + rg) * NF;
         uint2 lo[NJ], hi[NJ], lom[NJ], him[NJ];
@@ -377,14 +411,14 @@ __device__ __forceinline__ void pn_copy_out_kmajor(const char *X, uint4 *__restr
 
 // the tile's columns C0 .. C0 + 63 -> one k-major plane of 64 features ([rg_total][64] units): the saved part of X0 on the fused path
 // (the weight-gradient kernel rebuilds the rest from the embedding: backward.hip k_wgrad_x0)
-template <int C0>
+template <int C0, int NW = 4>
 __device__ __forceinline__ void pn_copy_out_kmajor_cols64(const char *X, uint4 *__restrict__ dst, long long rg0, int tid) {
     static_assert(C0 % 16 == 0, "a 16-column group boundary");
     const int lane = tid & 63, wave = tid >> 6;
     const int blk = ((lane >> 2) & 3) * PN_XRS + ((lane >> 4) * 16 + (lane & 3) * 4) * 2 + C0 * 2;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rg = wave * 2 + i;
+    for (int i = 0; i < 8 / NW; ++i) {
+        const int rg = wave * (8 / NW) + i;
         const char *src = X + rg * 8 * PN_XRS + blk;
         const uint2 lo = pn_lds_read_tr16(src), hi = pn_lds_read_tr16(src + 4 * PN_XRS);
         const uint2 lom = pn_lds_read_tr16(src + PN_XPLANE), him = pn_lds_read_tr16(src + PN_XPLANE + 4 * PN_XRS);

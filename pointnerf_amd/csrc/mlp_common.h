@@ -15,10 +15,22 @@
 #define PN_HC     128
 #define PN_TILE   64                 // neighbor rows per aggregator tile (2 MFMA row tiles).  Measured: 32-row tiles are 10 % slower (twice the weight-fragment traffic per MFMA)
 #define PN_MT     (PN_TILE / 32)
-#define PN_NTHR   256                // threads per aggregator workgroup: 4 waves (one per SIMD) x (64 rows x 64 cols), up to 512 registers each
+// Organisation of an aggregator workgroup (forward and backward tile kernels), two workgroups per CU either way:
+//   PN_NTHR 256 ("A", shipped): 4 waves x (2 feature blocks x 2 row blocks of the 64-row tile), up to 256 registers per wave, two waves per SIMD
+//   PN_NTHR 512 ("B", dev: EXTRA_DEFS=-DPN_NTHR=512): 8 waves, each ONE feature block x both row blocks in the GEMM phases (32 accumulator
+//                registers, 128 registers per wave, four waves per SIMD); the row-wise phases keep A's 4-threads-per-row mapping, split by role:
+//                waves 4..7 gather / build / embedding gradient, waves 0..3 tail / front.  Round 4 built and measured it on request of the
+//                round-3 review (tools/gemm_probe.hip had it 7 % ahead on a synthetic chain): parity green, but the REAL kernels are slower,
+//                forward 12.78 -> 14.56 ms, backward 13.85 -> 14.82 ms, render-only 5.18 -> 4.68 M rays/s -- every wave reads BOTH row blocks of
+//                the tile from LDS for half as many MFMAs, the LDS pipe is busy 33 % longer and the waves wait 3.7 x as long for an LDS issue
+//                slot (SQ_WAIT_INST_LDS), MFMA busy 0.49 -> 0.42 (profiles/r04_orgB_vs_orgA.txt).  One source for both.
+#ifndef PN_NTHR
+#define PN_NTHR   256
+#endif
 #define PN_NW     (PN_NTHR / 64)     // waves per aggregator workgroup
-#define PN_NT     (PN_H / (PN_NW * 32))   // MFMA column tiles per wave (1 with 8 waves, 2 with 4)
-#define PN_TPR    (PN_NTHR / PN_TILE)     // threads per tile row in the element-wise phases
+#define PN_NFB    (8 / PN_NW)        // 32-feature blocks per wave in the 256-wide GEMMs
+#define PN_ETHR   256                // threads of the row-wise element-wise phases
+#define PN_TPR    (PN_ETHR / PN_TILE)     // threads per tile row in those phases
 #define PN_CTILE  64                 // valid samples per colour-MLP tile
 
 // flat parameter vector (state_dict order, torch [out,in] row-major)
@@ -51,7 +63,7 @@ struct PnSaved {
     uint4 *h4r;                         // row-major [2][rows][32] last activation, both planes (alpha head / K-weighted sums of the backward)
     float *arow;                        // per row: pre-activation of the alpha head
     int4 *rmeta;                        // per row: {sample id or -1, point id or -1, bits(normalised weight), bits(final weight)}
-    unsigned long long *lmask;          // [row tiles][3 layers h1..h3][PN_NTHR]: LeakyReLU sign bits in the accumulator layout
+    unsigned *lmask;                    // [row tiles][3 layers h1..h3][8 feature blocks][64 lanes]: LeakyReLU sign bits in the accumulator layout
     unsigned *gscale;                   // [4]: bits of max |d decoded| over the valid samples (the backward derives its scale from it)
     // per valid sample (padded to colour tiles * 64)
     float *fs, *dfs, *c3;               // fp32 rows: aggregated feature [256] and its gradient, last colour post-activation [128]

@@ -75,7 +75,7 @@ def test_extract_2d_at_scale_properties():
         assert f1.shape == (1, 2_000_000, 168) and c1.shape == (1, 2_000_000, 9)
         for v in range(3):
             mv = mask[v]
-            assert 0.02 < float(mv.float().mean()) < 0.98
+            assert (0.02 if occ == 0 else 0.001) < float(mv.float().mean()) < 0.98      # (z-buffer of 96 x 128 pixels: ~1 % of 2 M points survive)
             fv, cv = f1[0, :, 56 * v:56 * (v + 1)], c1[0, :, 3 * v:3 * (v + 1)]
             assert float(fv[~mv].abs().max()) == 0.0 and float(cv[~mv].abs().max()) == 0.0
             assert float((cv[mv] - 0.25).abs().max()) <= 1e-6
