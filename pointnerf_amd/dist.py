@@ -38,11 +38,28 @@ def shard_slice(n_rays_global, r=None, w=None):
     return slice(b, b + base + (1 if r < rem else 0))
 
 
+class _HostCounts(list):
+    """the single-process form of ``global_counts``: plain numbers with the ``.clamp(min=)`` the callers apply to a denominator"""
+
+    class _N(float):
+        def clamp(self, min=None, max=None):
+            v = float(self)
+            v = v if min is None else (v if v > min else float(min))
+            v = v if max is None else (v if v < max else float(max))
+            return _HostCounts._N(v)
+
+
 def global_counts(*local_counts, device=None):
-    """All-reduced element counts (float tensor) used as the denominators of the loss means."""
-    t = torch.tensor([float(c) for c in local_counts], device=device)
-    if world() > 1:
-        dist.all_reduce(t)
+    """All-reduced element counts used as the denominators of the loss means (a float tensor under torch.distributed; plain numbers in a
+    single process).  No ``torch.tensor(list, device=...)``: a host -> device copy from pageable memory is a BLOCKING call on the stream --
+    round 4 found it in the kernel trace as the point where the host, until then a whole forward ahead of the device, waited for the device
+    and then paced every launch of the loss and of the backward's head (0.25 .. 0.5 ms of idle device per step)."""
+    if world() == 1:
+        return _HostCounts(_HostCounts._N(float(c)) for c in local_counts)
+    t = torch.zeros(len(local_counts), dtype=torch.float32, device=device)
+    for i, c in enumerate(local_counts):
+        t[i].fill_(float(c))                 # (a fill kernel with the number as its argument: asynchronous)
+    dist.all_reduce(t)
     return t
 
 

@@ -60,6 +60,7 @@ class FusedRender(torch.autograd.Function):
         # node is a reference cycle that only Python's cycle collector breaks: a training-mode forward that is never back-propagated (an evaluation
         # under enabled gradients) then holds its activation arena (tens of GB) until some later collection
         ctx.env, ctx.pts, ctx.fwd = env, pts, {k: fwd[k] for k in ("saved", "decoded", "weight", "opacity")}
+        env["_saved"] = fwd["saved"]              # (a caller that drops this result without a backward hands the arena block back itself)
         ctx.shapes = (tuple(emb.shape), tuple(conf.shape), tuple(pdir.shape), tuple(color.shape))
         ctx.n_mlp = len(mlp_params)
         ctx.mark_non_differentiable(fwd["opacity"], fwd["bg_trans"], fwd["blend_w"], fwd["decoded"], fwd["weight"])
@@ -101,6 +102,7 @@ class FusedRender(torch.autograd.Function):
         if fwd["saved"] is not None:
             ops.ARENA.give(fwd["saved"])  # hand the activation arena back for the next step
         fwd["saved"] = None
+        env.pop("_saved", None)
         gm = tuple(gflat[o:o + n].view(shp) for (o, n, shp) in env["layout"])
         assert len(gm) == ctx.n_mlp
         # the graph node outlives this call for as long as the caller keeps the loss: release the step's big tensors (query

@@ -12,6 +12,8 @@ boolean row-gather at the very end (the only host sync besides reading the valid
 distance and weighted average colour/dir/conf/embedding) used by ``probe_hole`` (run/train_ft.py:417-530): they touch
 one sample per ray, so they are small gathers on top of the dense render (``pnerf_gather_rows`` for the point rows).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -24,6 +26,10 @@ def gradient_clamp(sampled_conf, lo=0.0001, hi=1.0):
     """point_aggregators.py:722-724: clamp forward, identity backward."""
     diff = sampled_conf - torch.clamp(sampled_conf, min=lo, max=hi)
     return sampled_conf - diff.detach()
+
+
+# PNERF_SPECULATE=0: every training step waits for its counters before it is enqueued (rounds 1-3)
+SPECULATE = os.environ.get("PNERF_SPECULATE", "1") != "0"
 
 
 class NeuralPointsRayMarching(nn.Module):
@@ -47,6 +53,13 @@ class NeuralPointsRayMarching(nn.Module):
                 raise NotImplementedError("only radiance / alpha / off (every script's setting) is implemented")
         self.last_stats = None
         self._pool_rays = 0
+        self._pinned_words = None
+
+    def _host_words(self, n):
+        """pinned host memory for the step's asynchronous read-back of its counters"""
+        if self._pinned_words is None or self._pinned_words.numel() != n:
+            self._pinned_words = torch.empty(n, dtype=torch.int64).pin_memory()
+        return self._pinned_words
 
     def render_dense(self, campos, raydir, camrotc2w, near, far, bg_color=None, train=None):
         """The fused step on all R rays.  Returns (ray_color [R,3], opacity, bg_trans, blend_w, decoded, weight, dense)."""
@@ -64,14 +77,7 @@ class NeuralPointsRayMarching(nn.Module):
         # counts travel with the one host read below instead of synchronising a second time after the backward
         plan = getattr(self, "plan_sparse", None)
         plan = plan(dense) if (plan is not None and train) else None
-        if plan is not None:
-            both = torch.cat([dense["counters"].to(torch.int64), plan[1]]).cpu()
-            counters, self.sparse_plan = both[:8], (plan[0], int(both[8]), int(both[9]))
-        else:
-            counters = dense["counters"].cpu()                # the one sync: sizes the activation arena
-        n_valid = int(counters[0])
-        self.last_stats = dict(n_valid_samples=n_valid, rays_hit=int(counters[1]), n_selected=int(counters[2]),
-                               n_neighbor_rows=int(counters[3]), rays=R)
+        words = dense["counters"].to(torch.int64) if plan is None else torch.cat([dense["counters"].to(torch.int64), plan[1]])
         st = agg.mlp_state()
         rw = ops.host_array(npnt.Rw2c) if isinstance(npnt.Rw2c, torch.Tensor) else None
         cam = ops.make_camera(ops.host_array(campos).reshape(-1)[:3], ops.host_array(camrotc2w).reshape(-1)[:9],
@@ -79,9 +85,39 @@ class NeuralPointsRayMarching(nn.Module):
                               bg=None if bg_color is None else ops.host_array(bg_color).reshape(-1)[:3], rw2c=rw)
         mlp_params, layout = agg.ordered_params()
         env = dict(cam=cam, xyz=npnt.xyz.detach().reshape(-1, 3).contiguous(), raydir=raydir.detach().reshape(-1, 3).contiguous().float(),
-                   dense=dense, R=R, SR=int(opt.SR), K=int(opt.K), n_valid=n_valid, flat=st.flat, packed=st.packed_image(),
+                   dense=dense, R=R, SR=int(opt.SR), K=int(opt.K), n_valid=0, flat=st.flat, packed=st.packed_image(),
                    train=bool(train), layout=layout, want_grad_event=bool(train) and raydir.is_cuda and pdist.world() > 1)
-        out = FusedRender.apply(env, npnt.points_embeding, npnt.points_conf, npnt.points_dir, npnt.points_color, *mlp_params)
+        leaves = (npnt.points_embeding, npnt.points_conf, npnt.points_dir, npnt.points_color) + tuple(mlp_params)
+        # The step's one host read (number of valid samples: sizes the activation arena; number of hit rays: shapes of the outputs).
+        # Round 4: a TRAINING step whose arena already exists is enqueued BEFORE that read with the arena's capacity as the bound -- every
+        # kernel takes the actual counts from the device (`counters`, the class partition's tile counts), the host number is only "how much
+        # scratch is there" -- so the device starts the aggregator right behind the query instead of idling through the host's wake-up and
+        # its ~20 launches (0.2-0.3 ms per step in the kernel trace).  The counts arrive in pinned memory meanwhile; should they exceed the
+        # capacity (a batch larger than every one before it), the speculative result is dropped and the step runs again after the arena grew.
+        cap = ops.ARENA.capacity_samples(env["K"], raydir.device) if (train and raydir.is_cuda and SPECULATE) else 0
+        out = None
+        if cap > 0:
+            host = self._host_words(words.numel())
+            host.copy_(words, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record()
+            env["n_valid"] = cap
+            out = FusedRender.apply(env, *leaves)
+            ready.synchronize()
+            got = host.clone()
+        else:
+            got = words.cpu()                                 # the one sync
+        n_valid = int(got[0])
+        if out is not None and n_valid > cap:                 # (rare: the arena has to grow; nothing of the dropped result is used)
+            ops.ARENA.give(env.pop("_saved", None))
+            out, env = None, dict(env)
+        if plan is not None:
+            self.sparse_plan = (plan[0], int(got[8]), int(got[9]))
+        self.last_stats = dict(n_valid_samples=n_valid, rays_hit=int(got[1]), n_selected=int(got[2]), n_neighbor_rows=int(got[3]), rays=R,
+                               enqueued_before_host_read=out is not None)
+        if out is None:
+            env["n_valid"] = n_valid
+            out = FusedRender.apply(env, *leaves)
         return out + (dense,)
 
     def forward(self, campos, raydir, gt_image=None, bg_color=None, camrotc2w=None, pixel_idx=None, near=None, far=None,

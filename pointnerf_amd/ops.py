@@ -250,6 +250,27 @@ class Arena:
         if t is not None:
             self.free.append(t)
 
+    def capacity_samples(self, K, device):
+        """the number of valid samples the largest free block can hold the saved activations of (0: no free block yet): the capacity a
+        render step can be ENQUEUED with before the step's own count has reached the host (NeuralPointsRayMarching.render_dense)"""
+        best = max((t.numel() for t in self.free if t.device == torch.device(device)), default=0)
+        if best <= 0:
+            return 0
+        key = (best, int(K))
+        hit = getattr(self, "_cap_cache", {}).get(key)
+        if hit is not None:
+            return hit
+        fn = L.lib().pnerf_agg_saved_bytes
+        lo, hi = 0, best // 512
+        while lo < hi:                          # largest n with saved_bytes(n, K) <= best (monotone)
+            mid = (lo + hi + 1) // 2
+            if fn(mid, int(K)) <= best:
+                lo = mid
+            else:
+                hi = mid - 1
+        self._cap_cache = {key: lo}
+        return lo
+
     def reserve(self, nbytes, device):
         """make sure one free block of at least ``nbytes`` exists (a caller that knows its largest step sizes the arena once,
         instead of paying a ~2 s hipFree + hipMalloc of tens of GB when a later step is 15 % larger than every earlier one)"""
