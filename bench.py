@@ -83,6 +83,7 @@ def parse():
     ap.add_argument("--no-overlap-comm", action="store_true", help="N > 1: all-reduce the point gradients after the whole backward instead of behind the weight-gradient GEMMs")
     ap.add_argument("--point-grads", default="auto", choices=("auto", "dense", "sparse"),
                     help="N > 1: exchange of the per-point gradients: dense all-reduce (one bucket, overlapped), sparse touched-row exchange, auto = sparse from 6 M points")
+    ap.add_argument("--unfused-color-loss", action="store_true", help="A/B: the colour loss as ATen ops on the compacted hit rays (argsort + index_selects)")
     ap.add_argument("--unfused-zero-one", action="store_true", help="A/B: the zero-one regulariser as the reference's chain of ATen ops on a materialised conf_coefficient")
     ap.add_argument("--zero1", action="store_true", help="N > 1: shard the point-parameter Adam (reduce-scatter + all-gather) instead of all-reducing the gradients")
     ap.add_argument("--wgrad-planes", type=int, default=1, choices=(1, 2),
@@ -237,6 +238,7 @@ def main():
     model = build_model(opt, n_points, dev, points_fn)
     agg, npnt = model.aggregator, model.neural_points
     model.fused_zero_one = not args.unfused_zero_one     # the zero-one regulariser as one fused pass over the neighbor table (ops.ZeroOneConf)
+    model.fused_color_loss = not args.unfused_color_loss and not args.unfused_zero_one   # the colour loss over the dense ray colours (ops.ColorLossRays)
     mlp_params = [p for p in agg.parameters() if p.requires_grad]
     pt_params = [p for p in (npnt.points_embeding, npnt.points_conf, npnt.points_dir, npnt.points_color) if p.requires_grad]
     # the reference's two Adam instances (mvs_points_volumetric_model.py:80-91) as one-pass HIP updates; --zero1 shards the

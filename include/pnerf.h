@@ -117,6 +117,14 @@ int pnerf_zero_one_forward_rays(const float *d_conf, int n_points, const int32_t
                                 float *d_partial, void *stream);
 int pnerf_zero_one_backward_rays(const float *d_conf, int n_points, const int32_t *d_idx, const int32_t *d_ray_hit, int R, int slots_per_ray, float eps,
                                  const float *d_gscale, float *d_grad_conf, void *stream);
+/* the colour term of the training loss (models/base_rendering_model.py:543-551 "ray_masked_coarse_raycolor": sum over the rays that hit of
+ * (colour - gt)^2; the caller divides by its global element count) over the DENSE ray colours d_ray_color [R,3] / d_gt [R,3] with the rays' hit
+ * flags -- the hit rays are not compacted on the way to a scalar.  forward: d_partial[b], b < pnerf_color_loss_blocks(R), block sums.
+ * backward: d_grad_ray_color [R,3] = 2 d_gscale[0] (colour - gt) for a hit ray, 0 for a miss (every element is written). */
+int pnerf_color_loss_blocks(int R);
+int pnerf_color_loss_forward_rays(const float *d_ray_color, const float *d_gt, const int32_t *d_ray_hit, int R, float *d_partial, void *stream);
+int pnerf_color_loss_backward_rays(const float *d_ray_color, const float *d_gt, const int32_t *d_ray_hit, int R, const float *d_gscale,
+                                   float *d_grad_ray_color, void *stream);
 
 /* ---- aggregator MLP + renderer (PointAggregator.forward/viewmlp,
  * models/aggregators/point_aggregators.py:488-644,727-814; ray-dist,

@@ -73,6 +73,9 @@ PROTOTYPES = {
     "pnerf_zero_one_blocks": (c_int, [c_i64]),
     "pnerf_zero_one_forward": (c_int, [c_void_p, c_int, c_void_p, c_i64, c_f32, c_void_p, c_void_p]),
     "pnerf_zero_one_backward": (c_int, [c_void_p, c_int, c_void_p, c_i64, c_f32, c_void_p, c_void_p, c_void_p]),
+    "pnerf_color_loss_blocks": (c_int, [c_int]),
+    "pnerf_color_loss_forward_rays": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "pnerf_color_loss_backward_rays": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "pnerf_zero_one_forward_rays": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_f32, c_void_p, c_void_p]),
     "pnerf_zero_one_backward_rays": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_f32, c_void_p, c_void_p, c_void_p]),
     "pnerf_voxel_downsample_workspace_bytes": (c_size_t, [c_i64, c_int, c_int, c_int]),

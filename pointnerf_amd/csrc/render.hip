@@ -335,6 +335,56 @@ __global__ __launch_bounds__(TPB) void k_zero_one_backward_rays(const float *__r
 }
 }  // namespace
 
+namespace {
+// colour term of the training loss over the DENSE ray colours with the rays' hit flags (models/base_rendering_model.py:543-551:
+// ray_masked_coarse_raycolor = sum over the hit rays' (colour - gt)^2, the caller divides by its global element count): no compaction of the
+// hit rays (argsort + index_selects) on the way to a scalar.  partial[b] = block sums; backward writes d colour for EVERY ray (0 for a miss),
+// which is what the renderer's backward reads.
+__global__ __launch_bounds__(256) void k_color_loss_forward_rays(const float *__restrict__ col, const float *__restrict__ gt, const int *__restrict__ hit, int R,
+                                                                 float *__restrict__ partial) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < R; r += gridDim.x * 256)
+        if (hit[r] > 0) {
+            const float dx = col[3 * r] - gt[3 * r], dy = col[3 * r + 1] - gt[3 * r + 1], dz = col[3 * r + 2] - gt[3 * r + 2];
+            acc += (dx * dx + dy * dy) + dz * dz;
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void k_color_loss_backward_rays(const float *__restrict__ col, const float *__restrict__ gt, const int *__restrict__ hit, int R,
+                                                                  const float *__restrict__ gscale, float *__restrict__ gcol) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const float g = hit[r] > 0 ? 2.f * gscale[0] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gcol[3 * r + c] = g == 0.f ? 0.f : g * (col[3 * r + c] - gt[3 * r + c]);
+}
+}  // namespace
+extern "C" int pnerf_color_loss_blocks(int R) {
+    const int b = (R + 255) / 256;
+    return b < 1 ? 1 : (b > 1024 ? 1024 : b);
+}
+extern "C" int pnerf_color_loss_forward_rays(const float *d_ray_color, const float *d_gt, const int32_t *d_ray_hit, int R, float *d_partial, void *stream) {
+    if (!d_ray_color || !d_gt || !d_ray_hit || !d_partial || R < 0) return PNERF_E_INVAL;
+    PnProfScope prof(PNK_GATHER, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_color_loss_forward_rays, dim3(pnerf_color_loss_blocks(R)), dim3(256), 0, (hipStream_t)stream, d_ray_color, d_gt, d_ray_hit, R, d_partial);
+    PN_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pnerf_color_loss_backward_rays(const float *d_ray_color, const float *d_gt, const int32_t *d_ray_hit, int R, const float *d_gscale,
+                                              float *d_grad_ray_color, void *stream) {
+    if (R == 0) return 0;
+    if (!d_ray_color || !d_gt || !d_ray_hit || !d_gscale || !d_grad_ray_color || R < 0) return PNERF_E_INVAL;
+    PnProfScope prof(PNK_GATHER, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_color_loss_backward_rays, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_ray_color, d_gt, d_ray_hit, R, d_gscale, d_grad_ray_color);
+    PN_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pnerf_zero_one_forward_rays(const float *d_conf, int n_points, const int32_t *d_idx, const int32_t *d_ray_hit, int R, int slots_per_ray, float eps,
                                            float *d_partial, void *stream) {
     if (!d_conf || !d_partial || !d_idx || !d_ray_hit || n_points <= 0 || R < 0 || slots_per_ray <= 0) return PNERF_E_INVAL;

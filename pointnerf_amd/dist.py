@@ -67,12 +67,17 @@ def hot_path_loss(opt, out, gt_image, zero_epsilon=1e-3):
     """The lego script's training loss (models/base_rendering_model.py:543-551 ``ray_masked_coarse_raycolor`` x 1.0
     + 1e-6, and :630-641 ``zero_one`` on ``conf_coefficient`` x opt.zero_one_loss_weights[0]) with both means taken
     over the GLOBAL batch."""
-    pred = out["coarse_raycolor"][0]
-    gt = gt_image[0].index_select(0, out["_hit_index"]) if "_hit_index" in out else gt_image[0][out["ray_mask"][0] > 0]
-    cc, zo = out.get("conf_coefficient"), out.get("_zero_one")
+    cc, zo, dc = out.get("conf_coefficient"), out.get("_zero_one"), out.get("_dense_color")
     n_cc = cc.numel() if cc is not None else (zo[3] if zo is not None else 0)
-    n = global_counts(pred.numel(), n_cc, device=pred.device)
-    loss = ((pred - gt) ** 2).sum() / n[0].clamp(min=1.0) + 1e-6 / world()
+    if dc is not None:                # the renderer handed out (dense ray colours, hit flags, number of hit rays): one fused pass, no compaction
+        from . import ops
+        n = global_counts(3 * dc[2], n_cc, device=dc[0].device)
+        loss = ops.color_loss_sum_rays(dc[0], gt_image[0], dc[1]) / n[0].clamp(min=1.0) + 1e-6 / world()
+    else:
+        pred = out["coarse_raycolor"][0]
+        gt = gt_image[0].index_select(0, out["_hit_index"]) if "_hit_index" in out else gt_image[0][out["ray_mask"][0] > 0]
+        n = global_counts(pred.numel(), n_cc, device=pred.device)
+        loss = ((pred - gt) ** 2).sum() / n[0].clamp(min=1.0) + 1e-6 / world()
     if "conf_coefficient" in opt.zero_one_loss_items:
         if zo is not None:            # the renderer handed out (points_conf, neighbor table) instead of the tensor: one fused pass
             from . import ops

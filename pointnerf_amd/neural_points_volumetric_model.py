@@ -133,6 +133,16 @@ class NeuralPointsRayMarching(nn.Module):
         # synchronise once per tensor (nonzero), and the device would idle between forward, loss and backward while the
         # host catches up; with this the whole step is enqueued behind one synchronisation.
         n_hit = self.last_stats["rays_hit"]
+        # ``fused_color_loss`` (ours, like ``fused_zero_one`` below; set by callers whose loss goes through dist.hot_path_loss / the model shell
+        # of this package): a TRAINING step whose only consumer of the rendered colours is the colour loss gets the dense ray colours and the
+        # hit flags under "_dense_color" (ops.ColorLossRays: one pass forward, one backward, d colour written for every ray) and the compacted
+        # [1, R'', ...] outputs are not formed -- no argsort, no index_selects, no scatter-back in the backward (~25 launches per step)
+        if getattr(self, "fused_color_loss", False) and torch.is_grad_enabled() and getattr(opt, "prob", 0) == 0 \
+                and opt.sparse_loss_weight <= 0 and getattr(self, "fused_zero_one", False):
+            output = {"_dense_color": (ray_color, dense["ray_hit"], n_hit), "ray_mask": hit.to(torch.int8)[None]}
+            if "conf_coefficient" in opt.zero_one_loss_items:
+                output["_zero_one"] = (self.neural_points.points_conf, dense["sample_pidx"], dense["ray_hit"], n_hit * SR * K)
+            return output
         idx = torch.argsort(dense["ray_hit"], descending=True, stable=True)[:n_hit]
         take = lambda t: t.index_select(0, idx)
         output = {"_hit_index": idx}

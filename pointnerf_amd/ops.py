@@ -467,6 +467,36 @@ def zero_one_conf_sum_rays(conf, pidx_dense, ray_hit, eps):
     return ZeroOneConfRays.apply(conf, pidx_dense.contiguous(), ray_hit.contiguous(), eps)
 
 
+class ColorLossRays(torch.autograd.Function):
+    """sum over the rays that hit of (colour - gt)^2 on the DENSE ray colours [R,3] (pnerf_color_loss_forward_rays / _backward_rays): the
+    colour term of the training loss without the hit rays' compaction (argsort + index_selects + their scatter-back in the backward)."""
+
+    @staticmethod
+    def forward(ctx, ray_color, gt, ray_hit):
+        _need_cuda(ray_color, "ray_color")
+        lib = L.lib()
+        c, g = ray_color.detach().reshape(-1, 3).contiguous().float(), gt.detach().reshape(-1, 3).contiguous().float()
+        R = c.shape[0]
+        part = torch.empty(lib.pnerf_color_loss_blocks(R), dtype=torch.float32, device=c.device)
+        L.check(lib.pnerf_color_loss_forward_rays(_ptr(c), _ptr(g), _ptr(ray_hit), R, _ptr(part), _stream()), "pnerf_color_loss_forward_rays")
+        ctx.save_for_backward(c, g, ray_hit)
+        ctx.shape = ray_color.shape
+        return part.sum()
+
+    @staticmethod
+    def backward(ctx, gout):
+        c, g, ray_hit = ctx.saved_tensors
+        grad = torch.empty_like(c)
+        gs = gout.detach().reshape(1).to(torch.float32).contiguous()
+        L.check(L.lib().pnerf_color_loss_backward_rays(_ptr(c), _ptr(g), _ptr(ray_hit), c.shape[0], _ptr(gs), _ptr(grad), _stream()),
+                "pnerf_color_loss_backward_rays")
+        return grad.view(ctx.shape), None, None
+
+
+def color_loss_sum_rays(ray_color, gt, ray_hit):
+    return ColorLossRays.apply(ray_color, gt, ray_hit.contiguous())
+
+
 def set_inference_products(n):
     """Products per multiply-add of the inference forward: 3 (default, fp32-class accuracy, what the training forward always runs) or
     2 (render / evaluation option: ~1.5x less matrix work, ray colour within ~2e-5 of fp32).  Returns the previous setting."""

@@ -210,3 +210,9 @@ def test_emulated_step_with_a_capacity_above_the_actual_count(monkeypatch):
         else:
             err = float((exact[k] - loose[k]).abs().max()) / max(float(exact[k].abs().max()), 1e-12)
             assert err <= 2e-6, (k, err)
+
+
+def test_emulated_fused_color_loss_matches_the_compacted_chain():
+    """ops.ColorLossRays over the dense ray colours (no argsort / index_select of the hit rays) against the chain it replaces, through the
+    model and dist.hot_path_loss: the loss value and every gradient of the step (fused_color_loss on / off)."""
+    TB.fused_color_loss_equivalence(*_tiny_case(8, 12, 5), "cpu")

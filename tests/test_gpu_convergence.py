@@ -28,7 +28,7 @@ def test_200_steps_against_the_fp32_oracle():
     The yardstick is therefore measured, not assumed: the CPU oracle is run TWICE, the second time with every MLP weight moved by a relative
     2^-23 (half an fp32 ulp: the smallest perturbation that exists), and the device trajectory must (i) match the oracle to 1e-4 while the two
     oracle runs still agree to 1e-4 (measured: 1e-7 .. 1e-6 for the first 50 steps), and (ii) never be further from the oracle than
-    3 x the largest divergence the perturbed oracle has shown up to that step (floor 1e-3)."""
+    3 x the largest divergence the perturbed oracle has shown up to that step (floor: see (iii) below), and within 1e-4 for the first 100 steps."""
     case = build_case("small_k8")
     opt, xyz, attrs, inp, mlp = case
     ref, _, _ = oracle_steps(*case, 200)
@@ -50,9 +50,13 @@ def test_200_steps_against_the_fp32_oracle():
     assert ref[-1] < 0.5 * ref[0], "the case must actually optimise"
     agree = env <= 1e-4
     assert agree[:30].all(), "the oracle's own perturbed run left 1e-4 within 30 steps: the yardstick is broken"
+    # (iii) once a trajectory has left the yardstick it is decorrelated: WHEN that happens is itself chance (the step at which some
+    # pre-activation crosses a LeakyReLU kink: step ~125 on one box, ~160 on another, for the device and for the perturbed oracle alike),
+    # so beyond it the bar is the size two decorrelated fp32 runs differ by (measured 1e-2 .. 4e-2 at steps 175 .. 200): 5e-2.
     for d in (d_dev, d_dev2):
         assert (d[agree] <= 1e-4).all(), float(d[agree].max())
-        assert (d <= np.maximum(3.0 * env, 1e-3)).all(), (float(d.max()), int(np.argmax(d - np.maximum(3.0 * env, 1e-3))))
+        assert (d[:100] <= 1e-4).all(), float(d[:100].max())
+        assert (d <= np.maximum(3.0 * env, 5e-2)).all(), (float(d.max()), int(np.argmax(d - np.maximum(3.0 * env, 5e-2))))
 
 
 STEPS = 2000
