@@ -742,23 +742,11 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
         PN_TR(pn_trace_fwd, 14);
         if (K == 8 || K == 4 || K == 2 || K == 1) {
             // ---- alpha head + h4 copy + K-weighted sums + sigma in one pass (f_tail)
-#ifdef PN_EXP_NOTAIL
-            if (!ew) { if (PN_NW == 8 && tile + stride < ntiles) f_gather<PERS>(a, G, si1, p1, q); }
-#elif defined(PN_EXP_NOGATHER)
-            if (!ew) { }
-            else if (K == 8) f_tail<8, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
-#elif defined(PN_EXP_TAIL8)
-            if (!ew) { if (PN_NW == 8 && tile + stride < ntiles) f_gather<PERS>(a, G, si1, p1, q); }
-            else f_tail<8, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
-#else
             if (!ew) { if (PN_NW == 8 && tile + stride < ntiles) f_gather<PERS>(a, G, si1, p1, q); }
             else if (K == 8) f_tail<8, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
-#endif
-#if !defined(PN_EXP_NOTAIL) && !defined(PN_EXP_TAIL8)
             else if (K == 4) f_tail<4, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
             else if (K == 2) f_tail<2, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
             else f_tail<1, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
-#endif
             PN_TR(pn_trace_fwd, 15);
         } else {
         // ---- (any other K: three passes) alpha head (256 -> 1, softplus(x - 1), raw2out_density :262-265): 4 threads per row, 8-column groups interleaved
