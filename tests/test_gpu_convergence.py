@@ -82,9 +82,13 @@ def test_convergence_one_plane_vs_two_planes():
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/convergence_ab.json", "w") as fh:
         json.dump(out, fh)
-    # the problem is a real one: every run gains > 10 dB on views it never trained on
-    assert min(stat("psnr_heldout", 1).min(), stat("psnr_heldout", 2).min()) > out["psnr_heldout_before"] + 10.0
-    # the two arithmetics are one population: |difference of means| <= 3 standard errors (floors: 0.15 dB, 5 % of the loss)
+    # the problem is a real one: every run gains > 8 dB on views it never trained on (measured over 24 + 12 runs: mean + 14 dB, run-to-run standard
+    # deviation 1.0 .. 2.0 dB, worst + 11.0 -- a + 10 dB bar would fail one suite run in ten by chance alone)
+    assert min(stat("psnr_heldout", 1).min(), stat("psnr_heldout", 2).min()) > out["psnr_heldout_before"] + 8.0
+    # the two arithmetics are one population: |difference of means| <= 4 standard errors (floors: 0.15 dB, 5 % of the loss).  With 6 + 6 runs
+    # Welch's statistic has ~10 degrees of freedom: 3 standard errors is exceeded by chance in 1.3 % of the comparisons, i.e. by one of the three
+    # metrics in ~3 % of the suite runs (the round-end run stops at the first failure); 4 in 0.25 %.  The 12 + 12 runs of
+    # profiles/r04_convergence_ab.json sit at 0.35 (held-out PSNR), 1.8 (training PSNR) and 1.9 (training MSE, in favour of one plane).
     for key, floor in (("psnr_heldout", 0.15), ("psnr_train", 0.15), ("train_mse", 0.05 * out["train_mse"]["mean_two_planes"])):
         o = out[key]
-        assert o["difference_of_means"] <= max(3.0 * o["standard_error_of_the_difference"], floor), (key, o)
+        assert o["difference_of_means"] <= max(4.0 * o["standard_error_of_the_difference"], floor), (key, o)
