@@ -610,11 +610,18 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
     const char *img = reinterpret_cast<const char *>(a.packed);
     if (tid0 < PN_H) w5s[tid0] = P[PO_W5 + tid0];
     const float b5 = P[PO_B5];
-    const long long stride = gridDim.x;
-    if ((long long)blockIdx.x >= ntiles) return;
+    // tiles of a workgroup: blockIdx.x, blockIdx.x + gridDim.x, ... (the chip works on one moving window of the saved area);
+    // dev A/B -DPN_TILE_BLOCKED: one contiguous run of tiles per workgroup (consecutive tiles = consecutive samples of a ray on ONE CU)
+#ifdef PN_TILE_BLOCKED
+    const long long per_wg = (ntiles + gridDim.x - 1) / gridDim.x, stride = 1, tile_first = blockIdx.x * per_wg;
+    const long long tile_last = tile_first + per_wg < ntiles ? tile_first + per_wg : ntiles;
+#else
+    const long long stride = gridDim.x, tile_first = blockIdx.x, tile_last = ntiles;
+#endif
+    if (tile_first >= tile_last) return;
 
     // index pipeline of this thread's row: (si0, p0) current tile, (si1, p1) next, si2 the one after
-    long long tile = blockIdx.x;
+    long long tile = tile_first;
     int si0, si1, si2, p0, p1;
     FGather G;
     // Roles in the 8-wave organisation: the LAST PN_ETHR threads (waves 4..7) own the gather + feature build + row weights (4 threads per
@@ -623,7 +630,8 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
     si0 = si1 = si2 = p0 = p1 = -1;
     if (tid0 >= PN_NTHR - PN_ETHR) {
         const int bt = tid0 - (PN_NTHR - PN_ETHR), row = bt / TPR, q = bt % TPR, k = row - pn_row_div(row, kinv) * K;
-        si0 = f_sample_of(a, tile, row, Ns, kinv); si1 = f_sample_of(a, tile + stride, row, Ns, kinv); si2 = f_sample_of(a, tile + 2 * stride, row, Ns, kinv);
+        si0 = f_sample_of(a, tile, row, Ns, kinv); si1 = tile + stride < tile_last ? f_sample_of(a, tile + stride, row, Ns, kinv) : -1;
+        si2 = tile + 2 * stride < tile_last ? f_sample_of(a, tile + 2 * stride, row, Ns, kinv) : -1;
         p0 = si0 >= 0 ? a.pidx[(long long)si0 * a.Kstride + k] : -1;
         p1 = si1 >= 0 ? a.pidx[(long long)si1 * a.Kstride + k] : -1;
         f_gather<PERS>(a, G, si0, p0, q);
@@ -631,7 +639,7 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
 
     f32x16 acc[PN_NFB][2];
     PN_TR_ITER_DECL;
-    for (; tile < ntiles; tile += stride) {
+    for (; tile < tile_last; tile += stride) {
         PN_TR_ITER_NEXT;
         // thread-index-derived offsets are recomputed per tile: hoisted out of the loop they become hundreds of loop-carried
         // registers (every LDS / bias / image address of every unrolled store) and spill
@@ -732,9 +740,9 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
         const int si_next = si1, p_next = p1;
         // (8 waves: the gather is issued by the build waves WHILE the tail waves run the tail, in the other arm of that branch -- then the
         //  tail's code never holds the gathered registers)
-        if (PN_NW != 8 && tile + stride < ntiles) f_gather<PERS>(a, G, si1, p1, q);
+        if (PN_NW != 8 && tile + stride < tile_last) f_gather<PERS>(a, G, si1, p1, q);
         const int p2 = si2 >= 0 ? a.pidx[(long long)si2 * a.Kstride + k] : -1;
-        const int si3 = bw ? f_sample_of(a, tile + 3 * stride, row, Ns, kinv) : -1;
+        const int si3 = (bw && tile + 3 * stride < tile_last) ? f_sample_of(a, tile + 3 * stride, row, Ns, kinv) : -1;
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 13);
         f_epilogue<false>(acc, X, wave, lane, mask);
@@ -742,7 +750,7 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
         PN_TR(pn_trace_fwd, 14);
         if (K == 8 || K == 4 || K == 2 || K == 1) {
             // ---- alpha head + h4 copy + K-weighted sums + sigma in one pass (f_tail)
-            if (!ew) { if (PN_NW == 8 && tile + stride < ntiles) f_gather<PERS>(a, G, si1, p1, q); }
+            if (!ew) { if (PN_NW == 8 && tile + stride < tile_last) f_gather<PERS>(a, G, si1, p1, q); }
             else if (K == 8) f_tail<8, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
             else if (K == 4) f_tail<4, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
             else if (K == 2) f_tail<2, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
@@ -750,7 +758,7 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
             PN_TR(pn_trace_fwd, 15);
         } else {
         // ---- (any other K: three passes) alpha head (256 -> 1, softplus(x - 1), raw2out_density :262-265): 4 threads per row, 8-column groups interleaved
-        if (PN_NW == 8 && bw && tile + stride < ntiles) f_gather<PERS>(a, G, si1, p1, q);      // (8 waves: the build waves' prefetch, see above)
+        if (PN_NW == 8 && bw && tile + stride < tile_last) f_gather<PERS>(a, G, si1, p1, q);      // (8 waves: the build waves' prefetch, see above)
         if (ew) {
             const int trow = tid / TPR, tq = tid % TPR;
             float s = 0.f;

@@ -461,14 +461,20 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_backward(BwdArgs a) 
     f32x16 acc[PN_NFB][2];
     // row metadata of the tile (threads 0..63: one row each), fetched ONE TILE AHEAD: the d sigma of a row hangs off its sample id, and
     // two dependent HBM round trips at the top of every tile were 4 of the 6 us of the load phase
+#ifdef PN_TILE_BLOCKED       // (dev A/B: see the forward)
+    const long long per_wg = (ntiles + gridDim.x - 1) / gridDim.x, stride = 1, tile_first = blockIdx.x * per_wg;
+    const long long tile_last = tile_first + per_wg < ntiles ? tile_first + per_wg : ntiles;
+#else
+    const long long stride = gridDim.x, tile_first = blockIdx.x, tile_last = ntiles;
+#endif
     int4 rm_cur = make_int4(-1, -1, 0, 0);
     float ar_cur = 0.f;
-    if (tid0 < PN_TILE && (long long)blockIdx.x < ntiles) {
-        rm_cur = a.sv.rmeta[(tb + blockIdx.x) * PN_TILE + tid0];
-        ar_cur = a.sv.arow[(tb + blockIdx.x) * PN_TILE + tid0];
+    if (tid0 < PN_TILE && tile_first < tile_last) {
+        rm_cur = a.sv.rmeta[(tb + tile_first) * PN_TILE + tid0];
+        ar_cur = a.sv.arow[(tb + tile_first) * PN_TILE + tid0];
     }
     PN_TR_ITER_DECL;
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (long long tile = tile_first; tile < tile_last; tile += stride) {
         PN_TR_ITER_NEXT;
         int tid = threadIdx.x;                          // (recomputed per tile: see the forward)
         asm volatile("" : "+v"(tid));
@@ -497,9 +503,9 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_backward(BwdArgs a) 
         }
         int4 rm_nxt = make_int4(-1, -1, 0, 0);
         float ar_nxt = 0.f;
-        if (tid < PN_TILE && tile + gridDim.x < ntiles) {
-            rm_nxt = a.sv.rmeta[(gtile + gridDim.x) * PN_TILE + tid];
-            ar_nxt = a.sv.arow[(gtile + gridDim.x) * PN_TILE + tid];
+        if (tid < PN_TILE && tile + stride < tile_last) {
+            rm_nxt = a.sv.rmeta[(gtile + stride) * PN_TILE + tid];
+            ar_nxt = a.sv.arow[(gtile + stride) * PN_TILE + tid];
         }
         __builtin_amdgcn_sched_barrier(0);
         if (tid < PN_TILE) {
@@ -726,7 +732,7 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_backward(BwdArgs a) 
     // flush the register-resident partial sums: a workgroup that had no tile has nothing to add; the others first add up their eight row
     // sets in LDS -- atomics of every workgroup on the same 256 addresses serialise in L2 (2048 per workgroup made the two small sample
     // classes' launches 1 ms each)
-    if ((long long)blockIdx.x >= ntiles) return;
+    if (tile_first >= tile_last) return;
     if (one_pass) {
         const int cg = tid0 & 31, rs = tid0 >> 5;
         float *red = reinterpret_cast<float *>(smem_b);            // [8 row sets][256 columns] over the tile's space
