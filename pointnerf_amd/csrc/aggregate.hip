@@ -879,12 +879,15 @@ __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
         WC1.prefetch(reinterpret_cast<const uint4 *>(img + PKH_FC1), wave, lane);
         PN_LDS_BARRIER();                                 // the previous tile's readers are done with X
         if (si >= 0) {
-            const float4 *f = reinterpret_cast<const float4 *>(a.sv.fs + vs * PN_H + q * 64);
+            // the row's four threads take interleaved 16-byte pieces (piece 4 c + q): a wave's load instruction reads whole 64-byte segments of
+            // 16 rows, its LDS stores land on 8 consecutive banks per row (round 4; one contiguous quarter row per thread touched 64 different
+            // segments per instruction and put threads 0 / 2 and 1 / 3 of a row on the same banks: half of this kernel's LDS cycles were conflicts)
+            const float4 *f = reinterpret_cast<const float4 *>(a.sv.fs + vs * PN_H);
             float4 fv[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) fv[c] = f[c];
+            for (int c = 0; c < 16; ++c) fv[c] = f[4 * c + q];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) pn_x_store4<false>(X, row, q * 64 + 4 * c, fv[c].x, fv[c].y, fv[c].z, fv[c].w);
+            for (int c = 0; c < 16; ++c) pn_x_store4<false>(X, row, 16 * c + 4 * q, fv[c].x, fv[c].y, fv[c].z, fv[c].w);
             {   // positional_encoding(viewdirs, 4, ori=True)[..., 3:] = [sin(v_d 2^f) (d-major) | cos(...)]   networks.py:185-187
                 // thread q < 3 of the row: direction component q, its four frequencies (columns 256 + 4 q .. and 268 + 4 q ..)
                 const int r = si / a.SR;
@@ -902,7 +905,7 @@ __global__ __launch_bounds__(256, 2) void k_color_forward(FwdArgs a) {
             }
         } else {
 #pragma unroll
-            for (int c = 0; c < 18; ++c) pn_x_store4<false>(X, row, q * 72 + 4 * c, 0.f, 0.f, 0.f, 0.f);
+            for (int c = 0; c < 18; ++c) pn_x_store4<false>(X, row, 16 * c + 4 * q, 0.f, 0.f, 0.f, 0.f);
         }
         PN_LDS_BARRIER();
         float4 bias[4];
