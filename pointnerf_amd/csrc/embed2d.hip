@@ -140,10 +140,10 @@ extern "C" int pnerf_extract_2d(const float *d_cam_xyz, int64_t n_points, const 
                                 int n_maps, int HD, int WD, int depth_occ, float tolerate, float *d_feats, int feat_cols, float *d_colors,
                                 int color_cols, uint8_t *d_mask, void *d_ws, size_t ws_bytes, void *stream) {
     if (!views || !maps || n_views < 1 || n_views > PNERF_EX2D_MAX_VIEWS || n_maps < 1 || n_maps > PNERF_EX2D_MAX_MAPS || HD < 2 || WD < 2 ||
-        n_points < 0 || feat_cols < 0 || color_cols < 0 || (feat_cols && !d_feats) || (color_cols && !d_colors) || feat_cols + color_cols == 0)
+        n_points < 0 || feat_cols < 0 || color_cols < 0 || feat_cols + color_cols == 0)
         return PNERF_E_INVAL;
-    if (n_points == 0) return 0;
-    if (!d_cam_xyz || !d_ws) return PNERF_E_INVAL;
+    if (n_points == 0) return 0;                 // (nothing to write: the output pointers of an empty cloud may be null)
+    if ((feat_cols && !d_feats) || (color_cols && !d_colors) || !d_cam_xyz || !d_ws) return PNERF_E_INVAL;
     if (ws_bytes < pnerf_extract_2d_workspace_bytes(n_points, n_views, HD, WD, depth_occ)) return PNERF_E_WS;
     if ((long long)n_points * (feat_cols + color_cols) / 256 >= 0x7fffffffLL) return PNERF_E_UNSUP;
     Ex2dArgs a;

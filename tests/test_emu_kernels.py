@@ -216,3 +216,35 @@ def test_emulated_fused_color_loss_matches_the_compacted_chain():
     """ops.ColorLossRays over the dense ray colours (no argsort / index_select of the hit rays) against the chain it replaces, through the
     model and dist.hot_path_loss: the loss value and every gradient of the step (fused_color_loss on / off)."""
     TB.fused_color_loss_equivalence(*_tiny_case(8, 12, 5), "cpu")
+
+
+def test_emulated_extract_2d_edge_cases():
+    """csrc/embed2d.hip: no points; every point outside every image (rows of zeros, masks false); feature layers only (no colour map:
+    colors is None, the mask comes from the first feature map of a view); a one-channel map sampled exactly at its corner texels."""
+    import types
+    from shell_fakes import embed_inputs
+    from pointnerf_amd.mvs_points_model import MvsPointsModel
+    inp = embed_inputs(seed=3, n=64)
+    m = MvsPointsModel(types.SimpleNamespace(depth_occ=0, ref_vid=0, shading_feature_mlp_layer0=0))
+    common = (inp["intrinsics"], inp["c2ws"], inp["w2cs"])
+    f, c = m.extract_2d(inp["img_feats"], [0, 1], [0, 1], *common, inp["cam_xyz"][:, :0], inp["HD"], inp["WD"])
+    assert f.shape == (1, 0, 16) and c.shape == (1, 0, 6)
+    far = inp["cam_xyz"].clone()
+    far[..., 0] += 100.0                                            # far to the side: outside every image
+    for occ in (0, 1):
+        m.args.depth_occ = occ
+        f, c, mask = m.extract_2d(inp["img_feats"], [0, 1, 2], [0, 1, 2, 3], *common, far, inp["HD"], inp["WD"], return_mask=True)
+        assert float(f.abs().max()) == 0.0 and float(c.abs().max()) == 0.0 and not bool(mask.any())
+    m.args.depth_occ = 0
+    f, c, mask = m.extract_2d(inp["img_feats"], [1], [2, 3], *common, inp["cam_xyz"], inp["HD"], inp["WD"], cam_vid=0, return_mask=True)
+    assert c is None and f.shape == (1, 64, 48) and mask.shape == (1, 64)
+    assert torch.equal(mask[0], f[0].abs().sum(-1) > 0)
+    # corner texels: a point that projects exactly onto pixel (0, 0) / (WD - 1, HD - 1) of the current camera reads that texel unblended
+    HD, WD = inp["HD"], inp["WD"]
+    K = inp["intrinsics"][0, 0]
+    ramp = (torch.arange(HD * WD, dtype=torch.float32).reshape(1, 1, HD, WD)).repeat(3, 1, 1, 1)
+    z = 2.0
+    pts = torch.tensor([[[(0 - K[0, 2]) / K[0, 0] * z, (0 - K[1, 2]) / K[1, 1] * z, z],
+                         [((WD - 1) - K[0, 2]) / K[0, 0] * z, ((HD - 1) - K[1, 2]) / K[1, 1] * z, z]]], dtype=torch.float32)
+    f, c = m.extract_2d([inp["img_feats"][0], ramp], [0], [1], *common, pts, HD, WD, cam_vid=0)
+    assert torch.allclose(f[0, :, 0], torch.tensor([0.0, float(HD * WD - 1)]), atol=2e-3), f
