@@ -38,15 +38,9 @@ def shard_slice(n_rays_global, r=None, w=None):
     return slice(b, b + base + (1 if r < rem else 0))
 
 
-class _HostCounts(list):
-    """the single-process form of ``global_counts``: plain numbers with the ``.clamp(min=)`` the callers apply to a denominator"""
-
-    class _N(float):
-        def clamp(self, min=None, max=None):
-            v = float(self)
-            v = v if min is None else (v if v > min else float(min))
-            v = v if max is None else (v if v < max else float(max))
-            return _HostCounts._N(v)
+def at_least_one(n):
+    """a loss denominator: ``max(n, 1)`` for the plain number a single process gets from ``global_counts`` and for the all-reduced tensor element"""
+    return n.clamp(min=1.0) if isinstance(n, torch.Tensor) else max(float(n), 1.0)
 
 
 def global_counts(*local_counts, device=None):
@@ -55,7 +49,7 @@ def global_counts(*local_counts, device=None):
     round 4 found it in the kernel trace as the point where the host, until then a whole forward ahead of the device, waited for the device
     and then paced every launch of the loss and of the backward's head (0.25 .. 0.5 ms of idle device per step)."""
     if world() == 1:
-        return _HostCounts(_HostCounts._N(float(c)) for c in local_counts)
+        return [float(c) for c in local_counts]
     t = torch.zeros(len(local_counts), dtype=torch.float32, device=device)
     for i, c in enumerate(local_counts):
         t[i].fill_(float(c))                 # (a fill kernel with the number as its argument: asynchronous)
@@ -72,19 +66,19 @@ def hot_path_loss(opt, out, gt_image, zero_epsilon=1e-3):
     if dc is not None:                # the renderer handed out (dense ray colours, hit flags, number of hit rays): one fused pass, no compaction
         from . import ops
         n = global_counts(3 * dc[2], n_cc, device=dc[0].device)
-        loss = ops.color_loss_sum_rays(dc[0], gt_image[0], dc[1]) / n[0].clamp(min=1.0) + 1e-6 / world()
+        loss = ops.color_loss_sum_rays(dc[0], gt_image[0], dc[1]) / at_least_one(n[0]) + 1e-6 / world()
     else:
         pred = out["coarse_raycolor"][0]
         gt = gt_image[0].index_select(0, out["_hit_index"]) if "_hit_index" in out else gt_image[0][out["ray_mask"][0] > 0]
         n = global_counts(pred.numel(), n_cc, device=pred.device)
-        loss = ((pred - gt) ** 2).sum() / n[0].clamp(min=1.0) + 1e-6 / world()
+        loss = ((pred - gt) ** 2).sum() / at_least_one(n[0]) + 1e-6 / world()
     if "conf_coefficient" in opt.zero_one_loss_items:
         if zo is not None:            # the renderer handed out (points_conf, neighbor table) instead of the tensor: one fused pass
             from . import ops
-            loss = loss + ops.zero_one_conf_sum_rays(zo[0], zo[1], zo[2], zero_epsilon) / n[1].clamp(min=1.0) * opt.zero_one_loss_weights[0]
+            loss = loss + ops.zero_one_conf_sum_rays(zo[0], zo[1], zo[2], zero_epsilon) / at_least_one(n[1]) * opt.zero_one_loss_weights[0]
         elif cc is not None:
             v = cc.clamp(zero_epsilon, 1 - zero_epsilon)
-            loss = loss + (torch.log(v) + torch.log(1 - v)).sum() / n[1].clamp(min=1.0) * opt.zero_one_loss_weights[0]
+            loss = loss + (torch.log(v) + torch.log(1 - v)).sum() / at_least_one(n[1]) * opt.zero_one_loss_weights[0]
     return loss
 
 

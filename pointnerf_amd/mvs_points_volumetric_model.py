@@ -276,7 +276,7 @@ class MvsPointsVolumetricModel:
                 pred = self._raw[key][0] if (self._raw is not None and key == "coarse_raycolor") else out[key][0][hit]
                 gt = self.gt_image[0].index_select(0, hidx) if hidx is not None else self.gt_image[0][hit]
                 n = pdist.global_counts(pred.numel(), device=dev)[0]
-                loss = ((pred - gt) ** 2).sum() / n.clamp(min=1.0)
+                loss = ((pred - gt) ** 2).sum() / pdist.at_least_one(n)
             elif name.startswith("ray_miss"):
                 key = name[len("ray_miss") + 1:]
                 miss = torch.logical_not(hit)
@@ -286,7 +286,7 @@ class MvsPointsVolumetricModel:
             else:
                 pred, gt = out[name], self.gt_image
                 n = pdist.global_counts(pred.numel(), device=dev)[0]
-                loss = ((pred - gt) ** 2).sum() / n.clamp(min=1.0)
+                loss = ((pred - gt) ** 2).sum() / pdist.at_least_one(n)
             self.loss_total = self.loss_total + (loss * opt.color_loss_weights[i] + 1e-6 / W)
             setattr(self, "loss_" + name, loss)
         for i, name in enumerate(opt.zero_one_loss_items):
@@ -294,7 +294,7 @@ class MvsPointsVolumetricModel:
                 from . import ops
                 conf, pidx_dense, ray_hit, count = out["_zero_one"]
                 n = pdist.global_counts(count, device=dev)[0]
-                loss = ops.zero_one_conf_sum_rays(conf, pidx_dense, ray_hit, opt.zero_epsilon) / n.clamp(min=1.0)
+                loss = ops.zero_one_conf_sum_rays(conf, pidx_dense, ray_hit, opt.zero_epsilon) / pdist.at_least_one(n)
                 self.loss_total = self.loss_total + loss * opt.zero_one_loss_weights[i]
                 setattr(self, "loss_" + name, loss)
                 continue
@@ -302,12 +302,12 @@ class MvsPointsVolumetricModel:
                 continue
             val = torch.clamp(out[name], opt.zero_epsilon, 1 - opt.zero_epsilon)
             n = pdist.global_counts(val.numel(), device=dev)[0]
-            loss = (torch.log(val) + torch.log(1 - val)).sum() / n.clamp(min=1.0)
+            loss = (torch.log(val) + torch.log(1 - val)).sum() / pdist.at_least_one(n)
             self.loss_total = self.loss_total + loss * opt.zero_one_loss_weights[i]
             setattr(self, "loss_" + name, loss)
         for i, name in enumerate(opt.l2_size_loss_items):
             n = pdist.global_counts(out[name].numel(), device=dev)[0]
-            loss = (out[name] ** 2).sum() / n.clamp(min=1.0)
+            loss = (out[name] ** 2).sum() / pdist.at_least_one(n)
             self.loss_total = self.loss_total + loss * opt.l2_size_loss_weights[i]
             setattr(self, "loss_" + name, loss)
         if opt.sparse_loss_weight > 0:
