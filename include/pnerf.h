@@ -167,6 +167,13 @@ typedef struct pnerf_point_grads {   /* gradient accumulators (added to, never z
                                       * gradients are complete, i.e. BEFORE the weight-gradient GEMMs of the same call are
                                       * enqueued -- a data-parallel caller starts the all-reduce of the (large) point
                                       * gradients on another stream behind this event and overlaps it with those GEMMs */
+    const float *zero_one_gscale;    /* optional (NULL: none; pnerf_render_backward only): the conf gradient of the zero-one regulariser on the
+                                      * hit rays' conf_coefficient (pnerf_zero_one_backward_rays: += d_gscale[0] (1 / v - 1 / (1 - v)) per neighbor slot,
+                                      * empty slots on point 0) is added BY THIS CALL -- the term of a slot rides on the conf atomic the backward issues
+                                      * for that neighbor row anyway, the empty slots of the hit rays are one closed-form addition to point 0
+                                      * ((#rays hit x SR x K - #valid neighbor slots) identical terms): the regulariser's own pass of ~7 M atomics on
+                                      * the same addresses is not run */
+    float zero_one_eps;              /* its clamp bound (opt.zero_epsilon) */
 } pnerf_point_grads;
 
 /* bytes of saved activations per valid neighbor row / per valid sample (training forward) */

@@ -54,7 +54,8 @@ class MapDesc(ctypes.Structure):
 
 
 class PointGrads(ctypes.Structure):
-    _fields_ = [("embedding", c_void_p), ("conf", c_void_p), ("dir", c_void_p), ("color", c_void_p), ("ready_event", c_void_p)]
+    _fields_ = [("embedding", c_void_p), ("conf", c_void_p), ("dir", c_void_p), ("color", c_void_p), ("ready_event", c_void_p),
+                ("zero_one_gscale", c_void_p), ("zero_one_eps", c_f32)]
 
 
 # symbol -> (restype, argtypes); kept in lock-step with include/pnerf.h (tests/test_boundary.py checks it)

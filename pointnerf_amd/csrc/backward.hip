@@ -34,7 +34,18 @@ struct BwdArgs {
     const float *emb;
     float *gparams;
     float *g_emb, *g_conf, *g_dir, *g_color;
+    // optional (pnerf_point_grads.zero_one_gscale): the zero-one regulariser's conf gradient rides on this kernel's conf atomics
+    const float *conf, *zo_gs;
+    float zo_eps;
 };
+
+// d/d conf of log(v) + log(1 - v), v = clamp(clamp(conf, 1e-4, 1), eps, 1 - eps) with a straight-through inner clamp (the arithmetic of
+// render.hip pn_zero_one_value / k_zero_one_backward_rays), times the caller's scale
+__device__ __forceinline__ float pn_zero_one_grad(float conf, float eps, float gs) {
+    const float c = fminf(fmaxf(conf, 1e-4f), 1.0f);
+    if (!(c >= eps && c <= 1.f - eps)) return 0.f;
+    return gs * (1.f / c - 1.f / (1.f - c));
+}
 
 __device__ __forceinline__ void rot3b(const float *M, float x, float y, float z, bool transpose, float &ox, float &oy, float &oz) {
     if (!transpose) { ox = x * M[0] + y * M[3] + z * M[6]; oy = x * M[1] + y * M[4] + z * M[7]; oz = x * M[2] + y * M[5] + z * M[8]; }
@@ -357,6 +368,12 @@ __device__ __forceinline__ void b_front(const BwdArgs &a, char *X, const float *
                                         float *draw, const int *sidx, const int *prow, const float4 (&dfr)[4], const float *dfb0, float S, float invS, int tid,
                                         float (&gw5)[8], float &gb5t) {
     const int lane = tid & 63, cg = tid & 31, r0 = 8 * (tid >> 5);
+    // (zero-one regulariser riding on the conf atomic below: the row's confidence, requested now, used behind the butterfly)
+    float zo_conf = 0.f;
+    if (a.zo_gs && (lane & 3) == 0) {
+        const int rz = prow[r0 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1)];
+        if (rz >= 0) zo_conf = a.conf[rz];
+    }
     // the d f values of row i's sample: from the registers filled before the barrier (KC = 8, 4: one or two samples per thread), else
     // (KC = 2, 1: the rare classes, four or eight samples per thread) straight from memory
     auto df_of = [&](int j, float4 &ga, float4 &gb) {
@@ -393,7 +410,7 @@ __device__ __forceinline__ void b_front(const BwdArgs &a, char *X, const float *
                 const float alpha = pn_softplus_b(x), sg = pn_sigmoid_b(x);
                 const int rp = prow[r];
                 // w = wn * clamp(conf) with a straight-through clamp (gradiant_clamp, point_aggregators.py:722-724)
-                if (rp >= 0) atomicAdd(&a.g_conf[rp], (dsg[r] * alpha + dotf) * wnrm[r] * invS);
+                if (rp >= 0) atomicAdd(&a.g_conf[rp], (dsg[r] * alpha + dotf) * wnrm[r] * invS + (a.zo_gs ? pn_zero_one_grad(zo_conf, a.zo_eps, a.zo_gs[0]) : 0.f));
                 dr = dsg[r] * wrow[r] * sg;
             }
             draw[r] = dr;
@@ -566,7 +583,7 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_backward(BwdArgs a) 
                     const float x = xrow[trow];
                     const float alpha = pn_softplus_b(x), sg = pn_sigmoid_b(x);
                     // w = wn * clamp(conf) with a straight-through clamp (gradiant_clamp, point_aggregators.py:722-724)
-                    if (trp >= 0) atomicAdd(&a.g_conf[trp], (dsg[trow] * alpha + dotf) * wnrm[trow] * invS);
+                    if (trp >= 0) atomicAdd(&a.g_conf[trp], (dsg[trow] * alpha + dotf) * wnrm[trow] * invS + (a.zo_gs ? pn_zero_one_grad(a.conf[trp], a.zo_eps, a.zo_gs[0]) : 0.f));
                     dr = dsg[trow] * wrow[trow] * sg;
                 }
                 draw[trow] = dr;
@@ -1199,6 +1216,18 @@ int launch_wgrad_x0(const uint4 *A, const WgX0Args &g, const int *d_tiles, long 
 
 size_t pn_wgrad_partials_bytes() { return pn_align(PARTIAL_FLOATS * sizeof(float)); }
 
+namespace {
+// the empty neighbor slots of the hit rays read point 0 (neural_points.py:709): (#rays hit x SR x K - #valid neighbor slots) identical terms of the
+// zero-one regulariser's conf gradient, added once (query counters [1] and [3])
+__global__ void k_zero_one_empty(const float *__restrict__ conf, const int *__restrict__ counters, long long slots_per_ray, const float *__restrict__ gs, float eps,
+                                 float *__restrict__ g_conf) {
+    const long long n_empty = (long long)counters[1] * slots_per_ray - (long long)counters[3];
+    if (n_empty <= 0) return;
+    const float g = pn_zero_one_grad(conf[0], eps, gs[0]);
+    if (g != 0.f) atomicAdd(&g_conf[0], g * (float)n_empty);
+}
+}  // namespace
+
 int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, const float *d_params, const void *d_packed,
                            const float *d_raydir, const float *d_sample_loc, const int32_t *d_sample_pidx,
                            const int32_t *d_valid_list, const int32_t *d_counters, int R, int SR, int K,
@@ -1212,6 +1241,8 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     a.decoded = d_decoded; a.weight = d_weight; a.grad_decoded = d_grad_decoded; a.sv = sv;
     a.emb = pts->embedding;
     a.gparams = d_grad_params; a.g_emb = pg->embedding; a.g_conf = pg->conf; a.g_dir = pg->dir; a.g_color = pg->color;
+    a.conf = pts->conf; a.zo_gs = x0_saved ? nullptr : pg->zero_one_gscale; a.zo_eps = pg->zero_one_eps;       // (the fused render path only)
+    if (a.zo_gs && !a.conf) return PNERF_E_INVAL;
     if (!a.g_emb || !a.g_conf || !a.g_dir || !a.g_color) return PNERF_E_INVAL;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) != hipSuccess) return PNERF_E_LAUNCH;
@@ -1233,6 +1264,7 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
         const long long blocks = (n_valid + 255) / 256;
         hipLaunchKernelGGL(k_grad_max, dim3((unsigned)(blocks < 1024 ? (blocks > 0 ? blocks : 1) : 1024)), dim3(256), 0, s, sv.cls_list, d_counters, (long long)n_valid, d_grad_decoded, sv.gscale);
     }
+    if (a.zo_gs) hipLaunchKernelGGL(k_zero_one_empty, dim3(1), dim3(1), 0, s, a.conf, d_counters, (long long)SR * K, a.zo_gs, a.zo_eps, a.g_conf);
     { PnProfScope prof(PNK_COLOR_BWD, s);
       if (wg2) hipLaunchKernelGGL(k_color_backward<true>, dim3(grid_c), dim3(256), lds_c, s, a);
       else hipLaunchKernelGGL(k_color_backward<false>, dim3(grid_c), dim3(256), lds_c, s, a); }

@@ -61,8 +61,8 @@ def hot_path_loss(opt, out, gt_image, zero_epsilon=1e-3):
     """The lego script's training loss (models/base_rendering_model.py:543-551 ``ray_masked_coarse_raycolor`` x 1.0
     + 1e-6, and :630-641 ``zero_one`` on ``conf_coefficient`` x opt.zero_one_loss_weights[0]) with both means taken
     over the GLOBAL batch."""
-    cc, zo, dc = out.get("conf_coefficient"), out.get("_zero_one"), out.get("_dense_color")
-    n_cc = cc.numel() if cc is not None else (zo[3] if zo is not None else 0)
+    cc, zo, dc, zs = out.get("conf_coefficient"), out.get("_zero_one"), out.get("_dense_color"), out.get("_zero_one_sum")
+    n_cc = cc.numel() if cc is not None else (zo[3] if zo is not None else (zs[1] if zs is not None else 0))
     if dc is not None:                # the renderer handed out (dense ray colours, hit flags, number of hit rays): one fused pass, no compaction
         from . import ops
         n = global_counts(3 * dc[2], n_cc, device=dc[0].device)
@@ -73,7 +73,9 @@ def hot_path_loss(opt, out, gt_image, zero_epsilon=1e-3):
         n = global_counts(pred.numel(), n_cc, device=pred.device)
         loss = ((pred - gt) ** 2).sum() / at_least_one(n[0]) + 1e-6 / world()
     if "conf_coefficient" in opt.zero_one_loss_items:
-        if zo is not None:            # the renderer handed out (points_conf, neighbor table) instead of the tensor: one fused pass
+        if zs is not None:            # the render node computed the numerator itself (its conf gradient rides on the node's backward)
+            loss = loss + zs[0] / at_least_one(n[1]) * opt.zero_one_loss_weights[0]
+        elif zo is not None:          # the renderer handed out (points_conf, neighbor table) instead of the tensor: one fused pass
             from . import ops
             loss = loss + ops.zero_one_conf_sum_rays(zo[0], zo[1], zo[2], zero_epsilon) / at_least_one(n[1]) * opt.zero_one_loss_weights[0]
         elif cc is not None:

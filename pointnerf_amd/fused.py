@@ -9,6 +9,7 @@ script, lego_cuda.sh: default of --xyz_grad in neural_points.py:132).
 """
 import torch
 
+from . import _lib as L
 from . import ops
 
 
@@ -64,11 +65,31 @@ class FusedRender(torch.autograd.Function):
         ctx.shapes = (tuple(emb.shape), tuple(conf.shape), tuple(pdir.shape), tuple(color.shape))
         ctx.n_mlp = len(mlp_params)
         ctx.mark_non_differentiable(fwd["opacity"], fwd["bg_trans"], fwd["blend_w"], fwd["decoded"], fwd["weight"])
-        return fwd["ray_color"], fwd["opacity"], fwd["bg_trans"], fwd["blend_w"], fwd["decoded"], fwd["weight"]
+        # env["zero_one_eps"] (training): the numerator of the zero-one regulariser on the hit rays' conf_coefficient is a SEVENTH, differentiable
+        # output of this node (one pass over the dense neighbor table, pnerf_zero_one_forward_rays), so that its conf gradient can ride on
+        # the conf atomics of this node's backward instead of repeating ~7 M atomics on the same addresses in a pass of its own
+        ctx.zo = None
+        zo_sum = None
+        if env["train"] and env.get("zero_one_eps") is not None:
+            lib = L.lib()
+            dense, cflat = env["dense"], ctx.point_arrays[1].reshape(-1)
+            R_, slots = env["R"], env["SR"] * env["K"]
+            part = torch.empty(lib.pnerf_zero_one_blocks(R_ * 256), dtype=torch.float32, device=cflat.device)
+            L.check(lib.pnerf_zero_one_forward_rays(ops._ptr(cflat), cflat.numel(), ops._ptr(dense["sample_pidx"]), ops._ptr(dense["ray_hit"]), R_, slots,
+                                                    float(env["zero_one_eps"]), ops._ptr(part), ops._stream()), "pnerf_zero_one_forward_rays")
+            zo_sum = part.sum()
+            ctx.zo = float(env["zero_one_eps"])
+        if zo_sum is None:
+            zo_sum = torch.zeros((), dtype=torch.float32, device=fwd["ray_color"].device)
+            ctx.mark_non_differentiable(zo_sum)
+        return fwd["ray_color"], fwd["opacity"], fwd["bg_trans"], fwd["blend_w"], fwd["decoded"], fwd["weight"], zo_sum
 
     @staticmethod
     def backward(ctx, g_color, *unused):
         env, fwd = ctx.env, ctx.fwd
+        g_zo = unused[-1] if (ctx.zo is not None and unused) else None         # gradient of the seventh output (the zero-one numerator)
+        if g_color is None:
+            g_color = torch.zeros(env["R"], 3, dtype=torch.float32, device=env["raydir"].device)
         if not env["train"] or (fwd["saved"] is None and not ctx.recompute):
             raise RuntimeError("pointnerf_amd: backward through a render that was run with train=False")
         dev = g_color.device
@@ -90,11 +111,19 @@ class FusedRender(torch.autograd.Function):
         if env.get("want_grad_event"):            # data-parallel training: see pnerf_point_grads.ready_event
             ev = torch.cuda.Event()
             ev.record()                           # creates the hipEvent_t; re-recorded by the library between dgrad and wgrad
+        zo = None if g_zo is None else (g_zo.detach().reshape(1).to(torch.float32).contiguous(), ctx.zo)
         if env["n_valid"] > 0 and ctx.recompute:
             FusedRender._backward_in_chunks(env, ctx.pts, g_color.contiguous().float(), gflat, grads, ev)
         elif env["n_valid"] > 0:
             ops.render_backward(env["cam"], ctx.pts, env["packed"], env["flat"], env["raydir"], env["dense"], env["R"],
-                                env["SR"], env["K"], env["n_valid"], fwd, g_color, gflat, grads, ready_event=ev)
+                                env["SR"], env["K"], env["n_valid"], fwd, g_color, gflat, grads, ready_event=ev, zero_one=zo)
+            zo = None
+        if zo is not None:
+            # (no valid sample at all, or the chunk-by-chunk recompute whose chunks carry their own counters: the regulariser's own pass)
+            dense, cflat = env["dense"], ctx.point_arrays[1].reshape(-1)
+            L.check(L.lib().pnerf_zero_one_backward_rays(ops._ptr(cflat), cflat.numel(), ops._ptr(dense["sample_pidx"]), ops._ptr(dense["ray_hit"]), env["R"],
+                                                         env["SR"] * env["K"], zo[1], ops._ptr(zo[0]), ops._ptr(grads["points_conf"].reshape(-1)), ops._stream()),
+                    "pnerf_zero_one_backward_rays")
         FusedRender.point_grads_ready = ev
         # what the early all-reduce may touch: exactly the tensors this backward wrote (dist.allreduce_grads checks p.grad against them)
         FusedRender.point_grad_ptrs = {grads[n].data_ptr() for n in names}

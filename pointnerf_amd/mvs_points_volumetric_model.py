@@ -290,6 +290,13 @@ class MvsPointsVolumetricModel:
             self.loss_total = self.loss_total + (loss * opt.color_loss_weights[i] + 1e-6 / W)
             setattr(self, "loss_" + name, loss)
         for i, name in enumerate(opt.zero_one_loss_items):
+            if name == "conf_coefficient" and "_zero_one_sum" in out:  # fused into the render node (training steps)
+                zsum, count = out["_zero_one_sum"]
+                n = pdist.global_counts(count, device=dev)[0]
+                loss = zsum / pdist.at_least_one(n)
+                self.loss_total = self.loss_total + loss * opt.zero_one_loss_weights[i]
+                setattr(self, "loss_" + name, loss)
+                continue
             if name == "conf_coefficient" and "_zero_one" in out:      # fused form (NeuralPointsRayMarching.fused_zero_one)
                 from . import ops
                 conf, pidx_dense, ray_hit, count = out["_zero_one"]

@@ -30,6 +30,8 @@ def gradient_clamp(sampled_conf, lo=0.0001, hi=1.0):
 
 # PNERF_SPECULATE=0: every training step waits for its counters before it is enqueued (rounds 1-3)
 SPECULATE = os.environ.get("PNERF_SPECULATE", "1") != "0"
+# PNERF_ZERO_ONE_IN_RENDER=0 (dev A/B): the fused zero-one regulariser as its own forward / backward pass (round 3) instead of inside the render node
+ZERO_ONE_IN_RENDER = os.environ.get("PNERF_ZERO_ONE_IN_RENDER", "1") != "0"
 
 
 class NeuralPointsRayMarching(nn.Module):
@@ -62,7 +64,8 @@ class NeuralPointsRayMarching(nn.Module):
         return self._pinned_words
 
     def render_dense(self, campos, raydir, camrotc2w, near, far, bg_color=None, train=None):
-        """The fused step on all R rays.  Returns (ray_color [R,3], opacity, bg_trans, blend_w, decoded, weight, dense)."""
+        """The fused step on all R rays.  Returns (ray_color [R,3], opacity, bg_trans, blend_w, decoded, weight, zo_sum, dense); zo_sum =
+        the zero-one regulariser's numerator over the hit rays' conf_coefficient when ``_zero_one_in_render()`` (else a constant 0)."""
         opt, npnt, agg = self.opt, self.neural_points, self.aggregator
         train = torch.is_grad_enabled() if train is None else train
         if train and getattr(opt, "xyz_grad", 0) > 0:
@@ -87,6 +90,8 @@ class NeuralPointsRayMarching(nn.Module):
         env = dict(cam=cam, xyz=npnt.xyz.detach().reshape(-1, 3).contiguous(), raydir=raydir.detach().reshape(-1, 3).contiguous().float(),
                    dense=dense, R=R, SR=int(opt.SR), K=int(opt.K), n_valid=0, flat=st.flat, packed=st.packed_image(),
                    train=bool(train), layout=layout, want_grad_event=bool(train) and raydir.is_cuda and pdist.world() > 1)
+        if train and self._zero_one_in_render():
+            env["zero_one_eps"] = float(getattr(opt, "zero_epsilon", 1e-3))
         leaves = (npnt.points_embeding, npnt.points_conf, npnt.points_dir, npnt.points_color) + tuple(mlp_params)
         # The step's one host read (number of valid samples: sizes the activation arena; number of hit rays: shapes of the outputs).
         # Round 4: a TRAINING step whose arena already exists is enqueued BEFORE that read with the arena's capacity as the bound -- every
@@ -120,12 +125,20 @@ class NeuralPointsRayMarching(nn.Module):
             out = FusedRender.apply(env, *leaves)
         return out + (dense,)
 
+    def _zero_one_in_render(self):
+        """the zero-one regulariser on conf_coefficient as part of the render node (``fused_zero_one`` callers whose only consumer of
+        conf_coefficient is that loss): its numerator is an output of the node, its conf gradient rides on the node's own conf atomics"""
+        opt = self.opt
+        return ZERO_ONE_IN_RENDER and bool(getattr(self, "fused_zero_one", False)) and opt.sparse_loss_weight <= 0 and getattr(opt, "prob", 0) == 0 \
+            and "conf_coefficient" in getattr(opt, "zero_one_loss_items", ())
+
     def forward(self, campos, raydir, gt_image=None, bg_color=None, camrotc2w=None, pixel_idx=None, near=None, far=None,
                 focal=None, h=None, w=None, intrinsic=None, **kargs):
         opt = self.opt
         if "bg_ray" in kargs:
             bg_color = None
-        ray_color, opacity, bg_trans, blend_w, decoded, weight, dense = self.render_dense(campos, raydir, camrotc2w, near, far, bg_color)
+        ray_color, opacity, bg_trans, blend_w, decoded, weight, zo_sum, dense = self.render_dense(campos, raydir, camrotc2w, near, far, bg_color)
+        zo_in_render = torch.is_grad_enabled() and self._zero_one_in_render()
         hit = dense["ray_hit"] > 0
         SR, K = int(opt.SR), int(opt.K)
         # Indices of the hit rays WITHOUT a host round trip: their number is already on the host (the counters the arena was
@@ -141,7 +154,10 @@ class NeuralPointsRayMarching(nn.Module):
                 and opt.sparse_loss_weight <= 0 and getattr(self, "fused_zero_one", False):
             output = {"_dense_color": (ray_color, dense["ray_hit"], n_hit), "ray_mask": hit.to(torch.int8)[None]}
             if "conf_coefficient" in opt.zero_one_loss_items:
-                output["_zero_one"] = (self.neural_points.points_conf, dense["sample_pidx"], dense["ray_hit"], n_hit * SR * K)
+                if zo_in_render:
+                    output["_zero_one_sum"] = (zo_sum, n_hit * SR * K)
+                else:
+                    output["_zero_one"] = (self.neural_points.points_conf, dense["sample_pidx"], dense["ray_hit"], n_hit * SR * K)
             return output
         idx = torch.argsort(dense["ray_hit"], descending=True, stable=True)[:n_hit]
         take = lambda t: t.index_select(0, idx)
@@ -161,7 +177,10 @@ class NeuralPointsRayMarching(nn.Module):
         if want_w and only_zero_one:
             # (points_conf, the DENSE neighbor table, the rays' hit flags, number of conf_coefficient elements): the loss runs over the hit rays
             # of the dense table in place (ops.ZeroOneConfRays) -- no [R'', SR, K] copy of it
-            output["_zero_one"] = (self.neural_points.points_conf, dense["sample_pidx"], dense["ray_hit"], n_hit * SR * K)
+            if zo_in_render:        # (training: the numerator came out of the render node; evaluation under no_grad: the stand-alone pass)
+                output["_zero_one_sum"] = (zo_sum, n_hit * SR * K)
+            else:
+                output["_zero_one"] = (self.neural_points.points_conf, dense["sample_pidx"], dense["ray_hit"], n_hit * SR * K)
         elif want_w:
             output["weight"] = take(weight)[None].detach()
             output["blend_weight"] = take(blend_w)[None, ..., None].detach()

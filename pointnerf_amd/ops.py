@@ -350,13 +350,17 @@ def render_forward(cam, pts, packed, flat, raydir, dense, R, SR, K, n_valid, tra
                 blend_w=blend_w, saved=saved)
 
 
-def render_backward(cam, pts, packed, flat, raydir, dense, R, SR, K, n_valid, fwd, grad_ray_color, grad_flat, grads, ready_event=None):
+def render_backward(cam, pts, packed, flat, raydir, dense, R, SR, K, n_valid, fwd, grad_ray_color, grad_flat, grads, ready_event=None, zero_one=None):
     """pnerf_render_backward: accumulates into grad_flat (MLP) and grads = dict(points_embeding=..., points_conf=...,
-    points_dir=..., points_color=...) (device tensors, same shapes as the parameters)."""
+    points_dir=..., points_color=...) (device tensors, same shapes as the parameters).  ``zero_one`` = (scale [1] f32 device tensor, eps): the
+    conf gradient of the zero-one regulariser over the hit rays' neighbor table is added by the same call (pnerf_point_grads.zero_one_gscale;
+    ``dense`` must be the query's own output: its counters [1] and [3] count the empty slots)."""
     lib = L.lib()
     pg = L.PointGrads()
     pg.embedding, pg.conf = grads["points_embeding"].data_ptr(), grads["points_conf"].data_ptr()
     pg.dir, pg.color = grads["points_dir"].data_ptr(), grads["points_color"].data_ptr()
+    if zero_one is not None:
+        pg.zero_one_gscale, pg.zero_one_eps = zero_one[0].data_ptr(), float(zero_one[1])
     if ready_event is not None:          # a torch.cuda.Event that has been recorded once (so that its hipEvent_t exists)
         pg.ready_event = ready_event.cuda_event
     nws = lib.pnerf_render_backward_workspace_bytes(R, SR)

@@ -212,10 +212,12 @@ def test_emulated_step_with_a_capacity_above_the_actual_count(monkeypatch):
             assert err <= 2e-6, (k, err)
 
 
-def test_emulated_fused_color_loss_matches_the_compacted_chain():
-    """ops.ColorLossRays over the dense ray colours (no argsort / index_select of the hit rays) against the chain it replaces, through the
-    model and dist.hot_path_loss: the loss value and every gradient of the step (fused_color_loss on / off)."""
-    TB.fused_color_loss_equivalence(*_tiny_case(8, 12, 5), "cpu")
+@pytest.mark.parametrize("K,SR,size", [(8, 12, 5), (12, 8, 4)])
+def test_emulated_fused_losses_match_the_aten_chains(K, SR, size):
+    """the zero-one regulariser inside the render node (its conf gradient on the backward's own conf atomics, the empty slots in closed form)
+    and the colour loss over the dense ray colours against the ATen chains they replace: loss and every gradient of the step; K = 8 runs
+    the one-pass front, K = 12 the two-pass one"""
+    TB.fused_losses_equivalence(*_tiny_case(K, SR, size), "cpu")
 
 
 def test_emulated_extract_2d_edge_cases():
