@@ -64,7 +64,6 @@ class FusedRender(torch.autograd.Function):
         env["_saved"] = fwd["saved"]              # (a caller that drops this result without a backward hands the arena block back itself)
         ctx.shapes = (tuple(emb.shape), tuple(conf.shape), tuple(pdir.shape), tuple(color.shape))
         ctx.n_mlp = len(mlp_params)
-        ctx.mark_non_differentiable(fwd["opacity"], fwd["bg_trans"], fwd["blend_w"], fwd["decoded"], fwd["weight"])
         # env["zero_one_eps"] (training): the numerator of the zero-one regulariser on the hit rays' conf_coefficient is a SEVENTH, differentiable
         # output of this node (one pass over the dense neighbor table, pnerf_zero_one_forward_rays), so that its conf gradient can ride on
         # the conf atomics of this node's backward instead of repeating ~7 M atomics on the same addresses in a pass of its own
@@ -79,9 +78,14 @@ class FusedRender(torch.autograd.Function):
                                                     float(env["zero_one_eps"]), ops._ptr(part), ops._stream()), "pnerf_zero_one_forward_rays")
             zo_sum = part.sum()
             ctx.zo = float(env["zero_one_eps"])
+        # ONE call (a second one replaces the set): every output the backward does not differentiate.  decoded / weight / opacity are kept in
+        # ctx.fwd -- were they differentiable outputs, node -> ctx.fwd -> tensor -> grad_fn = node would be a reference cycle that holds the
+        # activation arena of every training forward that is never back-propagated
+        nondiff = [fwd["opacity"], fwd["bg_trans"], fwd["blend_w"], fwd["decoded"], fwd["weight"]]
         if zo_sum is None:
             zo_sum = torch.zeros((), dtype=torch.float32, device=fwd["ray_color"].device)
-            ctx.mark_non_differentiable(zo_sum)
+            nondiff.append(zo_sum)
+        ctx.mark_non_differentiable(*nondiff)
         return fwd["ray_color"], fwd["opacity"], fwd["bg_trans"], fwd["blend_w"], fwd["decoded"], fwd["weight"], zo_sum
 
     @staticmethod
