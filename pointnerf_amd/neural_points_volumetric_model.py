@@ -113,13 +113,14 @@ class NeuralPointsRayMarching(nn.Module):
         else:
             got = words.cpu()                                 # the one sync
         n_valid = int(got[0])
-        if out is not None and n_valid > cap:                 # (rare: the arena has to grow; nothing of the dropped result is used)
+        dropped = out is not None and n_valid > cap
+        if dropped:                                           # (rare: the arena has to grow; nothing of the dropped result is used)
             ops.ARENA.give(env.pop("_saved", None))
             out, env = None, dict(env)
         if plan is not None:
             self.sparse_plan = (plan[0], int(got[8]), int(got[9]))
         self.last_stats = dict(n_valid_samples=n_valid, rays_hit=int(got[1]), n_selected=int(got[2]), n_neighbor_rows=int(got[3]), rays=R,
-                               enqueued_before_host_read=out is not None)
+                               enqueued_before_host_read=out is not None, speculative_result_dropped=dropped)
         if out is None:
             env["n_valid"] = n_valid
             out = FusedRender.apply(env, *leaves)

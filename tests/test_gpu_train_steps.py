@@ -83,3 +83,56 @@ def test_three_training_steps_match_the_oracle(name):
         frac = float((e > 0.05 * opt.plr).float().mean())
         print("%-26s max err %.2e  frac > 5%% of plr: %.1e" % (k, float(e.max()), frac))
         assert float(e.max()) <= 2.0 * opt.plr * STEPS and frac <= 2e-3, (k, float(e.max()), frac)
+
+
+def test_step_enqueued_before_its_host_read_and_the_redo_when_the_arena_is_too_small():
+    """A training step is enqueued with the arena's capacity as its bound before its counters reach the host (render_dense): (i) a step whose
+    count exceeds the capacity (a batch larger than every one before it) drops the speculative result and runs again -- same loss and
+    gradients as with PNERF_SPECULATE=0; (ii) the next step of that size IS enqueued ahead; (iii) the arena does not leak."""
+    from pointnerf_amd import ops, neural_points_volumetric_model as NM
+    from pointnerf_amd import dist as pdist
+    from pointnerf_amd.neural_points import NeuralPoints
+    from pointnerf_amd.point_aggregators import PointAggregator
+    opt, xyz, attrs, inp, mlp = build_case("small_k8")
+    dev = torch.device("cuda:0")
+    d = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in inp.items()}
+    R = d["raydir"].shape[1]
+    small = dict(d, raydir=d["raydir"][:, : R // 8].contiguous(), gt_image=d["gt_image"][:, : R // 8].contiguous(), pixel_idx=d["pixel_idx"][:, : R // 8].contiguous())
+
+    def run(speculate):
+        NM.SPECULATE = speculate
+        ops.ARENA.free = []
+        agg = PointAggregator(opt).to(dev)
+        agg.load_state_dict(mlp)
+        agg.flatten_()
+        npnt = NeuralPoints(32, xyz.shape[0], opt, dev)
+        a = {k: v.to(dev) for k, v in attrs.items()}
+        npnt.set_points(xyz.to(dev), a["points_embeding"], points_color=a["points_color"], points_dir=a["points_dir"], points_conf=a["points_conf"], parameter=True)
+        model = NM.NeuralPointsRayMarching(aggregator=agg, neural_points=npnt, opt=opt)
+        model.fused_zero_one = model.fused_color_loss = True
+        params = list(agg.parameters()) + [npnt.points_embeding, npnt.points_conf, npnt.points_dir, npnt.points_color]
+        res, flags, drops, nvalid = [], [], [], []
+        for batch in (small, d, d):                   # small batch sizes the arena; the big one exceeds it; the third fits
+            for p in params:
+                p.grad = None
+            out = model(**batch)
+            flags.append(model.last_stats["enqueued_before_host_read"])
+            drops.append(model.last_stats["speculative_result_dropped"])
+            nvalid.append(model.last_stats["n_valid_samples"])
+            loss = pdist.hot_path_loss(opt, out, batch["gt_image"])
+            loss.backward()
+            res.append((float(loss.detach()), [p.grad.detach().cpu().clone() for p in params]))
+        return res, (flags, drops, nvalid), len(ops.ARENA.free)
+
+    try:
+        ref, f0, _ = run(False)
+        got, f1, nfree = run(True)
+    finally:
+        NM.SPECULATE = True
+    assert f0[0] == [False, False, False] and f1[0] == [False, False, True], (f0, f1)      # first: no arena yet; second: redo; third: ahead
+    assert f1[1] == [False, True, False] and f1[2][0] > 0 and f1[2][1] > 2 * f1[2][0], f1          # the second step WAS enqueued ahead and dropped
+    assert nfree == 1, nfree
+    for (l0, g0), (l1, g1) in zip(ref, got):
+        assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)
+        for a_, b_ in zip(g0, g1):
+            assert torch.allclose(a_, b_, rtol=1e-4, atol=2e-5 * float(a_.abs().max()))
