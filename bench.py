@@ -378,7 +378,7 @@ def main():
                                                "final_loss": float(lv.item()),
                                                "what": "the same step with --wgrad-planes 2: weight-gradient GEMM operands as 2 x f16 planes (22 bits), three "
                                                        "products per multiply-add -- the arithmetic of the forward and of the input-gradient chain; "
-                                                       "tests/test_gpu_convergence.py, tests/test_gpu_bench_config.py compare the two"}
+                                                       "tests/test_gpu_zz_convergence.py, tests/test_gpu_bench_config.py compare the two"}
             finally:
                 ops.set_wgrad_planes(1)
     if not np.isfinite(float(loss.item())) and not os.environ.get("PNERF_BENCH_ALLOW_NAN"):      # (the env switch exists for dev variants that drop work on purpose)

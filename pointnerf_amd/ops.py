@@ -513,11 +513,12 @@ def set_inference_products(n):
 def set_wgrad_planes(n):
     """f16 planes per operand of the weight-gradient GEMMs of the training backward: 1 (default: one plane rounded to nearest, one MFMA
     product) or 2 (both operands as two planes, three products: fp32-class weight gradients, the reference arithmetic of the convergence
-    A/B in tests/test_gpu_convergence.py; twice the saved / streamed bytes).  Process-wide; choose it between steps, never between a
+    A/B in tests/test_gpu_zz_convergence.py; twice the saved / streamed bytes).  Process-wide; choose it between steps, never between a
     training forward and its backward.  Returns the previous setting."""
     old = L.lib().pnerf_set_wgrad_planes(int(n))
     if old < 0:
         raise ValueError("weight-gradient planes must be 1 or 2")
+    ARENA._cap_cache = {}                 # pnerf_agg_saved_bytes depends on the mode: a capacity cached under the other mode is off by ~2x
     return old
 
 

@@ -1,4 +1,4 @@
-"""A self-consistent optimisation problem for the convergence A/B of the weight-gradient arithmetic (tests/test_gpu_convergence.py,
+"""A self-consistent optimisation problem for the convergence A/B of the weight-gradient arithmetic (tests/test_gpu_zz_convergence.py,
 tools/gpu_convergence.py): a TEACHER (cloud attributes + MLP) renders ground-truth colours of a ring of views with the HIP inference
 path; a perturbed STUDENT (same positions, embeddings / confidences / colours / directions moved, MLP pulled half-way to another
 initialisation) is optimised against them with the loop body of the reference (models/mvs_points_volumetric_model.py:98-118: forward,

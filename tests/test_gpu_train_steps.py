@@ -85,10 +85,8 @@ def test_three_training_steps_match_the_oracle(name):
         assert float(e.max()) <= 2.0 * opt.plr * STEPS and frac <= 2e-3, (k, float(e.max()), frac)
 
 
-def test_step_enqueued_before_its_host_read_and_the_redo_when_the_arena_is_too_small():
-    """A training step is enqueued with the arena's capacity as its bound before its counters reach the host (render_dense): (i) a step whose
-    count exceeds the capacity (a batch larger than every one before it) drops the speculative result and runs again -- same loss and
-    gradients as with PNERF_SPECULATE=0; (ii) the next step of that size IS enqueued ahead; (iii) the arena does not leak."""
+def _speculative_runs(batches_of):
+    """the batches of ``batches_of(d)`` with PNERF_SPECULATE off and on: ((loss, gradients) per step, (enqueued ahead, dropped, valid samples) per step, free arena blocks)"""
     from pointnerf_amd import ops, neural_points_volumetric_model as NM
     from pointnerf_amd import dist as pdist
     from pointnerf_amd.neural_points import NeuralPoints
@@ -97,7 +95,8 @@ def test_step_enqueued_before_its_host_read_and_the_redo_when_the_arena_is_too_s
     dev = torch.device("cuda:0")
     d = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in inp.items()}
     R = d["raydir"].shape[1]
-    small = dict(d, raydir=d["raydir"][:, : R // 8].contiguous(), gt_image=d["gt_image"][:, : R // 8].contiguous(), pixel_idx=d["pixel_idx"][:, : R // 8].contiguous())
+    first = lambda n: dict(d, raydir=d["raydir"][:, :n].contiguous(), gt_image=d["gt_image"][:, :n].contiguous(), pixel_idx=d["pixel_idx"][:, :n].contiguous())
+    batches = batches_of(first, R)
 
     def run(speculate):
         NM.SPECULATE = speculate
@@ -112,7 +111,7 @@ def test_step_enqueued_before_its_host_read_and_the_redo_when_the_arena_is_too_s
         model.fused_zero_one = model.fused_color_loss = True
         params = list(agg.parameters()) + [npnt.points_embeding, npnt.points_conf, npnt.points_dir, npnt.points_color]
         res, flags, drops, nvalid = [], [], [], []
-        for batch in (small, d, d):                   # small batch sizes the arena; the big one exceeds it; the third fits
+        for batch in batches:
             for p in params:
                 p.grad = None
             out = model(**batch)
@@ -129,10 +128,50 @@ def test_step_enqueued_before_its_host_read_and_the_redo_when_the_arena_is_too_s
         got, f1, nfree = run(True)
     finally:
         NM.SPECULATE = True
-    assert f0[0] == [False, False, False] and f1[0] == [False, False, True], (f0, f1)      # first: no arena yet; second: redo; third: ahead
-    assert f1[1] == [False, True, False] and f1[2][0] > 0 and f1[2][1] > 2 * f1[2][0], f1          # the second step WAS enqueued ahead and dropped
-    assert nfree == 1, nfree
     for (l0, g0), (l1, g1) in zip(ref, got):
         assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)
         for a_, b_ in zip(g0, g1):
             assert torch.allclose(a_, b_, rtol=1e-4, atol=2e-5 * float(a_.abs().max()))
+    return f0, f1, nfree
+
+
+def test_step_enqueued_before_its_host_read_and_the_redo_when_the_arena_is_too_small():
+    """A training step is enqueued with the arena's capacity as its bound before its counters reach the host (render_dense): (i) a step whose
+    count exceeds the capacity (a batch larger than every one before it) drops the speculative result and runs again -- same loss and
+    gradients as with PNERF_SPECULATE=0; (ii) the next step of that size IS enqueued ahead; (iii) the arena does not leak."""
+    f0, f1, nfree = _speculative_runs(lambda first, R: (first(R // 8), first(R), first(R)))   # small batch sizes the arena; the big one exceeds it; the third fits
+    assert f0[0] == [False, False, False] and f1[0] == [False, False, True], (f0, f1)      # first: no arena yet; second: redo; third: ahead
+    assert f1[1] == [False, True, False] and f1[2][0] > 0 and f1[2][1] > 2 * f1[2][0], f1          # the second step WAS enqueued ahead and dropped
+    assert nfree == 1, nfree
+
+
+def test_two_consecutive_steps_that_exceed_the_arena():
+    """a batch larger than the arena, then a larger one still: both speculative results are dropped and redone (each redo grows the arena; the too-small
+    block is released, not kept), a smaller batch in between is enqueued ahead, and every step's loss and gradients equal PNERF_SPECULATE=0."""
+    f0, f1, nfree = _speculative_runs(lambda first, R: (first(R // 8), first(R // 2), first(R), first(R // 2), first(R)))
+    nv = f1[2]
+    assert nv[0] > 0 and nv[1] > 1.3 * nv[0] and nv[2] > 1.3 * nv[1], nv             # (the arena's headroom is 15 %)
+    assert f0[0] == [False] * 5 and f0[1] == [False] * 5, f0
+    assert f1[1] == [False, True, True, False, False], f1                               # dropped: the two that outgrew the arena
+    assert f1[0] == [False, False, False, True, True], f1                               # kept as enqueued: the two that fit
+    assert nfree == 1, nfree
+
+
+def test_speculative_step_with_two_ranks_whose_counts_differ():
+    """world 2 (gloo, both ranks on cuda:0): in the second step rank 0 redoes, rank 1 does not; the collectives still pair up, the replicas agree and
+    the result equals PNERF_SPECULATE=0 (tests/spec_two_ranks.py)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29900 + os.getpid() % 90), os.path.join(here, "spec_two_ranks.py")]
+    out = subprocess.check_output(cmd, cwd=os.path.dirname(here), env=dict(os.environ, MASTER_ADDR="127.0.0.1"), timeout=600, stderr=subprocess.STDOUT).decode()
+    recs = json.loads([l for l in out.splitlines() if l.startswith("[{")][-1])
+    r0, r1 = recs
+    assert r0["ahead_without"] == [False] * 3 and r1["ahead_without"] == [False] * 3
+    assert r0["dropped"] == [False, True, False] and r0["ahead"] == [False, False, True], r0          # rank 0: redo in step 2
+    assert r1["dropped"] == [False, False, False] and r1["ahead"] == [False, True, True], r1          # rank 1: enqueued ahead in step 2, kept
+    for r in recs:
+        assert r["worst_loss_rel"] <= 1e-6 and r["worst_grad_rel"] <= 1e-4 and r["replica_spread"] == 0.0, r

@@ -2,7 +2,8 @@
 DESIGN 4.1) behave like optimisation with fp32-class weight gradients?  The reference's loop runs 200 000 steps
 (run/train_ft.py:829-937 around models/mvs_points_volumetric_model.py:98-118); round 3's longest check was 3 steps.
 
-* 200 steps of the oracle's small case against the fp32 CPU oracle with torch.optim.Adam: the loss of every step within 1e-3 relative.
+* 200 steps of the oracle's small case against the fp32 CPU oracle with torch.optim.Adam: deterministic to 1e-4 for the first 75 steps, inside the
+  envelope of an ensemble of perturbed oracle runs afterwards (tests/golden/trajectory_envelope.npz).
 * 2 000 steps of a teacher / student problem (tests/convergence_case.py) with one plane and with two planes per operand
   (ops.set_wgrad_planes), identical batches: final loss and held-out PSNR of the two arithmetics must agree within the spread that
   repeated runs of ONE arithmetic show (the backward's atomics make no two runs bit-identical)."""
@@ -22,41 +23,53 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 
 
-def test_200_steps_against_the_fp32_oracle():
-    """Two fp32 evaluations of this optimisation do not stay within 1e-3 of each other for 200 steps: Adam normalises every gradient element
-    to ~lr, so a difference in the last bit of one gradient grows step by step (and a LeakyReLU-kink flip moves an element by 2 lr at once).
-    The yardstick is therefore measured, not assumed: the CPU oracle is run TWICE, the second time with every MLP weight moved by a relative
-    2^-23 (half an fp32 ulp: the smallest perturbation that exists), and the device trajectory must (i) match the oracle to 1e-4 while the two
-    oracle runs still agree to 1e-4 (measured: 1e-7 .. 1e-6 for the first 50 steps), and (ii) never be further from the oracle than
-    3 x the largest divergence the perturbed oracle has shown up to that step (floor: see (iii) below), and within 1e-4 for the first 100 steps."""
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trajectory_envelope.npz")
+EARLY, LOOKAHEAD = 75, 25
+
+
+def envelope_bar(env):
+    """the bar of step t: 3 x the largest distance ANY member of the perturbed-oracle ensemble has shown up to step t + LOOKAHEAD, at least 1e-4.
+    (The look-ahead is what keeps the bar independent of WHEN a run decorrelates: a run that leaves the common trajectory 25 steps before the
+    earliest of the 16 ensemble members is still inside.)"""
+    run_max = np.maximum.accumulate(env)
+    ahead = np.concatenate([run_max[LOOKAHEAD:], np.full(LOOKAHEAD, run_max[-1])])
+    return np.maximum(3.0 * ahead, 1e-4)
+
+
+def test_200_steps_inside_the_oracle_ensemble():
+    """200 optimisation steps of the small case on the device against the fp32 CPU oracle (torch.optim.Adam around oracle/pyref.py: the reference's loop body,
+    models/mvs_points_volumetric_model.py:98-118).  Two fp32 evaluations of this optimisation do not stay together for 200 steps: Adam normalises every gradient
+    element to ~lr, so a last-bit difference grows step by step, and the step at which a run leaves the common trajectory is chance (a pre-activation crossing
+    a LeakyReLU kink).  No assertion here depends on when that happens:
+
+    (i)  steps 1 .. 75 are deterministic to rounding: the device loss is within 1e-4 relative of the oracle's (measured <= 3e-6 on every box seen: 30 x
+         margin), against the oracle run live on this box AND against the committed trajectory (which pins the fixture to this box's oracle);
+    (ii) over all 200 steps the device stays inside 3 x the ENVELOPE of an ensemble of 16 perturbed oracle runs (every MLP weight x (1 +- 2^-23), a
+         different sign mask per run; tests/golden/make_trajectory_envelope.py), with a 25-step look-ahead -- for the shipped one-plane weight gradients and
+         for the two-plane (fp32-class) ones alike."""
+    fx = np.load(GOLDEN)
+    ref, env = fx["reference"], fx["envelope"]
+    assert ref.shape == (200,) and fx["perturbed"].shape[0] >= 8
     case = build_case("small_k8")
-    opt, xyz, attrs, inp, mlp = case
-    ref, _, _ = oracle_steps(*case, 200)
-    g = torch.Generator().manual_seed(7)
-    mlp2 = {k: v * (1.0 + (torch.randint(0, 2, v.shape, generator=g).float() * 2 - 1) * 2.0 ** -23) for k, v in mlp.items()}
-    ref2, _, _ = oracle_steps(opt, xyz, attrs, inp, mlp2, 200)
+    live, _, _ = oracle_steps(*case, EARLY)
     ours, _, _ = device_steps(*case, 200)
     old = ops.set_wgrad_planes(2)
     try:
         ours2, _, _ = device_steps(*case, 200)
     finally:
         ops.set_wgrad_planes(old)
-    rel = lambda a, b: np.array([abs(x - y) / max(abs(y), 1e-6) for x, y in zip(a, b)])
-    d_dev, d_dev2, d_orc = rel(ours, ref), rel(ours2, ref), rel(ref2, ref)
-    env = np.maximum.accumulate(d_orc)
+    rel = lambda a, b: np.abs(np.asarray(a, dtype=np.float64) - b[: len(a)]) / np.maximum(np.abs(b[: len(a)]), 1e-6)
+    bar = envelope_bar(env)
+    d_live, d_dev, d_dev2 = rel(live, ref), rel(ours, ref), rel(ours2, ref)
     for t in (1, 10, 25, 50, 75, 100, 125, 150, 175, 200):
-        print("step %3d  loss device %.6f (two-plane %.6f) oracle %.6f perturbed oracle %.6f   relative to the oracle: device %.1e, two-plane device %.1e, perturbed oracle %.1e"
-              % (t, ours[t - 1], ours2[t - 1], ref[t - 1], ref2[t - 1], d_dev[t - 1], d_dev2[t - 1], d_orc[t - 1]))
+        print("step %3d  loss device %.6f (two-plane %.6f) oracle %.6f   relative to the oracle: device %.1e, two-plane device %.1e, ensemble envelope %.1e, bar %.1e"
+              % (t, ours[t - 1], ours2[t - 1], ref[t - 1], d_dev[t - 1], d_dev2[t - 1], env[t - 1], bar[t - 1]))
     assert ref[-1] < 0.5 * ref[0], "the case must actually optimise"
-    agree = env <= 1e-4
-    assert agree[:30].all(), "the oracle's own perturbed run left 1e-4 within 30 steps: the yardstick is broken"
-    # (iii) once a trajectory has left the yardstick it is decorrelated: WHEN that happens is itself chance (the step at which some
-    # pre-activation crosses a LeakyReLU kink: step ~125 on one box, ~160 on another, for the device and for the perturbed oracle alike),
-    # so beyond it the bar is the size two decorrelated fp32 runs differ by (measured 1e-2 .. 4e-2 at steps 175 .. 200): 5e-2.
-    for d in (d_dev, d_dev2):
-        assert (d[agree] <= 1e-4).all(), float(d[agree].max())
-        assert (d[:100] <= 1e-4).all(), float(d[:100].max())
-        assert (d <= np.maximum(3.0 * env, 5e-2)).all(), (float(d.max()), int(np.argmax(d - np.maximum(3.0 * env, 5e-2))))
+    assert d_live.max() <= 1e-4, "this box's oracle differs from the committed trajectory within %d steps: %g" % (EARLY, d_live.max())
+    for name, d, tr in (("one plane", d_dev, ours), ("two planes", d_dev2, ours2)):
+        assert d[:EARLY].max() <= 1e-4, (name, float(d[:EARLY].max()))
+        assert rel(tr[:EARLY], np.asarray(live, dtype=np.float64)).max() <= 1e-4, name
+        assert (d <= bar).all(), (name, int(np.argmax(d / bar)), float((d / bar).max()))
 
 
 STEPS = 2000

@@ -103,3 +103,24 @@ def test_query_embedding_restatement_equals_the_reference_functions(tag):
             continue
         assert np.array_equal(np.abs(g).sum(-1) == 0, np.abs(fx[key][0]).sum(-1) == 0), key        # the same rows masked out
         assert float(np.abs(g - fx[key][0]).max()) <= 5e-7, key
+
+
+def test_trajectory_envelope_fixture_is_a_usable_yardstick():
+    """tests/golden/trajectory_envelope.npz (make_trajectory_envelope.py: the oracle's 200-step loss trajectory + 16 half-ulp-perturbed runs): the
+    ensemble stays together to 1e-4 / 3 while the device test calls the steps deterministic, it does decorrelate later (else the envelope would
+    prove nothing), the bar is monotone, and the oracle on THIS machine reproduces the stored trajectory's first steps."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from cases import build_case
+    import test_gpu_train_steps as T
+    import test_gpu_zz_convergence as Z
+    fx = np.load(Z.GOLDEN)
+    ref, env, runs = fx["reference"], fx["envelope"], fx["perturbed"]
+    assert ref.shape == (200,) and runs.shape[0] >= 8 and runs.shape[1] == 200
+    assert np.array_equal(env, (np.abs(runs - ref) / np.maximum(np.abs(ref), 1e-6)).max(0))
+    assert env[: Z.EARLY].max() <= 1e-4 / 3 and env[-1] >= 1e-3
+    bar = Z.envelope_bar(env)
+    assert (np.diff(bar) >= 0).all() and bar[0] == 1e-4 and bar[-1] >= 3 * env.max() * 0.999
+    live, _, _ = T.oracle_steps(*build_case("small_k8"), 12)
+    assert np.abs(np.array(live) - ref[:12]).max() <= 1e-5 * ref[0]

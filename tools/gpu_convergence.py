@@ -1,4 +1,4 @@
-"""dev / evidence: the convergence A/B of tests/test_gpu_convergence.py with free parameters; prints one JSON line per run.
+"""dev / evidence: the convergence A/B of tests/test_gpu_zz_convergence.py with free parameters; prints one JSON line per run.
    python tools/gpu_convergence.py [steps = 2000] [runs per arithmetic = 2] [rays per step = 1024]"""
 import json, os, sys, time
 import torch
