@@ -41,6 +41,27 @@ PEAK_HBM_GBS = 8000.0
 # roofline.traffic is NOT measured inside a bench run: it is read from the committed PMC summary (separate rocprofv3 --pmc passes of this
 # same command, FETCH x 2 + WRITE per the guide; tools/gpu_round_profile.sh regenerates it)
 TRAFFIC_SOURCE = "profiles/traffic.json (static: rocprofv3 --pmc passes of this command, not measured in this run)"
+
+
+def measured_copy_gbs(dev, nbytes=1 << 30, reps=6):
+    """SURVEY 8d's HBM denominator beside the nominal 8 TB/s: a device-to-device copy of `nbytes` (16-byte accesses, read + write counted) timed with
+    events on the current stream, best of `reps` after one untimed pass"""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    b.copy_(a); torch.mul(a, 1.0, out=b)
+    best = float("inf")
+    for i in range(2 * reps):              # the runtime's copy and a vectorised elementwise kernel (x * 1.0): whichever is faster is the ceiling
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        if i % 2:
+            b.copy_(a)
+        else:
+            torch.mul(a, 1.0, out=b)
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    del a, b
+    return 2.0 * nbytes / (best * 1e-3) / 1e9
 # algorithmic HBM bytes of the weight-gradient GEMMs per neighbor row, read once: the inputs of layers 2 .. 4 as ONE f16 plane
 # (2 B x (256 + 288 + 256)), layer 1's input as its saved last 64 columns (2 B x 64) + the 128-byte embedding row + 16 B of row
 # metadata it is rebuilt from (k_wgrad_x0), and the four output gradients as one f16 plane (2 B x 4 x 256)
@@ -90,6 +111,7 @@ def parse():
                     help="f16 planes per operand of the weight-gradient GEMMs: 1 = shipped (one plane rounded to nearest, one product); 2 = both operands "
                          "as two planes, three products (fp32-class weight gradients).  The default run times 1 and ALSO reports 2 as config.fp32_class_variant")
     ap.add_argument("--no-fp32-class-variant", action="store_true", help="skip the supplementary --wgrad-planes 2 measurement of the default run")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="no GPU: time only the cpu_baseline leg (kind reference where /root/reference imports, else port) and print it")
     return ap.parse_args()
 
 
@@ -161,6 +183,55 @@ def cpu_baseline(opt, n_points, rays, threads, points_fn=None, rays_fn=None):
                        "aggregator + ray-march forward, loss, backward %.1f s" % (rays, t_query, xyz.shape[0], t_grid, t_render))
 
 
+def cpu_baseline_reference(opt, n_points, rays, threads, points_fn=None, rays_fn=None):
+    """`kind: reference`: the REFERENCE'S OWN modules on the host cores, where /root/reference exists (the authoring container; it does not
+    travel to the GPU box) -- the native query op as the reference's kernels compiled for the host (oracle/_ref/libref_query.so: query_worldcoords.cu run
+    block by block, serial, K <= 8), models/aggregators/point_aggregators.py PointAggregator.forward (:727-814), models/rendering/diff_ray_marching.py
+    ray_march, the training loss and torch autograd's backward through them.  Same bounded sample as the port."""
+    import argparse as _ap
+    from pointnerf_amd import scenes
+    from oracle import pyref
+    if "/root/reference" not in sys.path:
+        sys.path.insert(1, "/root/reference")
+    from models.aggregators.point_aggregators import PointAggregator                      # (reference)
+    from models.rendering.diff_ray_marching import ray_march                               # (reference)
+    from models.rendering.diff_render_func import find_render_function, find_blend_function   # (reference)
+    torch.set_num_threads(threads)
+    p = _ap.ArgumentParser()
+    PointAggregator.modify_commandline_options(p, True)
+    ro = p.parse_args([])
+    for k, v in vars(opt).items():
+        setattr(ro, k, v)
+    ro.agg_axis_weight = None
+    xyz = torch.from_numpy((points_fn or scenes.lego_points)(n_points))
+    attrs = {k: torch.from_numpy(v).requires_grad_(True) for k, v in scenes.point_attributes(xyz.shape[0], 32, 1).items()}
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):        # (the reference's constructor prints; stdout carries the one JSON line)
+        agg = PointAggregator(ro)
+    agg.load_state_dict(pyref.init_mlp_params(opt, seed=0), strict=True)
+    d = (rays_fn or scenes.random_rays)(0, 65536)
+    d["raydir"], d["gt_image"] = d["raydir"][:, :rays], d["gt_image"][:, :rays]
+    inp = pyref.to_torch_inputs(d)
+    t0 = time.time()
+    q = pyref.query(opt, xyz, inp, impl="ref")
+    t_query = time.time() - t0
+    t0 = time.time()
+    points = dict(xyz=xyz, **attrs)
+    nb = pyref.gather_neighbors(points, q["sample_pidx"], inp["camrotc2w"][0], inp["campos"][0])        # (the gather of neural_points.py:690-717)
+    out, ray_valid, weight, conf_c = agg(nb["color"], torch.eye(3), nb["dir"], nb["conf"], nb["emb"], nb["xyz_pers"], nb["xyz"], nb["mask"],
+                                         q["sample_loc"], q["sample_loc_w"], q["sample_ray_dirs"], q["hp"]["vsize"], 0)
+    rd = pyref.ray_dist(opt, q["sample_loc"], ray_valid)
+    color, _, opacity, acc, bw, bg_t, _ = ray_march(rd, ray_valid, out, find_render_function("radiance"), find_blend_function("alpha"), inp["bg_color"])
+    loss = pyref.training_loss(opt, dict(ray_mask=q["ray_mask"], coarse_raycolor=color, conf_coefficient=conf_c), inp)
+    loss.backward()
+    t_render = time.time() - t0
+    dt = t_query + t_render
+    return dict(value=rays / dt, unit="rays/s", cores=threads, kind="reference",
+                seconds={"query_reference_kernels_serial_incl_grid_build": t_query, "aggregator_raymarch_loss_backward": t_render},
+                sample="first %d rays of step 0 of the same workload through the reference's modules: native query (reference kernels on the host, 1 core) "
+                       "%.1f s, PointAggregator.forward + ray_march + loss + backward (torch CPU, %d threads) %.1f s" % (rays, t_query, threads, t_render))
+
+
 def rccl_selftest(dev, rank, world):
     """One small instance of every collective form the step uses, before anything is timed: a 1 KB all-reduce, an all_gather_into_tensor
     (gloo: all_gather), a reduce_scatter_tensor, and the side-stream in-place all-reduce of a bucket head behind an event with
@@ -200,8 +271,24 @@ def rccl_selftest(dev, rank, world):
     return "ok backend=%s world=%d" % (backend, world)
 
 
+def best_cpu_baseline(opt, n_points, rays, threads, points_fn=None, rays_fn=None):
+    """`reference` when the reference's modules import (only where /root/reference exists), the port otherwise (the GPU box)"""
+    if os.path.isdir("/root/reference/models/aggregators"):
+        try:
+            from oracle import query as oq
+            oq.build()
+            return cpu_baseline_reference(opt, n_points, rays, threads, points_fn, rays_fn)
+        except Exception as e:       # noqa: BLE001
+            print("cpu_baseline: the reference's modules did not run (%r): timing the port" % (e,), file=sys.stderr)
+    return cpu_baseline(opt, n_points, rays, threads, points_fn, rays_fn)
+
+
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        cfg_name, opt_fn, points_fn, n_default, rays_fn = _cfg()[args.config]
+        print(json.dumps(best_cpu_baseline(opt_fn(is_train=1), args.points or n_default, args.cpu_rays, min(os.cpu_count() or 1, 32), points_fn, rays_fn)))
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -451,21 +538,29 @@ def main():
             if os.path.exists(tf):
                 traffic = json.load(open(tf))
 
-            def mfma_entry(k):      # executed f16 products against the dense f16 MFMA peak
+            src = traffic.get("_source")
+            traffic_source = TRAFFIC_SOURCE if not src else TRAFFIC_SOURCE + "; collected at commit %s with `%s`" % (src.get("commit"), src.get("command"))
+            copy_gbs = measured_copy_gbs(dev)
+
+            def mfma_entry(k):      # SURVEY 8d's algorithmic flops against the dense f16 MFMA peak; the executed f16 products (x 3) beside it
                 t = per[k]["ms_per_step"] * 1e-3
-                return {"bound": "mfma", "kernel": k, "achieved": F16_PRODUCTS * alg_flop[k] / t / 1e12, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": F16_PRODUCTS * alg_flop[k] / t / 1e12 / PEAK_F16_MFMA_TFLOPS,
-                        "frac_algorithmic": alg_flop[k] / t / 1e12 / PEAK_F16_MFMA_TFLOPS,       # SURVEY 8d flops (no x3) against the same peak
-                        "frac_note": "frac = executed f16 products (3 per algorithmic multiply-add) / dense f16 MFMA peak = matrix-pipe utilisation; "
-                                     "frac_algorithmic = SURVEY 8d flops / the same peak",
-                        "traffic": traffic.get(k), "traffic_source": TRAFFIC_SOURCE,
-                        "algorithmic_tflops_f32_equivalent": alg_flop[k] / t / 1e12, "f16_products_per_multiply_add": F16_PRODUCTS,
+                return {"bound": "mfma", "kernel": k, "achieved": alg_flop[k] / t / 1e12, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": alg_flop[k] / t / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                        "achieved_executed": F16_PRODUCTS * alg_flop[k] / t / 1e12,
+                        "frac_executed": F16_PRODUCTS * alg_flop[k] / t / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                        "frac_note": "frac = SURVEY 8d algorithmic flops / dense f16 MFMA peak; frac_executed = executed f16 products (3 per algorithmic "
+                                     "multiply-add: two-plane operands) / the same peak = matrix-pipe utilisation",
+                        "traffic": traffic.get(k), "traffic_source": traffic_source,
+                        "f16_products_per_multiply_add": F16_PRODUCTS,
                         "algorithmic_flop_per_step": alg_flop[k], "ms_per_step": per[k]["ms_per_step"]}
 
             def hbm_entry(k):
                 t = per[k]["ms_per_step"] * 1e-3
                 return {"bound": "hbm", "kernel": k, "achieved": alg_byte[k] / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": alg_byte[k] / t / 1e9 / PEAK_HBM_GBS, "traffic": traffic.get(k), "traffic_source": TRAFFIC_SOURCE, "algorithmic_bytes_per_step": alg_byte[k],
+                        "frac": alg_byte[k] / t / 1e9 / PEAK_HBM_GBS,
+                        "peak_measured": copy_gbs, "frac_of_measured": alg_byte[k] / t / 1e9 / copy_gbs,
+                        "peak_measured_note": "device-to-device copy of 1 GiB (read + write counted), timed in this run",
+                        "traffic": traffic.get(k), "traffic_source": traffic_source, "algorithmic_bytes_per_step": alg_byte[k],
                         "ms_per_step": per[k]["ms_per_step"]}
             heavy = [k for k in ("agg_forward", "agg_backward", "wgrad") if k in per]
             if heavy:
@@ -484,7 +579,7 @@ def main():
                     out["kernels"][k]["tflops"] = alg_flop[k] / (per[k]["ms_per_step"] * 1e-3) / 1e12
         if world == 1 and args.cpu_rays > 0 and not args.render_only and args.config in ("lego", "chair"):
             try:
-                out["cpu_baseline"] = cpu_baseline(opt, n_points, args.cpu_rays, min(os.cpu_count() or 1, 32), points_fn, rays_fn)
+                out["cpu_baseline"] = best_cpu_baseline(opt, n_points, args.cpu_rays, min(os.cpu_count() or 1, 32), points_fn, rays_fn)
             except Exception as e:       # the checker failing must not hide the GPU number
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out))

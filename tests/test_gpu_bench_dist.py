@@ -31,7 +31,7 @@ def test_bench_json_contract_single_gpu():
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["peak"] > 0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     # the headline line carries the fp32-class weight-gradient variant of the same step (--wgrad-planes 2) next to the shipped arithmetic
     v = d["config"]["fp32_class_variant"]
     assert d["config"]["wgrad_planes"] == 1 and v["ms_per_step"] > 0 and v["value"] > 0 and abs(v["final_loss"]) < 1e3

@@ -115,7 +115,36 @@ def test_overlay_serves_extract_2d_and_query_embedding_of_the_reference_class():
     from pointnerf_amd import mvs_points_model as A
     assert M._ref.__file__.startswith(U.REF)
     assert M.MvsPointsModel is M._ref.MvsPointsModel and M.MvsPointsModel.__module__ == "models.mvs._reference_mvs_points_model"
-    assert M.MvsPointsModel.extract_2d is A.MvsPointsModel.extract_2d and M.MvsPointsModel.query_embedding is A.MvsPointsModel.query_embedding
+    assert M.MvsPointsModel.extract_2d is M._extract_2d and M.MvsPointsModel.query_embedding is M._query_embedding
+    assert M._ref_extract_2d.__module__ == "models.mvs._reference_mvs_points_model" and M._ref_extract_2d is not A.MvsPointsModel.extract_2d
     assert "gen_points" in vars(M._ref.MvsPointsModel) and M.MvsPointsModel.gen_points is not A.MvsPointsModel.gen_points
     import models.mvs_points_volumetric_model as shell
     assert shell.MvsPointsModel is M.MvsPointsModel
+
+
+def test_overlay_keeps_the_reference_methods_where_gradients_are_wanted(monkeypatch):
+    """the reference's extract_2d / query_embedding are differentiable (gen_points -> query_embedding carries the point features'
+    gradient to FeatureNet in the feed-forward training scripts, models/mvs/mvs_points_model.py:370); the HIP versions return leaves.  Through the
+    overlay a call whose feature maps / positions / confidences carry a gradient while autograd records runs the REFERENCE'S method; the same call
+    under no_grad, or with plain tensors, runs the library's."""
+    import torch
+    U.install()
+    import models.mvs.mvs_points_model as M
+    from pointnerf_amd import mvs_points_model as A
+    calls = []
+    monkeypatch.setattr(M, "_ref_extract_2d", lambda self, *a, **k: calls.append("ref_extract") or "R")
+    monkeypatch.setattr(M, "_ref_query_embedding", lambda self, *a, **k: calls.append("ref_query") or "R")
+    monkeypatch.setattr(A.MvsPointsModel, "extract_2d", lambda self, *a, **k: calls.append("hip_extract") or "H")
+    monkeypatch.setattr(A.MvsPointsModel, "query_embedding", lambda self, *a, **k: calls.append("hip_query") or "H")
+    me = object.__new__(M.MvsPointsModel)
+    feats = [torch.zeros(3, 3, 4, 4), torch.zeros(3, 8, 4, 4, requires_grad=True)]
+    plain = [f.detach() for f in feats]
+    xyz, conf = torch.zeros(1, 5, 3), torch.ones(1, 5, 1)
+    ex = lambda f, x: M.MvsPointsModel.extract_2d(me, f, [0], [0, 1], None, None, None, x, 4, 4, cam_vid=0)
+    qe = lambda f, x, c: M.MvsPointsModel.query_embedding(me, (4, 4), x, c, f, None, None, None, 0, pointdir_w=True)
+    assert ex(feats, xyz) == "R" and ex(plain, xyz) == "H" and ex(plain, xyz.clone().requires_grad_(True)) == "R"
+    with torch.no_grad():
+        assert ex(feats, xyz) == "H" and qe(feats, xyz, conf) == "H"
+    assert qe(feats, xyz, conf) == "R" and qe(plain, xyz, conf) == "H" and qe(plain, xyz, conf.clone().requires_grad_(True)) == "R"
+    assert qe(plain, xyz, None) == "H"
+    assert calls == ["ref_extract", "hip_extract", "ref_extract", "hip_extract", "hip_query", "ref_query", "hip_query", "ref_query", "hip_query"]

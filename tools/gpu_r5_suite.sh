@@ -6,7 +6,7 @@ export PYTHONPATH=$GRAFT_REPO_ROOT:$GRAFT_REPO_ROOT/tests
 T=$1; shift; O=gpurun_out/$T; mkdir -p $O
 ( hostname; rocm-smi --showproductname 2>/dev/null | grep -i "card series" | head -1; nproc ) > $O/box.txt 2>&1
 S=$(date +%s)
-timeout 3000 python -m pytest tests -m gpu -x -q --durations=30 "$@" > $O/tests.log 2>&1
+timeout 3000 python -m pytest tests -m gpu -x -q --durations=12 -rs "$@" > $O/tests.log 2>&1
 echo "pytest rc=$? wall=$(( $(date +%s) - S )) s" | tee -a $O/tests.log
 grep -v amdgpu.ids $O/tests.log | tail -45
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.log

@@ -28,6 +28,16 @@ for k in sorted(set(f) | set(w)):
     summary[k] = {"FETCH_SIZE_KiB_total": fk[0], "WRITE_SIZE_KiB_total": wk[0], "launches": max(fk[1], wk[1]),
                   "hbm_bytes_per_step_corrected": per_step_bytes, "launches_per_step": launches_per_step}
     traffic[k] = per_step_bytes
+import subprocess
+try:
+    commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"]).decode().strip()
+    dirty = bool(subprocess.check_output(["git", "status", "--porcelain", "--", "pointnerf_amd", "bench.py"]).decode().strip())
+except Exception:
+    commit, dirty = None, None
+# (the command of tools/gpu_profile.sh's --pmc passes; the library is the one built from `commit`)
+traffic["_source"] = {"commit": commit, "uncommitted_changes_in_the_library_or_bench": dirty, "tag": tag,
+                      "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- python bench.py --steps 3 --warmup 1 --cpu-rays 0 --no-prof --no-fp32-class-variant",
+                      "correction": "(2 x FETCH_SIZE + WRITE_SIZE) KiB per step (MI355X_MICROARCH.md, HBM section)"}
 json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
