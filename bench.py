@@ -232,6 +232,38 @@ def cpu_baseline_reference(opt, n_points, rays, threads, points_fn=None, rays_fn
                        "%.1f s, PointAggregator.forward + ray_march + loss + backward (torch CPU, %d threads) %.1f s" % (rays, t_query, threads, t_render))
 
 
+class Watchdog:
+    """A first contact with RCCL that hangs must leave a record, not a driver timeout: if the guarded block has not finished after `seconds`,
+    every rank writes what it knows (stage, rank, backend, library version, the NCCL_ / RCCL_ / HSA_ environment, the hint to rerun with
+    NCCL_DEBUG=INFO) to stderr and the process exits with code 17."""
+
+    def __init__(self, what, seconds, rank, world):
+        self.what, self.seconds, self.rank, self.world = what, seconds, rank, world
+
+    def _fire(self):
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:       # noqa: BLE001
+            ver = "unknown (%r)" % (e,)
+        env = {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_", "MASTER_", "HIP_VISIBLE", "ROCR_VISIBLE")) or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+        print(json.dumps({"bench_watchdog": "%s did not finish within %d s" % (self.what, self.seconds), "rank": self.rank, "world": self.world,
+                          "rccl_version": ver, "env": env,
+                          "hint": "rerun with NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,COLL (RCCL reads the NCCL_ variables); HSA_ENABLE_IPC_MODE_LEGACY=0 is required on this pool"}),
+              file=sys.stderr, flush=True)
+        os._exit(17)
+
+    def __enter__(self):
+        import threading
+        self.timer = threading.Timer(self.seconds, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
+
+
 def rccl_selftest(dev, rank, world):
     """One small instance of every collective form the step uses, before anything is timed: a 1 KB all-reduce, an all_gather_into_tensor
     (gloo: all_gather), a reduce_scatter_tensor, and the side-stream in-place all-reduce of a bucket head behind an event with
@@ -266,8 +298,12 @@ def rccl_selftest(dev, rank, world):
     assert float(bucket[0]) == want and float(bucket[-1]) == float(rank + 1), "side-stream bucket all-reduce"
     torch.cuda.synchronize()
     if rank == 0:
-        print("rccl_selftest: ok  backend=%s world=%d HSA_ENABLE_IPC_MODE_LEGACY=%s" % (backend, world, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")),
-              file=sys.stderr, flush=True)
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:            # noqa: BLE001
+            ver = "unknown"
+        print("rccl_selftest: ok  backend=%s world=%d rccl=%s HSA_ENABLE_IPC_MODE_LEGACY=%s NCCL_DEBUG=%s (set NCCL_DEBUG=INFO for RCCL's own log)"
+              % (backend, world, ver, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), os.environ.get("NCCL_DEBUG")), file=sys.stderr, flush=True)
     return "ok backend=%s world=%d" % (backend, world)
 
 
@@ -298,7 +334,8 @@ def main():
                          % (args.gpus, world, args.gpus, args.gpus))
     if world > 1:
         # "nccl" IS RCCL on ROCm.  PNERF_DIST_BACKEND=gloo exists only so that tests can run 2 ranks on a 1-GPU box.
-        torch.distributed.init_process_group(backend=os.environ.get("PNERF_DIST_BACKEND", "nccl"))
+        with Watchdog("init_process_group", 120, rank, world):
+            torch.distributed.init_process_group(backend=os.environ.get("PNERF_DIST_BACKEND", "nccl"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation (oracle/ is the checker only)")
     local = local % torch.cuda.device_count()
@@ -308,7 +345,8 @@ def main():
     from pointnerf_amd.fused import FusedRender
     selftest = None
     if world > 1:
-        selftest = rccl_selftest(dev, rank, world)       # raises on a wrong sum
+        with Watchdog("the collective self-test (first RCCL communicator + 4 small collectives)", int(os.environ.get("PNERF_SELFTEST_TIMEOUT", "60")), rank, world):
+            selftest = rccl_selftest(dev, rank, world)       # raises on a wrong sum
         if not selftest:
             raise SystemExit("bench.py: the collective self-test did not run: refusing to time a multi-GPU step")
     ops.set_wgrad_planes(args.wgrad_planes)

@@ -726,9 +726,15 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_backward(BwdArgs a) 
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 15);
         // ---- embedding gradient through [e | PE3(e)]: d e = dX[e] + sum_f 2^f (dX[sin_f] cos_f - dX[cos_f] sin_f)
-        if (rp >= 0) {
-            const float *dr_ = dx + row * LDDX;
+        // Round 5: the 32 values of a row leave as ONE lane-contiguous burst.  The (row, q) threads that form them own 8 columns each, so an
+        // atomic instruction used to touch 64 different 32-byte sectors (one dword each; the memory side turns every one into a 32-byte
+        // read-modify-write: 1 KB of write traffic per row, 7.3 GB per step at the bench configuration).  The values now go back into the
+        // row's own d X0 columns (which only their thread reads), and the wave -- it holds 16 whole rows -- sends them out two rows per
+        // instruction: lanes 0..31 = the 128-byte gradient row of one point, lanes 32..63 the next row's.
+        if (bw && rp >= 0) {
+            float *dr_ = dx + row * LDDX;
             const float e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+            float go[EPT];
 #pragma unroll
             for (int i = 0; i < EPT; ++i) {
                 const int dd = EPT * q + i;
@@ -741,7 +747,18 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_backward(BwdArgs a) 
                     g += fr * (t.x * c[f] - t.y * s[f]);
                     fr *= 2.f;
                 }
-                atomicAdd(&a.g_emb[(long long)rp * PN_F + dd], g * invS);
+                go[i] = g * invS;
+            }
+#pragma unroll
+            for (int i = 0; i < EPT; i += 4) *reinterpret_cast<float4 *>(dr_ + EPT * q + i) = make_float4(go[i], go[i + 1], go[i + 2], go[i + 3]);
+        }
+        PN_WAVE_LDS_SYNC();
+        if (bw) {
+            const int r0w = (row & ~15) + (lane >> 5), col = lane & 31;          // the wave's 16 rows, two per instruction
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = r0w + 2 * j, p = prow[r];
+                if (p >= 0) atomicAdd(&a.g_emb[(long long)p * PN_F + col], dx[r * LDDX + col]);
             }
         }
         PN_TR(pn_trace_bwd, 16);

@@ -192,7 +192,7 @@ def plan_sparse_exchange(pidx, n_points, group=None):
 
 def sparse_allreduce_rows(grads, touched, group=None, cap=None):
     """Sum over ranks of dense per-point gradients ``grads`` (list of [N, c_i] tensors, each rank's contribution zero outside its own
-    ``touched`` rows) by exchanging only touched rows: all-gather (ids padded with -1 to the largest count, rows [cap, sum c_i]),
+    ``touched`` rows) by exchanging only touched rows: all-gather (ids padded to the largest count with distinct rows whose values are zero, rows [cap, sum c_i]),
     then every rank zeroes its touched rows and adds the blocks of ALL ranks in rank order -- the same additions in the same order
     everywhere, so the replicas stay bitwise identical (a dense ring all-reduce has that property by construction).
     Bytes received per rank: W * cap * (4 + 4 sum c_i), against 2 (W - 1) / W * 4 N sum c_i for the dense ring.
@@ -210,9 +210,11 @@ def sparse_allreduce_rows(grads, touched, group=None, cap=None):
         dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=group)
         cap = int(cap.item())
     cap = max(int(cap), 1)
-    # padding: row id 0 with an all-zero row -- adding 0.0 to row 0 changes nothing, so no rank has to mask (a boolean-mask index is a
-    # device -> host read per rank block: W stalls inside the exchange) and every rank still performs the same additions in the same order
-    ids = torch.zeros(cap, dtype=torch.int64, device=dev)
+    # padding: all-zero rows -- adding 0.0 to a row changes nothing, so no rank has to mask (a boolean-mask index is a device -> host read
+    # per rank block: W stalls inside the exchange) and every rank still performs the same additions in the same order.  The padded entries
+    # name DISTINCT rows (entry j -> row j mod N): with one common row, a rank block with few touched rows issued (cap - count) x 39
+    # same-address atomics of index_add_ onto row 0's cache lines
+    ids = torch.arange(cap, dtype=torch.int64, device=dev).remainder_(max(int(flat[0].shape[0]), 1))
     ids[:touched.numel()] = touched
     rows = torch.zeros(cap, sum(cols), dtype=torch.float32, device=dev)
     if touched.numel():

@@ -182,3 +182,80 @@ def test_sparse_touched_row_exchange_equals_dense_allreduce(tmp_path):
     for r in range(1, world):
         for a, b in zip(res[0][0], res[r][0]):
             assert torch.equal(a, b)
+
+
+# ---- eight ranks (the world the driver's scaling run launches): every collective form of the step, three optimisation steps, replicas bit-identical
+def _eight_worker(rank, world, port, out_dir):
+    import math
+    from pointnerf_amd.optim import FusedAdam, ShardedAdam
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    N, F, K, R = 4000, 32, 8, 1003                                  # 1003 rays: not divisible by 8 (remainder 3)
+    sl = pdist.shard_slice(R)
+    n_mine = sl.stop - sl.start
+    assert n_mine == R // world + (1 if rank < R % world else 0)
+    lens = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(lens, torch.tensor([n_mine]))
+    assert sum(int(x) for x in lens) == R and sl.start == sum(int(x) for x in lens[:rank])       # contiguous, disjoint, complete
+
+    def adam(p, g, m, v, lr, b1, b2, eps, step):
+        m.lerp_(g, 1 - b1); v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        p.addcdiv_(m, (v.sqrt() / math.sqrt(1 - b2 ** step)).add_(eps), value=-lr / (1 - b1 ** step))
+
+    gen0 = torch.Generator().manual_seed(0)                          # identical initial replicas
+    make = lambda: ([torch.randn(256, 284, generator=gen0).requires_grad_(True), torch.randn(256, generator=gen0).requires_grad_(True)],
+                    [torch.randn(1, N, F, generator=gen0).requires_grad_(True), torch.randn(1, N, 1, generator=gen0).requires_grad_(True),
+                     torch.randn(1, N, 3, generator=gen0).requires_grad_(True), torch.randn(1, N, 3, generator=gen0).requires_grad_(True)])
+    gen0.manual_seed(0); mlp_d, pts_d = make()                       # dense all-reduce + FusedAdam
+    gen0.manual_seed(0); mlp_s, pts_s = make()                       # sparse touched-row exchange + FusedAdam
+    gen0.manual_seed(0); mlp_z, pts_z = make()                       # ZeRO-1 ShardedAdam on the point tensors
+    o_d = [FusedAdam(mlp_d, lr=5e-4, update=adam), FusedAdam(pts_d, lr=2e-3, update=adam)]
+    o_s = [FusedAdam(mlp_s, lr=5e-4, update=adam), FusedAdam(pts_s, lr=2e-3, update=adam)]
+    o_z = [FusedAdam(mlp_z, lr=5e-4, update=adam), ShardedAdam(pts_z, lr=2e-3, update=adam)]
+    for step in range(3):
+        gen = torch.Generator().manual_seed(1000 * step + rank)
+        # this rank's rays touch a rank-dependent number of rows (one rank none at all in step 1), some slots empty
+        n_samp = 0 if (step == 1 and rank == 5) else 40 + 13 * rank
+        pidx = torch.randint(0, N, (n_samp, K), generator=gen, dtype=torch.int32)
+        if n_samp:
+            pidx[torch.rand(n_samp, K, generator=gen) < 0.3] = -1
+        touched = pdist.touched_rows(pidx, N)
+        gm = [torch.randn(p.shape, generator=gen) for p in mlp_d]
+        gp = []
+        for p in pts_d:
+            g = torch.zeros(p.shape)
+            g[0, touched] = torch.randn(touched.numel(), p.shape[-1], generator=gen)
+            gp.append(g)
+        for ms, ps in ((mlp_d, pts_d), (mlp_s, pts_s), (mlp_z, pts_z)):
+            for p, g in zip(ms + ps, gm + gp):
+                p.grad = g.clone()
+        pdist.allreduce_grads(mlp_d, pts_d)
+        ids, counts = pdist.plan_sparse_exchange(pidx, N)
+        pdist.sparse_allreduce_rows([p.grad for p in pts_s], ids[: int(counts[0])].long(), cap=int(counts[1]))
+        pdist.allreduce_grads(mlp_s, [])
+        pdist.allreduce_grads(mlp_z, [])
+        for o in o_d + o_s + o_z:
+            o.step()
+    torch.save(dict(dense=[p.detach().clone() for p in mlp_d + pts_d], sparse=[p.detach().clone() for p in mlp_s + pts_s],
+                    zero1=[p.detach().clone() for p in mlp_z + pts_z]), os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_every_exchange_form_three_steps_replicas_identical(tmp_path):
+    """world 8 on gloo: `shard_slice` of a ray count that 8 does not divide, the dense gradient all-reduce, the sparse touched-row exchange
+    (`plan_sparse_exchange` + `sparse_allreduce_rows`, unequal counts, one rank with none) and the ZeRO-1 `ShardedAdam`, three Adam steps each:
+    every rank ends with BITWISE the same parameters, and the three forms agree to summation order."""
+    world = 8
+    port = 29500 + (os.getpid() + 1234) % 2000
+    mp.spawn(_eight_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(world)]
+    for form in ("dense", "sparse", "zero1"):
+        for r in range(1, world):
+            for a, b in zip(res[0][form], res[r][form]):
+                assert torch.equal(a, b), (form, r)
+    for form in ("sparse", "zero1"):
+        for a, b in zip(res[0]["dense"], res[0][form]):
+            # Adam turns a gradient difference of one ulp into a parameter difference of up to ~lr where the second moment is tiny; the sums agree to 1e-6
+            assert float((a - b).abs().max()) <= 1e-4 and float((a - b).abs().mean()) <= 1e-6, form

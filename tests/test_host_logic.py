@@ -72,3 +72,20 @@ def test_scene_generators_are_deterministic():
     assert np.array_equal(r1["raydir"], r2["raydir"]) and r1["raydir"].shape == (1, 128, 3)
     c2w, intr = scenes.synth_camera(30.0)
     assert abs(intr[0, 0] - 1111.111) < 1e-2 and abs(np.linalg.norm(c2w[:3, 3]) - 4.0) < 1e-5
+
+
+def test_bench_watchdog_leaves_a_record_and_exits():
+    """bench.py's guard around the first RCCL contact: a block that does not finish in time ends the process with code 17 and one JSON line on stderr
+    (stage, rank, RCCL version, the NCCL_/HSA_ environment, the NCCL_DEBUG hint); a block that does finish is left alone."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "with bench.Watchdog('fast stage', 5, 0, 8): pass\n"
+            "with bench.Watchdog('the stuck stage', 1, 3, 8): time.sleep(30)\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, NCCL_DEBUG="WARN"))
+    assert r.returncode == 17, (r.returncode, r.stderr[-500:])
+    rec = json.loads([l for l in r.stderr.splitlines() if l.startswith("{")][-1])
+    assert "the stuck stage" in rec["bench_watchdog"] and rec["rank"] == 3 and rec["world"] == 8 and rec["env"]["NCCL_DEBUG"] == "WARN" and "NCCL_DEBUG=INFO" in rec["hint"]
