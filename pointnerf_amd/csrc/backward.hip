@@ -511,7 +511,14 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_backward(BwdArgs a) 
             m1[fb] = a.sv.lmask[(gtile * 3 + 0) * 512 + o]; m2[fb] = a.sv.lmask[(gtile * 3 + 1) * 512 + o]; m3[fb] = a.sv.lmask[(gtile * 3 + 2) * 512 + o];
         }
         float dsg_v = 0.f;
-        if (tid < PN_TILE && rm_cur.x >= 0) dsg_v = a.grad_decoded[(long long)rm_cur.x * 4];
+        // the row's ray direction (for d dir, behind layer 3): requested with the burst -- it hangs off the sample id, and as a dependent load
+        // behind the extras' barrier it was 1-2 us of one wave's latency per tile with the other three waves waiting
+        float rdx = 0.f, rdy = 0.f, rdz = 0.f;
+        if (tid < PN_TILE && rm_cur.x >= 0) {
+            dsg_v = a.grad_decoded[(long long)rm_cur.x * 4];
+            const int r = rm_cur.x / a.SR;
+            rdx = a.raydir[3 * r]; rdy = a.raydir[3 * r + 1]; rdz = a.raydir[3 * r + 2];
+        }
         pn_f4 h4v[4096 / PN_NTHR];
 #pragma unroll
         for (int i = 0; i < 4096 / PN_NTHR; ++i) {
@@ -673,14 +680,29 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_backward(BwdArgs a) 
                 const float4 a1 = *reinterpret_cast<const float4 *>(X + (w >> 1) * PN_XPLANE + tid * PN_XRS + 512 + (w & 1) * 32 + 16);
                 u.x += a0.x; u.y += a0.y; u.z += a0.z; u.w += a0.w; v.x += a1.x; v.y += a1.y; v.z += a1.z; v.w += a1.w;
             }
+            float vx, vy, vz, gx = 0.f, gy = 0.f, gz = 0.f;
             if (p >= 0) {
-                const int r = sidx[tid] / a.SR;
-                float vx, vy, vz, gx, gy, gz;
-                rot3b(a.cam.rw2c, a.raydir[3 * r], a.raydir[3 * r + 1], a.raydir[3 * r + 2], true, vx, vy, vz);
+                rot3b(a.cam.rw2c, rdx, rdy, rdz, true, vx, vy, vz);
                 // features (q - v, q . v) with q = dir @ Rw2c^T  ->  d q = dex[3:6] + dex[6] * v ; d dir = d q @ Rw2c
                 rot3b(a.cam.rw2c, u.w + v.z * vx, v.x + v.z * vy, v.y + v.z * vz, false, gx, gy, gz);
-                atomicAdd(&a.g_color[3 * p], u.x * invS); atomicAdd(&a.g_color[3 * p + 1], u.y * invS); atomicAdd(&a.g_color[3 * p + 2], u.z * invS);
-                atomicAdd(&a.g_dir[3 * p], gx * invS); atomicAdd(&a.g_dir[3 * p + 1], gy * invS); atomicAdd(&a.g_dir[3 * p + 2], gz * invS);
+            }
+            // Round 5: the six values go back into the row's (consumed) extras slots and leave three lanes per point: a point's 12 bytes of
+            // d colour / d dir are one or two 32-byte sectors instead of three (every lane of the old form hit its own sector)
+            float *slot = reinterpret_cast<float *>(X + tid * PN_XRS + 512);
+            *reinterpret_cast<float4 *>(slot) = make_float4(u.x * invS, u.y * invS, u.z * invS, gx * invS);
+            *reinterpret_cast<float2 *>(slot + 4) = make_float2(gy * invS, gz * invS);
+        }
+        PN_WAVE_LDS_SYNC();
+        if (tid < PN_TILE) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int e = 64 * j + tid, r = (e * 21846) >> 16, c = e - 3 * r;          // e / 3 for e < 192
+                const int p = prow[r];
+                if (p >= 0) {
+                    const float *slot = reinterpret_cast<const float *>(X + r * PN_XRS + 512);
+                    atomicAdd(&a.g_color[3 * p + c], slot[c]);
+                    atomicAdd(&a.g_dir[3 * p + c], slot[3 + c]);
+                }
             }
         }
         PnGemmW<16, 8, PN_NFB> W2;

@@ -1,0 +1,202 @@
+// role_probe.hip -- dev tool (not part of the product): ONE bounded experiment on the aggregator tile kernels' organisation (round 5).
+//
+// The shipped organisation ("A"): 4 waves per 64-row tile, two workgroups per CU; every wave runs the whole sequence
+//     build X0 -> 4 x [GEMM (MFMA) -> transposing copy-out of the layer's input (LDS -> HBM) -> barrier -> epilogue (split into planes) -> barrier] -> tail
+// so the matrix pipe only works during the GEMM parts (0.5 busy in the real kernels), and what overlaps with what is left to the phase of the
+// CU's second workgroup.  The untried organisation ("R", role-specialised): ONE 8-wave workgroup per CU with TWO tile buffers in LDS (2 x 74 KB);
+// waves 0..3 issue ONLY GEMMs and their own epilogues (the accumulators live in their registers) for tile t, waves 4..7 do everything else -- the
+// copy-outs of tile t's layer inputs (their stores have their own vmcnt queue: round 2 found that stores issued by the GEMM waves stall the weight
+// fragments), the tail of tile t - 1 and the build of tile t + 1 in the other buffer -- handing over at workgroup barriers (gfx950 has one barrier
+// per workgroup: the roles run in lock-step, eight intervals per tile).
+//
+// Round 4's lesson (organisation B looked 7 % faster on a probe whose stand-in phases issued no LDS traffic, and was 7-14 % slower in the real kernels):
+// the non-GEMM phases here are the REAL copy-out (pn_copy_out_kmajor: transposing LDS reads of both planes + 1 KB-run stream stores to HBM) and
+// stand-ins for build / tail that issue the real phases' LDS traffic (build: both planes of a 64 x 288 tile written; tail: both planes of 64 x 256
+// read and streamed to HBM as the saved h4 planes) and VALU counts of the real phases' order (tools/analyze_trace.py: ~600 / ~800 per thread).
+// A is calibrated against the real forward: 12.8 ms / 423 tiles per CU = 30 us per tile and CU.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fno-vectorize -I../pointnerf_amd/csrc -I../include role_probe.hip -o role_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include "f16x3.h"
+
+struct Bufs { const char *img; uint4 *sv[4]; pn_f4 *h4; float *out; int ring; };
+
+__device__ __forceinline__ float valu_chain(float x, int n) {            // n dependent-free-ish fmas on four chains
+    float f0 = x, f1 = x + 1.f, f2 = x + 2.f, f3 = x + 3.f;
+    for (int i = 0; i < n; i += 4) { f0 = __builtin_fmaf(f0, 1.0001f, 0.5f); f1 = __builtin_fmaf(f1, 1.0001f, 0.5f); f2 = __builtin_fmaf(f2, 1.0001f, 0.5f); f3 = __builtin_fmaf(f3, 1.0001f, 0.5f); }
+    return (f0 + f1) + (f2 + f3);
+}
+// build stand-in, iterations [i0, i1) of 18: thread t of 256 writes 16-byte units u = t + 256 i of both planes (64 rows x 37 units = 2368 -> 9.25 per
+// thread and plane; 18 iterations x 1 unit x 2 planes ~ the whole 64 x 288 tile) with `valu` VALU instructions per iteration in front
+__device__ __forceinline__ float build_part(char *X, int t, int i0, int i1, int valu, float keep) {
+    for (int i = i0; i < i1; ++i) {
+        keep = valu_chain(keep, valu);
+        const int u = (t + 256 * (i >> 1)) % 2368, plane = i & 1;
+        const unsigned w = 0x2c002c00u + (__float_as_uint(keep) & 7u);
+        *reinterpret_cast<uint4 *>(X + plane * PN_XPLANE + (u / 37) * PN_XRS + (u % 37) * 16) = make_uint4(w, w, w, w);
+    }
+    return keep;
+}
+// tail stand-in, rows [i0, i1) of the thread's 8 (the real f_tail's mapping: thread -> columns 8 (t & 31) .. of rows 8 (t >> 5) ..): both planes read,
+// streamed to HBM (the saved h4 planes), `valu` VALU instructions per row
+__device__ __forceinline__ float tail_part(const char *X, pn_f4 *h4, long long row0, int t, int i0, int i1, int valu, float keep) {
+    const int cg = t & 31, r0 = 8 * (t >> 5);
+    for (int i = i0; i < i1; ++i) {
+        const int r = r0 + i;
+        const uint4 h = *reinterpret_cast<const uint4 *>(X + r * PN_XRS + cg * 16);
+        const uint4 m = *reinterpret_cast<const uint4 *>(X + PN_XPLANE + r * PN_XRS + cg * 16);
+        pn_f4 th = {__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(h.z), __uint_as_float(h.w)};
+        pn_f4 tm = {__uint_as_float(m.x), __uint_as_float(m.y), __uint_as_float(m.z), __uint_as_float(m.w)};
+        PN_STREAM_STORE(th, h4 + (row0 + r) * 32 + cg);
+        PN_STREAM_STORE(tm, h4 + (row0 + 64 + r) * 32 + cg);
+        keep += valu_chain(__uint_as_float(h.x ^ m.y), valu) * 1e-30f;
+    }
+    return keep;
+}
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[2][2], char *X, int wave, int lane) {
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v[i] = acc[fb][rb][4 * g + i] * 1e-3f + 0.0625f; v[i] = fmaxf(v[i], 0.01f * v[i]); }
+                pn_x_store4<false>(X, 32 * rb + (lane & 31), pn_d_feat(2 * wave + fb, g, lane), v[0], v[1], v[2], v[3]);
+            }
+}
+
+// ---------------------------------------------------------------- A: the shipped organisation with the realistic other phases
+__global__ __launch_bounds__(256, 2) void k_org_a(Bufs b, int tiles, int vb, int vt, int copy) {
+    extern __shared__ __attribute__((aligned(16))) char smem_p[];
+    char *X = smem_p;
+    for (int i = threadIdx.x; i < PN_XBYTES / 4; i += 256) reinterpret_cast<unsigned *>(X)[i] = 0x2c002c00u + (i & 7);
+    __syncthreads();
+    f32x16 acc[2][2];
+    float keep = 0.f;
+    for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const long long slot = t % b.ring;
+        keep = build_part(X, tid, 0, 18, vb, keep);
+        PN_LDS_BARRIER();
+#pragma unroll 1
+        for (int layer = 0; layer < 4; ++layer) {
+            acc_zero(acc);
+            pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(b.img + (size_t)layer * PN_IMG(16, 8)), 2 * wave, lane, acc);
+            if (copy) pn_copy_out_kmajor<PN_H>(X, b.sv[layer], slot * 8, tid);
+            PN_LDS_BARRIER();
+            epilogue(acc, X, wave, lane);
+            PN_LDS_BARRIER();
+        }
+        keep += acc[0][0][0] * 1e-30f;
+        keep = tail_part(X, b.h4, slot * 128, tid, 0, 8, vt, keep);
+        PN_LDS_BARRIER();
+    }
+    if (keep == 123.456f) b.out[threadIdx.x] = keep;
+}
+
+// ---------------------------------------------------------------- R: role-specialised, one 8-wave workgroup per CU, two tile buffers
+// support schedule over the 8 intervals of tile t (G0 E0 G1 E1 G2 E2 G3 E3): tail(t - 1) rows and build(t + 1) iterations done in each
+struct Sched { int tail[9], build[9]; };       // prefix sums: interval k does [tail[k], tail[k+1]) and [build[k], build[k+1])
+__global__ __launch_bounds__(512, 1) void k_org_r(Bufs b, int tiles, int vb, int vt, int copy, Sched s) {
+    extern __shared__ __attribute__((aligned(16))) char smem_p[];
+    for (int i = threadIdx.x; i < 2 * PN_XBYTES / 4; i += 512) reinterpret_cast<unsigned *>(smem_p)[i] = 0x2c002c00u + (i & 7);
+    __syncthreads();
+    f32x16 acc[2][2];
+    float keep = 0.f;
+    int it = 0;
+    for (int t = blockIdx.x; t < tiles; t += gridDim.x, ++it) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const bool gemm_role = wave < 4;
+        char *X = smem_p + (it & 1) * PN_XBYTES, *Xo = smem_p + ((it & 1) ^ 1) * PN_XBYTES;
+        const long long slot = t % b.ring, slot_prev = (t + b.ring - (int)gridDim.x % b.ring) % b.ring;
+        const int st = tid - 256;
+#pragma unroll 1
+        for (int layer = 0; layer < 4; ++layer) {
+            // ---- interval G_layer
+            if (gemm_role) {
+                acc_zero(acc);
+                pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(b.img + (size_t)layer * PN_IMG(16, 8)), 2 * wave, lane, acc);
+            } else {
+                if (copy) pn_copy_out_kmajor<PN_H>(X, b.sv[layer], slot * 8, st);
+                keep = tail_part(Xo, b.h4, slot_prev * 128, st, s.tail[2 * layer], s.tail[2 * layer + 1], vt, keep);
+                keep = build_part(Xo, st, s.build[2 * layer], s.build[2 * layer + 1], vb, keep);
+            }
+            PN_LDS_BARRIER();
+            // ---- interval E_layer
+            if (gemm_role) {
+                epilogue(acc, X, wave, lane);
+            } else {
+                keep = tail_part(Xo, b.h4, slot_prev * 128, st, s.tail[2 * layer + 1], s.tail[2 * layer + 2], vt, keep);
+                keep = build_part(Xo, st, s.build[2 * layer + 1], s.build[2 * layer + 2], vb, keep);
+            }
+            PN_LDS_BARRIER();
+        }
+        if (gemm_role) keep += acc[0][0][0] * 1e-30f;
+    }
+    if (keep == 123.456f) b.out[threadIdx.x] = keep;
+}
+
+template <class F> static float time_best(F launch) {
+    hipEvent_t a, e;
+    hipEventCreate(&a); hipEventCreate(&e);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(a, 0); launch(); hipEventRecord(e, 0); hipEventSynchronize(e);
+        float ms = 0.f; hipEventElapsedTime(&ms, a, e);
+        if (rep && ms < best) best = ms;
+    }
+    return best;
+}
+
+int main(int argc, char **argv) {
+    Bufs b;
+    char *img; float *out;
+    const int ring = 4096;                                    // tiles of saved planes before the ring wraps: 4 x 128 MB + 256 MB, beyond L2 and MALL
+    hipMalloc(&img, 4 * PN_IMG(16, 8)); hipMemset(img, 0x2c, 4 * PN_IMG(16, 8));
+    hipMalloc(&out, 4096);
+    b.img = img; b.out = out; b.ring = ring;
+    for (int l = 0; l < 4; ++l) hipMalloc(&b.sv[l], (size_t)ring * 8 * PN_H * 16);
+    hipMalloc(&b.h4, (size_t)ring * 128 * 32 * 16);
+    const int per_cu = 200, tiles = 256 * per_cu;
+    hipFuncSetAttribute((const void *)k_org_a, hipFuncAttributeMaxDynamicSharedMemorySize, PN_XBYTES + 1024);
+    hipFuncSetAttribute((const void *)k_org_r, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PN_XBYTES + 1024);
+    // support schedules of R: where the 8 tail rows and the 18 build iterations of the neighbouring tiles go (G0 E0 G1 E1 G2 E2 G3 E3)
+    const Sched scheds[] = {
+        {{0, 1, 3, 4, 6, 7, 8, 8, 8}, {0, 0, 0, 0, 0, 2, 8, 10, 18}},     // tail first, then build; more in the E intervals (no copy-out there)
+        {{0, 2, 4, 6, 8, 8, 8, 8, 8}, {0, 0, 0, 0, 0, 4, 9, 13, 18}},     // even split
+        {{0, 0, 3, 3, 6, 6, 8, 8, 8}, {0, 0, 0, 0, 2, 2, 10, 10, 18}},    // everything in the E intervals
+    };
+    // VALU per build iteration / per tail row: 32 / 96 ~ the real phases (600 / 800 per thread and tile); 0 / 0 = LDS + HBM traffic only
+    const int cfg[][3] = {{32, 96, 1}, {0, 0, 1}, {32, 96, 0}, {64, 192, 1}};
+    for (auto &c : cfg) {
+        const float a1 = time_best([&] { hipLaunchKernelGGL(k_org_a, dim3(256), dim3(256), PN_XBYTES + 1024 + 40 * 1024, 0, b, tiles / 2, c[0], c[1], c[2]); });
+        const float a2 = time_best([&] { hipLaunchKernelGGL(k_org_a, dim3(512), dim3(256), PN_XBYTES + 1024, 0, b, tiles, c[0], c[1], c[2]); });
+        printf("{\"org\": \"A, one workgroup per CU\", \"valu_build_tail\": [%d, %d], \"copy_out\": %d, \"us_per_tile_and_cu\": %.2f}\n", c[0], c[1], c[2], a1 * 1e3 / (per_cu / 2));
+        printf("{\"org\": \"A, two workgroups per CU (shipped)\", \"valu_build_tail\": [%d, %d], \"copy_out\": %d, \"us_per_tile_and_cu\": %.2f}\n", c[0], c[1], c[2], a2 * 1e3 / per_cu);
+        for (int k = 0; k < 3; ++k) {
+            const Sched s = scheds[k];
+            const float r = time_best([&] { hipLaunchKernelGGL(k_org_r, dim3(256), dim3(512), 2 * PN_XBYTES + 1024, 0, b, tiles, c[0], c[1], c[2], s); });
+            printf("{\"org\": \"R, role-specialised, schedule %d\", \"valu_build_tail\": [%d, %d], \"copy_out\": %d, \"us_per_tile_and_cu\": %.2f, \"vs_A\": %.3f}\n", k, c[0], c[1], c[2],
+                   r * 1e3 / per_cu, r / a2);
+        }
+        fflush(stdout);
+    }
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { printf("error: %s\n", hipGetErrorString(e)); return 1; }
+    return 0;
+}
