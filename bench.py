@@ -579,6 +579,7 @@ def main():
             src = traffic.get("_source")
             traffic_source = TRAFFIC_SOURCE if not src else TRAFFIC_SOURCE + "; collected at commit %s with `%s`" % (src.get("commit"), src.get("command"))
             copy_gbs = measured_copy_gbs(dev)
+            mfma_meas = {"random_operands": ops.mfma_rate_tflops(2), "constant_operands": ops.mfma_rate_tflops(1)}
 
             def mfma_entry(k):      # SURVEY 8d's algorithmic flops against the dense f16 MFMA peak; the executed f16 products (x 3) beside it
                 t = per[k]["ms_per_step"] * 1e-3
@@ -586,6 +587,11 @@ def main():
                         "frac": alg_flop[k] / t / 1e12 / PEAK_F16_MFMA_TFLOPS,
                         "achieved_executed": F16_PRODUCTS * alg_flop[k] / t / 1e12,
                         "frac_executed": F16_PRODUCTS * alg_flop[k] / t / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                        "peak_measured": mfma_meas["random_operands"], "peak_measured_constant_operands": mfma_meas["constant_operands"],
+                        "frac_executed_of_measured": F16_PRODUCTS * alg_flop[k] / t / 1e12 / mfma_meas["random_operands"],
+                        "peak_measured_note": "register-resident v_mfma_f32_32x32x16_f16 on all CUs, timed in this run (pnerf_debug_mfma_rate): with pseudo-random f16 "
+                                              "operands (they toggle like a GEMM's fragments) and with one constant -- the power management holds the clock down "
+                                              "when the pipe's inputs switch, so the nominal peak is not reachable on real data",
                         "frac_note": "frac = SURVEY 8d algorithmic flops / dense f16 MFMA peak; frac_executed = executed f16 products (3 per algorithmic "
                                      "multiply-add: two-plane operands) / the same peak = matrix-pipe utilisation",
                         "traffic": traffic.get(k), "traffic_source": traffic_source,

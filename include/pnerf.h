@@ -327,6 +327,11 @@ int pnerf_point_dirs(const float *d_cam_xyz, int64_t n_points, const float *cam_
  * D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31]).  The tests pin with it the fragment layout and the un-flushed handling of f16
  * subnormal inputs that the two-plane GEMMs of the aggregator (csrc/f16x3.h) rely on. */
 int pnerf_debug_mfma_f16(const void *d_a, const void *d_b, float *d_out, void *stream);
+/* measurement aid of bench.py (roofline.peak_measured of the matrix-pipe entries; no reference counterpart): `iters` x 32 register-resident
+ * v_mfma_f32_32x32x16_f16 per wave on 2 x 256-thread workgroups per CU, operands all zero (mode 0), one constant (1) or pseudo-random f16 in
+ * +-[0.5, 1) (2: they toggle like a GEMM's fragments).  Asynchronous on `stream`; the caller times it with events.  *flop_out = the flops the
+ * launch executes; d_scratch: >= 256 floats of device memory (never written in practice). */
+int pnerf_debug_mfma_rate(int mode, int iters, float *d_scratch, double *flop_out, void *stream);
 /* the counter-based uniforms of the jittered ray sampling (pnerf_query with jitter > 0 draws U[r * D + d] = uniform(seed, r * D + d)):
  * d_out[i] = uniform(seed, first + i) in [0, 1).  With these the jittered samples are a deterministic function of the inputs and
  * equal the reference's near_far_linear_ray_generation (diff_ray_marching.py:369-385, CPU) fed the same numbers, bit for bit. */

@@ -523,6 +523,24 @@ def set_wgrad_planes(n):
 
 
 # ------------------------------------------------------------------------------------------ profiling
+def mfma_rate_tflops(mode=2, ms_target=60.0, device=None):
+    """TFLOP/s of register-resident v_mfma_f32_32x32x16_f16 on the whole chip (pnerf_debug_mfma_rate; mode 0 zero operands, 1 one constant,
+    2 pseudo-random f16: operands that toggle like a GEMM's): the matrix-pipe ceiling bench.py reports beside the nominal 2.5 PFLOP/s.
+    Two launches: a short one to settle the clock, one of ~``ms_target`` that is timed."""
+    import ctypes
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    scratch = torch.zeros(256, dtype=torch.float32, device=dev)
+    flop = ctypes.c_double(0.0)
+    iters = max(int(ms_target / 1000.0 * 2.4e9 / (2 * 32 * 32)), 64)          # two waves per SIMD x 32 MFMAs of 32 cycles per iteration
+    for it in (iters // 4, iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(L.lib().pnerf_debug_mfma_rate(int(mode), int(it), _ptr(scratch), ctypes.byref(flop), _stream()), "pnerf_debug_mfma_rate")
+        e1.record()
+        e1.synchronize()
+    return flop.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+
 def prof_enable(on=True):
     L.lib().pnerf_prof_enable(1 if on else 0)
 

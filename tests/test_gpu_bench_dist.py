@@ -116,3 +116,12 @@ def test_point_gradients_reach_autograd_as_views_of_one_bucket():
     assert [g.data_ptr() for g in got] == list(ptrs)
     assert got[0].data_ptr() == bucket.data_ptr() and head >= sum(g.numel() for g in got)
     assert float(bucket[:head].abs().sum()) > 0
+
+
+def test_measured_matrix_pipe_ceiling_is_sane():
+    """ops.mfma_rate_tflops (pnerf_debug_mfma_rate): the f16 matrix pipe's sustained rate, timed on this box -- between a fifth of the nominal 2.5 PFLOP/s and
+    the nominal figure, and not HIGHER with operands that toggle than with one constant (measured on MI355X: 1.70 vs 2.33 PFLOP/s)."""
+    from pointnerf_amd import ops
+    const, rnd = ops.mfma_rate_tflops(1, ms_target=30.0), ops.mfma_rate_tflops(2, ms_target=30.0)
+    print("matrix pipe, register-resident f16 MFMA: constant operands %.0f TFLOP/s, pseudo-random operands %.0f TFLOP/s" % (const, rnd))
+    assert 500.0 < rnd <= 1.05 * const and const < 2700.0, (const, rnd)

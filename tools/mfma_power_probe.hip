@@ -1,0 +1,68 @@
+// mfma_power_probe.hip -- dev tool: what the f16 matrix pipe of this chip sustains when the OPERANDS TOGGLE like real data.
+// Register-resident v_mfma_f32_32x32x16_f16 only (no LDS, no memory in the loop), four independent accumulators per wave, two waves per SIMD, all 256 CUs,
+// ~1 s per run so that the power management settles.  Operands: all zero / one constant / pseudo-random f16 in +-[0.5, 1) (new values every 8 MFMAs from a
+// register ring, so the pipe's inputs change like a GEMM's fragments).  Prints TFLOP/s; 2.5 PFLOP/s is the guide's dense peak.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 mfma_power_probe.hip -o mfma_power_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ unsigned prn(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_mfma(int iters, float *out) {
+    uint4 ra[4], rb[4];
+    for (int i = 0; i < 4; ++i) {
+        unsigned w[8];
+        for (int j = 0; j < 8; ++j) {
+            const unsigned r = prn(threadIdx.x * 64 + blockIdx.x * 7919 + i * 8 + j);
+            w[j] = MODE == 0 ? 0u : MODE == 1 ? 0x2c002c00u : ((r & 0x83ff83ffu) | 0x38003800u);
+        }
+        ra[i] = make_uint4(w[0], w[1], w[2], w[3]); rb[i] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+    f16v acc[4];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const h8 a = __builtin_bit_cast(h8, ra[s]), b = __builtin_bit_cast(h8, rb[(s + it) & 3]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[k], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc[k], 0, 0, 0);
+        }
+        if (MODE == 2 && (it & 63) == 63) for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) acc[k][r] *= 1e-3f;      // keep the sums finite
+    }
+    float s = 0.f;
+    for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) s += acc[k][r];
+    if (s == 123.456f) out[threadIdx.x] = s;
+}
+
+template <int MODE> static void run(const char *name, float *out) {
+    const int iters = 500000, wgs = 512;
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(a, 0);
+        hipLaunchKernelGGL(k_mfma<MODE>, dim3(wgs), dim3(256), 0, 0, iters, out);
+        hipEventRecord(b, 0); hipEventSynchronize(b);
+        float ms = 0.f; hipEventElapsedTime(&ms, a, b);
+        if (rep && ms < best) best = ms;
+    }
+    const double flop = (double)wgs * 4 * iters * 32 * (2.0 * 32 * 32 * 16);
+    printf("{\"operands\": \"%s\", \"ms\": %.1f, \"tflops\": %.0f, \"frac_of_2500\": %.3f}\n", name, best, flop / (best * 1e-3) / 1e12, flop / (best * 1e-3) / 1e12 / 2500.0);
+    fflush(stdout);
+}
+
+int main() {
+    float *out;
+    hipMalloc(&out, 4096);
+    run<0>("all zero", out);
+    run<1>("one constant (0.0625)", out);
+    run<2>("pseudo-random f16 in +-[0.5, 1)", out);
+    run<1>("one constant (0.0625), again", out);
+    return hipDeviceSynchronize() == hipSuccess ? 0 : 1;
+}

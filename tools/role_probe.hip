@@ -20,7 +20,9 @@
 #include <stdio.h>
 #include "f16x3.h"
 
-struct Bufs { const char *img; uint4 *sv[4]; pn_f4 *h4; float *out; int ring; };
+struct Bufs { const char *img; uint4 *sv[4]; pn_f4 *h4; float *out; int ring; int noisy; };
+// noisy = 1: weights and activations are pseudo-random numbers (the epilogue keeps them so): the operands toggle like real data.  noisy = 0: every
+// operand is the constant 0.0625 -- the matrix pipe then draws far less power and the chip clocks higher (which is how round 2-4's probes ran)
 
 __device__ __forceinline__ float valu_chain(float x, int n) {            // n dependent-free-ish fmas on four chains
     float f0 = x, f1 = x + 1.f, f2 = x + 2.f, f3 = x + 3.f;
@@ -33,7 +35,7 @@ __device__ __forceinline__ float build_part(char *X, int t, int i0, int i1, int 
     for (int i = i0; i < i1; ++i) {
         keep = valu_chain(keep, valu);
         const int u = (t + 256 * (i >> 1)) % 2368, plane = i & 1;
-        const unsigned w = 0x2c002c00u + (__float_as_uint(keep) & 7u);
+        const unsigned w = 0x2c002c00u + (__float_as_uint(keep) & 7u) + (unsigned)(t * 2654435761u >> 20 & 0x03ff03ffu);
         *reinterpret_cast<uint4 *>(X + plane * PN_XPLANE + (u / 37) * PN_XRS + (u % 37) * 16) = make_uint4(w, w, w, w);
     }
     return keep;
@@ -62,7 +64,7 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[2][2]) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
-__device__ __forceinline__ void epilogue(const f32x16 (&acc)[2][2], char *X, int wave, int lane) {
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[2][2], char *X, int wave, int lane, int noisy = 0) {
 #pragma unroll
     for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
@@ -71,38 +73,61 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[2][2], char *X, int
             for (int g = 0; g < 4; ++g) {
                 float v[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { v[i] = acc[fb][rb][4 * g + i] * 1e-3f + 0.0625f; v[i] = fmaxf(v[i], 0.01f * v[i]); }
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = acc[fb][rb][4 * g + i] * 1e-3f + 0.0625f;
+                    if (noisy) v[i] = __builtin_amdgcn_fractf(acc[fb][rb][4 * g + i] * 0.37f + 0.11f * i) - 0.5f;      // bounded, data-dependent
+                    v[i] = fmaxf(v[i], 0.01f * v[i]);
+                }
                 pn_x_store4<false>(X, 32 * rb + (lane & 31), pn_d_feat(2 * wave + fb, g, lane), v[0], v[1], v[2], v[3]);
             }
 }
+__device__ __forceinline__ unsigned prn(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+__device__ __forceinline__ unsigned prn_h2(unsigned i) {          // two f16 in [-1, 1): sign + exponent 0x38..0x3b + random mantissa
+    const unsigned r = prn(i);
+    return ((r & 0x83ff83ffu) | 0x38003800u) + ((r >> 3) & 0x0c000c00u & 0x0c000c00u) * 0;
+}
+__global__ void k_fill(unsigned *p, size_t n) { for (size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = prn_h2((unsigned)i); }
 
 // ---------------------------------------------------------------- A: the shipped organisation with the realistic other phases
+// TRACE: thread 0 of every workgroup stamps the 100 MHz clock at the phase boundaries of its tile iterations 20 .. 25 (the real kernels' PN_PHASE_TRACE)
+#define TR_SLOTS 16
+__device__ unsigned long long g_trace[512 * 6 * TR_SLOTS];
+#define TR(ph) do { if (TRACE && tid == 0 && titer >= 20 && titer < 26) g_trace[((size_t)blockIdx.x * 6 + (titer - 20)) * TR_SLOTS + (ph)] = wall_clock64(); } while (0)
+template <bool TRACE>
 __global__ __launch_bounds__(256, 2) void k_org_a(Bufs b, int tiles, int vb, int vt, int copy) {
     extern __shared__ __attribute__((aligned(16))) char smem_p[];
     char *X = smem_p;
-    for (int i = threadIdx.x; i < PN_XBYTES / 4; i += 256) reinterpret_cast<unsigned *>(X)[i] = 0x2c002c00u + (i & 7);
+    for (int i = threadIdx.x; i < PN_XBYTES / 4; i += 256) reinterpret_cast<unsigned *>(X)[i] = b.noisy ? prn_h2(i) : 0x2c002c00u + (i & 7);
     __syncthreads();
     f32x16 acc[2][2];
     float keep = 0.f;
+    int titer = -1;
     for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+        ++titer;
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const long long slot = t % b.ring;
+        TR(0);
         keep = build_part(X, tid, 0, 18, vb, keep);
         PN_LDS_BARRIER();
+        TR(1);
 #pragma unroll 1
         for (int layer = 0; layer < 4; ++layer) {
             acc_zero(acc);
             pn_gemm_f16x3<16, 8, 2>(X, reinterpret_cast<const uint4 *>(b.img + (size_t)layer * PN_IMG(16, 8)), 2 * wave, lane, acc);
+            TR(2 + 3 * layer);
             if (copy) pn_copy_out_kmajor<PN_H>(X, b.sv[layer], slot * 8, tid);
             PN_LDS_BARRIER();
-            epilogue(acc, X, wave, lane);
+            TR(3 + 3 * layer);
+            epilogue(acc, X, wave, lane, b.noisy);
             PN_LDS_BARRIER();
+            TR(4 + 3 * layer);
         }
         keep += acc[0][0][0] * 1e-30f;
         keep = tail_part(X, b.h4, slot * 128, tid, 0, 8, vt, keep);
         PN_LDS_BARRIER();
+        TR(14);
     }
     if (keep == 123.456f) b.out[threadIdx.x] = keep;
 }
@@ -112,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void k_org_a(Bufs b, int tiles, int vb, int
 struct Sched { int tail[9], build[9]; };       // prefix sums: interval k does [tail[k], tail[k+1]) and [build[k], build[k+1])
 __global__ __launch_bounds__(512, 1) void k_org_r(Bufs b, int tiles, int vb, int vt, int copy, Sched s) {
     extern __shared__ __attribute__((aligned(16))) char smem_p[];
-    for (int i = threadIdx.x; i < 2 * PN_XBYTES / 4; i += 512) reinterpret_cast<unsigned *>(smem_p)[i] = 0x2c002c00u + (i & 7);
+    for (int i = threadIdx.x; i < 2 * PN_XBYTES / 4; i += 512) reinterpret_cast<unsigned *>(smem_p)[i] = b.noisy ? prn_h2(i) : 0x2c002c00u + (i & 7);
     __syncthreads();
     f32x16 acc[2][2];
     float keep = 0.f;
@@ -139,7 +164,7 @@ __global__ __launch_bounds__(512, 1) void k_org_r(Bufs b, int tiles, int vb, int
             PN_LDS_BARRIER();
             // ---- interval E_layer
             if (gemm_role) {
-                epilogue(acc, X, wave, lane);
+                epilogue(acc, X, wave, lane, b.noisy);
             } else {
                 keep = tail_part(Xo, b.h4, slot_prev * 128, st, s.tail[2 * layer + 1], s.tail[2 * layer + 2], vt, keep);
                 keep = build_part(Xo, st, s.build[2 * layer + 1], s.build[2 * layer + 2], vb, keep);
@@ -173,7 +198,8 @@ int main(int argc, char **argv) {
     for (int l = 0; l < 4; ++l) hipMalloc(&b.sv[l], (size_t)ring * 8 * PN_H * 16);
     hipMalloc(&b.h4, (size_t)ring * 128 * 32 * 16);
     const int per_cu = 200, tiles = 256 * per_cu;
-    hipFuncSetAttribute((const void *)k_org_a, hipFuncAttributeMaxDynamicSharedMemorySize, PN_XBYTES + 1024);
+    hipFuncSetAttribute((const void *)k_org_a<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PN_XBYTES + 1024 + 40 * 1024);
+    hipFuncSetAttribute((const void *)k_org_a<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PN_XBYTES + 1024);
     hipFuncSetAttribute((const void *)k_org_r, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PN_XBYTES + 1024);
     // support schedules of R: where the 8 tail rows and the 18 build iterations of the neighbouring tiles go (G0 E0 G1 E1 G2 E2 G3 E3)
     const Sched scheds[] = {
@@ -183,18 +209,38 @@ int main(int argc, char **argv) {
     };
     // VALU per build iteration / per tail row: 32 / 96 ~ the real phases (600 / 800 per thread and tile); 0 / 0 = LDS + HBM traffic only
     const int cfg[][3] = {{32, 96, 1}, {0, 0, 1}, {32, 96, 0}, {64, 192, 1}};
+    for (int noisy = 0; noisy < 2; ++noisy)
     for (auto &c : cfg) {
-        const float a1 = time_best([&] { hipLaunchKernelGGL(k_org_a, dim3(256), dim3(256), PN_XBYTES + 1024 + 40 * 1024, 0, b, tiles / 2, c[0], c[1], c[2]); });
-        const float a2 = time_best([&] { hipLaunchKernelGGL(k_org_a, dim3(512), dim3(256), PN_XBYTES + 1024, 0, b, tiles, c[0], c[1], c[2]); });
-        printf("{\"org\": \"A, one workgroup per CU\", \"valu_build_tail\": [%d, %d], \"copy_out\": %d, \"us_per_tile_and_cu\": %.2f}\n", c[0], c[1], c[2], a1 * 1e3 / (per_cu / 2));
-        printf("{\"org\": \"A, two workgroups per CU (shipped)\", \"valu_build_tail\": [%d, %d], \"copy_out\": %d, \"us_per_tile_and_cu\": %.2f}\n", c[0], c[1], c[2], a2 * 1e3 / per_cu);
+        b.noisy = noisy;
+        if (noisy) { hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, 0, (unsigned *)img, (size_t)PN_IMG(16, 8)); hipDeviceSynchronize(); }
+        const float a1 = time_best([&] { hipLaunchKernelGGL(k_org_a<false>, dim3(256), dim3(256), PN_XBYTES + 1024 + 40 * 1024, 0, b, tiles / 2, c[0], c[1], c[2]); });
+        const float a2 = time_best([&] { hipLaunchKernelGGL(k_org_a<false>, dim3(512), dim3(256), PN_XBYTES + 1024, 0, b, tiles, c[0], c[1], c[2]); });
+        printf("{\"noisy\": %d, \"org\": \"A, one workgroup per CU\", \"valu_build_tail\": [%d, %d], \"copy_out\": %d, \"us_per_tile_and_cu\": %.2f}\n", noisy, c[0], c[1], c[2], a1 * 1e3 / (per_cu / 2));
+        printf("{\"noisy\": %d, \"org\": \"A, two workgroups per CU (shipped)\", \"valu_build_tail\": [%d, %d], \"copy_out\": %d, \"us_per_tile_and_cu\": %.2f}\n", noisy, c[0], c[1], c[2], a2 * 1e3 / per_cu);
         for (int k = 0; k < 3; ++k) {
             const Sched s = scheds[k];
             const float r = time_best([&] { hipLaunchKernelGGL(k_org_r, dim3(256), dim3(512), 2 * PN_XBYTES + 1024, 0, b, tiles, c[0], c[1], c[2], s); });
-            printf("{\"org\": \"R, role-specialised, schedule %d\", \"valu_build_tail\": [%d, %d], \"copy_out\": %d, \"us_per_tile_and_cu\": %.2f, \"vs_A\": %.3f}\n", k, c[0], c[1], c[2],
+            printf("{\"noisy\": %d, \"org\": \"R, role-specialised, schedule %d\", \"valu_build_tail\": [%d, %d], \"copy_out\": %d, \"us_per_tile_and_cu\": %.2f, \"vs_A\": %.3f}\n", noisy, k, c[0], c[1], c[2],
                    r * 1e3 / per_cu, r / a2);
         }
         fflush(stdout);
+    }
+    {   // phase timeline of A with two workgroups per CU (realistic VALU counts, copy-outs on): mean us per phase over the workgroups' iterations 20 .. 25
+        hipLaunchKernelGGL(k_org_a<true>, dim3(512), dim3(256), PN_XBYTES + 1024, 0, b, tiles, 32, 96, 1);
+        hipDeviceSynchronize();
+        static unsigned long long h[512 * 6 * TR_SLOTS];
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), sizeof(h));
+        const char *names[14] = {"build + barrier", "GEMM1", "copy-out + barrier", "E1 + barrier", "GEMM2", "copy-out + barrier", "E2 + barrier", "GEMM3", "copy-out + barrier",
+                                 "E3 + barrier", "GEMM4", "copy-out + barrier", "E4 + barrier", "tail + barrier"};
+        printf("{\"org\": \"A, two workgroups per CU, phase timeline (us, mean over 512 workgroups x 6 tiles)\"");
+        double total = 0;
+        for (int ph = 0; ph < 14; ++ph) {
+            double sum = 0; int n = 0;
+            for (int w = 0; w < 512 * 6; ++w) { const unsigned long long a = h[w * TR_SLOTS + ph], z = h[w * TR_SLOTS + ph + 1]; if (a && z > a) { sum += (double)(z - a) * 0.01; ++n; } }
+            printf(", \"%02d %s\": %.2f", ph, names[ph], n ? sum / n : -1.0);
+            total += n ? sum / n : 0;
+        }
+        printf(", \"tile_iteration_us\": %.2f}\n", total);
     }
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) { printf("error: %s\n", hipGetErrorString(e)); return 1; }
