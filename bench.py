@@ -345,7 +345,7 @@ def main():
     from pointnerf_amd.fused import FusedRender
     selftest = None
     if world > 1:
-        with Watchdog("the collective self-test (first RCCL communicator + 4 small collectives)", int(os.environ.get("PNERF_SELFTEST_TIMEOUT", "60")), rank, world):
+        with Watchdog("the collective self-test (first RCCL communicator + 4 small collectives)", int(os.environ.get("PNERF_SELFTEST_TIMEOUT", "90")), rank, world):
             selftest = rccl_selftest(dev, rank, world)       # raises on a wrong sum
         if not selftest:
             raise SystemExit("bench.py: the collective self-test did not run: refusing to time a multi-GPU step")

@@ -519,10 +519,14 @@ __device__ __forceinline__ float pn_softplus(float x) {
 // alpha dot products are then reduced over the 32 lanes that share the rows by a transposing butterfly (8 -> 4 -> 2 -> 1 values per
 // lane: 7 + 2 shuffles instead of 8 x 5), softplus runs once per row, sigma is summed over a sample's rows by log2(KC) more shuffles.
 // Round 2 made three passes (alpha head, h4 copy, K-sums: 64 LDS reads per thread and two barriers); this is 16 reads and no barrier.
+// KC = 0 (round 5): any other K (12 / 6 / 3 of the Barn configuration, ...): the per-ROW half of the pass -- both planes read once, streamed
+// out as the backward's h4, the alpha head's dot product, butterfly, softplus -- with the rows' weighted alpha left in `wraw` for the K-sums
+// pass that follows behind one barrier (a sample's rows then straddle the threads' 8-row strips).  The three-pass form it replaces read the
+// tile three times with two barriers.
 template <int KC, bool TRAIN>
 __device__ __forceinline__ void f_tail(const FwdArgs &a, const char *X, const float *w5s, const float *wrow, const int *sidx, float b5,
-                                       long long tile, long long gtile, int tid) {
-    constexpr int NS = 8 / KC;                      // samples per thread
+                                       long long tile, long long gtile, int tid, float *wraw = nullptr) {
+    constexpr int NS = KC == 0 ? 1 : 8 / (KC == 0 ? 1 : KC);                      // samples per thread
     const int lane = tid & 63, cg = tid & 31, r0 = 8 * (tid >> 5);
     const float4 wa = *reinterpret_cast<const float4 *>(w5s + 8 * cg), wb = *reinterpret_cast<const float4 *>(w5s + 8 * cg + 4);
     float pa[8];
@@ -544,17 +548,19 @@ __device__ __forceinline__ void f_tail(const FwdArgs &a, const char *X, const fl
         s = pn_fma2_lo(h.x, m.x, wa.x, s); s = pn_fma2_hi(h.x, m.x, wa.y, s); s = pn_fma2_lo(h.y, m.y, wa.z, s); s = pn_fma2_hi(h.y, m.y, wa.w, s);
         s = pn_fma2_lo(h.z, m.z, wb.x, s); s = pn_fma2_hi(h.z, m.z, wb.y, s); s = pn_fma2_lo(h.w, m.w, wb.z, s); s = pn_fma2_hi(h.w, m.w, wb.w, s);
         pa[i] = s;
-        const float w = wrow[r];
-        float4 &f0 = fa[i / KC], &f1 = fb[i / KC];
-        f0.x = pn_fma2_lo(h.x, m.x, w, f0.x); f0.y = pn_fma2_hi(h.x, m.x, w, f0.y); f0.z = pn_fma2_lo(h.y, m.y, w, f0.z); f0.w = pn_fma2_hi(h.y, m.y, w, f0.w);
-        f1.x = pn_fma2_lo(h.z, m.z, w, f1.x); f1.y = pn_fma2_hi(h.z, m.z, w, f1.y); f1.z = pn_fma2_lo(h.w, m.w, w, f1.z); f1.w = pn_fma2_hi(h.w, m.w, w, f1.w);
+        if (KC != 0) {
+            const float w = wrow[r];
+            float4 &f0 = fa[i / (KC == 0 ? 1 : KC)], &f1 = fb[i / (KC == 0 ? 1 : KC)];
+            f0.x = pn_fma2_lo(h.x, m.x, w, f0.x); f0.y = pn_fma2_hi(h.x, m.x, w, f0.y); f0.z = pn_fma2_lo(h.y, m.y, w, f0.z); f0.w = pn_fma2_hi(h.y, m.y, w, f0.w);
+            f1.x = pn_fma2_lo(h.z, m.z, w, f1.x); f1.y = pn_fma2_hi(h.z, m.z, w, f1.y); f1.z = pn_fma2_lo(h.w, m.w, w, f1.z); f1.w = pn_fma2_hi(h.w, m.w, w, f1.w);
+        }
         // 128 registers per wave in the 8-wave organisation: at most two rows' planes in flight (the scheduler otherwise hoists all 16 reads)
         if (PN_NW == 8 && (i & 1)) __builtin_amdgcn_sched_barrier(0);
     }
     // f rows of the thread's samples (class-ordered list: the colour MLP reads them in that order)
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const long long vs = tile * (PN_TILE / KC) + (r0 / KC) + j;
+    for (int j = 0; j < (KC == 0 ? 0 : NS); ++j) {
+        const long long vs = tile * (PN_TILE / (KC == 0 ? 1 : KC)) + (r0 / (KC == 0 ? 1 : KC)) + j;
         if (vs < a.cap_samples) {
             *reinterpret_cast<float4 *>(a.sv.fs + vs * PN_H + 8 * cg) = fa[j];
             *reinterpret_cast<float4 *>(a.sv.fs + vs * PN_H + 8 * cg + 4) = fb[j];
@@ -575,11 +581,15 @@ __device__ __forceinline__ void f_tail(const FwdArgs &a, const char *X, const fl
         const float x = pa[0] + b5 - 1.0f;
         float sg = pn_softplus(x) * wrow[r];
         if (TRAIN && (lane & 3) == 0) a.sv.arow[gtile * PN_TILE + r] = x;
+        if (KC == 0) {              // the row's share of sigma: summed per sample by the K-sums pass
+            if ((lane & 3) == 0) wraw[r] = sg;
+            return;
+        }
         // sigma of a sample = sum over its KC rows: rows i differ in the low log2(KC) bits of i = lane bits 2 .. (b2 is i's bit 0)
         if (KC >= 2) sg += __shfl_xor(sg, 4, 64);
         if (KC >= 4) sg += __shfl_xor(sg, 8, 64);
         if (KC >= 8) sg += __shfl_xor(sg, 16, 64);
-        if ((lane & 3) == 0 && (i % KC) == 0) {
+        if ((lane & 3) == 0 && (i % (KC == 0 ? 1 : KC)) == 0) {
             const int si = sidx[r];
             if (si >= 0) a.decoded[(long long)si * 4] = sg;
         }
@@ -757,41 +767,29 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
             else f_tail<1, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid);
             PN_TR(pn_trace_fwd, 15);
         } else {
-        // ---- (any other K: three passes) alpha head (256 -> 1, softplus(x - 1), raw2out_density :262-265): 4 threads per row, 8-column groups interleaved
+        // ---- (any other K: two passes) the per-row half in f_tail's mapping (alpha head 256 -> 1, softplus(x - 1), raw2out_density :262-265; h4 planes
+        // streamed out for the backward), then the K-weighted sums
         if (PN_NW == 8 && bw && tile + stride < tile_last) f_gather<PERS>(a, G, si1, p1, q);      // (8 waves: the build waves' prefetch, see above)
-        if (ew) {
-            const int trow = tid / TPR, tq = tid % TPR;
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c0 = 8 * (tq + 4 * j);
-                s = pn_x_dot8(X, trow, c0, *reinterpret_cast<const float4 *>(w5s + c0), *reinterpret_cast<const float4 *>(w5s + c0 + 4), s);
-            }
-            s = group_sum<TPR>(s);
-            if (tq == 0) {
-                const float x = s + b5 - 1.0f;
-                wraw[trow] = pn_softplus(x) * wrow[trow];
-                if (TRAIN) a.sv.arow[gtile * PN_TILE + trow] = x;
-            }
-        }
-        if (TRAIN) {     // h4 planes, row-major, for the backward's alpha head
-#pragma unroll
-            for (int i = 0; i < 4096 / PN_NTHR; ++i) {
-                const int e = tid + PN_NTHR * i, plane = e >> 11, r = (e >> 5) & 63, u = e & 31;
-                const uint4 v = *reinterpret_cast<const uint4 *>(X + plane * PN_XPLANE + r * PN_XRS + u * 16);
-                pn_f4 t = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-                PN_STREAM_STORE(t, reinterpret_cast<pn_f4 *>(a.sv.h4r + ((long long)plane * a.sv.rows + gtile * PN_TILE + r) * 32 + u));
-            }
-        }
+        if (ew) f_tail<0, TRAIN>(a, X, w5s, wrow, sidx, b5, tile, gtile, tid, wraw);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 15);
         // ---- K-weighted sums -> f[256] per sample (HBM), sigma
-        for (int e = tid; e < TS * 64; e += PN_NTHR) {
-            const int ls = e >> 6, c4 = e & 63;
-            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int kk = 0; kk < K; ++kk) pn_x_axpy4(X, ls * K + kk, c4 * 4, wrow[ls * K + kk], f);
+        for (int e = tid; e < TS * 32; e += PN_NTHR) {          // item = (sample, 8 columns): 16-byte reads of both planes, K rows
+            const int ls = e >> 5, cg = e & 31;
+            float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0;
+            for (int kk = 0; kk < K; ++kk) {
+                const int r = ls * K + kk;
+                const uint4 h = *reinterpret_cast<const uint4 *>(X + r * PN_XRS + cg * 16);
+                const uint4 m = *reinterpret_cast<const uint4 *>(X + PN_XPLANE + r * PN_XRS + cg * 16);
+                const float w = wrow[r];
+                f0.x = pn_fma2_lo(h.x, m.x, w, f0.x); f0.y = pn_fma2_hi(h.x, m.x, w, f0.y); f0.z = pn_fma2_lo(h.y, m.y, w, f0.z); f0.w = pn_fma2_hi(h.y, m.y, w, f0.w);
+                f1.x = pn_fma2_lo(h.z, m.z, w, f1.x); f1.y = pn_fma2_hi(h.z, m.z, w, f1.y); f1.z = pn_fma2_lo(h.w, m.w, w, f1.z); f1.w = pn_fma2_hi(h.w, m.w, w, f1.w);
+            }
             const long long vs = tile * TS + ls;
-            if (vs < a.cap_samples) *reinterpret_cast<float4 *>(a.sv.fs + vs * PN_H + c4 * 4) = f;
+            if (vs < a.cap_samples) {
+                *reinterpret_cast<float4 *>(a.sv.fs + vs * PN_H + 8 * cg) = f0;
+                *reinterpret_cast<float4 *>(a.sv.fs + vs * PN_H + 8 * cg + 4) = f1;
+            }
         }
         if (tid < TS) {
             const int si = sidx[tid * K];

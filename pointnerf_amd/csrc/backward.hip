@@ -363,11 +363,15 @@ __device__ __forceinline__ float pn_sigmoid_b(float x) {
 // d conf, d x), then dY4 = (w d f + d x W5) * LeakyReLU'(h4) written IN PLACE -- a thread only rewrites the elements it alone reads, so
 // there is no barrier between the two halves; d x of a row reaches the 32 lanes that share the row through LDS inside the wave.
 // dfr[2 j], dfr[2 j + 1] = the thread's 8 columns of the d f row of its sample j (KC >= 4), dfb0 = where they come from.  gw5 = d W5 of the thread's 8 columns (scaled).
+// KC = 0 (round 5): any other K (12 / 6 / 3 of the Barn configuration, ...).  Nothing in the front is per SAMPLE except which d f row a tile row
+// uses, so the same pass serves every K with that index taken at run time (j = row / K - r0 / K; the thread's 8 rows then span up to three
+// samples, whose d f values come straight from memory like KC = 2, 1); the two-pass form it replaces read the tile twice with a barrier between.
 template <int KC>
 __device__ __forceinline__ void b_front(const BwdArgs &a, char *X, const float *w5s, const float *wrow, const float *wnrm, const float *dsg, const float *xrow,
                                         float *draw, const int *sidx, const int *prow, const float4 (&dfr)[4], const float *dfb0, float S, float invS, int tid,
-                                        float (&gw5)[8], float &gb5t) {
+                                        float (&gw5)[8], float &gb5t, unsigned kinv = 0u) {
     const int lane = tid & 63, cg = tid & 31, r0 = 8 * (tid >> 5);
+    const int j0 = KC == 0 ? pn_row_div(r0, kinv) : 0;
     // (zero-one regulariser riding on the conf atomic below: the row's confidence, requested now, used behind the butterfly)
     float zo_conf = 0.f;
     if (a.zo_gs && (lane & 3) == 0) {
@@ -383,7 +387,7 @@ __device__ __forceinline__ void b_front(const BwdArgs &a, char *X, const float *
     float pd[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int r = r0 + i, j = i / KC;
+        const int r = r0 + i, j = KC == 0 ? pn_row_div(r, kinv) - j0 : i / (KC == 0 ? 1 : KC);
         const uint4 h = *reinterpret_cast<const uint4 *>(X + r * PN_XRS + cg * 16);
         const uint4 m = *reinterpret_cast<const uint4 *>(X + PN_XPLANE + r * PN_XRS + cg * 16);
         float4 ga, gb;
@@ -422,7 +426,7 @@ __device__ __forceinline__ void b_front(const BwdArgs &a, char *X, const float *
     float drsum = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int r = r0 + i, j = i / KC;
+        const int r = r0 + i, j = KC == 0 ? pn_row_div(r, kinv) - j0 : i / (KC == 0 ? 1 : KC);
         const uint4 h = *reinterpret_cast<const uint4 *>(X + r * PN_XRS + cg * 16);
         const uint4 m = *reinterpret_cast<const uint4 *>(X + PN_XPLANE + r * PN_XRS + cg * 16);
         const bool live = sidx[r] >= 0;          // a row without a sample: its d f values are whatever memory held (0 x NaN is NaN)
@@ -471,9 +475,7 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_backward(BwdArgs a) 
     float S, invS;
     pn_scale_from_bits(a.sv.gscale[0], S, invS);
     if (tid0 < PN_H) w5s[tid0] = P[PO_W5 + tid0];
-    const bool one_pass = K == 8 || K == 4 || K == 2 || K == 1;       // b_front (whole samples per thread); other K: the two-pass front
-    float4 gw5v = make_float4(0.f, 0.f, 0.f, 0.f);      // two-pass front: d W5 of columns 4 (tid & 63) .. + 3 (scaled)
-    float gw5[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // one-pass front: d W5 of columns 8 (tid & 31) .. + 7 (scaled)
+    float gw5[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // d W5 of columns 8 (tid & 31) .. + 7 (scaled)
     float gb5t = 0.f;
     f32x16 acc[PN_NFB][2];
     // row metadata of the tile (threads 0..63: one row each), fetched ONE TILE AHEAD: the d sigma of a row hangs off its sample id, and
@@ -562,72 +564,15 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_backward(BwdArgs a) 
             const float *ep = a.emb + (long long)rp * PN_F + EPT * q;
             e0 = *reinterpret_cast<const float4 *>(ep); e1 = *reinterpret_cast<const float4 *>(ep + 4);
         }
-        if (one_pass) {
-            // ---- alpha head backward + dY4 in one pass (b_front)
+        {
+            // ---- alpha head backward + dY4 in one pass (b_front): K = 8 / 4 / 2 / 1 with compile-time sample boundaries, any other K at run time
             if (!ew) { PN_EMU_MATCH_WAVE_SYNC(); }
             else if (K == 8) b_front<8>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
             else if (K == 4) b_front<4>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
             else if (K == 2) b_front<2>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
-            else b_front<1>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
+            else if (K == 1) b_front<1>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
+            else b_front<0>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t, kinv);
             PN_TR(pn_trace_bwd, 2);
-        } else {
-        // ---- (any other K: two passes) alpha head backward (4 threads per row): d w_k = d sigma alpha_k + d f . h4_k ; d x = d sigma w sigmoid(x)
-        if (ew) {
-            const int trow = tid / TPR, tq = tid % TPR, rsi = sidx[trow], trp = prow[trow];
-            float dotf = 0.f;
-            if (rsi >= 0) {
-                const float *df = a.sv.dfs + (tile * TS + pn_row_div(trow, kinv)) * PN_H;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c0 = 8 * (tq + 4 * j);
-                    dotf = pn_x_dot8(X, trow, c0, *reinterpret_cast<const float4 *>(df + c0), *reinterpret_cast<const float4 *>(df + c0 + 4), dotf);
-                }
-            }
-            dotf = group_sum_b<TPR>(dotf) * S;
-            if (tq == 0) {
-                float dr = 0.f;
-                if (rsi >= 0) {
-                    const float x = xrow[trow];
-                    const float alpha = pn_softplus_b(x), sg = pn_sigmoid_b(x);
-                    // w = wn * clamp(conf) with a straight-through clamp (gradiant_clamp, point_aggregators.py:722-724)
-                    if (trp >= 0) atomicAdd(&a.g_conf[trp], (dsg[trow] * alpha + dotf) * wnrm[trow] * invS + (a.zo_gs ? pn_zero_one_grad(a.conf[trp], a.zo_eps, a.zo_gs[0]) : 0.f));
-                    dr = dsg[trow] * wrow[trow] * sg;
-                }
-                draw[trow] = dr;
-            }
-        }
-        PN_LDS_BARRIER();
-        PN_TR(pn_trace_bwd, 2);
-        // ---- dY4 = (w d f + d x W5) * LeakyReLU'(h4), in place; d W5 / d b5 partial sums ride along
-        {
-            const int c4 = tid & 63;
-            const float4 w5 = *reinterpret_cast<const float4 *>(w5s + c4 * 4);
-            float4 gq[64 / PN_NW];                           // the d f values of the thread's rows, requested in one burst (the accumulators are dead here)
-#pragma unroll
-            for (int i = 0; i < 64 / PN_NW; ++i) {
-                const int r = (tid >> 6) + PN_NW * i;
-                gq[i] = *reinterpret_cast<const float4 *>(a.sv.dfs + (tile * TS + pn_row_div(r, kinv)) * PN_H + c4 * 4);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 64 / PN_NW; ++i) {
-                const int r = (tid >> 6) + PN_NW * i;
-                const int si = sidx[r];
-                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (si >= 0) {
-                    const float4 hv = pn_x_load4(X, r, c4 * 4);
-                    const float4 g = gq[i];
-                    const float w = wrow[r] * S, dr = draw[r];
-                    o.x = (w * g.x + dr * w5.x) * pn_lrelu_grad(hv.x);
-                    o.y = (w * g.y + dr * w5.y) * pn_lrelu_grad(hv.y);
-                    o.z = (w * g.z + dr * w5.z) * pn_lrelu_grad(hv.z);
-                    o.w = (w * g.w + dr * w5.w) * pn_lrelu_grad(hv.w);
-                    gw5v.x += dr * hv.x; gw5v.y += dr * hv.y; gw5v.z += dr * hv.z; gw5v.w += dr * hv.w;
-                }
-                pn_x_store4<true>(X, r, c4 * 4, o.x, o.y, o.z, o.w);
-            }
-            if (tid < PN_TILE) gb5t += draw[tid];
-        }
         }
         // (round 4: the first weight-fragment chunks of every GEMM are requested in FRONT of the barrier that precedes it -- see the forward)
         PnGemmW<16, 8, PN_NFB> W4;
@@ -789,7 +734,7 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_backward(BwdArgs a) 
     // sets in LDS -- atomics of every workgroup on the same 256 addresses serialise in L2 (2048 per workgroup made the two small sample
     // classes' launches 1 ms each)
     if (tile_first >= tile_last) return;
-    if (one_pass) {
+    {
         const int cg = tid0 & 31, rs = tid0 >> 5;
         float *red = reinterpret_cast<float *>(smem_b);            // [8 row sets][256 columns] over the tile's space
         PN_LDS_BARRIER();
@@ -809,11 +754,6 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_backward(BwdArgs a) 
             for (int r = 0; r < 8; ++r) b += red[8 * PN_H + r];
             atomicAdd(&a.gparams[PO_B5], b * invS);
         }
-    } else {
-        const int c4 = tid0 & 63;
-        atomicAdd(&a.gparams[PO_W5 + c4 * 4], gw5v.x * invS); atomicAdd(&a.gparams[PO_W5 + c4 * 4 + 1], gw5v.y * invS);
-        atomicAdd(&a.gparams[PO_W5 + c4 * 4 + 2], gw5v.z * invS); atomicAdd(&a.gparams[PO_W5 + c4 * 4 + 3], gw5v.w * invS);
-        if (tid0 < PN_TILE) atomicAdd(&a.gparams[PO_B5], gb5t * invS);
     }
 }
 

@@ -11,7 +11,9 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ unsigned prn(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 
-template <int MODE>
+// ORDER 0: an operand pair feeds four consecutive MFMAs (only the accumulator changes); 1: every MFMA changes ONE operand (A and B alternately, a Gray
+// order); 2: every MFMA changes BOTH operands
+template <int MODE, int ORDER = 0>
 __global__ __launch_bounds__(256, 2) void k_mfma(int iters, float *out) {
     uint4 ra[4], rb[4];
     for (int i = 0; i < 4; ++i) {
@@ -25,13 +27,23 @@ __global__ __launch_bounds__(256, 2) void k_mfma(int iters, float *out) {
     f16v acc[4];
     for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     for (int it = 0; it < iters; ++it) {
+        if (ORDER == 0) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const h8 a = __builtin_bit_cast(h8, ra[s]), b = __builtin_bit_cast(h8, rb[(s + it) & 3]);
+            for (int s = 0; s < 4; ++s) {
+                const h8 a = __builtin_bit_cast(h8, ra[s]), b = __builtin_bit_cast(h8, rb[(s + it) & 3]);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[k], 0, 0, 0);
+                for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[k], 0, 0, 0);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc[k], 0, 0, 0);
+                for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc[k], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                // ORDER 1: (a, b) indices walk a Gray sequence: j -> a = (j + 1) / 2 & 3, b = j / 2 & 3; ORDER 2: both move every step
+                const int ia = ORDER == 1 ? ((j + 1) >> 1) & 3 : j & 3, ib = ORDER == 1 ? (j >> 1) & 3 : (j + (j >> 2)) & 3;
+                const h8 a = __builtin_bit_cast(h8, ra[ia]), b = __builtin_bit_cast(h8, rb[ib]);
+                acc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[j & 3], 0, 0, 0);
+            }
         }
         if (MODE == 2 && (it & 63) == 63) for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) acc[k][r] *= 1e-3f;      // keep the sums finite
     }
@@ -40,14 +52,14 @@ __global__ __launch_bounds__(256, 2) void k_mfma(int iters, float *out) {
     if (s == 123.456f) out[threadIdx.x] = s;
 }
 
-template <int MODE> static void run(const char *name, float *out) {
+template <int MODE, int ORDER = 0> static void run(const char *name, float *out) {
     const int iters = 500000, wgs = 512;
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(a, 0);
-        hipLaunchKernelGGL(k_mfma<MODE>, dim3(wgs), dim3(256), 0, 0, iters, out);
+        hipLaunchKernelGGL((k_mfma<MODE, ORDER>), dim3(wgs), dim3(256), 0, 0, iters, out);
         hipEventRecord(b, 0); hipEventSynchronize(b);
         float ms = 0.f; hipEventElapsedTime(&ms, a, b);
         if (rep && ms < best) best = ms;
@@ -63,6 +75,10 @@ int main() {
     run<0>("all zero", out);
     run<1>("one constant (0.0625)", out);
     run<2>("pseudo-random f16 in +-[0.5, 1)", out);
+    run<2, 1>("pseudo-random, every MFMA changes ONE operand", out);
+    run<2, 2>("pseudo-random, every MFMA changes BOTH operands", out);
+    run<2, 0>("pseudo-random f16 in +-[0.5, 1), operand pair held for 4 MFMAs, again", out);
+    run<1, 2>("one constant, the both-change instruction order", out);
     run<1>("one constant (0.0625), again", out);
     return hipDeviceSynchronize() == hipSuccess ? 0 : 1;
 }
