@@ -142,6 +142,13 @@ class MvsPointsVolumetricModel:
         if self.device.type == "cuda":
             self.aggregator.flatten_()
             self.net_ray_marching.fused_zero_one = True      # compute_losses takes the fused zero-one pass (ops.ZeroOneConf)
+            # the colour loss over the renderer's DENSE ray colours (ops.ColorLossRays; no compaction of the hit rays, no scatter back): taken when
+            # every colour-loss item that carries a gradient is a ray_masked one -- the lego script's items are (ray_masked 1.0, ray_miss 0.0,
+            # full image 0.0); ray_miss predicts the constant background and has no gradient, a full-image item with a non-zero weight would
+            # need the gradient of the filled image and keeps the compacted form
+            items = list(zip(getattr(opt, "color_loss_items", []), getattr(opt, "color_loss_weights", [])))
+            self.net_ray_marching.fused_color_loss = bool(items) and all(
+                n == "ray_masked_coarse_raycolor" or n.startswith("ray_miss") or float(w) == 0.0 for n, w in items)
         self.model_names = ["ray_marching"]
 
     def get_networks(self):
@@ -269,8 +276,31 @@ class MvsPointsVolumetricModel:
         dev = out["coarse_raycolor"].device
         hit = out["ray_mask"][0] > 0
         hidx = out.get("_hit_index")                      # hit-ray indices from the renderer: indexing without a synchronisation
+        dense = out.get("_dense_color")                   # fused colour loss (training steps): (dense ray colours, hit flags, number of hit rays)
         self.loss_total = 0
         for i, name in enumerate(opt.color_loss_items):
+            if dense is not None:
+                # every item from the dense per-ray tensors, no boolean-mask index (each is a device -> host synchronisation): the ray_masked
+                # item through the fused pass (it carries the gradient), the others from the filled image (no gradient: see create_network_models)
+                from . import ops
+                if name == "ray_masked_coarse_raycolor":
+                    n = pdist.global_counts(3 * dense[2], device=dev)[0]
+                    loss = ops.color_loss_sum_rays(dense[0], self.gt_image[0], dense[1]) / pdist.at_least_one(n)
+                else:
+                    with torch.no_grad():
+                        key = name[len("ray_miss") + 1:] if name.startswith("ray_miss") else (name[len("ray_masked") + 1:] if name.startswith("ray_masked") else name)
+                        sq = (out[key][0] - self.gt_image[0]) ** 2
+                        if name.startswith("ray_miss"):
+                            loss = (sq * torch.logical_not(hit)[:, None]).sum() / 3.0
+                        elif name.startswith("ray_masked"):
+                            n = pdist.global_counts(3 * dense[2], device=dev)[0]
+                            loss = (sq * hit[:, None]).sum() / pdist.at_least_one(n)
+                        else:
+                            n = pdist.global_counts(sq.numel(), device=dev)[0]
+                            loss = sq.sum() / pdist.at_least_one(n)
+                self.loss_total = self.loss_total + (loss * opt.color_loss_weights[i] + 1e-6 / W)
+                setattr(self, "loss_" + name, loss)
+                continue
             if name.startswith("ray_masked"):
                 key = name[len("ray_masked") + 1:]
                 pred = self._raw[key][0] if (self._raw is not None and key == "coarse_raycolor") else out[key][0][hit]

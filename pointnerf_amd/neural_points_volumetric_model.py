@@ -147,13 +147,15 @@ class NeuralPointsRayMarching(nn.Module):
         # synchronise once per tensor (nonzero), and the device would idle between forward, loss and backward while the
         # host catches up; with this the whole step is enqueued behind one synchronisation.
         n_hit = self.last_stats["rays_hit"]
-        # ``fused_color_loss`` (ours, like ``fused_zero_one`` below; set by callers whose loss goes through dist.hot_path_loss / the model shell
-        # of this package): a TRAINING step whose only consumer of the rendered colours is the colour loss gets the dense ray colours and the
+        # ``fused_color_loss`` (ours, like ``fused_zero_one`` below; set by callers whose loss goes through dist.hot_path_loss, and by the model
+        # shell of this package when every colour-loss item with a non-zero weight is a ray_masked / ray_miss one -- the lego script's
+        # setting: MvsPointsVolumetricModel.create_network_models): a TRAINING step whose only consumer of the rendered colours is the colour loss gets the dense ray colours and the
         # hit flags under "_dense_color" (ops.ColorLossRays: one pass forward, one backward, d colour written for every ray) and the compacted
         # [1, R'', ...] outputs are not formed -- no argsort, no index_selects, no scatter-back in the backward (~25 launches per step)
         if getattr(self, "fused_color_loss", False) and torch.is_grad_enabled() and getattr(opt, "prob", 0) == 0 \
                 and opt.sparse_loss_weight <= 0 and getattr(self, "fused_zero_one", False):
-            output = {"_dense_color": (ray_color, dense["ray_hit"], n_hit), "ray_mask": hit.to(torch.int8)[None]}
+            output = {"_dense_color": (ray_color, dense["ray_hit"], n_hit), "ray_mask": hit.to(torch.int8)[None],
+                      "_dense_aux": (opacity.detach(), bg_trans.detach())}       # (for fill_invalid's full-size visuals: references, no work)
             if "conf_coefficient" in opt.zero_one_loss_items:
                 if zo_in_render:
                     output["_zero_one_sum"] = (zo_sum, n_hit * SR * K)
@@ -225,6 +227,27 @@ def fill_invalid(output, bg_color, tonemap_func=None, bg_ray=None, prob=0):
     ``unmask``).  ``bg_ray`` [B,R,3] replaces the constant background like :104-106."""
     ray_mask = output["ray_mask"]
     B, OR = ray_mask.shape
+    if "_dense_color" in output:
+        # the fused-colour-loss form of a training step (NeuralPointsRayMarching.forward): the renderer's results are DENSE over the R rays
+        # already, so "filling" is a select per ray -- no scatter, no index tensor.  The filled tensors are detached: the colour loss takes
+        # its gradient through ops.ColorLossRays on the dense colours (MvsPointsVolumetricModel.compute_losses), these are the visuals.
+        ray_color, ray_hit, _ = output["_dense_color"]
+        opacity, bg_trans = output["_dense_aux"]
+        dev = ray_color.device
+        hitb = (ray_hit > 0)
+        bgt = torch.where(hitb, bg_trans, torch.ones((), dtype=torch.float32, device=dev))[None, :, None]
+        if bg_ray is not None:
+            col = bgt * bg_ray.to(dev) + torch.where(hitb[:, None], ray_color.detach(), torch.zeros((), dtype=torch.float32, device=dev))[None]
+        else:
+            bg = torch.ones([OR, 3], dtype=torch.float32, device=dev) * bg_color.to(dev).reshape(-1, 3)
+            if tonemap_func is not None:
+                bg = tonemap_func(bg)
+            col = torch.where(hitb[:, None], ray_color.detach(), bg)[None]
+        op = torch.where(hitb[:, None], opacity, torch.zeros((), dtype=torch.float32, device=dev))[None]
+        qs = torch.where(hitb[:, None], torch.zeros((), dtype=torch.float32, device=dev), torch.ones([OR, 3], dtype=torch.float32, device=dev))[None]
+        out = dict(output)
+        out.update(coarse_is_background=bgt, coarse_mask=1 - bgt, coarse_raycolor=col, coarse_point_opacity=op, queried_shading=qs)
+        return out
     sel = output["_hit_index"] if "_hit_index" in output else ray_mask[0] > 0      # index tensor: no nonzero() synchronisation
     dev = output["coarse_raycolor"].device
     bgt = torch.ones([B, OR, 1], dtype=torch.float32, device=dev)

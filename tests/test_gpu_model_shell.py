@@ -68,6 +68,9 @@ def test_optimize_parameters_matches_the_oracle_loop(tmp_path):
             assert abs(losses[k] - v) <= 1e-4 * max(1.0, abs(v)), (step, k, losses[k], v)
         assert m.output["coarse_raycolor"].shape == (1, R, 3) and m.output["coarse_point_opacity"].shape == (1, R, opt.SR)
         assert m.output["ray_mask"].shape == (1, R) and m.coarse_raycolor is m.output["coarse_raycolor"]
+        # the lego script's items (ray_masked 1.0, ray_miss 0.0, full image 0.0) take the fused colour loss over the renderer's dense ray colours:
+        # no compaction of the hit rays in a training step, the filled image is a per-ray select (round 5)
+        assert m.net_ray_marching.fused_color_loss and "_dense_color" in m._raw and "coarse_raycolor" not in m._raw and "_hit_index" not in m._raw
     assert abs(float(m.top_ray_miss_loss[0]) - max(p["ray_miss_coarse_raycolor"] for p in ref_parts)) <= 1e-4 * max(1.0, ref_parts[0]["ray_miss_coarse_raycolor"])
     assert abs(m.optimizer.param_groups[0]["lr"] - o_mlp.param_groups[0]["lr"]) < 1e-12
     sd = m.aggregator.state_dict()

@@ -31,7 +31,7 @@ for k in sorted(set(f) | set(w)):
 import subprocess
 try:
     commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"]).decode().strip()
-    dirty = bool(subprocess.check_output(["git", "status", "--porcelain", "--", "pointnerf_amd", "bench.py"]).decode().strip())
+    dirty = bool(subprocess.check_output(["git", "status", "--porcelain", "--", "pointnerf_amd/csrc", "bench.py"]).decode().strip())
 except Exception:
     commit, dirty = None, None
 # (the command of tools/gpu_profile.sh's --pmc passes; the library is the one built from `commit`)
