@@ -32,6 +32,7 @@ __device__ __forceinline__ float valu_chain(float x, int n) {            // n de
 // build stand-in, iterations [i0, i1) of 18: thread t of 256 writes 16-byte units u = t + 256 i of both planes (64 rows x 37 units = 2368 -> 9.25 per
 // thread and plane; 18 iterations x 1 unit x 2 planes ~ the whole 64 x 288 tile) with `valu` VALU instructions per iteration in front
 __device__ __forceinline__ float build_part(char *X, int t, int i0, int i1, int valu, float keep) {
+    if (valu < 0) return keep;                       // (valu < 0: the phase is skipped altogether -- the bare chain)
     for (int i = i0; i < i1; ++i) {
         keep = valu_chain(keep, valu);
         const int u = (t + 256 * (i >> 1)) % 2368, plane = i & 1;
@@ -44,6 +45,7 @@ __device__ __forceinline__ float build_part(char *X, int t, int i0, int i1, int 
 // streamed to HBM (the saved h4 planes), `valu` VALU instructions per row
 __device__ __forceinline__ float tail_part(const char *X, pn_f4 *h4, long long row0, int t, int i0, int i1, int valu, float keep) {
     const int cg = t & 31, r0 = 8 * (t >> 5);
+    if (valu < 0) return keep;
     for (int i = i0; i < i1; ++i) {
         const int r = r0 + i;
         const uint4 h = *reinterpret_cast<const uint4 *>(X + r * PN_XRS + cg * 16);
@@ -208,7 +210,7 @@ int main(int argc, char **argv) {
         {{0, 0, 3, 3, 6, 6, 8, 8, 8}, {0, 0, 0, 0, 2, 2, 10, 10, 18}},    // everything in the E intervals
     };
     // VALU per build iteration / per tail row: 32 / 96 ~ the real phases (600 / 800 per thread and tile); 0 / 0 = LDS + HBM traffic only
-    const int cfg[][3] = {{32, 96, 1}, {0, 0, 1}, {32, 96, 0}, {64, 192, 1}};
+    const int cfg[][3] = {{32, 96, 1}, {0, 0, 1}, {32, 96, 0}, {64, 192, 1}, {-1, -1, 1}, {-1, -1, 0}};      // the last two: no build / tail at all (chain + copy-outs, bare chain)
     for (int noisy = 0; noisy < 2; ++noisy)
     for (auto &c : cfg) {
         b.noisy = noisy;
