@@ -21,6 +21,10 @@ __global__ __launch_bounds__(256, 2) void k_mfma(int iters, float *out) {
         for (int j = 0; j < 8; ++j) {
             const unsigned r = prn(threadIdx.x * 64 + blockIdx.x * 7919 + i * 8 + j);
             w[j] = MODE == 0 ? 0u : MODE == 1 ? 0x2c002c00u : ((r & 0x83ff83ffu) | 0x38003800u);
+            // MODE 3: both operands keep only their top 4 mantissa bits (the low 6 are zero); MODE 4: only the B operand does (a cross term h x m with a
+            // coarsened residual plane); MODE 5: B keeps only its top 2 mantissa bits
+            if (MODE == 3 || (MODE == 4 && j >= 4)) w[j] &= 0xffc0ffc0u;
+            if (MODE == 5 && j >= 4) w[j] &= 0xff00ff00u;
         }
         ra[i] = make_uint4(w[0], w[1], w[2], w[3]); rb[i] = make_uint4(w[4], w[5], w[6], w[7]);
     }
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void k_mfma(int iters, float *out) {
                 acc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[j & 3], 0, 0, 0);
             }
         }
-        if (MODE == 2 && (it & 63) == 63) for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) acc[k][r] *= 1e-3f;      // keep the sums finite
+        if (MODE >= 2 && (it & 63) == 63) for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) acc[k][r] *= 1e-3f;      // keep the sums finite
     }
     float s = 0.f;
     for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) s += acc[k][r];
@@ -75,6 +79,9 @@ int main() {
     run<0>("all zero", out);
     run<1>("one constant (0.0625)", out);
     run<2>("pseudo-random f16 in +-[0.5, 1)", out);
+    run<3>("pseudo-random, BOTH operands with 4 mantissa bits (low 6 zero)", out);
+    run<4>("pseudo-random, B operand with 4 mantissa bits, A full", out);
+    run<5>("pseudo-random, B operand with 2 mantissa bits, A full", out);
     run<2, 1>("pseudo-random, every MFMA changes ONE operand", out);
     run<2, 2>("pseudo-random, every MFMA changes BOTH operands", out);
     run<2, 0>("pseudo-random f16 in +-[0.5, 1), operand pair held for 4 MFMAs, again", out);
