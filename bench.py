@@ -111,6 +111,9 @@ def parse():
                     help="f16 planes per operand of the weight-gradient GEMMs: 1 = shipped (one plane rounded to nearest, one product); 2 = both operands "
                          "as two planes, three products (fp32-class weight gradients).  The default run times 1 and ALSO reports 2 as config.fp32_class_variant")
     ap.add_argument("--no-fp32-class-variant", action="store_true", help="skip the supplementary --wgrad-planes 2 measurement of the default run")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="bring-up on a 1-GPU box: --gpus 1 with a one-rank RCCL group and EVERY collective of the step executed (as identities): the "
+                         "calls, streams and in-place forms the 8-GPU run will make, on the real backend")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="no GPU: time only the cpu_baseline leg (kind reference where /root/reference imports, else port) and print it")
     return ap.parse_args()
 
@@ -332,7 +335,11 @@ def main():
         # --gpus N without N ranks would print an N = 1 number under an N-GPU label, with no collective ever exercised
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with python -m torch.distributed.run --nproc-per-node %d ... bench.py --gpus %d"
                          % (args.gpus, world, args.gpus, args.gpus))
-    if world > 1:
+    dist_on = world > 1 or args.force_collectives
+    if args.force_collectives:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29800 + os.getpid() % 100))
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if dist_on:
         # "nccl" IS RCCL on ROCm.  PNERF_DIST_BACKEND=gloo exists only so that tests can run 2 ranks on a 1-GPU box.
         with Watchdog("init_process_group", 120, rank, world):
             torch.distributed.init_process_group(backend=os.environ.get("PNERF_DIST_BACKEND", "nccl"))
@@ -344,7 +351,8 @@ def main():
     from pointnerf_amd import ops, dist as pdist
     from pointnerf_amd.fused import FusedRender
     selftest = None
-    if world > 1:
+    pdist.FORCE_COLLECTIVES = bool(args.force_collectives)
+    if dist_on:
         with Watchdog("the collective self-test (first RCCL communicator + 4 small collectives)", int(os.environ.get("PNERF_SELFTEST_TIMEOUT", "90")), rank, world):
             selftest = rccl_selftest(dev, rank, world)       # raises on a wrong sum
         if not selftest:
@@ -369,8 +377,8 @@ def main():
     # the reference's two Adam instances (mvs_points_volumetric_model.py:80-91) as one-pass HIP updates; --zero1 shards the
     # update and its state over the ranks (reduce-scatter / all-gather instead of all-reduce)
     from pointnerf_amd.optim import FusedAdam, ShardedAdam, step_all
-    zero1 = args.zero1 and world > 1
-    sparse = world > 1 and not zero1 and (args.point_grads == "sparse" or (args.point_grads == "auto" and n_points >= 6_000_000))
+    zero1 = args.zero1 and dist_on
+    sparse = dist_on and not zero1 and (args.point_grads == "sparse" or (args.point_grads == "auto" and n_points >= 6_000_000))
     opt_mlp = FusedAdam(mlp_params, lr=opt.lr, betas=(0.9, 0.999))
     opt_pts = ShardedAdam(pt_params, lr=opt.plr, betas=(0.9, 0.999)) if zero1 else FusedAdam(pt_params, lr=opt.plr, betas=(0.9, 0.999))
 
@@ -388,7 +396,7 @@ def main():
         out = model(**inp)
         loss = loss_fn(opt, out, inp, world)
         loss.backward()
-        if world > 1 and comm_marks is not None:
+        if dist_on and comm_marks is not None:
             comm_marks.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
             comm_marks[-1][0].record()
         # no-op at N=1; RCCL over xGMI otherwise.  The three point tensors only the renderer writes (88 % of the bytes) start
@@ -403,7 +411,7 @@ def main():
         else:
             early = [] if (zero1 or args.no_overlap_comm) else [npnt.points_embeding, npnt.points_dir, npnt.points_color]
             pdist.allreduce_grads(mlp_params, [] if zero1 else pt_params, ready_event=FusedRender.point_grads_ready if early else None, early_params=early)
-        if world > 1 and comm_marks is not None:
+        if dist_on and comm_marks is not None:
             comm_marks[-1][1].record()        # main stream: backward done -> every gradient summed = the communication that did NOT hide
         step_all([opt_mlp, opt_pts])          # both Adam instances in one launch (ShardedAdam, when --zero1, steps on its own)
         return loss, model.last_stats
@@ -438,12 +446,12 @@ def main():
     if not args.no_prof:
         ops.prof_enable(True)
         ops.prof_collect()
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # step boundaries on the stream the kernels run on
-    comm_marks = [] if world > 1 else None
+    comm_marks = [] if dist_on else None
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.warmup, total):
@@ -451,7 +459,7 @@ def main():
         marks[i - args.warmup + 1].record()
         stats.append(st)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -464,7 +472,7 @@ def main():
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     dt_local = dt
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if dist_on:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -485,7 +493,7 @@ def main():
         extra = {"ms_step_cold_grid": timed(cold), "ms_step_without_optimizer": timed(no_adam)}
         # the SAME step with fp32-class weight gradients (both operands of every weight-gradient GEMM as two f16 planes, three products:
         # pnerf_set_wgrad_planes(2)) -- the headline's arithmetic caveat priced in the same run, outside the timed region
-        if args.wgrad_planes == 1 and world == 1 and not args.no_fp32_class_variant:
+        if args.wgrad_planes == 1 and not dist_on and not args.no_fp32_class_variant:
             ops.set_wgrad_planes(2)
             try:
                 need2 = int(L.lib().pnerf_agg_saved_bytes(biggest, int(opt.K)))
@@ -510,7 +518,7 @@ def main():
         raise SystemExit("bench.py: non-finite loss after %d steps -- the timed path produced NaN/Inf, the number would be meaningless" % total)
     per_rank_ms = [dt / args.steps * 1e3]
     exposed_ms = replica_spread = None
-    if world > 1:                                   # self-check for the scaling record: the RCCL world and every rank's own step time
+    if dist_on:                                     # self-check for the scaling record: the RCCL world and every rank's own step time
         t_all = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
         torch.distributed.all_gather(t_all, torch.tensor([dt_local / args.steps * 1e3], device=dev, dtype=torch.float64))
         per_rank_ms = [float(t.item()) for t in t_all]
@@ -543,7 +551,7 @@ def main():
                           "parity_note": ("the synthetic Barn shell puts up to ~70 points in a 0.009 cell, beyond P = 11: the reference switches to a wall-clock-seeded "
                                           "reservoir there (parity undefined); the HIP path and the oracle both keep the first P by index, so parity on this "
                                           "configuration is HIP-vs-oracle truncation only (pointnerf_amd/config.py barn_opt)") if args.config == "barn" else None,
-                          "parallelism": "ray-shard dp%d, point cloud + MLP replicated" % world, "point_grad_exchange": ("none" if world == 1 else ("zero1 reduce-scatter" if zero1 else ("sparse touched rows" if sparse else "dense all-reduce, one bucket, overlapped"))), "world_size": world, "ms_per_step_by_rank": per_rank_ms, "ms_allreduce_exposed_by_rank": exposed_ms, "replica_param_checksum_spread": replica_spread,
+                          "parallelism": "ray-shard dp%d, point cloud + MLP replicated" % world, "point_grad_exchange": ("none" if not dist_on else ("zero1 reduce-scatter" if zero1 else ("sparse touched rows" if sparse else "dense all-reduce, one bucket, overlapped"))), "world_size": world, "ms_per_step_by_rank": per_rank_ms, "ms_allreduce_exposed_by_rank": exposed_ms, "replica_param_checksum_spread": replica_spread,
                           "valid_samples_per_step": smp, "neighbor_rows_per_step": rows,
                           "rays_hit_per_step": float(np.mean([s["rays_hit"] for s in stats])), "final_loss": float(loss.item()),
                           "device_allocs_in_timed_region": int(extra_allocs), "setup_steps": 2,
@@ -621,13 +629,13 @@ def main():
             for k in alg_flop:
                 if k in per:
                     out["kernels"][k]["tflops"] = alg_flop[k] / (per[k]["ms_per_step"] * 1e-3) / 1e12
-        if world == 1 and args.cpu_rays > 0 and not args.render_only and args.config in ("lego", "chair"):
+        if not dist_on and args.cpu_rays > 0 and not args.render_only and args.config in ("lego", "chair"):
             try:
                 out["cpu_baseline"] = best_cpu_baseline(opt, n_points, args.cpu_rays, min(os.cpu_count() or 1, 32), points_fn, rays_fn)
             except Exception as e:       # the checker failing must not hide the GPU number
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

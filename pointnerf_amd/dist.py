@@ -25,6 +25,18 @@ def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+# Test / bring-up switch (bench.py --force-collectives): with an initialised process group of ONE rank, run every collective of the step anyway (each is
+# then the identity).  RCCL refuses two ranks on one device, so on a 1-GPU box this is the only way the step's collective calls -- the side-stream
+# all-reduce of the gradient bucket behind the library's event, the in-place reduce-scatter / all-gather of ZeRO-1, all_gather_into_tensor of the sparse
+# exchange -- execute on the real backend before an 8-GPU node does.
+FORCE_COLLECTIVES = False
+
+
+def active():
+    """True when the step's collectives have to run: more than one rank, or the bring-up switch with an initialised group"""
+    return world() > 1 or (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
+
+
 def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
@@ -48,7 +60,7 @@ def global_counts(*local_counts, device=None):
     single process).  No ``torch.tensor(list, device=...)``: a host -> device copy from pageable memory is a BLOCKING call on the stream --
     round 4 found it in the kernel trace as the point where the host, until then a whole forward ahead of the device, waited for the device
     and then paced every launch of the loss and of the backward's head (0.25 .. 0.5 ms of idle device per step)."""
-    if world() == 1:
+    if not active():
         return [float(c) for c in local_counts]
     t = torch.zeros(len(local_counts), dtype=torch.float32, device=device)
     for i, c in enumerate(local_counts):
@@ -96,7 +108,7 @@ def allreduce_grads(mlp_params, point_params, ready_event=None, early_params=())
     of weight-gradient GEMMs instead of following them; the calling stream waits for the side stream before it returns.
     Only valid for parameters whose ``.grad`` IS the tensor the renderer's backward wrote (``zero_grad(set_to_none=True)`` and no
     other contribution in the graph: embedding, dir and colour -- not the confidences, which also receive the zero-one loss)."""
-    if world() == 1:
+    if not active():
         return
     # the side-stream all-reduce is only sound on the very tensor the renderer's backward wrote: if autograd cloned it (a non-stealable
     # layout, a pre-existing .grad, a hook) or added another contribution, p.grad is a different tensor that is completed on the main
@@ -185,7 +197,7 @@ def plan_sparse_exchange(pidx, n_points, group=None):
         ids[:nz.numel()] = nz
         cnt = torch.tensor([nz.numel()], dtype=torch.int64)
     cap = cnt.clone()
-    if world() > 1:
+    if active():
         dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=group)
     return ids, torch.cat([cnt, cap])
 
@@ -199,7 +211,7 @@ def sparse_allreduce_rows(grads, touched, group=None, cap=None):
     ``cap`` = the largest touched count over the ranks when the caller already knows it (``plan_sparse_exchange``: no host
     synchronisation in here then)."""
     W = dist.get_world_size(group)
-    if W == 1:
+    if W == 1 and not FORCE_COLLECTIVES:
         return
     dev = grads[0].device
     assert all(g.is_contiguous() and g.dim() >= 2 for g in grads)

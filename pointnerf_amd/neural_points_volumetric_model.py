@@ -89,7 +89,7 @@ class NeuralPointsRayMarching(nn.Module):
         mlp_params, layout = agg.ordered_params()
         env = dict(cam=cam, xyz=npnt.xyz.detach().reshape(-1, 3).contiguous(), raydir=raydir.detach().reshape(-1, 3).contiguous().float(),
                    dense=dense, R=R, SR=int(opt.SR), K=int(opt.K), n_valid=0, flat=st.flat, packed=st.packed_image(),
-                   train=bool(train), layout=layout, want_grad_event=bool(train) and raydir.is_cuda and pdist.world() > 1)
+                   train=bool(train), layout=layout, want_grad_event=bool(train) and raydir.is_cuda and pdist.active())
         if train and self._zero_one_in_render():
             env["zero_one_eps"] = float(getattr(opt, "zero_epsilon", 1e-3))
         leaves = (npnt.points_embeding, npnt.points_conf, npnt.points_dir, npnt.points_color) + tuple(mlp_params)

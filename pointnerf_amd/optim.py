@@ -161,7 +161,9 @@ class ShardedAdam:
         W, shard = self.world, self.shard
         mine = slice(self.rank * shard, (self.rank + 1) * shard)
         gs = self.flat_grad[mine]
-        if W > 1:
+        from . import dist as pdist
+        comm = W > 1 or (pdist.FORCE_COLLECTIVES and dist.is_initialized())      # (one rank + the bring-up switch: the collectives run as identities)
+        if comm:
             if dist.get_backend(self.group) == "gloo":       # gloo has no reduce_scatter: all-reduce in place (CPU tests only)
                 dist.all_reduce(self.flat_grad, group=self.group)
             else:
@@ -169,7 +171,7 @@ class ShardedAdam:
         ps = self.flat_param[mine]
         self._update(ps, gs, self.exp_avg, self.exp_avg_sq, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
                      self.step_count)
-        if W > 1:
+        if comm:
             if dist.get_backend(self.group) == "gloo":
                 dist.all_gather(list(self.flat_param.view(W, shard).unbind(0)), ps.clone(), group=self.group)
             else:

@@ -125,3 +125,44 @@ def test_measured_matrix_pipe_ceiling_is_sane():
     const, rnd = ops.mfma_rate_tflops(1, ms_target=30.0), ops.mfma_rate_tflops(2, ms_target=30.0)
     print("matrix pipe, register-resident f16 MFMA: constant operands %.0f TFLOP/s, pseudo-random operands %.0f TFLOP/s" % (const, rnd))
     assert 500.0 < rnd <= 1.05 * const and const < 2700.0, (const, rnd)
+
+
+def test_collective_selftest_on_rccl_with_one_rank():
+    """RCCL refuses two ranks on one device, so the 2-rank tests above run over gloo; this runs bench.rccl_selftest on the REAL backend ("nccl" = RCCL)
+    with a world of one: the library loads, a communicator forms, and every collective form the step uses is a valid call on that backend
+    (all_reduce, all_gather_into_tensor, the in-place reduce_scatter_tensor, the side-stream all-reduce of a bucket head behind an event with
+    record_stream) -- gloo has no reduce_scatter and takes list-form all_gather, so those two forms run nowhere else before the 8-GPU node."""
+    code = (
+        "import os, sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29700 + os.getpid() %% 200), RANK='0', WORLD_SIZE='1')\n"
+        "import bench\n"
+        "with bench.Watchdog('init_process_group', 120, 0, 1):\n"
+        "    torch.distributed.init_process_group(backend='nccl')\n"
+        "torch.cuda.set_device(0)\n"
+        "dev = torch.device('cuda', 0)\n"
+        "with bench.Watchdog('selftest', 90, 0, 1):\n"
+        "    print(bench.rccl_selftest(dev, 0, 1))\n"
+        "torch.distributed.destroy_process_group()\n"
+        "print('rccl one-rank ok')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "rccl one-rank ok" in r.stdout and "ok backend=nccl world=1" in r.stdout, (r.returncode, r.stdout[-800:], r.stderr[-1500:])
+
+
+def test_every_collective_of_the_step_on_rccl_with_one_rank():
+    """bench.py --force-collectives: a one-rank RCCL group with every collective of the step executed (as identities) -- the overlapped one-bucket
+    all-reduce on the side stream behind the library's event, the after-backward form, ZeRO-1's in-place reduce-scatter / all-gather and the sparse
+    touched-row exchange with all_gather_into_tensor: the calls the 8-GPU run makes, on the backend it makes them on.  Being identities, each form
+    must reproduce the plain single-GPU step's loss."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--rays", "8192", "--points", "300000", "--cpu-rays", "0",
+            "--no-fp32-class-variant"]
+    plain = _last_json(subprocess.check_output(base, cwd=ROOT, timeout=900))
+    for extra, label in (([], "dense all-reduce"), (["--no-overlap-comm"], "dense all-reduce"), (["--zero1"], "zero1"), (["--point-grads", "sparse"], "sparse")):
+        r = subprocess.run(base + ["--force-collectives"] + extra, cwd=ROOT, capture_output=True, timeout=900)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert b"rccl_selftest: ok  backend=nccl world=1" in r.stderr, r.stderr.decode()[-1500:]
+        d = _last_json(r.stdout)
+        c = d["config"]
+        assert c["point_grad_exchange"].startswith(label) and c["collective_selftest"].startswith("ok backend=nccl"), c["point_grad_exchange"]
+        assert c["replica_param_checksum_spread"] == 0.0 and len(c["ms_allreduce_exposed_by_rank"]) == 1
+        assert abs(c["final_loss"] - plain["config"]["final_loss"]) <= 1e-5 * max(1.0, abs(plain["config"]["final_loss"])), (extra, c["final_loss"], plain["config"]["final_loss"])
