@@ -175,3 +175,34 @@ def test_evaluation_loop_through_the_shell_matches_the_oracle(tmp_path):
         assert abs(avg[k] - want) <= 1e-4 * max(1.0, abs(want)), (k, avg[k], want)
     assert abs(psnr - avg["coarse_raycolor_psnr"]) < 1e-9 and len(got) == 2 and got[0].shape == (H, W, 3)
     assert float(got[0].abs().sum()) > 0 and float(got[0][:300].abs().sum()) == 0
+
+
+def test_training_step_on_a_batch_that_hits_nothing(tmp_path):
+    """A training batch may see no geometry at all (random pixels of a sky region, a shard of a sharded batch): the shell's step -- fused colour loss over
+    the dense ray colours, zero-one numerator of zero elements, backward, both Adams -- must run, report the reference's value for the masked item
+    (0: base_rendering_model.py:545-551 takes the mean only when a ray hit), fill the image with the background and leave the network unchanged
+    (every gradient is exactly zero; Adam on an all-zero gradient from zero moments moves nothing)."""
+    opt, m, xyz, attrs, mlp, size, seed = _scene("small_k8", tmp_path, prob_freq=100, prob_num_step=1, ray_jitter=0.0)
+    d = scenes.block_rays(theta_deg=30.0, x0=400 - size // 2, y0=400 - size // 2, size=size)
+    d["raydir"] = d["raydir"] + np.array([9.0, 0.0, 0.0], dtype=np.float32)                 # every ray far off to the side of the cloud
+    inp = pyref.to_torch_inputs(d)
+    m.setup(opt, train_len=10)
+    m.train()
+    before = {k: v.detach().clone() for k, v in m.aggregator.state_dict().items()}
+    emb0 = m.neural_points.points_embeding.detach().clone()
+    for step in range(2):
+        data = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in inp.items()}
+        data["id"] = torch.tensor([3])
+        m.set_input(data)
+        m.optimize_parameters(total_steps=step)
+        losses = {k: float(v) for k, v in m.get_current_losses().items()}
+        assert all(np.isfinite(v) for v in losses.values()), losses
+        assert losses["ray_masked_coarse_raycolor"] == 0.0 and not bool((m.output["ray_mask"] > 0).any())
+        R = inp["raydir"].shape[1]
+        assert m.output["coarse_raycolor"].shape == (1, R, 3)
+        assert float((m.output["coarse_raycolor"][0] - inp["bg_color"].to(DEV).reshape(1, 3)).abs().max()) == 0.0
+        miss_ref = float(((inp["bg_color"].reshape(1, 3) - inp["gt_image"][0]) ** 2).sum() / 3.0)
+        assert abs(losses["ray_miss_coarse_raycolor"] - miss_ref) <= 1e-5 * max(1.0, miss_ref)
+    for k, v in m.aggregator.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    assert torch.equal(m.neural_points.points_embeding.detach(), emb0)
