@@ -5,8 +5,11 @@
 //   extract_from_2d_grid             models/mvs/mvs_utils.py:411-421            (F.grid_sample bilinear, zeros padding, align_corners)
 //   the "dir" block of query_embedding  models/mvs/mvs_points_model.py:239-251
 // The reference compacts the in-image points (masked_select), samples them, and scatters the rows back into a zero tensor; here nothing is
-// compacted: pass 1 = one thread per (point, view) (projection, mask, z-buffer atomicMin), pass 2 = one thread per OUTPUT ELEMENT (a wave
-// writes consecutive columns of a point's row: coalesced; the four texels of a column are one channel plane of an L2-resident map).
+// compacted: pass 1 = one thread per (point, view) (projection, mask, z-buffer atomicMin); pass 2 (round 5) = one workgroup per 64 points: lanes
+// are POINTS (neighbouring candidates project to neighbouring texels: a wave's four texel loads of a channel touch a few lines of ONE plane --
+// the first form, one thread per output element with lanes = channels, sent every lane to its own plane: 64 lines per load instruction),
+// the items (map, chunk of 8 channels) are dealt over the four waves, results go to an LDS tile [64][columns] and leave as whole rows.
+// Same arithmetic per element as before (bit-identical outputs).  Column counts whose tile exceeds 64 KB of LDS take the first form.
 // HBM: N * (12 + 16 V + 4 (F + 3 V)) B.  fp32 with the reference's operation order, no FMA contraction (built with -ffp-contract=off):
 // the in-image mask and the z-buffer cell are threshold decisions on the projected pixel.
 #include "pn_common.h"
@@ -102,6 +105,44 @@ __global__ void k_ex2d_sample(Ex2dArgs a, const float4 *__restrict__ proj, const
     (is_color ? colors[i * a.color_cols + cc] : feats[i * a.feat_cols + cc]) = val;
 }
 
+// pass 2, tiled: see the header.  LDS: tile[64][cols + 1] floats (the + 1 keeps the lanes' row-strided writes off one bank)
+constexpr int EX_PTS = 64, EX_CH = 8;
+__global__ __launch_bounds__(256) void k_ex2d_sample_tiled(Ex2dArgs a, const float4 *__restrict__ proj, const unsigned *__restrict__ zbuf, float *__restrict__ feats,
+                                                           float *__restrict__ colors, unsigned char *__restrict__ mask_out) {
+    extern __shared__ float ex_tile[];
+    const int cols = a.feat_cols + a.color_cols, ld = cols + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long i0 = (long long)blockIdx.x * EX_PTS, i = i0 + lane;
+    const int npts = (int)((a.n - i0) < EX_PTS ? (a.n - i0) : EX_PTS);
+    for (int e = tid; e < EX_PTS * ld; e += 256) ex_tile[e] = 0.f;            // columns no map writes stay zero
+    __syncthreads();
+    // items: (map m, channel chunk k) in map order, dealt round-robin over the waves
+    int item = 0;
+    for (int m = 0; m < a.n_maps; ++m) {
+        const pnerf_map_desc &M = a.maps[m];
+        const int chunks = (M.C + EX_CH - 1) / EX_CH;
+        for (int k = 0; k < chunks; ++k, ++item) {
+            if ((item & 3) != wave || lane >= npts) continue;
+            const float4 q = proj[(long long)M.view * a.n + i];
+            bool in = q.w > 0.f;
+            if (in && a.occ) {
+                const long long cell = (long long)ceilf(q.x) * a.HD + (long long)ceilf(q.y);
+                in = q.z <= ord_back(zbuf[(long long)M.view * a.WD * a.HD + cell]) + a.tolerate;                       // :361
+            }
+            if (k == 0 && mask_out && M.first_of_view) mask_out[(long long)M.view * a.n + i] = in ? 1 : 0;
+            if (!in) continue;
+            const float gx = q.x / (((float)a.WD - 1.f) / 2.f) - 1.f, gy = q.y / (((float)a.HD - 1.f) / 2.f) - 1.f;  // :313-314, :349-350
+            const int c0 = k * EX_CH, c1 = c0 + EX_CH < M.C ? c0 + EX_CH : M.C;
+            float *dst = ex_tile + lane * ld + (M.is_color ? a.feat_cols : 0) + M.out_col;
+            for (int c = c0; c < c1; ++c) dst[c] = bilinear((const float *)M.d_map + (long long)c * M.H * M.W, M.H, M.W, gx, gy);
+        }
+    }
+    __syncthreads();
+    // the tile's feature rows / colour rows are contiguous in the outputs: whole-row stores
+    for (int e = tid; e < npts * a.feat_cols; e += 256) feats[i0 * a.feat_cols + e] = ex_tile[(e / a.feat_cols) * ld + e % a.feat_cols];
+    for (int e = tid; e < npts * a.color_cols; e += 256) colors[i0 * a.color_cols + e] = ex_tile[(e / a.color_cols) * ld + a.feat_cols + e % a.color_cols];
+}
+
 struct DirArgs {
     const float *xyz; long long n; int n_views;
     float cam_pos[PNERF_EX2D_MAX_VIEWS][3];     // the views' camera centres in the CURRENT camera's frame
@@ -170,8 +211,14 @@ extern "C" int pnerf_extract_2d(const float *d_cam_xyz, int64_t n_points, const 
     if (d_mask && hipMemsetAsync(d_mask, 0, (size_t)n_views * n_points, s) != hipSuccess) return PNERF_E_LAUNCH;
     hipLaunchKernelGGL(k_ex2d_project, dim3(pn_cdiv((long long)n_points * n_views, 256)), dim3(256), 0, s, a, proj, zbuf);
     PN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ex2d_sample, dim3(pn_cdiv((long long)n_points * (feat_cols + color_cols), 256)), dim3(256), 0, s, a, proj, zbuf, d_feats,
-                       d_colors, d_mask);
+    const size_t tile_bytes = (size_t)EX_PTS * (feat_cols + color_cols + 1) * sizeof(float);
+    if (tile_bytes <= 64 * 1024) {
+        if (hipFuncSetAttribute((const void *)k_ex2d_sample_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes) != hipSuccess) return PNERF_E_LAUNCH;
+        hipLaunchKernelGGL(k_ex2d_sample_tiled, dim3(pn_cdiv((long long)n_points, EX_PTS)), dim3(256), tile_bytes, s, a, proj, zbuf, d_feats, d_colors, d_mask);
+    } else {
+        hipLaunchKernelGGL(k_ex2d_sample, dim3(pn_cdiv((long long)n_points * (feat_cols + color_cols), 256)), dim3(256), 0, s, a, proj, zbuf, d_feats,
+                           d_colors, d_mask);
+    }
     PN_CHECK_LAUNCH();
     return 0;
 }
