@@ -341,7 +341,7 @@ def main():
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
     if dist_on:
         # "nccl" IS RCCL on ROCm.  PNERF_DIST_BACKEND=gloo exists only so that tests can run 2 ranks on a 1-GPU box.
-        with Watchdog("init_process_group", 120, rank, world):
+        with Watchdog("init_process_group", int(os.environ.get("PNERF_INIT_TIMEOUT", "300")), rank, world):      # (ranks of a fresh box may reach this a minute apart: first import of torch)
             torch.distributed.init_process_group(backend=os.environ.get("PNERF_DIST_BACKEND", "nccl"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation (oracle/ is the checker only)")
@@ -353,7 +353,7 @@ def main():
     selftest = None
     pdist.FORCE_COLLECTIVES = bool(args.force_collectives)
     if dist_on:
-        with Watchdog("the collective self-test (first RCCL communicator + 4 small collectives)", int(os.environ.get("PNERF_SELFTEST_TIMEOUT", "90")), rank, world):
+        with Watchdog("the collective self-test (first RCCL communicator + 4 small collectives)", int(os.environ.get("PNERF_SELFTEST_TIMEOUT", "180")), rank, world):
             selftest = rccl_selftest(dev, rank, world)       # raises on a wrong sum
         if not selftest:
             raise SystemExit("bench.py: the collective self-test did not run: refusing to time a multi-GPU step")
