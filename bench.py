@@ -358,6 +358,10 @@ def main():
         if not selftest:
             raise SystemExit("bench.py: the collective self-test did not run: refusing to time a multi-GPU step")
     ops.set_wgrad_planes(args.wgrad_planes)
+    # N > 1: a rank that stops inside a later collective (a mismatch between the ranks' call sequences) also leaves a record
+    run_guard = Watchdog("model build + set-up + the timed steps", int(os.environ.get("PNERF_RUN_TIMEOUT", "1500")), rank, world) if dist_on else None
+    if run_guard is not None:
+        run_guard.__enter__()
 
     # is_train=1: the reference trains with 30 % segment jitter (point_query.py:81); the in-kernel RNG path is what a
     # training step runs, so it is what is timed (parity runs -- tests/ -- use jitter off, where results are bit-defined)
@@ -635,6 +639,8 @@ def main():
             except Exception as e:       # the checker failing must not hide the GPU number
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out))
+    if run_guard is not None:
+        run_guard.__exit__(None, None, None)
     if dist_on:
         torch.distributed.destroy_process_group()
 
