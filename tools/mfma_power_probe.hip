@@ -56,6 +56,56 @@ __global__ __launch_bounds__(256, 2) void k_mfma(int iters, float *out) {
     if (s == 123.456f) out[threadIdx.x] = s;
 }
 
+// ---- the fp8 pipe with toggling operands (what a (f16 h.h) + (fp8 h.m) + (fp8 m.h) scheme would run its two cross terms on): legacy
+// v_mfma_f32_32x32x16_fp8_fp8 (K = 16 per instruction) and the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64), pseudo-random e4m3 bytes
+typedef int i8v __attribute__((ext_vector_type(8)));
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void k_mfma_fp8(int iters, float *out) {
+    unsigned w[4][16];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) w[i][j] = prn(threadIdx.x * 64 + blockIdx.x * 7919 + i * 16 + j) & 0xbfbfbfbfu;      // (no NaN encodings)
+    f16v acc[4];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (KIND == 0) {
+                const long a = ((long)w[s][1] << 32) | w[s][0], b = ((long)w[(s + it) & 3][9] << 32) | w[(s + it) & 3][8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a, b, acc[k], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(b, a, acc[k], 0, 0, 0);
+            } else {
+                i8v a, b;
+                for (int j = 0; j < 8; ++j) { a[j] = (int)w[s][j]; b[j] = (int)w[(s + it) & 3][8 + j]; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[k], 0, 0, 0, 127, 0, 116);      // B scaled by 2^-11
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b, a, acc[k], 0, 0, 0, 116, 0, 127);
+            }
+        }
+        if ((it & 63) == 63) for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) acc[k][r] *= 1e-3f;
+    }
+    float sum = 0.f;
+    for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) sum += acc[k][r];
+    if (sum == 123.456f) out[threadIdx.x] = sum;
+}
+template <int KIND> static void run_fp8(const char *name, float *out) {
+    const int iters = KIND == 0 ? 500000 : 125000, wgs = 512, K = KIND == 0 ? 16 : 64;
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(a, 0);
+        hipLaunchKernelGGL(k_mfma_fp8<KIND>, dim3(wgs), dim3(256), 0, 0, iters, out);
+        hipEventRecord(b, 0); hipEventSynchronize(b);
+        float ms = 0.f; hipEventElapsedTime(&ms, a, b);
+        if (rep && ms < best) best = ms;
+    }
+    const double flop = (double)wgs * 4 * iters * 32 * (2.0 * 32 * 32 * K);
+    printf("{\"operands\": \"%s\", \"ms\": %.1f, \"tflops\": %.0f, \"x_the_f16_rate_with_toggling_operands\": %.2f}\n", name, best, flop / (best * 1e-3) / 1e12, flop / (best * 1e-3) / 1e12 / 1700.0);
+    fflush(stdout);
+}
+
 template <int MODE, int ORDER = 0> static void run(const char *name, float *out) {
     const int iters = 500000, wgs = 512;
     hipEvent_t a, b;
@@ -87,5 +137,7 @@ int main() {
     run<2, 0>("pseudo-random f16 in +-[0.5, 1), operand pair held for 4 MFMAs, again", out);
     run<1, 2>("one constant, the both-change instruction order", out);
     run<1>("one constant (0.0625), again", out);
+    run_fp8<0>("fp8 e4m3 pseudo-random bytes, v_mfma_f32_32x32x16_fp8_fp8", out);
+    run_fp8<1>("fp8 e4m3 pseudo-random bytes, v_mfma_scale_f32_32x32x64_f8f6f4 (one operand scaled 2^-11)", out);
     return hipDeviceSynchronize() == hipSuccess ? 0 : 1;
 }
