@@ -13,7 +13,8 @@
 // the non-GEMM phases here are the REAL copy-out (pn_copy_out_kmajor: transposing LDS reads of both planes + 1 KB-run stream stores to HBM) and
 // stand-ins for build / tail that issue the real phases' LDS traffic (build: both planes of a 64 x 288 tile written; tail: both planes of 64 x 256
 // read and streamed to HBM as the saved h4 planes) and VALU counts of the real phases' order (tools/analyze_trace.py: ~600 / ~800 per thread).
-// A is calibrated against the real forward: 12.8 ms / 423 tiles per CU = 30 us per tile and CU.
+// A is calibrated against the real forward: 12.8 ms / 423 tiles per CU = 30 us per tile and CU (reproduced with noisy = 1: operands that toggle).
+// Also here: organisation E (weight-stationary over two tiles: half the L2 -> L1 weight stream per row), see k_org_e.
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fno-vectorize -I../pointnerf_amd/csrc -I../include role_probe.hip -o role_probe
 #include <hip/hip_runtime.h>
@@ -178,6 +179,101 @@ __global__ __launch_bounds__(512, 1) void k_org_r(Bufs b, int tiles, int vb, int
     if (keep == 123.456f) b.out[threadIdx.x] = keep;
 }
 
+// ---------------------------------------------------------------- E: weight-stationary over TWO tiles -- one 4-wave workgroup per CU, two tile buffers in LDS,
+// every wave 2 feature blocks x 4 row blocks (both tiles): each weight fragment is fetched from L2 once per 128 rows (half the L2 -> L1 weight stream per
+// row; the LDS fragment reads per row stay A's), 128 accumulator registers per wave (one wave per SIMD: up to 512 registers, the compiler may place
+// accumulators in AccVGPRs).  Is the L2 weight stream worth a tile pair under the power wall?
+template <int NC, int MB>
+__device__ __forceinline__ void gemm_e(const char *X0, const char *X1, const uint4 *__restrict__ img, int fb0, int lane, f32x16 (&acc)[2][4]) {
+    constexpr int PF = 2, NS = PF + 1;
+    const int xo = (lane & 31) * PN_XRS + (lane >> 5) * 16;
+    const uint4 *wp = img + (size_t)fb0 * 128 + lane;
+    uint4 wh[NS][2], wm[NS][2], xh[2][4], xm[2][4];
+    auto load_w = [&](auto cc) {
+        constexpr int c = decltype(cc)::value, st = c % NS;
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb) { wh[st][fb] = wp[(c * MB + fb) * 128]; wm[st][fb] = wp[(c * MB + fb) * 128 + 64]; }
+    };
+    auto load_x = [&](auto cc) {
+        constexpr int c = decltype(cc)::value, st = c & 1;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const char *xb = (rb < 2 ? X0 : X1) + xo + (rb & 1) * 32 * PN_XRS + c * 32;
+            xh[st][rb] = *reinterpret_cast<const uint4 *>(xb);
+            xm[st][rb] = *reinterpret_cast<const uint4 *>(xb + PN_XPLANE);
+        }
+    };
+    pn_static_for<PF>([&](auto cc) { load_w(cc); });
+    load_x(std::integral_constant<int, 0>{});
+    pn_static_for<NC>([&](auto cc) {
+        constexpr int c = decltype(cc)::value, sw = c % NS, sx = c & 1;
+        if constexpr (c + PF < NC) load_w(std::integral_constant<int, c + PF>{});
+        if constexpr (c + 1 < NC) load_x(std::integral_constant<int, c + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    const pn_h8 a = __builtin_bit_cast(pn_h8, p == 2 ? wm[sw][fb] : wh[sw][fb]);
+                    const pn_h8 b = __builtin_bit_cast(pn_h8, p == 1 ? xm[sx][rb] : xh[sx][rb]);
+                    acc[fb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[fb][rb], 0, 0, 0);
+                }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+__global__ __launch_bounds__(256, 1) void k_org_e(Bufs b, int tiles, int vb, int vt, int copy) {
+    extern __shared__ __attribute__((aligned(16))) char smem_p[];
+    char *X0 = smem_p, *X1 = smem_p + PN_XBYTES;
+    for (int i = threadIdx.x; i < 2 * PN_XBYTES / 4; i += 256) reinterpret_cast<unsigned *>(smem_p)[i] = b.noisy ? prn_h2(i) : 0x2c002c00u + (i & 7);
+    __syncthreads();
+    f32x16 acc[2][4];
+    float keep = 0.f;
+    for (int t = 2 * blockIdx.x; t < tiles; t += 2 * gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const long long slot0 = t % b.ring, slot1 = (t + 1) % b.ring;
+        keep = build_part(X0, tid, 0, 18, vb, keep);
+        keep = build_part(X1, tid, 0, 18, vb, keep);
+        PN_LDS_BARRIER();
+#pragma unroll 1
+        for (int layer = 0; layer < 4; ++layer) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            gemm_e<16, 8>(X0, X1, reinterpret_cast<const uint4 *>(b.img + (size_t)layer * PN_IMG(16, 8)), 2 * wave, lane, acc);
+            if (copy) { pn_copy_out_kmajor<PN_H>(X0, b.sv[layer], slot0 * 8, tid); pn_copy_out_kmajor<PN_H>(X1, b.sv[layer], slot1 * 8, tid); }
+            PN_LDS_BARRIER();
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            v[i] = acc[fb][rb][4 * g + i] * 1e-3f + 0.0625f;
+                            if (b.noisy) v[i] = __builtin_amdgcn_fractf(acc[fb][rb][4 * g + i] * 0.37f + 0.11f * i) - 0.5f;
+                            v[i] = fmaxf(v[i], 0.01f * v[i]);
+                        }
+                        pn_x_store4<false>(rb < 2 ? X0 : X1, 32 * (rb & 1) + (lane & 31), pn_d_feat(2 * wave + fb, g, lane), v[0], v[1], v[2], v[3]);
+                    }
+            PN_LDS_BARRIER();
+        }
+        keep += acc[0][0][0] * 1e-30f;
+        keep = tail_part(X0, b.h4, slot0 * 128, tid, 0, 8, vt, keep);
+        keep = tail_part(X1, b.h4, slot1 * 128, tid, 0, 8, vt, keep);
+        PN_LDS_BARRIER();
+    }
+    if (keep == 123.456f) b.out[threadIdx.x] = keep;
+}
+
 template <class F> static float time_best(F launch) {
     hipEvent_t a, e;
     hipEventCreate(&a); hipEventCreate(&e);
@@ -203,6 +299,7 @@ int main(int argc, char **argv) {
     hipFuncSetAttribute((const void *)k_org_a<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PN_XBYTES + 1024 + 40 * 1024);
     hipFuncSetAttribute((const void *)k_org_a<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PN_XBYTES + 1024);
     hipFuncSetAttribute((const void *)k_org_r, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PN_XBYTES + 1024);
+    hipFuncSetAttribute((const void *)k_org_e, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PN_XBYTES + 1024);
     // support schedules of R: where the 8 tail rows and the 18 build iterations of the neighbouring tiles go (G0 E0 G1 E1 G2 E2 G3 E3)
     const Sched scheds[] = {
         {{0, 1, 3, 4, 6, 7, 8, 8, 8}, {0, 0, 0, 0, 0, 2, 8, 10, 18}},     // tail first, then build; more in the E intervals (no copy-out there)
@@ -219,6 +316,11 @@ int main(int argc, char **argv) {
         const float a2 = time_best([&] { hipLaunchKernelGGL(k_org_a<false>, dim3(512), dim3(256), PN_XBYTES + 1024, 0, b, tiles, c[0], c[1], c[2]); });
         printf("{\"noisy\": %d, \"org\": \"A, one workgroup per CU\", \"valu_build_tail\": [%d, %d], \"copy_out\": %d, \"us_per_tile_and_cu\": %.2f}\n", noisy, c[0], c[1], c[2], a1 * 1e3 / (per_cu / 2));
         printf("{\"noisy\": %d, \"org\": \"A, two workgroups per CU (shipped)\", \"valu_build_tail\": [%d, %d], \"copy_out\": %d, \"us_per_tile_and_cu\": %.2f}\n", noisy, c[0], c[1], c[2], a2 * 1e3 / per_cu);
+        {
+            const float e = time_best([&] { hipLaunchKernelGGL(k_org_e, dim3(256), dim3(256), 2 * PN_XBYTES + 1024, 0, b, tiles, c[0], c[1], c[2]); });
+            printf("{\"noisy\": %d, \"org\": \"E, weight-stationary over two tiles, one 4-wave workgroup per CU\", \"valu_build_tail\": [%d, %d], \"copy_out\": %d, \"us_per_tile_and_cu\": %.2f, \"vs_A\": %.3f}\n",
+                   noisy, c[0], c[1], c[2], e * 1e3 / per_cu, e / a2);
+        }
         for (int k = 0; k < 3; ++k) {
             const Sched s = scheds[k];
             const float r = time_best([&] { hipLaunchKernelGGL(k_org_r, dim3(256), dim3(512), 2 * PN_XBYTES + 1024, 0, b, tiles, c[0], c[1], c[2], s); });
