@@ -526,19 +526,27 @@ def set_wgrad_planes(n):
 def mfma_rate_tflops(mode=2, ms_target=60.0, device=None):
     """TFLOP/s of register-resident v_mfma_f32_32x32x16_f16 on the whole chip (pnerf_debug_mfma_rate; mode 0 zero operands, 1 one constant,
     2 pseudo-random f16: operands that toggle like a GEMM's): the matrix-pipe ceiling bench.py reports beside the nominal 2.5 PFLOP/s.
-    Two launches: a short one to settle the clock, one of ~``ms_target`` that is timed."""
+    The clock needs time to come up from idle and to settle under the power management: launches of ~``ms_target`` are repeated until two
+    consecutive ones agree to 3 % (at most eight) and the last one is reported -- the SUSTAINED rate (the first launches of a cold process run at the
+    clock's way up from idle, the first ones with toggling operands at a clock the power management has not yet taken back)."""
     import ctypes
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     scratch = torch.zeros(256, dtype=torch.float32, device=dev)
     flop = ctypes.c_double(0.0)
     iters = max(int(ms_target / 1000.0 * 2.4e9 / (2 * 32 * 32)), 64)          # two waves per SIMD x 32 MFMAs of 32 cycles per iteration
-    for it in (iters // 4, iters):
+    last = 0.0
+    for _ in range(8):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        L.check(L.lib().pnerf_debug_mfma_rate(int(mode), int(it), _ptr(scratch), ctypes.byref(flop), _stream()), "pnerf_debug_mfma_rate")
+        L.check(L.lib().pnerf_debug_mfma_rate(int(mode), int(iters), _ptr(scratch), ctypes.byref(flop), _stream()), "pnerf_debug_mfma_rate")
         e1.record()
         e1.synchronize()
-    return flop.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        rate = flop.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        settled = last > 0.0 and abs(rate - last) <= 0.03 * last
+        last = rate
+        if settled:
+            break
+    return last
 
 
 def prof_enable(on=True):

@@ -122,9 +122,11 @@ def test_measured_matrix_pipe_ceiling_is_sane():
     """ops.mfma_rate_tflops (pnerf_debug_mfma_rate): the f16 matrix pipe's sustained rate, timed on this box -- between a fifth of the nominal 2.5 PFLOP/s and
     the nominal figure, and not HIGHER with operands that toggle than with one constant (measured on MI355X: 1.70 vs 2.33 PFLOP/s)."""
     from pointnerf_amd import ops
+    ops.mfma_rate_tflops(1, ms_target=30.0)                  # (the first call of a cold process also pays the clock's way up from idle)
     const, rnd = ops.mfma_rate_tflops(1, ms_target=30.0), ops.mfma_rate_tflops(2, ms_target=30.0)
     print("matrix pipe, register-resident f16 MFMA: constant operands %.0f TFLOP/s, pseudo-random operands %.0f TFLOP/s" % (const, rnd))
-    assert 500.0 < rnd <= 1.05 * const and const < 2700.0, (const, rnd)
+    # sanity only (this is a measurement aid, not a parity claim): both inside physical bounds, toggling operands not clearly FASTER than constants
+    assert 500.0 < rnd < 2700.0 and 500.0 < const < 2700.0 and rnd <= 1.15 * const, (const, rnd)
 
 
 def test_collective_selftest_on_rccl_with_one_rank():
