@@ -798,12 +798,17 @@ template <int N> __device__ __forceinline__ void pn_wait_vm_stages(int stages) {
 // RS = rows per stage (16 or 32), NST = ring depth.  A stage is one barrier, one LDS round trip for the fragments and RS / 16 x 9 MFMAs per wave,
 // and the two waves of a SIMD run it in lockstep: with 16-row stages a stage took ~1.1 us whatever it streamed -- the kernel was bound by
 // the per-stage rendezvous, not by HBM.  32-row stages halve the rendezvous per row; four ring slots of 32 .. 34 KB keep ~100 KB per CU in flight.
-template <int NFB, int MF, int RS, int NST>
+// TWO (round 5): the fp32-class mode (pnerf_set_wgrad_planes(2)) in ONE pass -- a stage holds both planes of both operands,
+// [dYh | Xh | dYm | Xm], and every fragment pair gets the three products dYh Xh + dYh Xm + dYm Xh.  Round 4 ran the one-plane kernel three times
+// per layer (six plane streams, three partial reductions); this streams four.
+template <int NFB, int MF, int RS, int NST, bool TWO = false>
 __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, const uint4 *__restrict__ B,
-                                                   const int *__restrict__ d_tiles, float *__restrict__ partial) {
+                                                   const int *__restrict__ d_tiles, float *__restrict__ partial,
+                                                   const uint4 *__restrict__ Am = nullptr, const uint4 *__restrict__ Bm = nullptr) {
     constexpr int RG = RS / 8;                                // row groups (8 rows) per stage
     constexpr int AU = RG * MF, BU = RG * NFB;                // units (16 B) of one plane of a stage
-    constexpr int STAGE = AU + BU;                            // [dY | X]
+    constexpr int HALF = AU + BU;                             // [dY | X] of one plane pair
+    constexpr int STAGE = TWO ? 2 * HALF : HALF;              // TWO: [dYh | Xh | dYm | Xm]
     constexpr int NI = STAGE / 64, NIW = (NI + 7) / 8;        // wave-instructions per stage, per wave (the last ones are padded)
     static_assert((NST - 2) * NIW <= 63 && NST >= 3 && NST <= 5, "vmcnt is a 6-bit count");
     constexpr int MTW = MF / 64, NTW = NFB >= 256 ? 2 : 1;    // m-tiles / main n-tiles per wave
@@ -838,7 +843,9 @@ __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, 
             const uint4 *dst = smem_w + (pad ? NST * STAGE : buf * STAGE + u0);
             const uint4 *src;
             if (u0 < AU) src = A + rg * MF + u0;
-            else src = B + rg * NFB + (u0 - AU);
+            else if (u0 < HALF) src = B + rg * NFB + (u0 - AU);
+            else if (u0 < HALF + AU) src = Am + rg * MF + (u0 - HALF);
+            else src = Bm + rg * NFB + (u0 - HALF - AU);
             __builtin_amdgcn_global_load_lds(src + lane, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
     };
@@ -859,24 +866,51 @@ __global__ __launch_bounds__(512) void k_wgrad_f16(const uint4 *__restrict__ A, 
             for (int kk = 0; kk < RS / 16; ++kk) {            // 16 rows (two row groups) per MFMA k-step
                 const uint4 *fa = st + (2 * kk + (lane >> 5)) * MF + (lane & 31);
                 const uint4 *fb = st + AU + (2 * kk + (lane >> 5)) * NFB + (lane & 31);
-                pn_h8 ah[MTW], bh[NTW];
+                pn_h8 ah[MTW], bh[NTW], am[TWO ? MTW : 1], bm[TWO ? NTW : 1];
 #pragma unroll
                 for (int i = 0; i < MTW; ++i) ah[i] = __builtin_bit_cast(pn_h8, fa[(MTW * wm + i) * 32]);
 #pragma unroll
                 for (int i = 0; i < NTW; ++i) bh[i] = __builtin_bit_cast(pn_h8, fb[(NTW * wn + i) * 32]);
+                if (TWO) {
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i) am[i] = __builtin_bit_cast(pn_h8, fa[HALF + (MTW * wm + i) * 32]);
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i) bm[i] = __builtin_bit_cast(pn_h8, fb[HALF + (NTW * wn + i) * 32]);
+                }
 #pragma unroll
                 for (int i = 0; i < MTW; ++i)
 #pragma unroll
                     for (int j = 0; j < NTW; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                if (TWO) {
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[i], bh[j], acc[i][j], 0, 0, 0);
+                }
                 if (has_tail) {
-                    pn_h8 tah;
+                    pn_h8 tah, tam = ah[0];
                     if (MF == 256) tah = wn == 0 ? ah[0] : wn == 1 ? ah[1] : wn == 2 ? ah[MTW > 2 ? 2 : 0] : ah[MTW > 3 ? 3 : 0];
                     else tah = wn == 0 ? ah[0] : ah[MTW > 1 ? 1 : 0];
+                    if (TWO) {
+                        if (MF == 256) tam = wn == 0 ? am[0] : wn == 1 ? am[TWO && MTW > 1 ? 1 : 0] : wn == 2 ? am[TWO && MTW > 2 ? 2 : 0] : am[TWO && MTW > 3 ? 3 : 0];
+                        else tam = wn == 0 ? am[0] : am[TWO && MTW > 1 ? 1 : 0];
+                    }
                     if (TAIL_B) {
                         acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, __builtin_bit_cast(pn_h8, fb[NMAIN]), acct, 0, 0, 0);
+                        if (TWO) {
+                            acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, __builtin_bit_cast(pn_h8, fb[HALF + NMAIN]), acct, 0, 0, 0);
+                            acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tam, __builtin_bit_cast(pn_h8, fb[NMAIN]), acct, 0, 0, 0);
+                        }
                     } else {
                         acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tah, ones, acct, 0, 0, 0);
+                        if (TWO) acct = __builtin_amdgcn_mfma_f32_32x32x16_f16(tam, ones, acct, 0, 0, 0);      // (the bias gradient takes both planes of dY)
                     }
                 }
             }
@@ -925,18 +959,19 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_f16(const float *__restric
     }
 }
 
-template <int NFB, int MF, int RS, int NST>
+template <int NFB, int MF, int RS, int NST, bool TWO = false>
 int launch_wgrad_f16(const uint4 *A, const uint4 *B, const int *d_tiles, long long rows_max, float *partial, const unsigned *gscale,
-                     float *grad, int dst_w, int ldc, int Nreal, int bias_col, int dst_b, hipStream_t s) {
+                     float *grad, int dst_w, int ldc, int Nreal, int bias_col, int dst_b, hipStream_t s, const uint4 *Am = nullptr, const uint4 *Bm = nullptr) {
     int chunks = WG_CHUNKS;
     const long long tiles = rows_max / PN_TILE;
     if (tiles < chunks) chunks = (int)(tiles > 0 ? tiles : 1);
     if ((size_t)chunks * 256 * 288 > PARTIAL_FLOATS) return PNERF_E_WS;
-    constexpr size_t lds = ((size_t)NST * (RS / 8) * (MF + NFB) + 64) * 16;   // the stages [dY | X] + the pad slot
+    if (TWO && (!Am || !Bm)) return PNERF_E_INVAL;
+    constexpr size_t lds = ((size_t)NST * (TWO ? 2 : 1) * (RS / 8) * (MF + NFB) + 64) * 16;   // the stages [dY | X] (TWO: both planes of each) + the pad slot
     static_assert(lds <= 160 * 1024, "wgrad ring");
-    if (hipFuncSetAttribute((const void *)k_wgrad_f16<NFB, MF, RS, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PNERF_E_LAUNCH;
+    if (hipFuncSetAttribute((const void *)k_wgrad_f16<NFB, MF, RS, NST, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PNERF_E_LAUNCH;
     { PnProfScope prof(PNK_WGRAD, s);
-    hipLaunchKernelGGL((k_wgrad_f16<NFB, MF, RS, NST>), dim3(chunks), dim3(512), lds, s, A, B, d_tiles, partial); }
+    hipLaunchKernelGGL((k_wgrad_f16<NFB, MF, RS, NST, TWO>), dim3(chunks), dim3(512), lds, s, A, B, d_tiles, partial, Am, Bm); }
     PnProfScope prof(PNK_WGRAD_REDUCE, s);
     hipLaunchKernelGGL(k_wgrad_reduce_f16, dim3(pn_cdiv((long long)MF * 288, 64)), dim3(256), 0, s, partial, chunks, MF, Nreal, bias_col, gscale, grad, dst_w, ldc, dst_b);
     PN_CHECK_LAUNCH();
@@ -1268,6 +1303,23 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     const int *dt = sv.cls_info + PN_CI_TILES;
     int rc;
     float *g = d_grad_params;
+    const int *ct = sv.cls_info + PN_CI_CTILES;
+    if (wg2) {
+        // two-plane weight-gradient mode: dW = dYh^T Xh + dYh^T Xm + dYm^T Xh in ONE pass per layer (k_wgrad_f16<.., TWO>: a stage holds both planes of
+        // both operands; round 4 ran the one-plane kernel three times per layer).  16-row stages: four planes of 32 rows would not leave four ring slots.
+        // The bias gradients take both planes of dY: the operands' own ones column (layers 1 and 3) has a zero residual, the constant-ones tail
+        // (layers 2 and 4) is multiplied with dYh and dYm.
+        if ((rc = launch_wgrad_f16<PN_NF1, PN_H, 16, 4, true>(sv.dy1k, sv.x0k, dt, rows, d_partials, sv.gscale, g, PO_W1, PN_IN1, PN_IN1, PN_ONES1, PO_B1, s, sv.dy1m, sv.x0m))) return rc;
+        if ((rc = launch_wgrad_f16<PN_H, PN_H, 16, 4, true>(sv.dy2k, sv.h1k, dt, rows, d_partials, sv.gscale, g, PO_W2, PN_H, PN_H, PN_H, PO_B2, s, sv.dy2m, sv.h1m))) return rc;
+        if ((rc = launch_wgrad_f16<PN_NF1, PN_H, 16, 4, true>(sv.dy3k, sv.h2k, dt, rows, d_partials, sv.gscale, g, PO_W3, PN_IN3, PN_IN3, PN_ONES3, PO_B3, s, sv.dy3m, sv.h2m))) return rc;
+        if ((rc = launch_wgrad_f16<PN_H, PN_H, 16, 4, true>(sv.dy4k, sv.h3k, dt, rows, d_partials, sv.gscale, g, PO_W4, PN_H, PN_H, PN_H, PO_B4, s, sv.dy4m, sv.h3m))) return rc;
+        // the three colour layers: samples instead of neighbor rows, 128 output features; their bias gradients were summed by k_color_backward
+        if ((rc = launch_wgrad_f16<PN_NF1, PN_HC, 16, 4, true>(sv.dc1k, sv.xck, ct, sv.samples, d_partials, sv.gscale, g, PO_WC1, PN_INC, PN_INC, -1, 0, s, sv.dc1m, sv.xcm))) return rc;
+        if ((rc = launch_wgrad_f16<PN_HC, PN_HC, 16, 4, true>(sv.dc2k, sv.c1k, ct, sv.samples, d_partials, sv.gscale, g, PO_WC2, PN_HC, PN_HC, -1, 0, s, sv.dc2m, sv.c1m))) return rc;
+        if ((rc = launch_wgrad_f16<PN_HC, PN_HC, 16, 4, true>(sv.dc3k, sv.c2k, ct, sv.samples, d_partials, sv.gscale, g, PO_WC3, PN_HC, PN_HC, -1, 0, s, sv.dc3m, sv.c2m))) return rc;
+        (void)smp;
+        return 0;
+    }
     if (x0_saved) {        // the stand-alone aggregator (perspective coordinates from its caller): X0 planes saved by the forward
         if ((rc = launch_wgrad_f16<PN_NF1, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy1k, sv.x0k, dt, rows, d_partials, sv.gscale, g, PO_W1, PN_IN1, PN_IN1, PN_ONES1, PO_B1, s))) return rc;
     } else {               // the fused path: X0 rebuilt from the gather
@@ -1279,26 +1331,6 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     if ((rc = launch_wgrad_f16<PN_H, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy2k, sv.h1k, dt, rows, d_partials, sv.gscale, g, PO_W2, PN_H, PN_H, PN_H, PO_B2, s))) return rc;
     if ((rc = launch_wgrad_f16<PN_NF1, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy3k, sv.h2k, dt, rows, d_partials, sv.gscale, g, PO_W3, PN_IN3, PN_IN3, PN_ONES3, PO_B3, s))) return rc;
     if ((rc = launch_wgrad_f16<PN_H, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy4k, sv.h3k, dt, rows, d_partials, sv.gscale, g, PO_W4, PN_H, PN_H, PN_H, PO_B4, s))) return rc;
-    const int *ct = sv.cls_info + PN_CI_CTILES;
-    if (wg2) {
-        // two-plane weight-gradient mode: dW = dYh^T Xh (above) + dYh^T Xm + dYm^T Xh -- the same kernel on the residual planes, its reduction
-        // ADDS to the gradient.  The constant-ones tail (bias gradient of layers 2 and 4) must not be counted with dYh twice: bias column -1
-        // for the dYh^T Xm launches; the operands' own ones column (layers 1 and 3) has a zero residual.
-        if ((rc = launch_wgrad_f16<PN_NF1, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy1k, sv.x0m, dt, rows, d_partials, sv.gscale, g, PO_W1, PN_IN1, PN_IN1, PN_ONES1, PO_B1, s))) return rc;
-        if ((rc = launch_wgrad_f16<PN_NF1, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy1m, sv.x0k, dt, rows, d_partials, sv.gscale, g, PO_W1, PN_IN1, PN_IN1, PN_ONES1, PO_B1, s))) return rc;
-        if ((rc = launch_wgrad_f16<PN_H, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy2k, sv.h1m, dt, rows, d_partials, sv.gscale, g, PO_W2, PN_H, PN_H, -1, PO_B2, s))) return rc;
-        if ((rc = launch_wgrad_f16<PN_H, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy2m, sv.h1k, dt, rows, d_partials, sv.gscale, g, PO_W2, PN_H, PN_H, PN_H, PO_B2, s))) return rc;
-        if ((rc = launch_wgrad_f16<PN_NF1, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy3k, sv.h2m, dt, rows, d_partials, sv.gscale, g, PO_W3, PN_IN3, PN_IN3, PN_ONES3, PO_B3, s))) return rc;
-        if ((rc = launch_wgrad_f16<PN_NF1, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy3m, sv.h2k, dt, rows, d_partials, sv.gscale, g, PO_W3, PN_IN3, PN_IN3, PN_ONES3, PO_B3, s))) return rc;
-        if ((rc = launch_wgrad_f16<PN_H, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy4k, sv.h3m, dt, rows, d_partials, sv.gscale, g, PO_W4, PN_H, PN_H, -1, PO_B4, s))) return rc;
-        if ((rc = launch_wgrad_f16<PN_H, PN_H, PN_WG_RS, PN_WG_NST>(sv.dy4m, sv.h3k, dt, rows, d_partials, sv.gscale, g, PO_W4, PN_H, PN_H, PN_H, PO_B4, s))) return rc;
-        if ((rc = launch_wgrad_f16<PN_NF1, PN_HC, 16, 4>(sv.dc1k, sv.xcm, ct, sv.samples, d_partials, sv.gscale, g, PO_WC1, PN_INC, PN_INC, -1, 0, s))) return rc;
-        if ((rc = launch_wgrad_f16<PN_NF1, PN_HC, 16, 4>(sv.dc1m, sv.xck, ct, sv.samples, d_partials, sv.gscale, g, PO_WC1, PN_INC, PN_INC, -1, 0, s))) return rc;
-        if ((rc = launch_wgrad_f16<PN_HC, PN_HC, 16, 4>(sv.dc2k, sv.c1m, ct, sv.samples, d_partials, sv.gscale, g, PO_WC2, PN_HC, PN_HC, -1, 0, s))) return rc;
-        if ((rc = launch_wgrad_f16<PN_HC, PN_HC, 16, 4>(sv.dc2m, sv.c1k, ct, sv.samples, d_partials, sv.gscale, g, PO_WC2, PN_HC, PN_HC, -1, 0, s))) return rc;
-        if ((rc = launch_wgrad_f16<PN_HC, PN_HC, 16, 4>(sv.dc3k, sv.c2m, ct, sv.samples, d_partials, sv.gscale, g, PO_WC3, PN_HC, PN_HC, -1, 0, s))) return rc;
-        if ((rc = launch_wgrad_f16<PN_HC, PN_HC, 16, 4>(sv.dc3m, sv.c2k, ct, sv.samples, d_partials, sv.gscale, g, PO_WC3, PN_HC, PN_HC, -1, 0, s))) return rc;
-    }
     // the three colour layers: samples instead of neighbor rows, 128 output features; their bias gradients were summed by k_color_backward
     (void)smp;
     if ((rc = launch_wgrad_f16<PN_NF1, PN_HC, 16, 4>(sv.dc1k, sv.xck, ct, sv.samples, d_partials, sv.gscale, g, PO_WC1, PN_INC, PN_INC, -1, 0, s))) return rc;
