@@ -281,6 +281,7 @@ extern "C" int pnerf_query(const pnerf_grid_params *gp, const void *d_grid_ws, c
     const int grid = nbk < 16 * ncu ? nbk : 16 * ncu;
     if (K <= 4) hipLaunchKernelGGL(k_neighbors<4>, dim3(grid), dim3(TPB), 0, s, g, gp->kernel_size[0], radius2, R, SR, K, d_sample_loc, sel_off, d_sample_pidx, d_sample_nn);
     else if (K <= 8) hipLaunchKernelGGL(k_neighbors<8>, dim3(grid), dim3(TPB), 0, s, g, gp->kernel_size[0], radius2, R, SR, K, d_sample_loc, sel_off, d_sample_pidx, d_sample_nn);
+    else if (K <= 12) hipLaunchKernelGGL(k_neighbors<12>, dim3(grid), dim3(TPB), 0, s, g, gp->kernel_size[0], radius2, R, SR, K, d_sample_loc, sel_off, d_sample_pidx, d_sample_nn);      // (configs[4]: K = 12)
     else hipLaunchKernelGGL(k_neighbors<16>, dim3(grid), dim3(TPB), 0, s, g, gp->kernel_size[0], radius2, R, SR, K, d_sample_loc, sel_off, d_sample_pidx, d_sample_nn);
     }
     PnProfScope prof(PNK_COMPACT, s);
