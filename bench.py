@@ -337,7 +337,12 @@ def main():
                          % (args.gpus, world, args.gpus, args.gpus))
     dist_on = world > 1 or args.force_collectives
     if args.force_collectives:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29800 + os.getpid() % 100))
+        if "MASTER_PORT" not in os.environ:             # a port nobody holds (a fixed one can collide with a neighbouring run)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
     if dist_on:
         # "nccl" IS RCCL on ROCm.  PNERF_DIST_BACKEND=gloo exists only so that tests can run 2 ranks on a 1-GPU box.

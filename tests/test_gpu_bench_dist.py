@@ -63,10 +63,18 @@ def test_touched_flags_kernel_equals_the_torch_form():
     assert pdist.touched_flags(torch.zeros(4, 8, dtype=torch.int32, device=dev), 0).numel() == 0
 
 
+def _free_port():
+    """a port nobody holds right now (fixed port formulas of neighbouring tests can collide)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _two_ranks(extra, port_off):
     env = dict(os.environ, PNERF_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29600 + (os.getpid() + port_off) % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--rays", "4096", "--points", "300000", "--cpu-rays", "0"] + extra
     out = subprocess.check_output(cmd, cwd=ROOT, env=env, timeout=900, stderr=subprocess.STDOUT)
     assert b"rccl_selftest: ok" in out and b"world=2" in out, out.decode()[-2000:]        # every collective form of the step ran once before the timing
@@ -137,7 +145,9 @@ def test_collective_selftest_on_rccl_with_one_rank():
     code = (
         "import os, sys, torch\n"
         "sys.path.insert(0, %r)\n"
-        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29700 + os.getpid() %% 200), RANK='0', WORLD_SIZE='1')\n"
+        "import socket\n"
+        "sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')\n"
         "import bench\n"
         "with bench.Watchdog('init_process_group', 120, 0, 1):\n"
         "    torch.distributed.init_process_group(backend='nccl')\n"

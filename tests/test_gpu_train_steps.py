@@ -165,8 +165,12 @@ def test_speculative_step_with_two_ranks_whose_counts_differ():
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
+    import socket
+    with socket.socket() as sk:                       # a port nobody holds right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29900 + os.getpid() % 90), os.path.join(here, "spec_two_ranks.py")]
+           "--master-port", str(port), os.path.join(here, "spec_two_ranks.py")]
     out = subprocess.check_output(cmd, cwd=os.path.dirname(here), env=dict(os.environ, MASTER_ADDR="127.0.0.1"), timeout=600, stderr=subprocess.STDOUT).decode()
     recs = json.loads([l for l in out.splitlines() if l.startswith("[{")][-1])
     r0, r1 = recs
