@@ -13,6 +13,14 @@ from pointnerf_amd import dist as pdist
 from oracle import pyref
 
 
+def _free_port():
+    """a port nobody holds right now"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _grads(opt, xyz, attrs, inp, mlp, sl):
     mlp = {k: v.clone().requires_grad_(True) for k, v in mlp.items()}
     pts = dict(xyz=xyz, **{k: v.clone().requires_grad_(True) for k, v in attrs.items()})
@@ -49,7 +57,7 @@ def test_two_rank_ray_shard_equals_single_process():
     loss1, m1, p1 = _grads(opt, xyz, attrs, inp, mlp, slice(None))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -105,7 +113,7 @@ def test_model_shell_loss_items_are_globally_normalised(tmp_path):
     one = _shell_losses(str(tmp_path), raw, gt, bg, slice(0, raw["ray_mask"].shape[1]), hb)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_shell_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
     for p in procs:
         p.start()
@@ -172,7 +180,7 @@ def test_sparse_touched_row_exchange_equals_dense_allreduce(tmp_path):
     """three ranks: the touched-row exchange gives the dense all-reduce's sums (fp32 association aside) and BITWISE the same
     tensors on every rank"""
     world = 3
-    port = 29500 + (os.getpid() + 777) % 2000
+    port = _free_port()
     mp.spawn(_sparse_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     res = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(world)]
     for r in range(world):
@@ -248,7 +256,7 @@ def test_eight_ranks_every_exchange_form_three_steps_replicas_identical(tmp_path
     (`plan_sparse_exchange` + `sparse_allreduce_rows`, unequal counts, one rank with none) and the ZeRO-1 `ShardedAdam`, three Adam steps each:
     every rank ends with BITWISE the same parameters, and the three forms agree to summation order."""
     world = 8
-    port = 29500 + (os.getpid() + 1234) % 2000
+    port = _free_port()
     mp.spawn(_eight_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     res = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(world)]
     for form in ("dense", "sparse", "zero1"):
