@@ -13,7 +13,11 @@ the hot path over one batch of `--rays` rays per GPU, inputs already resident in
     -> backward -> [N>1: RCCL all-reduce of the gradients] -> 2x Adam (MLP lr, points plr) .
 N>1 shards the rays of the global batch across ranks with the point cloud and MLP replicated (weak scaling:
 per-GPU ray count fixed); the only collectives are the gradient all-reduce and a 2-float loss normaliser.
-Rank 0 prints ONE JSON line; `value` is whole-job rays/sec.
+Rank 0 prints ONE JSON line; `value` is whole-job rays/sec.  `roofline` (dominant kernel): `frac` = SURVEY 8d algorithmic work / nominal peak,
+`frac_executed` = executed f16 products / nominal peak, `peak_measured` = the ceiling timed in this run (f16 MFMA with toggling operands:
+pnerf_debug_mfma_rate; HBM entries: a 1 GiB device copy), `traffic` = PMC bytes of the committed profile pass (stamped with its commit).
+`cpu_baseline`: kind "port" (oracle) on the GPU box, "reference" where /root/reference imports (`--cpu-baseline-only`).
+`--force-collectives`: one-rank RCCL bring-up of every collective of the step; N > 1 runs are guarded by watchdogs that leave a record.
 """
 import argparse
 import json
