@@ -89,3 +89,24 @@ def test_bench_watchdog_leaves_a_record_and_exits():
     assert r.returncode == 17, (r.returncode, r.stderr[-500:])
     rec = json.loads([l for l in r.stderr.splitlines() if l.startswith("{")][-1])
     assert "the stuck stage" in rec["bench_watchdog"] and rec["rank"] == 3 and rec["world"] == 8 and rec["env"]["NCCL_DEBUG"] == "WARN" and "NCCL_DEBUG=INFO" in rec["hint"]
+
+
+def test_fill_invalid_on_dense_results_equals_the_scatter_form():
+    """neural_points_volumetric_model.py:87-123 two ways: the compacted form (the R'' hit rays scattered back into full-size tensors: the reference's)
+    and the dense form a training step with the fused colour loss hands over (per-ray selects on results that are dense already): same tensors."""
+    import torch
+    from pointnerf_amd.neural_points_volumetric_model import fill_invalid
+    g = torch.Generator().manual_seed(3)
+    R, SR = 37, 6
+    hit = torch.rand(R, generator=g) < 0.6
+    ray_color, opacity, bg_trans = torch.rand(R, 3, generator=g), torch.rand(R, SR, generator=g), torch.rand(R, generator=g)
+    idx = torch.nonzero(hit).squeeze(1)
+    bg = torch.tensor([[0.2, 0.9, 0.4]])
+    compact = dict(ray_mask=hit.to(torch.int8)[None], _hit_index=idx, coarse_raycolor=ray_color[idx][None], coarse_point_opacity=opacity[idx][None],
+                   coarse_is_background=bg_trans[idx][None, :, None], queried_shading=torch.zeros(1, idx.numel(), 3))
+    dense = dict(ray_mask=hit.to(torch.int8)[None], _dense_color=(ray_color, hit.to(torch.int32), int(hit.sum())), _dense_aux=(opacity, bg_trans))
+    for bg_ray in (None, torch.rand(1, R, 3, generator=g)):
+        a, b = fill_invalid(compact, bg, bg_ray=bg_ray), fill_invalid(dense, bg, bg_ray=bg_ray)
+        for k in ("coarse_raycolor", "coarse_point_opacity", "coarse_is_background", "coarse_mask", "queried_shading"):
+            assert a[k].shape == b[k].shape and torch.allclose(a[k], b[k], rtol=0, atol=1e-7), (k, bg_ray is not None)
+        assert not b["coarse_raycolor"].requires_grad
