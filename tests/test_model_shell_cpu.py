@@ -349,3 +349,41 @@ def test_evaluation_loop_scores_views_like_the_reference():
     for k in ("coarse_raycolor", "ray_masked_coarse_raycolor", "coarse_raycolor_psnr", "ray_masked_coarse_raycolor_psnr"):
         assert abs(avg[k] - np.mean([r[k] for r in refs])) <= 1e-5 * max(1.0, abs(np.mean([r[k] for r in refs]))), k
     assert abs(psnr - avg["coarse_raycolor_psnr"]) < 1e-12           # the first item of test_color_loss_items is what test() returns
+
+
+def test_compute_losses_on_the_fused_colour_form_equals_the_compacted_form(tmp_path, monkeypatch):
+    """MvsPointsVolumetricModel.compute_losses with the renderer's dense results (`_dense_color`: the form a device training step hands over since round 5)
+    against the same data in the compacted form: every loss item of the lego script (ray_masked 1.0, ray_miss 0.0, full image 0.0) and the total agree,
+    and only the ray_masked item carries a gradient to the ray colours.  The fused pass itself (ops.ColorLossRays, a HIP kernel) is replaced by its
+    torch statement here; tests/test_gpu_backward.py compares the kernel with that statement on the device."""
+    import torch
+    from pointnerf_amd import config, ops
+    from pointnerf_amd.mvs_points_volumetric_model import create_model
+    from pointnerf_amd.neural_points_volumetric_model import fill_invalid
+    monkeypatch.setattr(ops, "color_loss_sum_rays", lambda color, gt, ray_hit: (((color - gt) ** 2) * (ray_hit > 0)[:, None]).sum())
+    g = torch.Generator().manual_seed(9)
+    R, SR = 41, 8
+    hit = torch.rand(R, generator=g) < 0.55
+    idx = torch.nonzero(hit).squeeze(1)
+    gt, bg = torch.rand(1, R, 3, generator=g), torch.ones(1, 3)
+    opacity, bg_trans = torch.rand(R, SR, generator=g), torch.rand(R, generator=g)
+    res = {}
+    for form in ("compacted", "dense"):
+        color = torch.rand(R, 3, generator=torch.Generator().manual_seed(10)).requires_grad_(True)
+        opt = config.lego_train_opt(gpu_ids=[], checkpoints_dir=str(tmp_path), name="run_" + form, num_point=0, K=4, SR=SR)
+        m = create_model(opt)
+        m.set_input(dict(gt_image=gt, bg_color=bg))
+        if form == "compacted":
+            raw = dict(ray_mask=hit.to(torch.int8)[None], _hit_index=idx, coarse_raycolor=color[idx][None], coarse_point_opacity=opacity[idx][None],
+                       coarse_is_background=bg_trans[idx][None, :, None], queried_shading=torch.zeros(1, idx.numel(), 3))
+        else:
+            raw = dict(ray_mask=hit.to(torch.int8)[None], _dense_color=(color, hit.to(torch.int32), int(hit.sum())), _dense_aux=(opacity, bg_trans))
+        m._raw, m.output = raw, fill_invalid(raw, bg)
+        m.compute_losses()
+        m.loss_total.backward()
+        res[form] = ({k: float(v) for k, v in m.get_current_losses().items()}, color.grad.clone())
+    (la, ga), (lb, gb) = res["compacted"], res["dense"]
+    assert set(la) == set(lb)
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-6 * max(1.0, abs(la[k])), (k, la[k], lb[k])
+    assert torch.allclose(ga, gb, rtol=1e-6, atol=1e-9) and float(gb[~hit].abs().max()) == 0.0 and float(gb[hit].abs().max()) > 0.0
