@@ -327,6 +327,11 @@ int pnerf_point_dirs(const float *d_cam_xyz, int64_t n_points, const float *cam_
  * D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31]).  The tests pin with it the fragment layout and the un-flushed handling of f16
  * subnormal inputs that the two-plane GEMMs of the aggregator (csrc/f16x3.h) rely on. */
 int pnerf_debug_mfma_f16(const void *d_a, const void *d_b, float *d_out, void *stream);
+/* ONE tile GEMM in the mixed format of csrc/mixq.h (f16 h.h + e4m3 cross terms): d_out [64][256] = d_x [64][K] d_w[256][K]^T, K in {256, 272, 288}
+ * (columns >= 256 run the classic three f16 products), through the tile's LDS format and a packed weight image written to d_img
+ * (>= pnerf_mlp_packed_bytes()).  Tests measure it against float64 on the device and against the numpy restatement of the format on the host
+ * emulator.  The arithmetic stands behind the nn.Linear layers of models/aggregators/point_aggregators.py:286-344. */
+int pnerf_debug_mix_gemm(const float *d_w, int K, const float *d_x, void *d_img, float *d_out, void *stream);
 /* measurement aid of bench.py (roofline.peak_measured of the matrix-pipe entries; no reference counterpart): `iters` x 32 register-resident
  * v_mfma_f32_32x32x16_f16 per wave on 2 x 256-thread workgroups per CU, operands all zero (mode 0), one constant (1) or pseudo-random f16 in
  * +-[0.5, 1) (2: they toggle like a GEMM's fragments).  Asynchronous on `stream`; the caller times it with events.  *flop_out = the flops the

@@ -115,6 +115,7 @@ PROTOTYPES = {
     "pnerf_raymarch_backward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_f32), c_int, c_int,
                                         c_void_p, c_void_p, c_void_p]),
     "pnerf_debug_mfma_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pnerf_debug_mix_gemm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pnerf_debug_mfma_rate": (c_int, [c_int, c_int, c_void_p, ctypes.POINTER(ctypes.c_double), c_void_p]),
     "pnerf_debug_uniform": (c_int, [ctypes.c_uint64, ctypes.c_uint64, c_i64, c_void_p, c_void_p]),
     "pnerf_debug_split": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_int, c_void_p]),

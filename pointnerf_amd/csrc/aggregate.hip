@@ -13,7 +13,7 @@
 // Two workgroups (4 waves each) share a CU: the second one hides the first one's latencies (its VALU / LDS work does not run under
 // the first one's MFMAs: tools/gemm_probe.hip).  In training mode the operands of the weight-gradient GEMMs are written once, already
 // split into their f16 planes and transposed to the k-major order that kernel streams.
-#include "f16x3.h"
+#include "mixq.h"
 
 // ------------------------------------------------------------------------------ layout / packing
 extern "C" int pnerf_mlp_layout(int feat_dim, int64_t *offsets) {
@@ -23,7 +23,7 @@ extern "C" int pnerf_mlp_layout(int feat_dim, int64_t *offsets) {
     for (int i = 0; i <= PNERF_MLP_NTENSORS; ++i) offsets[i] = o[i];
     return 0;
 }
-extern "C" size_t pnerf_mlp_packed_bytes(void) { return (size_t)PKH_END; }
+extern "C" size_t pnerf_mlp_packed_bytes(void) { return (size_t)PKM_END; }
 
 namespace {
 // two-plane f16 images of the aggregator and colour layers (f16x3.h): forward W[m][k] (trans = 0: m = output unit, k = input column)
@@ -57,6 +57,79 @@ __global__ __launch_bounds__(256) void k_pack_h(PackHTable t, const float *__res
         o[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     }
 }
+
+// mixed-format images of the eight aggregator GEMMs (mixq.h): per (superchunk, feature block, lane) four f16 h fragments, two e4m3 fragments
+// [q8(wm 2^11 / 2^e) x 8 | q8(wh / 2^e) x 8] per 8-column group with the lane's block scale e, then the classic two-plane tail chunks
+struct PackMDesc { int src, ld, trans, Mreal, Kreal, NT, MB, dst; };
+struct PackMTable { PackMDesc d[8]; };
+__global__ __launch_bounds__(256) void k_pack_mix(PackMTable t, const float *__restrict__ params, char *__restrict__ packed) {
+    pn_mode_saturate();
+    const PackMDesc d = t.d[blockIdx.y];
+    auto W = [&](int m, int k) -> float { return (m < d.Mreal && k < d.Kreal) ? (d.trans ? params[d.src + k * d.ld + m] : params[d.src + m * d.ld + k]) : 0.f; };
+    uint4 *img = reinterpret_cast<uint4 *>(packed + d.dst);
+    unsigned *sc = reinterpret_cast<unsigned *>(img + PN_MIMG_U4(d.NT, d.MB));
+    const int nsup = PN_MIX_NS * d.MB * 64, ntail = d.NT * d.MB * 64;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < nsup + ntail; e += gridDim.x * 256) {
+        if (e < nsup) {
+            const int lane = e & 63, mb = (e >> 6) % d.MB, s = (e >> 6) / d.MB, m = 32 * mb + (lane & 31), hf = lane >> 5;
+            uint4 *o = img + ((size_t)(s * d.MB + mb) * 8) * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k0 = 64 * s + 16 * r + 8 * hf;
+                unsigned h[4], lo[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pn_split2_rne(W(m, k0 + 2 * j), W(m, k0 + 2 * j + 1), h[j], lo[j]);
+                o[r * 64] = make_uint4(h[0], h[1], h[2], h[3]);
+            }
+            unsigned scw = 0u;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float wh[16], wm[16], mx = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float w = W(m, 8 * (8 * s + 4 * j + 2 * hf + (i >> 3)) + (i & 7));
+#ifdef PN_EMU
+                    const float wc = fmaxf(fminf(w, 65504.f), -65504.f);
+#else
+                    const float wc = w;
+#endif
+                    wh[i] = (float)(_Float16)wc; wm[i] = w - wh[i];
+                    mx = fmaxf(mx, fmaxf(fabsf(wh[i]), fabsf(wm[i]) * 2048.f));
+                }
+                int ex = 0;
+                const float fr = frexpf(mx, &ex);
+                int be = mx > 0.f ? (fr > 0.875f ? ex - 8 : ex - 9) : 0;            // the largest slot / 2^be lies in (224, 448]
+                be = be < -100 ? -100 : (be > 100 ? 100 : be);
+                const float sh = __uint_as_float((unsigned)(be + 127) << 23), sm = __uint_as_float((unsigned)(be + 127 - 11) << 23);
+                scw |= (unsigned)(be + 127) << (8 * j);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    unsigned q[4];
+#pragma unroll
+                    for (int w4 = 0; w4 < 4; ++w4) {
+                        const float *src = (w4 < 2 ? wm : wh) + 8 * tt + 4 * (w4 & 1);
+                        const float scl = w4 < 2 ? sm : sh;
+                        pn_s2 r = {0, 0};
+                        r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, src[0], src[1], scl, false);
+                        r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, src[2], src[3], scl, true);
+                        q[w4] = __builtin_bit_cast(unsigned, r);
+                    }
+                    o[(4 + 2 * j + tt) * 64] = make_uint4(q[0], q[1], q[2], q[3]);
+                }
+            }
+            sc[(size_t)(s * d.MB + mb) * 64 + lane] = scw;
+        } else {
+            const int e2 = e - nsup, lane = e2 & 63, mb = (e2 >> 6) % d.MB, tc = (e2 >> 6) / d.MB, m = 32 * mb + (lane & 31);
+            const int k0 = 256 + 16 * tc + 8 * (lane >> 5);
+            unsigned h[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pn_split2_sat(W(m, k0 + 2 * j), W(m, k0 + 2 * j + 1), h[j], lo[j]);
+            uint4 *o = img + (size_t)PN_MIX_NS * d.MB * 8 * 64 + ((size_t)(tc * d.MB + mb) * 2) * 64 + lane;
+            o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+            o[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+    }
+}
 }  // namespace
 
 extern "C" int pnerf_mlp_pack(const float *d_params, void *d_packed, void *stream) {
@@ -80,6 +153,68 @@ extern "C" int pnerf_mlp_pack(const float *d_params, void *d_packed, void *strea
     }};
     PnProfScope prof(PNK_PACK, (hipStream_t)stream);
     hipLaunchKernelGGL(k_pack_h, dim3(40, 14), dim3(256), 0, (hipStream_t)stream, th, d_params, (char *)d_packed);
+    PackMTable tm = {{
+        {PO_W1, PN_IN1, 0, PN_H, PN_IN1, 2, 8, PKM_F1},
+        {PO_W2, PN_H, 0, PN_H, PN_H, 0, 8, PKM_F2},
+        {PO_W3, PN_IN3, 0, PN_H, PN_IN3, 1, 8, PKM_F3},
+        {PO_W4, PN_H, 0, PN_H, PN_H, 0, 8, PKM_F4},
+        {PO_W4, PN_H, 1, PN_H, PN_H, 0, 8, PKM_D4},
+        {PO_W3, PN_IN3, 1, PN_IN3, PN_H, 0, 9, PKM_D3},
+        {PO_W2, PN_H, 1, PN_H, PN_H, 0, 8, PKM_D2},
+        {PO_W1, PN_IN1, 1, 32 * PN_MB_D1, PN_H, 0, PN_MB_D1, PKM_D1},
+    }};
+    hipLaunchKernelGGL(k_pack_mix, dim3(12, 8), dim3(256), 0, (hipStream_t)stream, tm, d_params, (char *)d_packed);
+    PN_CHECK_LAUNCH();
+    return 0;
+}
+
+namespace {
+// ---- debug: one mixed tile GEMM D[64][256] = X[64][K] W[256][K]^T through the tile's LDS format and a packed image (tests: against float64 on the
+// device, against the numpy restatement of the format on the host emulator)
+template <int NT>
+__global__ __launch_bounds__(256) void k_debug_mix_gemm(const float *__restrict__ x, const char *__restrict__ img, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_d[];
+    pn_mode_saturate();
+    constexpr int K = 256 + 16 * NT;
+    char *X = smem_d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < PN_TILE * (K / 4); e += 256) {
+        const int row = e / (K / 4), col = 4 * (e % (K / 4));
+        const float4 v = *reinterpret_cast<const float4 *>(x + row * K + col);
+        if (col < 256) pn_xq_store4(X, row, col, v.x, v.y, v.z, v.w);
+        else pn_xt_store4(X, row, col, v.x, v.y, v.z, v.w);
+    }
+    __syncthreads();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    pn_gemm_mix<PN_MIX_NS, NT, 8, 2>(X, img, 2 * wave, lane, acc);
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) out[(32 * rb + (lane & 31)) * PN_H + pn_d_feat(2 * wave + fb, g, lane) + i] = acc[fb][rb][4 * g + i];
+}
+}  // namespace
+
+extern "C" int pnerf_debug_mix_gemm(const float *d_w, int K, const float *d_x, void *d_img, float *d_out, void *stream) {
+    if (!d_w || !d_x || !d_img || !d_out || (K != 256 && K != 272 && K != 288)) return PNERF_E_INVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int NT = (K - 256) / 16;
+    PackMTable tm = {{{0, K, 0, PN_H, K, NT, 8, 0}}};
+    hipLaunchKernelGGL(k_pack_mix, dim3(12, 1), dim3(256), 0, s, tm, d_w, (char *)d_img);
+    const void *fn = NT == 0 ? (const void *)k_debug_mix_gemm<0> : NT == 1 ? (const void *)k_debug_mix_gemm<1> : (const void *)k_debug_mix_gemm<2>;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PN_XBYTES) != hipSuccess) return PNERF_E_LAUNCH;
+    if (NT == 0) hipLaunchKernelGGL(k_debug_mix_gemm<0>, dim3(1), dim3(256), PN_XBYTES, s, d_x, (const char *)d_img, d_out);
+    else if (NT == 1) hipLaunchKernelGGL(k_debug_mix_gemm<1>, dim3(1), dim3(256), PN_XBYTES, s, d_x, (const char *)d_img, d_out);
+    else hipLaunchKernelGGL(k_debug_mix_gemm<2>, dim3(1), dim3(256), PN_XBYTES, s, d_x, (const char *)d_img, d_out);
     PN_CHECK_LAUNCH();
     return 0;
 }

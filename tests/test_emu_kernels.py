@@ -49,6 +49,27 @@ def test_emulated_forward_matches_oracle():
     TR._compare(*build_case("small_k4"))
 
 
+@pytest.mark.parametrize("K", [256, 272, 288])
+def test_emulated_mixed_tile_gemm_matches_the_numpy_restatement(K):
+    """csrc/mixq.h: LDS row format, packed image, block scales, unit schedule -- the emulated kernel equals the numpy restatement of the
+    format to fp32 accumulation noise, and both are within 4e-6 of sum |terms| of the exact product"""
+    import ctypes
+    import mix_case
+    from emu_util import emu_lib
+    for big in (False, True):
+        x, w = mix_case.build(K, big=big)
+        out = np.zeros((64, 256), np.float32)
+        img = np.zeros(emu_lib().pnerf_mlp_packed_bytes(), np.uint8)
+        P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        assert emu_lib().pnerf_debug_mix_gemm(P(w), K, P(x), P(img), P(out), None) == 0
+        ref = mix_case.restate(x, w)
+        ex, sab = mix_case.exact(x, w)
+        assert np.abs(out - ref).max() <= 2e-6 * np.abs(ref).max(), np.abs(out - ref).max()
+        e = (out - ex) / sab
+        print("K", K, "big", big, "rms err / sum|terms| %.2e  max %.2e" % (np.sqrt((e ** 2).mean()), np.abs(e).max()))
+        assert np.abs(e).max() <= 1e-5 and np.sqrt((e ** 2).mean()) <= 2e-6
+
+
 def test_emulated_f16_mfma_layout_and_subnormals():
     import ctypes
     import mfma_case

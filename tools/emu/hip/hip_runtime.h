@@ -171,6 +171,65 @@ template <class V, class E> static inline emu_f32x16 emu_mfma_32x32x16(V a, V b,
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_32x32x2f32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma_32x32x16<emu_bf16x8, __bf16>((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_32x32x16<emu_f16x8, _Float16>((a), (b), (c))
+// ---- gfx950 e4m3 conversions and the block-scaled 8-bit MFMA (semantics measured by tools/mx_probe.hip: value / scale, round to nearest even,
+// subnormal step 2^-9, saturation at +-448 as under MODE.FP16_OVFL = 1; byte j of a lane's A registers meets byte j of the same lane's B
+// registers; 2^(byte - 127) per lane from the byte of the scale operand that op_sel names)
+static inline unsigned char emu_e4m3_enc(float v) {
+    if (std::isnan(v)) return 0x7f;
+    const unsigned char sg = std::signbit(v) ? 0x80 : 0;
+    double a = std::fabs((double)v);
+    if (a >= 448.0) return sg | 0x7e;
+    if (a < 0.015625) {                                   // subnormal: multiples of 2^-9
+        const int q = (int)std::nearbyint(a * 512.0);
+        return q >= 8 ? (sg | 0x08) : (sg | (unsigned char)q);
+    }
+    int e; std::frexp(a, &e); e -= 1;                       // a in [2^e, 2^(e + 1))
+    int q = (int)std::nearbyint(std::ldexp(a, 3 - e));    // 8 .. 16
+    if (q == 16) { q = 8; e += 1; }
+    if (e > 8 || (e == 8 && q > 14)) return sg | 0x7e;
+    return sg | (unsigned char)(((e + 7) << 3) | (q - 8));
+}
+static inline float emu_e4m3_dec(unsigned char b) {
+    const int e = (b >> 3) & 15, m = b & 7;
+    if (e == 15 && m == 7) return NAN;
+    const float v = e == 0 ? std::ldexp((float)m, -9) : std::ldexp(1.0f + m / 8.0f, e - 7);
+    return (b & 0x80) ? -v : v;
+}
+typedef short emu_s2 __attribute__((ext_vector_type(2)));
+static inline emu_s2 emu_cvt_scalef32_pk_fp8(emu_s2 old, float a, float b, float scale, bool hi) {
+    const unsigned short w = (unsigned short)(emu_e4m3_enc(a / scale) | (emu_e4m3_enc(b / scale) << 8));
+    old[hi ? 1 : 0] = (short)w;
+    return old;
+}
+#define __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(old, src, scale, hi) emu_cvt_scalef32_pk_fp8((old), (float)(src)[0], (float)(src)[1], (scale), (hi))
+#define __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(old, a, b, scale, hi) emu_cvt_scalef32_pk_fp8((old), (a), (b), (scale), (hi))
+typedef int emu_i8v __attribute__((ext_vector_type(8)));
+static inline emu_f32x16 emu_mfma_scale_32x32x64_e4m3(emu_i8v a, emu_i8v b, emu_f32x16 c, int osa, int sa, int osb, int sb) {
+    const int l = emu::lane_id();
+    struct { emu_i8v a, b; } ab = {a, b};
+    static_assert(sizeof(ab) == 64, "two 32-byte fragments");
+    char mine[64 * 64];
+    memcpy(mine, emu::wave_exchange(&ab, 64), sizeof(mine));
+    const int sc[2] = {(sa >> (8 * osa)) & 255, (sb >> (8 * osb)) & 255};
+    const char *t2 = emu::wave_exchange(sc, 8);
+    const int j = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        double acc = c[r];
+        for (int kh = 0; kh < 2; ++kh) {
+            const unsigned char *A = (const unsigned char *)mine + 64 * (i + 32 * kh), *B = (const unsigned char *)mine + 64 * (j + 32 * kh) + 32;
+            int sA[2], sB[2];
+            memcpy(sA, t2 + 64 * (i + 32 * kh), 8); memcpy(sB, t2 + 64 * (j + 32 * kh), 8);
+            double s = 0.0;
+            for (int q = 0; q < 32; ++q) s += (double)emu_e4m3_dec(A[q]) * (double)emu_e4m3_dec(B[q]);
+            acc += std::ldexp(s, (sA[0] - 127) + (sB[1] - 127));
+        }
+        c[r] = (float)acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, cbsz, blgp, osa, sa, osb, sb) emu_mfma_scale_32x32x64_e4m3((a), (b), (c), (osa), (sa), (osb), (sb))
+#define __builtin_amdgcn_s_setreg(a, b) ((void)0)
 // v_cvt_pkrtz_f16_f32: two floats -> two halfs, round toward zero (finite inputs never become inf)
 typedef _Float16 emu_h2 __attribute__((ext_vector_type(2)));
 static inline _Float16 emu_f16_rtz(float x) {
