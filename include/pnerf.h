@@ -212,6 +212,15 @@ int pnerf_set_inference_products(int n);
  * twice the bytes (pnerf_agg_saved_bytes grows accordingly: size the arena AFTER choosing the mode, and keep the mode fixed between a
  * training forward and its backward).  Returns the previous setting, or PNERF_E_INVAL for n not in {1, 2}.  Process-wide. */
 int pnerf_set_wgrad_planes(int n);
+/* Arithmetic of the CROSS TERMS of the aggregator's tile GEMMs (the four 256-wide nn.Linear layers of
+ * models/aggregators/point_aggregators.py:286-344, forward and input-gradient chain).  Every fp32 operand is h + m (two f16 numbers, 22 bits) and
+ * a product is h*h + (h*m + m*h): the leading term always runs on f16 factors; the two cross terms, 2^-11 of the result, run on
+ * 8 (default, csrc/mixq.h): e4m3 factors on v_mfma_scale_f32_32x32x64_f8f6f4 (weights with per-lane block scales), 2 instead of 3 matrix-pipe
+ *    passes per multiply-add, 1.3e-6 rms of sum |terms| per 256-term dot product (tests/test_gpu_mix.py);
+ * 16 (csrc/f16x3.h, the arithmetic of rounds 2-5): f16 factors, 3e-8 rms.
+ * The two-plane weight-gradient mode (pnerf_set_wgrad_planes(2)) and the two-product inference option always use 16.  Returns the previous
+ * setting, or PNERF_E_INVAL.  Process-wide; may change between a training forward and its backward (the saved activations do not depend on it). */
+int pnerf_set_cross_terms(int bits);
 
 /* Backward of pnerf_render_forward for dL/d(ray_color) = d_grad_ray_color [R,3]:
  * accumulates dL/d(MLP params) into d_grad_params (flat, pnerf_mlp_layout order) and

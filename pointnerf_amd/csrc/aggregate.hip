@@ -14,6 +14,7 @@
 // the first one's MFMAs: tools/gemm_probe.hip).  In training mode the operands of the weight-gradient GEMMs are written once, already
 // split into their f16 planes and transposed to the k-major order that kernel streams.
 #include "mixq.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------ layout / packing
 extern "C" int pnerf_mlp_layout(int feat_dim, int64_t *offsets) {
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void k_debug_mix_gemm(const float *__restrict_
     pn_mode_saturate();
     constexpr int K = 256 + 16 * NT;
     char *X = smem_d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int e = tid; e < PN_TILE * (K / 4); e += 256) {
         const int row = e / (K / 4), col = 4 * (e % (K / 4));
         const float4 v = *reinterpret_cast<const float4 *>(x + row * K + col);
@@ -527,7 +528,8 @@ __device__ __forceinline__ void f_gather(const FwdArgs &a, FGather &G, int si_, 
 
 // X0 row of the tile: [e(32) | PE3(e) (192) | PE5(dists) (60) | 1 | 0 0 0], the row's raw weight and layer-3 extras
 // (point_aggregators.py:773-784, :425-428, :506, :566; networks.py:175-190)
-template <bool PERS>
+// MIX: the tile in the mixed format of mixq.h (columns < 256: h plane + e4m3 units; from 256 on the two f16 planes, h to nearest)
+template <bool PERS, bool MIX = false>
 __device__ __forceinline__ void f_build(const FwdArgs &a, const FGather &G, char *X, float *exb, float *wraw, int *sidx, int si, int p, int row, int q) {
     const float dwx = G.px - G.lx, dwy = G.py - G.ly, dwz = G.pz - G.lz;
     float ppx, ppy, pcz, spx, spy, scz;
@@ -546,6 +548,21 @@ __device__ __forceinline__ void f_build(const FwdArgs &a, const FGather &G, char
     const float db = q == 0 ? d4 : d5;
     // the thread's 8 embedding dims and their 3 octaves
     const float e[8] = {G.e0.x, G.e0.y, G.e0.z, G.e0.w, G.e1.x, G.e1.y, G.e1.z, G.e1.w};
+    if (MIX) {
+        pn_xq_store4(X, row, EPT * q, e[0], e[1], e[2], e[3]);
+        pn_xq_store4(X, row, EPT * q + 4, e[4], e[5], e[6], e[7]);
+        // two dims = 12 consecutive columns (a multiple of four from column 32 + 48 q on): three 4-column stores
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            const int col = PN_F + (EPT * q + i) * 6;
+            float s0[3], c0[3], s1[3], c1[3];
+            pn_pe_octaves<3>(e[i], s0, c0);
+            pn_pe_octaves<3>(e[i + 1], s1, c1);
+            pn_xq_store4(X, row, col, s0[0], c0[0], s0[1], c0[1]);
+            pn_xq_store4(X, row, col + 4, s0[2], c0[2], s1[0], c1[0]);
+            pn_xq_store4(X, row, col + 8, s1[1], c1[1], s1[2], c1[2]);
+        }
+    } else {
     pn_x_store4<false>(X, row, EPT * q, e[0], e[1], e[2], e[3]);
     pn_x_store4<false>(X, row, EPT * q + 4, e[4], e[5], e[6], e[7]);
 #pragma unroll
@@ -558,6 +575,7 @@ __device__ __forceinline__ void f_build(const FwdArgs &a, const FGather &G, char
         pn_x_store2(X, row, PN_F + dd * 6 + 4, s[2], c[2]);
         if (PN_NW == 8 && (i & 1)) __builtin_amdgcn_sched_barrier(0);      // (register budget of the 8-wave organisation)
     }
+    }
     // PE5 of distance components q and q + 4
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -566,10 +584,16 @@ __device__ __forceinline__ void f_build(const FwdArgs &a, const FGather &G, char
             float s[5], c[5];
             pn_pe_octaves<5>(j == 0 ? da : db, s, c);
 #pragma unroll
-            for (int f = 0; f < 5; ++f) pn_x_store2(X, row, PN_F * 7 + (comp * 5 + f) * 2, s[f], c[f]);
+            for (int f = 0; f < 5; ++f) {
+                if (MIX) pn_xa_store2(X, row, PN_F * 7 + (comp * 5 + f) * 2, s[f], c[f]);
+                else pn_x_store2(X, row, PN_F * 7 + (comp * 5 + f) * 2, s[f], c[f]);
+            }
         }
     }
-    if (q == 3) pn_x_store4<false>(X, row, PN_ONES1, 1.f, 0.f, 0.f, 0.f);
+    if (q == 3) {
+        if (MIX) pn_xt_store4(X, row, PN_ONES1, 1.f, 0.f, 0.f, 0.f);
+        else pn_x_store4<false>(X, row, PN_ONES1, 1.f, 0.f, 0.f, 0.f);
+    }
     if (q == 0) {
         float vx, vy, vz, qx, qy, qz;
         rot3(a.cam.rw2c, G.rx, G.ry, G.rz, true, vx, vy, vz);
@@ -602,7 +626,7 @@ __device__ __forceinline__ void f_acc_bias(const float *__restrict__ bias, int w
 // Sign word: one v_alignbit_b32 per element shifts the element's sign bit into a 32-bit accumulator (MSB first), element
 // e = (rb * 4 + g) * 4 + i of a lane's feature block -> bit 31 - e of the block's word; bit set = negative = slope 0.01 in the backward.
 // mw[fb] = the word of the wave's feature block fb (global block PN_NFB * wave + fb): stored as lmask[tile][layer][block][lane].
-template <bool BITS>
+template <bool BITS, bool MIX = false>
 __device__ __forceinline__ void f_epilogue(const f32x16 (&acc)[PN_NFB][2], char *X, int wave, int lane, unsigned (&mw)[PN_NFB]) {
 #pragma unroll
     for (int fb = 0; fb < PN_NFB; ++fb) mw[fb] = 0u;
@@ -620,7 +644,8 @@ __device__ __forceinline__ void f_epilogue(const f32x16 (&acc)[PN_NFB][2], char 
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.01f * v[i]);
-                pn_x_store4<false>(X, 32 * rb + (lane & 31), f0, v[0], v[1], v[2], v[3]);
+                if (MIX) pn_xq_store4(X, 32 * rb + (lane & 31), f0, v[0], v[1], v[2], v[3]);
+                else pn_x_store4<false>(X, 32 * rb + (lane & 31), f0, v[0], v[1], v[2], v[3]);
             }
 }
 // the sign words of a layer -> lmask[gtile][layer][block][lane]
@@ -735,8 +760,13 @@ __device__ __forceinline__ void f_tail(const FwdArgs &a, const char *X, const fl
 PN_TR_DECL(pn_trace_fwd);
 #endif
 // WG2: the two-plane weight-gradient mode (pnerf_set_wgrad_planes(2)): every saved GEMM operand also leaves its residual plane, X0 whole
+// NP = 4: the mixed format of mixq.h (f16 h.h + e4m3 cross terms: the default since round 6); NP = 3 / 2: f16x3.h's three / two f16 products
 template <bool TRAIN, bool PERS, int NP, bool WG2 = false>
 __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
+    constexpr bool MIX = NP == 4;
+    constexpr int NPC = MIX ? 3 : NP;          // (what the classic templates are instantiated with where MIX compiles them away)
+    static_assert(!(MIX && WG2), "the two-plane weight-gradient mode keeps f16x3.h's arithmetic everywhere");
+    pn_mode_saturate();
     extern __shared__ __attribute__((aligned(16))) char smem_f[];
     char *X = smem_f;
     float *exb = reinterpret_cast<float *>(smem_f + FL_EX), *w5s = reinterpret_cast<float *>(smem_f + FL_W5);
@@ -797,13 +827,15 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
         const long long gtile = tb + tile;               // tile index inside the saved area
         PN_LDS_BARRIER();                                 // the previous tile's readers are done with X and the row arrays
         PN_TR(pn_trace_fwd, 0); PN_TR_HWID(pn_trace_fwd);
-        if (bw) f_build<PERS>(a, G, X, exb, wraw, sidx, si0, p0, row, q);
+        if (bw) f_build<PERS, MIX>(a, G, X, exb, wraw, sidx, si0, p0, row, q);
         // Round 4: what the next GEMM needs from GLOBAL memory -- its bias (the accumulators' initial value) and its first weight-fragment
         // chunks -- is requested in front of the barrier that precedes it, not behind: neither depends on LDS, and the L2 round trip
         // (0.6 .. 1.1 us per layer in profiles/r03_phase_trace.json: the "acc = bias" phases) passes under the barrier wait.
         f_acc_bias(P + PO_B1, wave, lane, acc);
-        PnGemmW<18, 8, PN_NFB, PN_WPF, NP> W1;
-        W1.prefetch(reinterpret_cast<const uint4 *>(img + PKH_F1), PN_NFB * wave, lane);
+        PnGemmW<18, 8, PN_NFB, PN_WPF, NPC> W1;
+        PnMixW<PN_MIX_NS, 2, 8, PN_NFB> M1;
+        if constexpr (MIX) M1.prefetch(img + PKM_F1, PN_NFB * wave, lane);
+        else W1.prefetch(reinterpret_cast<const uint4 *>(img + PKH_F1), PN_NFB * wave, lane);
         PN_LDS_BARRIER();
         if (bw && q == 0) {      // weights of the row: normalise over the K slots, multiply by the clamped confidence (:801-811)
             const int ls = pn_row_div(row, kinv);
@@ -825,58 +857,87 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
         // behind 20 stores waits for their acknowledgements from HBM before its first weight fragment counts as arrived (round 2 order:
         // every GEMM phase carried 1 .. 3 us of that).  Behind the GEMM the stores have the epilogue and two barriers to drain.
         PN_TR(pn_trace_fwd, 2);
-        pn_gemm_f16x3_run<18, 8, PN_NFB, PN_WPF, NP>(X, W1, lane, acc);
+        if constexpr (MIX) pn_gemm_mix_run<PN_MIX_NS, 2, 8, PN_NFB>(X, M1, lane, acc);
+        else pn_gemm_f16x3_run<18, 8, PN_NFB, PN_WPF, NPC>(X, W1, lane, acc);
         if (TRAIN) {           // (behind the GEMM: see above)
-            if (WG2) pn_copy_out_kmajor<PN_NF1, true, PN_NW>(X, a.sv.x0k, gtile * 8, tid, a.sv.x0m);
+            if (MIX) {         // the mixed tile's h plane IS the nearest f16: the k-major plane is its transpose
+                if (a.save_x0) pn_copy_out_kmajor_h<PN_NF1, PN_XRS, PN_NW>(X, a.sv.x0k, gtile * 8, tid);
+                else pn_copy_out_kmajor_cols64_h<224, PN_NW>(X, a.sv.x0k, gtile * 8, tid);
+            } else if (WG2) pn_copy_out_kmajor<PN_NF1, true, PN_NW>(X, a.sv.x0k, gtile * 8, tid, a.sv.x0m);
             else if (a.save_x0) pn_copy_out_kmajor<PN_NF1, false, PN_NW>(X, a.sv.x0k, gtile * 8, tid);
             else pn_copy_out_kmajor_cols64<224, PN_NW>(X, a.sv.x0k, gtile * 8, tid);       // the fused path: only the last 64 columns (k_wgrad_x0)
         }
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 3);
-        f_epilogue<TRAIN>(acc, X, wave, lane, mask);
+        f_epilogue<TRAIN, MIX>(acc, X, wave, lane, mask);
         if (TRAIN) f_store_masks(a.sv.lmask, gtile, 0, wave, lane, mask);
         f_acc_bias(P + PO_B2, wave, lane, acc);
-        PnGemmW<16, 8, PN_NFB, PN_WPF, NP> W2;
-        W2.prefetch(reinterpret_cast<const uint4 *>(img + PKH_F2), PN_NFB * wave, lane);
+        PnGemmW<16, 8, PN_NFB, PN_WPF, NPC> W2;
+        PnMixW<PN_MIX_NS, 0, 8, PN_NFB> M2;
+        if constexpr (MIX) M2.prefetch(img + PKM_F2, PN_NFB * wave, lane);
+        else W2.prefetch(reinterpret_cast<const uint4 *>(img + PKH_F2), PN_NFB * wave, lane);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 4);
         // ---- layer 2: 256 -> 256
         PN_TR(pn_trace_fwd, 5);
-        pn_gemm_f16x3_run<16, 8, PN_NFB, PN_WPF, NP>(X, W2, lane, acc);
-        if (TRAIN) pn_copy_out_kmajor<PN_H, WG2, PN_NW>(X, a.sv.h1k, gtile * 8, tid, a.sv.h1m);      // (behind the GEMM: see below)
+        if constexpr (MIX) pn_gemm_mix_run<PN_MIX_NS, 0, 8, PN_NFB>(X, M2, lane, acc);
+        else pn_gemm_f16x3_run<16, 8, PN_NFB, PN_WPF, NPC>(X, W2, lane, acc);
+        if (TRAIN) {      // (behind the GEMM: see below)
+            if (MIX) pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X, a.sv.h1k, gtile * 8, tid);
+            else pn_copy_out_kmajor<PN_H, WG2, PN_NW>(X, a.sv.h1k, gtile * 8, tid, a.sv.h1m);
+        }
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 6);
-        f_epilogue<TRAIN>(acc, X, wave, lane, mask);
+        f_epilogue<TRAIN, MIX>(acc, X, wave, lane, mask);
         if (TRAIN) f_store_masks(a.sv.lmask, gtile, 1, wave, lane, mask);
         if (tid < PN_TILE) {     // the row's extras next to h2: columns 256..262, the ones column, zeros up to 271
             const float4 u = *reinterpret_cast<const float4 *>(exb + tid * 8), v = *reinterpret_cast<const float4 *>(exb + tid * 8 + 4);
-            pn_x_store4<false>(X, tid, PN_H, u.x, u.y, u.z, u.w);
-            pn_x_store4<false>(X, tid, PN_H + 4, v.x, v.y, v.z, v.w);
-            pn_x_store4<false>(X, tid, PN_H + 8, 0.f, 0.f, 0.f, 0.f);
-            pn_x_store4<false>(X, tid, PN_H + 12, 0.f, 0.f, 0.f, 0.f);
+            if (MIX) {
+                pn_xt_store4(X, tid, PN_H, u.x, u.y, u.z, u.w);
+                pn_xt_store4(X, tid, PN_H + 4, v.x, v.y, v.z, v.w);
+                pn_xt_store4(X, tid, PN_H + 8, 0.f, 0.f, 0.f, 0.f);
+                pn_xt_store4(X, tid, PN_H + 12, 0.f, 0.f, 0.f, 0.f);
+            } else {
+                pn_x_store4<false>(X, tid, PN_H, u.x, u.y, u.z, u.w);
+                pn_x_store4<false>(X, tid, PN_H + 4, v.x, v.y, v.z, v.w);
+                pn_x_store4<false>(X, tid, PN_H + 8, 0.f, 0.f, 0.f, 0.f);
+                pn_x_store4<false>(X, tid, PN_H + 12, 0.f, 0.f, 0.f, 0.f);
+            }
         }
         f_acc_bias(P + PO_B3, wave, lane, acc);
-        PnGemmW<17, 8, PN_NFB, PN_WPF, NP> W3;
-        W3.prefetch(reinterpret_cast<const uint4 *>(img + PKH_F3), PN_NFB * wave, lane);
+        PnGemmW<17, 8, PN_NFB, PN_WPF, NPC> W3;
+        PnMixW<PN_MIX_NS, 1, 8, PN_NFB> M3;
+        if constexpr (MIX) M3.prefetch(img + PKM_F3, PN_NFB * wave, lane);
+        else W3.prefetch(reinterpret_cast<const uint4 *>(img + PKH_F3), PN_NFB * wave, lane);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 7);
         // ---- layer 3: 256 + 7 -> 256
         PN_TR(pn_trace_fwd, 8);
-        pn_gemm_f16x3_run<17, 8, PN_NFB, PN_WPF, NP>(X, W3, lane, acc);
-        if (TRAIN) pn_copy_out_kmajor<PN_NF1, WG2, PN_NW>(X, a.sv.h2k, gtile * 8, tid, a.sv.h2m);      // (behind the GEMM: see below)
+        if constexpr (MIX) pn_gemm_mix_run<PN_MIX_NS, 1, 8, PN_NFB>(X, M3, lane, acc);
+        else pn_gemm_f16x3_run<17, 8, PN_NFB, PN_WPF, NPC>(X, W3, lane, acc);
+        if (TRAIN) {      // (behind the GEMM: see below)
+            if (MIX) pn_copy_out_kmajor_h<PN_NF1, PN_XRS, PN_NW>(X, a.sv.h2k, gtile * 8, tid);
+            else pn_copy_out_kmajor<PN_NF1, WG2, PN_NW>(X, a.sv.h2k, gtile * 8, tid, a.sv.h2m);
+        }
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 9);
-        f_epilogue<TRAIN>(acc, X, wave, lane, mask);
+        f_epilogue<TRAIN, MIX>(acc, X, wave, lane, mask);
         if (TRAIN) f_store_masks(a.sv.lmask, gtile, 2, wave, lane, mask);
         f_acc_bias(P + PO_B4, wave, lane, acc);
-        PnGemmW<16, 8, PN_NFB, PN_WPF, NP> W4;
-        W4.prefetch(reinterpret_cast<const uint4 *>(img + PKH_F4), PN_NFB * wave, lane);
+        PnGemmW<16, 8, PN_NFB, PN_WPF, NPC> W4;
+        PnMixW<PN_MIX_NS, 0, 8, PN_NFB> M4;
+        if constexpr (MIX) M4.prefetch(img + PKM_F4, PN_NFB * wave, lane);
+        else W4.prefetch(reinterpret_cast<const uint4 *>(img + PKH_F4), PN_NFB * wave, lane);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 10);
         // ---- layer 4: 256 -> 256
         PN_TR(pn_trace_fwd, 11);
-        pn_gemm_f16x3_run<16, 8, PN_NFB, PN_WPF, NP>(X, W4, lane, acc);
-        if (TRAIN) pn_copy_out_kmajor<PN_H, WG2, PN_NW>(X, a.sv.h3k, gtile * 8, tid, a.sv.h3m);
+        if constexpr (MIX) pn_gemm_mix_run<PN_MIX_NS, 0, 8, PN_NFB>(X, M4, lane, acc);
+        else pn_gemm_f16x3_run<16, 8, PN_NFB, PN_WPF, NPC>(X, W4, lane, acc);
+        if (TRAIN) {
+            if (MIX) pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X, a.sv.h3k, gtile * 8, tid);
+            else pn_copy_out_kmajor<PN_H, WG2, PN_NW>(X, a.sv.h3k, gtile * 8, tid, a.sv.h3m);
+        }
         PN_TR(pn_trace_fwd, 12);
         // the next tile's point data and the indices of the two after it: requested here, consumed at the top of the next
         // iteration -- their HBM latency passes under the element-wise tail of this tile (nothing of this tile waits for memory any more)
@@ -1113,6 +1174,30 @@ extern "C" int pnerf_set_wgrad_planes(int n) {
     return old;
 }
 
+// e4m3 cross terms (mixq.h; 8: the default) or f16 cross terms (16: f16x3.h's three f16 products, the round-2..5 arithmetic) in the aggregator's
+// tile GEMMs, forward and input-gradient chain (include/pnerf.h: pnerf_set_cross_terms)
+static int pn_cross_terms_ = 8;
+int pn_cross_terms() { return pn_cross_terms_; }
+extern "C" int pnerf_set_cross_terms(int bits) {
+    if (bits != 8 && bits != 16) return PNERF_E_INVAL;
+    const int old = pn_cross_terms_;
+    pn_cross_terms_ = bits;
+    return old;
+}
+// which tile kernels run the mixed format when the cross terms are e4m3: bit 0 = inference forward, bit 1 = training forward, bit 2 = backward
+// (dev A/B: PNERF_MIX_MASK in the environment overrides the default)
+#ifndef PN_MIX_DEFAULT_MASK
+#define PN_MIX_DEFAULT_MASK 7
+#endif
+int pn_mix_mask() {
+    static int mask = -1;
+    if (mask < 0) {
+        const char *e = getenv("PNERF_MIX_MASK");
+        mask = e ? atoi(e) & 7 : PN_MIX_DEFAULT_MASK;
+    }
+    return pn_cross_terms_ == 8 ? mask : 0;
+}
+
 // shared with render.hip
 int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, const float *d_params, const void *d_packed,
                           const float *d_raydir, const float *d_sample_loc, const float *d_xyz_pers, const float *d_loc_pers,
@@ -1139,7 +1224,10 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
     const size_t lds_a = FL_BYTES, lds_c = CL_BYTES;
     const bool pers = d_xyz_pers != nullptr;
     const bool np2 = !train && pn_inference_products == 2;      // inference with the weights' high plane only (f16x3.h: NP)
+    const bool mix = !wg2 && !np2 && (pn_mix_mask() & (train ? 2 : 1));      // mixq.h: f16 h.h + e4m3 cross terms
     const void *kfn = wg2   ? (pers ? (const void *)k_agg_forward<true, true, 3, true> : (const void *)k_agg_forward<true, false, 3, true>)
+                    : mix   ? (train ? (pers ? (const void *)k_agg_forward<true, true, 4> : (const void *)k_agg_forward<true, false, 4>)
+                                     : (pers ? (const void *)k_agg_forward<false, true, 4> : (const void *)k_agg_forward<false, false, 4>))
                     : train ? (pers ? (const void *)k_agg_forward<true, true, 3> : (const void *)k_agg_forward<true, false, 3>)
                     : np2   ? (pers ? (const void *)k_agg_forward<false, true, 2> : (const void *)k_agg_forward<false, false, 2>)
                             : (pers ? (const void *)k_agg_forward<false, true, 3> : (const void *)k_agg_forward<false, false, 3>);
@@ -1159,6 +1247,10 @@ int pn_agg_forward_launch(const pnerf_camera *cam, const pnerf_points *pts, cons
             const int grid_a = (int)(tiles < 2LL * ncu ? (tiles > 0 ? tiles : 1) : 2LL * ncu);     // two workgroups per CU
             if (wg2 && pers) hipLaunchKernelGGL((k_agg_forward<true, true, 3, true>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
             else if (wg2) hipLaunchKernelGGL((k_agg_forward<true, false, 3, true>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            else if (mix && train && pers) hipLaunchKernelGGL((k_agg_forward<true, true, 4>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            else if (mix && train) hipLaunchKernelGGL((k_agg_forward<true, false, 4>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            else if (mix && pers) hipLaunchKernelGGL((k_agg_forward<false, true, 4>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+            else if (mix) hipLaunchKernelGGL((k_agg_forward<false, false, 4>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
             else if (train && pers) hipLaunchKernelGGL((k_agg_forward<true, true, 3>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
             else if (train) hipLaunchKernelGGL((k_agg_forward<true, false, 3>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
             else if (np2 && pers) hipLaunchKernelGGL((k_agg_forward<false, true, 2>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);

@@ -13,7 +13,7 @@
 //   k_wgrad_f16      : dW = dY^T X as split-K MFMA GEMMs over the saved k-major f16 planes, full dW tile
 //                      resident in accumulators, deterministic partial-sum reduction
 // LeakyReLU masks: 1 bit per element, written by the forward in the accumulator layout (layers 1-3), sign of the saved h4 (layer 4).
-#include "f16x3.h"
+#include "mixq.h"
 
 namespace {
 constexpr int WG_CHUNKS = 256;                 // split-K factor of the wgrad GEMMs
@@ -315,6 +315,7 @@ template <int AF> __device__ __forceinline__ void b_acc_zero(f32x16 (&acc)[AF][2
 }
 // dgrad epilogue: accumulators x LeakyReLU' (sign bit of the forward's word of the feature block: element e = (rb * 4 + g) * 4 + i at bit
 // 31 - e) -> both planes of the next dY tile
+template <bool MIX = false>
 __device__ __forceinline__ void b_epilogue(const f32x16 (&acc)[PN_NFB][2], const unsigned (&mask)[PN_NFB], char *X, int wave, int lane) {
 #pragma unroll
     for (int fb = 0; fb < PN_NFB; ++fb) {
@@ -329,7 +330,8 @@ __device__ __forceinline__ void b_epilogue(const f32x16 (&acc)[PN_NFB][2], const
                     const int e = (rb * 4 + g) * 4 + i;
                     v[i] = acc[fb][rb][4 * g + i] * ((int)(mw << e) < 0 ? 0.01f : 1.f);
                 }
-                pn_x_store4<true>(X, 32 * rb + (lane & 31), pn_d_feat(PN_NFB * wave + fb, g, lane), v[0], v[1], v[2], v[3]);
+                if (MIX) pn_xq_store4(X, 32 * rb + (lane & 31), pn_d_feat(PN_NFB * wave + fb, g, lane), v[0], v[1], v[2], v[3]);
+                else pn_x_store4<true>(X, 32 * rb + (lane & 31), pn_d_feat(PN_NFB * wave + fb, g, lane), v[0], v[1], v[2], v[3]);
             }
     }
 }
@@ -366,7 +368,9 @@ __device__ __forceinline__ float pn_sigmoid_b(float x) {
 // KC = 0 (round 5): any other K (12 / 6 / 3 of the Barn configuration, ...).  Nothing in the front is per SAMPLE except which d f row a tile row
 // uses, so the same pass serves every K with that index taken at run time (j = row / K - r0 / K; the thread's 8 rows then span up to three
 // samples, whose d f values come straight from memory like KC = 2, 1); the two-pass form it replaces read the tile twice with a barrier between.
-template <int KC>
+// MIX: dY4 leaves in the mixed format of mixq.h: h (nearest f16) in plane 0 and, in place of the thread's 16 bytes of the h4 residual plane, the
+// group's e4m3 unit [q8(h) x 8 | q8(m 2^11) x 8] -- a thread still rewrites only bytes it alone reads
+template <int KC, bool MIX = false>
 __device__ __forceinline__ void b_front(const BwdArgs &a, char *X, const float *w5s, const float *wrow, const float *wnrm, const float *dsg, const float *xrow,
                                         float *draw, const int *sidx, const int *prow, const float4 (&dfr)[4], const float *dfb0, float S, float invS, int tid,
                                         float (&gw5)[8], float &gb5t, unsigned kinv = 0u) {
@@ -447,7 +451,9 @@ __device__ __forceinline__ void b_front(const BwdArgs &a, char *X, const float *
 #pragma unroll
         for (int c = 0; c < 4; ++c) pn_split2_sat(o[2 * c], o[2 * c + 1], oh[c], om[c]);
         *reinterpret_cast<uint4 *>(X + r * PN_XRS + cg * 16) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
-        *reinterpret_cast<uint4 *>(X + PN_XPLANE + r * PN_XRS + cg * 16) = make_uint4(om[0], om[1], om[2], om[3]);
+        if (MIX) *reinterpret_cast<uint4 *>(X + PN_XPLANE + r * PN_XRS + cg * 16) =
+                     make_uint4(pn_q8x4(oh[0], oh[1], 1.0f), pn_q8x4(oh[2], oh[3], 1.0f), pn_q8x4(om[0], om[1], PN_MIX_MSC), pn_q8x4(om[2], om[3], PN_MIX_MSC));
+        else *reinterpret_cast<uint4 *>(X + PN_XPLANE + r * PN_XRS + cg * 16) = make_uint4(om[0], om[1], om[2], om[3]);
     }
     if (cg == 0) gb5t += drsum;
 }
@@ -455,8 +461,11 @@ __device__ __forceinline__ void b_front(const BwdArgs &a, char *X, const float *
 #ifdef PN_PHASE_TRACE
 PN_TR_DECL(pn_trace_bwd);
 #endif
-template <bool WG2>
+// MIX: the four input-gradient GEMMs in the mixed format of mixq.h (f16 h.h + e4m3 cross terms; the default since round 6)
+template <bool WG2, bool MIX = false>
 __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_backward(BwdArgs a) {
+    static_assert(!(MIX && WG2), "the two-plane weight-gradient mode keeps f16x3.h's arithmetic everywhere");
+    pn_mode_saturate();
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     char *X = smem_b;
     float *wrow = reinterpret_cast<float *>(smem_b + BL_ROW), *wnrm = wrow + PN_TILE, *draw = wnrm + PN_TILE, *dsg = draw + PN_TILE, *xrow = dsg + PN_TILE;
@@ -567,30 +576,35 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_backward(BwdArgs a) 
         {
             // ---- alpha head backward + dY4 in one pass (b_front): K = 8 / 4 / 2 / 1 with compile-time sample boundaries, any other K at run time
             if (!ew) { PN_EMU_MATCH_WAVE_SYNC(); }
-            else if (K == 8) b_front<8>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
-            else if (K == 4) b_front<4>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
-            else if (K == 2) b_front<2>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
-            else if (K == 1) b_front<1>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
-            else b_front<0>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t, kinv);
+            else if (K == 8) b_front<8, MIX>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
+            else if (K == 4) b_front<4, MIX>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
+            else if (K == 2) b_front<2, MIX>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
+            else if (K == 1) b_front<1, MIX>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t);
+            else b_front<0, MIX>(a, X, w5s, wrow, wnrm, dsg, xrow, draw, sidx, prow, dfr, dfb0, S, invS, tid, gw5, gb5t, kinv);
             PN_TR(pn_trace_bwd, 2);
         }
         // (round 4: the first weight-fragment chunks of every GEMM are requested in FRONT of the barrier that precedes it -- see the forward)
         PnGemmW<16, 8, PN_NFB> W4;
-        W4.prefetch(reinterpret_cast<const uint4 *>(img + PKH_D4), PN_NFB * wave, lane);
+        PnMixW<PN_MIX_NS, 0, 8, PN_NFB> M4;
+        if constexpr (MIX) M4.prefetch(img + PKM_D4, PN_NFB * wave, lane);
+        else W4.prefetch(reinterpret_cast<const uint4 *>(img + PKH_D4), PN_NFB * wave, lane);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 3);
         // ---- layer 4: dY4 -> d h3
         // (every dY tile is copied out BEHIND its GEMM: stores and loads of a wave share one in-order vmcnt queue, see the forward)
         b_acc_zero(acc);
         PN_TR(pn_trace_bwd, 4);
-        pn_gemm_f16x3_run<16, 8, PN_NFB>(X, W4, lane, acc);
+        if constexpr (MIX) pn_gemm_mix_run<PN_MIX_NS, 0, 8, PN_NFB>(X, M4, lane, acc);
+        else pn_gemm_f16x3_run<16, 8, PN_NFB>(X, W4, lane, acc);
         pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X, a.sv.dy4k, gtile * 8, tid);
         if (WG2) pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X + PN_XPLANE, a.sv.dy4m, gtile * 8, tid);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 5);
-        b_epilogue(acc, m3, X, wave, lane);
+        b_epilogue<MIX>(acc, m3, X, wave, lane);
         PnGemmW<16, 9, PN_NFB> W3;
-        W3.prefetch(reinterpret_cast<const uint4 *>(img + PKH_D3), PN_NFB * wave, lane);
+        PnMixW<PN_MIX_NS, 0, 9, PN_NFB> M3;
+        if constexpr (MIX) M3.prefetch(img + PKM_D3, PN_NFB * wave, lane);
+        else W3.prefetch(reinterpret_cast<const uint4 *>(img + PKH_D3), PN_NFB * wave, lane);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 6);
         // ---- layer 3: dY3 -> d h2, and the extras block (input columns 256..262 of W3), K split over the waves
@@ -603,18 +617,21 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_backward(BwdArgs a) 
         if (wave < 4) {
             f32x16 acce[1][2];
             b_acc_zero(acce);
-            pn_gemm_f16x3<4, 9, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D3), 8, lane, acce, 4 * wave);
+            // (mixed format: wave w takes superchunk w of the block -- the same K split, four f16 chunks and two e4m3 MFMAs per row block)
+            if constexpr (MIX) pn_gemm_mix<1, 0, 9, 1>(X, img + PKM_D3, 8, lane, acce, wave);
+            else pn_gemm_f16x3<4, 9, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D3), 8, lane, acce, 4 * wave);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
                 *reinterpret_cast<float4 *>(X + (wave >> 1) * PN_XPLANE + (32 * rb + (lane & 31)) * PN_XRS + 512 + (wave & 1) * 32 + (lane >> 5) * 16) =
                     make_float4(acce[0][rb][0], acce[0][rb][1], acce[0][rb][2], acce[0][rb][3]);
         }
-        pn_gemm_f16x3_run<16, 9, PN_NFB>(X, W3, lane, acc);
+        if constexpr (MIX) pn_gemm_mix_run<PN_MIX_NS, 0, 9, PN_NFB>(X, M3, lane, acc);
+        else pn_gemm_f16x3_run<16, 9, PN_NFB>(X, W3, lane, acc);
         pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X, a.sv.dy3k, gtile * 8, tid);
         if (WG2) pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X + PN_XPLANE, a.sv.dy3m, gtile * 8, tid);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 8);
-        b_epilogue(acc, m2, X, wave, lane);
+        b_epilogue<MIX>(acc, m2, X, wave, lane);
         PN_LDS_BARRIER();
         if (tid < PN_TILE) {        // d colour, d dir of the row's point from the extras' gradient
             const int p = prow[tid];
@@ -651,7 +668,9 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_backward(BwdArgs a) 
             }
         }
         PnGemmW<16, 8, PN_NFB> W2;
-        W2.prefetch(reinterpret_cast<const uint4 *>(img + PKH_D2), PN_NFB * wave, lane);
+        PnMixW<PN_MIX_NS, 0, 8, PN_NFB> M2;
+        if constexpr (MIX) M2.prefetch(img + PKM_D2, PN_NFB * wave, lane);
+        else W2.prefetch(reinterpret_cast<const uint4 *>(img + PKH_D2), PN_NFB * wave, lane);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 9);
         // ---- layer 2: dY2 -> d h1
@@ -659,18 +678,26 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_backward(BwdArgs a) 
         //  reads, one per 128-byte line: 16.65 ms against 16.19 ms -- the load phase is not waiting for HBM.)
         b_acc_zero(acc);
         PN_TR(pn_trace_bwd, 10);
-        pn_gemm_f16x3_run<16, 8, PN_NFB>(X, W2, lane, acc);
+        if constexpr (MIX) pn_gemm_mix_run<PN_MIX_NS, 0, 8, PN_NFB>(X, M2, lane, acc);
+        else pn_gemm_f16x3_run<16, 8, PN_NFB>(X, W2, lane, acc);
         pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X, a.sv.dy2k, gtile * 8, tid);
         if (WG2) pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X + PN_XPLANE, a.sv.dy2m, gtile * 8, tid);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 11);
-        b_epilogue(acc, m1, X, wave, lane);
+        b_epilogue<MIX>(acc, m1, X, wave, lane);
         PN_LDS_BARRIER();
         PN_TR(pn_trace_bwd, 12);
         // ---- layer 1: dY1 -> d X0 (columns 0..223), fp32 into LDS
         b_acc_zero(acc);
         PN_TR(pn_trace_bwd, 13);
-        if (PN_NFB == 2) {       // seven feature blocks over four waves: 2 2 2 1
+        if constexpr (MIX) {
+            if (PN_NFB == 2) {
+                if (wave < 3) pn_gemm_mix<PN_MIX_NS, 0, PN_MB_D1, PN_NFB>(X, img + PKM_D1, 2 * wave, lane, acc);
+                else pn_gemm_mix<PN_MIX_NS, 0, PN_MB_D1, 1>(X, img + PKM_D1, 6, lane, acc);
+            } else if (wave < PN_MB_D1) {
+                pn_gemm_mix<PN_MIX_NS, 0, PN_MB_D1, 1>(X, img + PKM_D1, wave, lane, acc);
+            }
+        } else if (PN_NFB == 2) {       // seven feature blocks over four waves: 2 2 2 1
             if (wave < 3) pn_gemm_f16x3<16, PN_MB_D1, PN_NFB>(X, reinterpret_cast<const uint4 *>(img + PKH_D1), 2 * wave, lane, acc);
             else pn_gemm_f16x3<16, PN_MB_D1, 1>(X, reinterpret_cast<const uint4 *>(img + PKH_D1), 6, lane, acc);
         } else if (wave < PN_MB_D1) {      // over eight waves: one each, the last wave idle
@@ -1267,7 +1294,8 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
     const bool wg2 = sv.wg2 != 0;                      // two-plane weight-gradient mode (the forward of this step ran in it: same process-wide setting)
     if (wg2) x0_saved = true;
     const void *kcb = wg2 ? (const void *)k_color_backward<true> : (const void *)k_color_backward<false>;
-    const void *kab = wg2 ? (const void *)k_agg_backward<true> : (const void *)k_agg_backward<false>;
+    const bool mix = !wg2 && (pn_mix_mask() & 4);      // mixq.h: e4m3 cross terms in the input-gradient chain
+    const void *kab = wg2 ? (const void *)k_agg_backward<true> : mix ? (const void *)k_agg_backward<false, true> : (const void *)k_agg_backward<false>;
     if (hipFuncSetAttribute(kcb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess) return PNERF_E_LAUNCH;
     if (hipFuncSetAttribute(kab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess) return PNERF_E_LAUNCH;
     // the forward left the class partition of the valid samples in the saved area (aggregate.hip: pn_classify)
@@ -1290,6 +1318,7 @@ int pn_agg_backward_launch(const pnerf_camera *cam, const pnerf_points *pts, con
           const long long tiles = (n_valid + a.TS - 1) / a.TS;                    // worst-case grid, two workgroups per CU
           const int grid_a = (int)(tiles < 2LL * ncu ? (tiles > 0 ? tiles : 1) : 2LL * ncu);
           if (wg2) hipLaunchKernelGGL(k_agg_backward<true>, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
+          else if (mix) hipLaunchKernelGGL((k_agg_backward<false, true>), dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
           else hipLaunchKernelGGL(k_agg_backward<false>, dim3(grid_a), dim3(PN_NTHR), lds_a, s, a);
       } }
     PN_CHECK_LAUNCH();

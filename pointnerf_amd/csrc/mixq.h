@@ -39,7 +39,7 @@ typedef short pn_s2 __attribute__((ext_vector_type(2)));
 #define PN_MIX_MSC 0.00048828125f            // 2^-11: scale of the residual slots (value / scale = m 2^11)
 #define PN_MIX_MSC_BYTE 116                  // 127 - 11
 #ifndef PN_MIX_LEAD
-#define PN_MIX_LEAD 4                        // units of weight fragments requested ahead
+#define PN_MIX_LEAD 2                        // units of weight fragments requested ahead
 #endif
 #define PN_MIMG_U4(nt, mb) ((PN_MIX_NS * 8 + (nt) * 2) * (mb) * 64)
 #define PN_MIMG(nt, mb) (PN_MIMG_U4(nt, mb) * 16 + PN_MIX_NS * (mb) * 256)
@@ -124,40 +124,73 @@ __device__ __forceinline__ void pn_xt_store4(char *X, int row, int col, float v0
     *reinterpret_cast<uint2 *>(X + PN_XPLANE + row * PN_XRS + col * 2) = make_uint2(m0, m1);
 }
 
-// ---- the weight-fragment registers of one mixed tile GEMM.  Units of the static schedule, per superchunk: H0 H1 H2 H3 (one f16 chunk each)
-// Q0 Q1 (one e4m3 MFMA each); then the NT classic tail chunks.  load<U>() requests unit U, prefetch() the first LEAD units.
+// ---- the weight-fragment registers of one mixed tile GEMM.  Units of the static schedule, per superchunk: HA (f16 chunks 0, 1) HB (chunks 2, 3)
+// Q0 Q1 (one e4m3 MFMA each per accumulator block); then the NT classic tail chunks (h plane, m plane).  Every unit is TWO 16-byte fragments per
+// feature block on the weight side and two per row block on the tile side, and 8 or 4 MFMAs per (2 x 2 block) wave = 256 .. 320 pipe cycles; its
+// weight fragments are requested LEAD units ahead into a ring of LEAD + 1 register sets (48 registers with two feature blocks: f16x3.h's budget),
+// the tile's fragments one unit ahead into a ring of two.  The image is addressed as a wave-uniform base (scalar registers) + the lane's 32-bit
+// offset, so that the unit offsets cost scalar adds, not 64-bit vector address pairs.
+// load<U>() requests unit U, prefetch() the first LEAD units.
 // NSR = superchunks this GEMM runs (4, or 1: the layer-3 extras block of the backward, one superchunk per wave).
 template <int NSR, int NT, int MB, int NFB, int LEAD = PN_MIX_LEAD>
 struct PnMixW {
-    static constexpr int NU = 6 * NSR + NT, PF = LEAD < NU ? LEAD : NU;
-    uint4 wh[4][NFB], wq[2][NFB][2], wth[NT ? NT : 1][NFB], wtm[NT ? NT : 1][NFB];
+    static constexpr int NU = 4 * NSR + NT, PF = LEAD < NU ? LEAD : NU, NS = LEAD + 1;
+    uint4 r[NS][NFB][2];
     unsigned wsc[NFB];
-    const uint4 *wp, *tp;
-    const unsigned *sp;
+    // buffer addressing: descriptor of the layer's image (scalar registers) + the lane's 32-bit offset (ONE vector register for every load of the
+    // GEMM) + a wave-uniform scalar offset per load: no 64-bit vector address pairs and no vector adds for the unit offsets, which exceed the
+    // 4 KB immediate range of a global load (the compiler otherwise forms every one of them with v_add_co / v_addc pairs)
+#ifdef PN_EMU
+    const char *base;
+#else
+    __amdgpu_buffer_rsrc_t rs;
+#endif
+    int wo, to, so;        // wave-uniform byte offsets inside the image: (superchunk s0, block fb0), the tail chunks at fb0, the block scales at (s0, fb0)
+    int lo;                // lane * 16
+    __device__ __forceinline__ uint4 ld16(int soff) const {
+#ifdef PN_EMU
+        return *reinterpret_cast<const uint4 *>(base + soff + lo);
+#else
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, lo, soff, 0));
+#endif
+    }
+    __device__ __forceinline__ unsigned ld4(int soff) const {
+#ifdef PN_EMU
+        return *reinterpret_cast<const unsigned *>(base + soff + (lo >> 2));
+#else
+        return __builtin_amdgcn_raw_buffer_load_b32(rs, lo >> 2, soff, 0);
+#endif
+    }
     template <int U> __device__ __forceinline__ void load() {
-        if constexpr (U < 6 * NSR) {
-            constexpr int s = U / 6, j = U % 6;
+        constexpr int sl = U % NS;
+        if constexpr (U < 4 * NSR) {
+            constexpr int s = U / 4, j = U % 4;
 #pragma unroll
             for (int fb = 0; fb < NFB; ++fb) {
-                const uint4 *p = wp + ((s * MB + fb) * 8) * 64;
-                if constexpr (j < 4) wh[j][fb] = p[j * 64];
-                else {
-                    wq[j - 4][fb][0] = p[(4 + 2 * (j - 4)) * 64]; wq[j - 4][fb][1] = p[(5 + 2 * (j - 4)) * 64];
-                    if constexpr (j == 4) wsc[fb] = sp[(s * MB + fb) * 64];
-                }
+                r[sl][fb][0] = ld16(wo + ((s * MB + fb) * 8 + 2 * j) * 1024);
+                r[sl][fb][1] = ld16(wo + ((s * MB + fb) * 8 + 2 * j + 1) * 1024);
+                if constexpr (j == 2) wsc[fb] = ld4(so + (s * MB + fb) * 256);
             }
         } else {
-            constexpr int t = U - 6 * NSR;
+            constexpr int t = U - 4 * NSR;
 #pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) { wth[t][fb] = tp[((t * MB + fb) * 2) * 64]; wtm[t][fb] = tp[((t * MB + fb) * 2 + 1) * 64]; }
+            for (int fb = 0; fb < NFB; ++fb) {
+                r[sl][fb][0] = ld16(to + ((t * MB + fb) * 2) * 1024);
+                r[sl][fb][1] = ld16(to + ((t * MB + fb) * 2 + 1) * 1024);
+            }
         }
     }
-    // img = the layer's image; fb0 = first feature block of this wave; s0 = first superchunk (NSR < 4 only)
+    // img = the layer's image (uniform); fb0 = first feature block of this wave (wave-uniform); s0 = first superchunk (NSR < 4 only; wave-uniform)
     __device__ __forceinline__ void prefetch(const char *img, int fb0, int lane, int s0 = 0) {
-        const uint4 *u = reinterpret_cast<const uint4 *>(img);
-        wp = u + ((size_t)(s0 * MB + fb0) * 8) * 64 + lane;
-        tp = u + (size_t)PN_MIX_NS * MB * 8 * 64 + (size_t)fb0 * 2 * 64 + lane;
-        sp = reinterpret_cast<const unsigned *>(u + PN_MIMG_U4(NT, MB)) + (size_t)(s0 * MB + fb0) * 64 + lane;
+#ifdef PN_EMU
+        base = img;
+#else
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(img), 0, PN_MIMG(NT, MB), 0x00020000);
+#endif
+        wo = (s0 * MB + fb0) * 8 * 1024;
+        to = PN_MIX_NS * MB * 8 * 1024 + fb0 * 2 * 1024;
+        so = PN_MIMG_U4(NT, MB) * 16 + (s0 * MB + fb0) * 256;
+        lo = lane * 16;
         pn_static_for<PF>([&](auto uu) { load<decltype(uu)::value>(); });
     }
 };
@@ -167,68 +200,66 @@ struct PnMixW {
 template <int NSR, int NT, int MB, int NFB, int LEAD = PN_MIX_LEAD, int AF>
 __device__ __forceinline__ void pn_gemm_mix_run(const char *X, PnMixW<NSR, NT, MB, NFB, LEAD> &W, int lane, f32x16 (&acc)[AF][2], int s0 = 0) {
     static_assert(NFB <= AF, "accumulator blocks");
-    constexpr int NU = 6 * NSR + NT;
+    constexpr int NU = 4 * NSR + NT, NS = LEAD + 1;
     const char *xb = X + (lane & 31) * PN_XRS + (lane >> 5) * 16 + s0 * 128;                  // h plane: chunk c at 32 c
     const char *qb = X + PN_XPLANE + (lane & 31) * PN_XRS + (lane >> 5) * 32 + s0 * 128;      // plane 1: MFMA j of superchunk s at 128 s + 64 j
-    uint4 xh[2][2], xq[2][2][2], xth[2][2], xtm[2][2];
+    uint4 x[2][2][2];
     auto load_x = [&](auto uu) {
-        constexpr int u = decltype(uu)::value;
-        if constexpr (u < 6 * NSR) {
-            constexpr int s = u / 6, j = u % 6;
+        constexpr int u = decltype(uu)::value, sl = u & 1;
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                if constexpr (j < 4) xh[j & 1][rb] = *reinterpret_cast<const uint4 *>(xb + rb * 32 * PN_XRS + (4 * s + j) * 32);
-                else {
-                    xq[j & 1][rb][0] = *reinterpret_cast<const uint4 *>(qb + rb * 32 * PN_XRS + 128 * s + 64 * (j - 4));
-                    xq[j & 1][rb][1] = *reinterpret_cast<const uint4 *>(qb + rb * 32 * PN_XRS + 128 * s + 64 * (j - 4) + 16);
+        for (int rb = 0; rb < 2; ++rb) {
+            if constexpr (u < 4 * NSR) {
+                constexpr int s = u / 4, j = u % 4;
+                if constexpr (j < 2) {
+                    x[sl][rb][0] = *reinterpret_cast<const uint4 *>(xb + rb * 32 * PN_XRS + (4 * s + 2 * j) * 32);
+                    x[sl][rb][1] = *reinterpret_cast<const uint4 *>(xb + rb * 32 * PN_XRS + (4 * s + 2 * j + 1) * 32);
+                } else {
+                    x[sl][rb][0] = *reinterpret_cast<const uint4 *>(qb + rb * 32 * PN_XRS + 128 * s + 64 * (j - 2));
+                    x[sl][rb][1] = *reinterpret_cast<const uint4 *>(qb + rb * 32 * PN_XRS + 128 * s + 64 * (j - 2) + 16);
                 }
-            }
-        } else {
-            constexpr int t = u - 6 * NSR;
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                xth[t & 1][rb] = *reinterpret_cast<const uint4 *>(xb + rb * 32 * PN_XRS + 512 + 32 * t);
-                xtm[t & 1][rb] = *reinterpret_cast<const uint4 *>(xb + PN_XPLANE + rb * 32 * PN_XRS + 512 + 32 * t);
+            } else {
+                constexpr int t = u - 4 * NSR;
+                x[sl][rb][0] = *reinterpret_cast<const uint4 *>(xb + rb * 32 * PN_XRS + 512 + 32 * t);
+                x[sl][rb][1] = *reinterpret_cast<const uint4 *>(xb + PN_XPLANE + rb * 32 * PN_XRS + 512 + 32 * t);
             }
         }
     };
     load_x(std::integral_constant<int, 0>{});
     PN_GEMM_PRIO_BEGIN();
     pn_static_for<NU>([&](auto uu) {
-        constexpr int u = decltype(uu)::value;
+        constexpr int u = decltype(uu)::value, sw = u % NS, sx = u & 1;
         if constexpr (u + LEAD < NU) W.template load<u + LEAD>();
         if constexpr (u + 1 < NU) load_x(std::integral_constant<int, u + 1>{});
         __builtin_amdgcn_sched_barrier(0);      // (loads stay in front of the unit's MFMAs: see f16x3.h)
-        if constexpr (u < 6 * NSR) {
-            constexpr int j = u % 6;
-            if constexpr (j < 4) {
+        if constexpr (u < 4 * NSR) {
+            constexpr int j = u % 4;
+            if constexpr (j < 2) {
 #pragma unroll
-                for (int fb = 0; fb < NFB; ++fb)
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
-                        acc[fb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pn_h8, W.wh[j][fb]), __builtin_bit_cast(pn_h8, xh[j & 1][rb]), acc[fb][rb], 0, 0, 0);
+                    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb)
+                            acc[fb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pn_h8, W.r[sw][fb][c]), __builtin_bit_cast(pn_h8, x[sx][rb][c]), acc[fb][rb], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb) {
-                        struct { uint4 a, b; } wa = {W.wq[j - 4][fb][0], W.wq[j - 4][fb][1]}, xa = {xq[j & 1][rb][0], xq[j & 1][rb][1]};
+                        struct { uint4 a, b; } wa = {W.r[sw][fb][0], W.r[sw][fb][1]}, xa = {x[sx][rb][0], x[sx][rb][1]};
                         acc[fb][rb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_bit_cast(pn_i8v, wa), __builtin_bit_cast(pn_i8v, xa), acc[fb][rb], 0, 0,
-                                                                                      j - 4, (int)W.wsc[fb], 0, PN_MIX_MSC_BYTE);
+                                                                                      j - 2, (int)W.wsc[fb], 0, PN_MIX_MSC_BYTE);
                     }
             }
         } else {
-            constexpr int t = u - 6 * NSR;
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
                 for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
-                    for (int rb = 0; rb < 2; ++rb) {
-                        const pn_h8 a = __builtin_bit_cast(pn_h8, p == 2 ? W.wtm[t][fb] : W.wth[t][fb]);
-                        const pn_h8 b = __builtin_bit_cast(pn_h8, p == 1 ? xtm[t & 1][rb] : xth[t & 1][rb]);
-                        acc[fb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[fb][rb], 0, 0, 0);
-                    }
+                    for (int rb = 0; rb < 2; ++rb)
+                        acc[fb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pn_h8, W.r[sw][fb][p == 2 ? 1 : 0]), __builtin_bit_cast(pn_h8, x[sx][rb][p == 1 ? 1 : 0]),
+                                                                             acc[fb][rb], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     });

@@ -88,6 +88,8 @@ int pn_classify(const PnSaved &sv, const int32_t *d_valid_list, const int32_t *d
 size_t pn_cls_bytes(long long samples);
 void pn_cls_carve(void *base, long long samples, PnSaved &s);
 size_t pn_saved_bytes(long long n_valid, int K, long long *rows_out, long long *samples_out);
+int pn_cross_terms();                   // 8 (default: mixq.h, e4m3 cross terms in the aggregator's tile GEMMs) or 16 (f16x3.h's three f16 products)
+int pn_mix_mask();                      // bit 0 / 1 / 2: the inference forward / training forward / backward tile kernels run the mixed format (0 when the cross terms are f16)
 int pn_wgrad_planes();                  // 1 (default: one f16 plane per weight-gradient operand) or 2 (both operands as two planes, three products)
 PnSaved pn_saved_carve(void *base, long long n_valid, int K);
 
