@@ -11,8 +11,9 @@ script values); configs[2] is `--gpus 8` of the default.  One "step" is one opti
 the hot path over one batch of `--rays` rays per GPU, inputs already resident in HBM:
     query (grid cached: xyz is fixed) -> aggregator MLP -> ray-march -> masked MSE + conf regulariser
     -> backward -> [N>1: RCCL all-reduce of the gradients] -> 2x Adam (MLP lr, points plr) .
-N>1 shards the rays of the global batch across ranks with the point cloud and MLP replicated (weak scaling:
-per-GPU ray count fixed); the only collectives are the gradient all-reduce and a 2-float loss normaliser.
+N>1 shards the rays of ONE global batch of `--rays` rays contiguously across the ranks (BASELINE.json configs[2] as SURVEY 8d defines it:
+"scaling": "strong"), point cloud and MLP replicated; `--weak` keeps `--rays` rays PER GPU instead (the optional weak-scaling variant);
+the only collectives are the gradient all-reduce and a 2-float loss normaliser.
 Rank 0 prints ONE JSON line; `value` is whole-job rays/sec.  `roofline` (dominant kernel): `frac` = SURVEY 8d algorithmic work / nominal peak,
 `frac_executed` = executed f16 products / nominal peak, `peak_measured` = the ceiling timed in this run (f16 MFMA with toggling operands:
 pnerf_debug_mfma_rate; HBM entries: a 1 GiB device copy), `traffic` = PMC bytes of the committed profile pass (stamped with its commit).
@@ -39,6 +40,10 @@ FLOP_SAMPLE_WGRAD = 2 * (280 * 128 + 2 * 128 * 128)
 # the four 256-wide aggregator layers run on v_mfma_f32_32x32x16_f16 with two-plane operands: THREE f16 products per algorithmic
 # multiply-add (csrc/f16x3.h), so the matrix pipe executes 3x the algorithmic flops; its roofline is the dense f16 peak
 F16_PRODUCTS = 3
+# csrc/mixq.h (round 6): the leading product on f16 factors + the two cross terms on e4m3 factors at half the pipe cycles each = 2 f16-product
+# equivalents on the 256 columns of a layer that run the mixed format (its tail columns, 16 / 32 of layers 3 / 1 of the forward, keep three)
+MIX_PRODUCTS_BWD = 2.0
+MIX_PRODUCTS_FWD = (4 * 256 * 2.0 + 48 * 3.0) / (4 * 256 + 48)
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense BF16/F16 MFMA (measured 2178-2495)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense (no kernel of the path uses it any more)
 PEAK_HBM_GBS = 8000.0
@@ -99,7 +104,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="lego", choices=sorted(CONFIGS), help="BASELINE.json configuration (default: configs[1], the headline)")
-    ap.add_argument("--rays", type=int, default=65536, help="rays per GPU per step")
+    ap.add_argument("--rays", type=int, default=65536, help="rays of the global batch per step (N > 1: split contiguously over the ranks; with --weak: rays per GPU)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: weak scaling (--rays rays per GPU, global batch N x --rays) instead of the default strong scaling (configs[2])")
+    ap.add_argument("--no-variants", action="store_true", help="skip the supplementary variants of the default run (f16 cross terms, e4m3 forward, reference shell, fp32-class weight gradients)")
     ap.add_argument("--points", type=int, default=0, help="neural points (0 = the configuration's own count)")
     ap.add_argument("--cpu-rays", type=int, default=12288, help="rays of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events")
@@ -198,11 +205,20 @@ def cpu_baseline_reference(opt, n_points, rays, threads, points_fn=None, rays_fn
     import argparse as _ap
     from pointnerf_amd import scenes
     from oracle import pyref
-    if "/root/reference" not in sys.path:
-        sys.path.insert(1, "/root/reference")
-    from models.aggregators.point_aggregators import PointAggregator                      # (reference)
-    from models.rendering.diff_ray_marching import ray_march                               # (reference)
-    from models.rendering.diff_render_func import find_render_function, find_blend_function   # (reference)
+    # (a `models` package may already be in sys.modules -- pointnerf_amd's overlay installs one: drop it, import the reference's, and check where
+    #  every module came from before the result is labelled 'reference')
+    for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+        del sys.modules[k]
+    if sys.path[0] != "/root/reference":
+        sys.path.insert(0, "/root/reference")
+    import models.aggregators.point_aggregators as _ref_pa                                  # (reference)
+    import models.rendering.diff_ray_marching as _ref_rm                                    # (reference)
+    import models.rendering.diff_render_func as _ref_rf                                     # (reference)
+    for _m in (_ref_pa, _ref_rm, _ref_rf):
+        if not os.path.abspath(_m.__file__).startswith("/root/reference/"):
+            raise RuntimeError("%s was imported from %s, not from the reference checkout" % (_m.__name__, _m.__file__))
+    PointAggregator, ray_march = _ref_pa.PointAggregator, _ref_rm.ray_march
+    find_render_function, find_blend_function = _ref_rf.find_render_function, _ref_rf.find_blend_function
     torch.set_num_threads(threads)
     p = _ap.ArgumentParser()
     PointAggregator.modify_commandline_options(p, True)
@@ -368,9 +384,30 @@ def main():
             raise SystemExit("bench.py: the collective self-test did not run: refusing to time a multi-GPU step")
     ops.set_wgrad_planes(args.wgrad_planes)
     # N > 1: a rank that stops inside a later collective (a mismatch between the ranks' call sequences) also leaves a record
-    run_guard = Watchdog("model build + set-up + the timed steps", int(os.environ.get("PNERF_RUN_TIMEOUT", "1500")), rank, world) if dist_on else None
+    # (re-armed per phase: a slow but healthy run -- a cold first build, the Barn cloud on 8 ranks -- is not killed by one global budget)
+    guard_s = int(os.environ.get("PNERF_RUN_TIMEOUT", "1500"))
+    run_guard = Watchdog("model build + set-up", guard_s, rank, world) if dist_on else None
     if run_guard is not None:
         run_guard.__enter__()
+
+    def rearm(what):
+        nonlocal run_guard
+        if run_guard is not None:
+            run_guard.__exit__(None, None, None)
+            run_guard = Watchdog(what, guard_s, rank, world)
+            run_guard.__enter__()
+    try:
+        _run(args, world, rank, dev, dist_on, selftest, rearm)
+    finally:
+        if run_guard is not None:
+            run_guard.__exit__(None, None, None)
+    if dist_on:
+        torch.distributed.destroy_process_group()
+
+
+def _run(args, world, rank, dev, dist_on, selftest, rearm):
+    from pointnerf_amd import ops, dist as pdist
+    from pointnerf_amd.fused import FusedRender
 
     # is_train=1: the reference trains with 30 % segment jitter (point_query.py:81); the in-kernel RNG path is what a
     # training step runs, so it is what is timed (parity runs -- tests/ -- use jitter off, where results are bit-defined)
@@ -378,6 +415,10 @@ def main():
     n_points = args.points or n_default
     if args.config == "chair":
         args.rays = min(args.rays, 4096)               # configs[0] is a 64x64 crop
+    strong = world > 1 and not args.weak                # configs[2]: the identical global batch split over the ranks
+    rays_rank = args.rays // world if strong else args.rays
+    if strong and rays_rank * world != args.rays:
+        raise SystemExit("bench.py: --rays %d is not a multiple of --gpus %d" % (args.rays, world))
     opt = opt_fn(is_train=0 if args.render_only else 1)
     if args.render_only:
         ops.set_inference_products(args.inference_products)
@@ -397,7 +438,7 @@ def main():
 
     comm_marks = None                         # (event pairs around the gradient exchange on the main stream; filled in the timed region)
     total = args.warmup + args.steps
-    inputs = [step_inputs(i, rank, world, args.rays, dev, rays_fn) for i in range(total)]   # resident in HBM before timing
+    inputs = [step_inputs(i, rank, world, rays_rank, dev, rays_fn) for i in range(total)]   # resident in HBM before timing
 
     def one_step(inp):
         nonlocal comm_marks
@@ -456,6 +497,7 @@ def main():
     for i in range(args.warmup):
         one_step(inputs[i])
     torch.cuda.synchronize()
+    rearm("the timed steps")
     if not args.no_prof:
         ops.prof_enable(True)
         ops.prof_collect()
@@ -504,9 +546,62 @@ def main():
             opt_mlp.zero_grad(set_to_none=True); opt_pts.zero_grad(set_to_none=True)
             loss_fn(opt, model(**inputs[-1]), inputs[-1], world).backward()
         extra = {"ms_step_cold_grid": timed(cold), "ms_step_without_optimizer": timed(no_adam)}
+        # ---- variants of the SAME step, outside the timed region (each: two settling steps, then up to 10 timed ones)
+        def variant(what, setup, restore, step_fn=None):
+            step_fn = step_fn or one_step
+            setup()
+            try:
+                for _ in range(2):
+                    step_fn(inputs[0])
+                nv = min(args.steps, 10)
+                torch.cuda.synchronize(); tv0 = time.perf_counter()
+                for i in range(nv):
+                    lv, _ = step_fn(inputs[args.warmup + i])
+                torch.cuda.synchronize()
+                msv = (time.perf_counter() - tv0) / nv * 1e3
+            finally:
+                restore()
+            return {"ms_per_step": msv, "value": rays_rank / (msv * 1e-3), "unit": "rays/s", "steps": nv, "final_loss": float(lv.item()), "what": what}
+
+        if not dist_on and not args.no_variants:
+            # (a) f16 cross terms everywhere: the arithmetic of rounds 2-5 (csrc/f16x3.h: three f16 products per multiply-add in forward and backward)
+            extra["f16_cross_terms_variant"] = variant(
+                "pnerf_set_cross_terms(16): f16 cross terms in every tile GEMM (three f16 products per multiply-add, the round-5 arithmetic); the headline runs "
+                "the backward's input-gradient chain with e4m3 cross terms (csrc/mixq.h)",
+                lambda: ops.set_cross_terms(16), lambda: ops.set_cross_terms(8))
+            # (b) e4m3 cross terms in the training forward as well: sigma / RGB 1e-5 .. 6e-5 from the oracle (bar 1e-4, tests/test_gpu_mix.py), NOT the
+            # default because LeakyReLU pre-activations that close to zero take the other branch than the fp32 oracle's (gradient comparisons see it)
+            extra["e4m3_forward_variant"] = variant(
+                "pnerf_set_cross_terms_where(7): e4m3 cross terms in the training forward too (sigma / RGB within 6e-5 of the oracle instead of 1e-6: inside "
+                "north_star's 1e-4, but the LeakyReLU masks then differ from the fp32 oracle's near zero -- not the default)",
+                lambda: ops.set_cross_terms(8, where=7), lambda: ops.set_cross_terms(8, where=4))
+            # (c) the route the reference's UNMODIFIED shell takes through the overlay (models/mvs_points_volumetric_model.py:98-118, base_rendering_model.py
+            # :533-662): the losses as ATen chains on the compacted outputs and two torch.optim.Adam instances
+            shell = {}
+
+            def shell_setup():
+                shell["flags"] = (model.fused_zero_one, model.fused_color_loss)
+                model.fused_zero_one = model.fused_color_loss = False
+                shell["mlp"] = torch.optim.Adam(mlp_params, lr=opt.lr, betas=(0.9, 0.999))
+                shell["pts"] = torch.optim.Adam(pt_params, lr=opt.plr, betas=(0.9, 0.999))
+
+            def shell_restore():
+                model.fused_zero_one, model.fused_color_loss = shell["flags"]
+
+            def shell_step(inp):
+                shell["mlp"].zero_grad(set_to_none=True); shell["pts"].zero_grad(set_to_none=True)
+                out = model(**inp)
+                loss = loss_fn(opt, out, inp, world)
+                loss.backward()
+                shell["mlp"].step(); shell["pts"].step()
+                return loss, model.last_stats
+            extra["reference_shell_variant"] = variant(
+                "the step as the reference's unmodified mvs_points_volumetric_model.py runs it through the overlay (INTEGRATION.md 2): compacted outputs, the colour "
+                "loss and the zero-one regulariser as ATen chains (--unfused-color-loss --unfused-zero-one), two torch.optim.Adam instances",
+                shell_setup, shell_restore, shell_step)
         # the SAME step with fp32-class weight gradients (both operands of every weight-gradient GEMM as two f16 planes, three products:
         # pnerf_set_wgrad_planes(2)) -- the headline's arithmetic caveat priced in the same run, outside the timed region
-        if args.wgrad_planes == 1 and not dist_on and not args.no_fp32_class_variant:
+        if args.wgrad_planes == 1 and not dist_on and not args.no_fp32_class_variant and not args.no_variants:
             ops.set_wgrad_planes(2)
             try:
                 need2 = int(L.lib().pnerf_agg_saved_bytes(biggest, int(opt.K)))
@@ -520,7 +615,7 @@ def main():
                     lv, _ = one_step(inputs[args.warmup + i])
                 torch.cuda.synchronize()
                 msv = (time.perf_counter() - tv0) / nv * 1e3
-                extra["fp32_class_variant"] = {"ms_per_step": msv, "value": args.rays / (msv * 1e-3), "unit": "rays/s", "steps": nv,
+                extra["fp32_class_variant"] = {"ms_per_step": msv, "value": rays_rank / (msv * 1e-3), "unit": "rays/s", "steps": nv,
                                                "final_loss": float(lv.item()),
                                                "what": "the same step with --wgrad-planes 2: weight-gradient GEMM operands as 2 x f16 planes (22 bits), three "
                                                        "products per multiply-add -- the arithmetic of the forward and of the input-gradient chain; "
@@ -547,19 +642,23 @@ def main():
         replica_spread = float(max((c - c_all[0]).abs().max() for c in c_all))
     if rank == 0:
         from pointnerf_amd.fused import FusedRender
-        rays_total = args.rays * world * args.steps
+        rays_total = rays_rank * world * args.steps
         rows = float(np.mean([s["n_neighbor_rows"] for s in stats])); smp = float(np.mean([s["n_valid_samples"] for s in stats]))
         headline = args.config == "lego"
         name = ("rays/sec (render only, %d products per multiply-add, supplementary)" % args.inference_products) if args.render_only else "rays/sec (render+bwd)"
         out = {"metric": name + (" NeRF-synth lego 800^2, K=8, 128 samp/ray" if headline else " %s, K=%d, %d samp/ray" % (cfg_name, opt.K, opt.SR)),
                "value": rays_total / dt, "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "median_ms_per_step": median_ms,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32 in / out / accumulate; forward and input-gradient GEMM operands as 2 x f16 planes (22-bit) on the f16 MFMA, 3 products per multiply-add; weight-gradient GEMM operands as "
+               "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+               "dtype": "f32 in / out / accumulate; forward GEMM operands as 2 x f16 planes (22-bit) on the f16 MFMA, 3 products per multiply-add; input-gradient GEMMs: f16 leading product + "
+                        "e4m3 cross terms (csrc/mixq.h), 2 product equivalents; weight-gradient GEMM operands as "
                         + ("one f16 plane each" if args.wgrad_planes == 1 else "2 x f16 planes each, 3 products (--wgrad-planes 2: fp32-class)"), "data": "synthetic",
                "neighbor_rows_per_s": rows * world * args.steps / dt, "valid_samples_per_s": smp * world * args.steps / dt,
-               "config": {"workload": "BASELINE.json %s, %d neural points, K=%d, SR=%d, D=%d, %d rays/GPU/step, fwd+loss+bwd+Adam, grid cached"
-                                      % (cfg_name, n_points, opt.K, opt.SR, opt.z_depth_dim, args.rays),
+               "config": {"workload": "BASELINE.json %s, %d neural points, K=%d, SR=%d, D=%d, %s, fwd+loss+bwd+Adam, grid cached"
+                                      % (cfg_name, n_points, opt.K, opt.SR, opt.z_depth_dim,
+                                         ("configs[2]: one global batch of %d rays/step split contiguously over %d GPUs (%d rays/GPU/step)" % (args.rays, world, rays_rank)) if strong
+                                         else ("%d rays/GPU/step" % rays_rank) + (" (weak-scaling variant: global batch %d)" % (rays_rank * world) if world > 1 else "")),
+                          "rays_per_gpu_per_step": rays_rank, "global_batch_rays": rays_rank * world,
                           "wgrad_planes": args.wgrad_planes, "collective_selftest": selftest,
                           "parity_note": ("the synthetic Barn shell puts up to ~70 points in a 0.009 cell, beyond P = 11: the reference switches to a wall-clock-seeded "
                                           "reservoir there (parity undefined); the HIP path and the oracle both keep the first P by index, so parity on this "
@@ -572,10 +671,12 @@ def main():
                           "arena_budget_bytes": ops.arena_budget_bytes(),
                           "backward_ray_chunks": None if getattr(FusedRender, "last_chunks", None) is None else
                           {"rays_per_chunk": FusedRender.last_chunks[0], "rays": FusedRender.last_chunks[1]},
-                          "arithmetic": "f32 inputs / outputs / accumulation throughout; every GEMM of the forward and of the input-gradient chain "
-                                        "(aggregator and colour MLP) runs on v_mfma_f32_32x32x16_f16 with every f32 operand carried as two f16 planes "
+                          "arithmetic": "f32 inputs / outputs / accumulation throughout; every GEMM of the forward (aggregator and colour MLP) and of the colour "
+                                        "MLP's input-gradient chain runs on v_mfma_f32_32x32x16_f16 with every f32 operand carried as two f16 planes "
                                         "(x = h + m to 2^-22) and three products per multiply-add (h*h + h*m + m*h), f32 accumulate: sigma/RGB within "
-                                        "1.1e-6 of the f32 oracle at this configuration (bar 1e-4); the weight-gradient GEMMs (aggregator and colour layers) "
+                                        "1.1e-6 of the f32 oracle at this configuration (bar 1e-4); the aggregator's four input-gradient GEMMs run the leading "
+                                        "product h*h on f16 and the two cross terms on e4m3 factors (v_mfma_scale_f32_32x32x64_f8f6f4, csrc/mixq.h: 1.3e-6 rms of "
+                                        "sum |terms| per dot product; the LeakyReLU masks come from the fp32-class forward); the weight-gradient GEMMs (aggregator and colour layers) "
                                         "(sums over millions of rows) stream the saved inputs and the output gradients as ONE f16 plane each, rounded to nearest "
                                         "(one product, f32 accumulate; error budget: csrc/backward.hip k_wgrad_f16, tests/test_split_f16_cpu.py; measured "
                                         "against float64: tests/test_gpu_bench_config.py)", **extra}}
@@ -585,6 +686,9 @@ def main():
             alg_flop = {"agg_forward": rows * FLOP_ROW_FWD, "agg_backward": rows * FLOP_ROW_DGRAD, "wgrad": rows * FLOP_ROW_WGRAD + smp * FLOP_SAMPLE_WGRAD,
                         "color_forward": smp * FLOP_SAMPLE_FWD}
             alg_byte = {"agg_forward": rows * BYTES_ROW_FWD, "agg_backward": rows * BYTES_ROW_BWD, "wgrad": rows * BYTES_ROW_WGRAD + smp * BYTES_SAMPLE_WGRAD}
+            # SURVEY 8d's own figures (activations on chip, nothing saved): gather Nv x 172 forward, gradient scatter 2 x Nv x 168 backward; the
+            # weight-gradient GEMMs stream nothing in that model (the reference's cuBLAS wgrad reads the activations it kept in HBM)
+            survey_byte = {"agg_forward": rows * 172.0, "agg_backward": rows * 2 * 168.0}
             if args.wgrad_planes == 2:
                 # --wgrad-planes 2: every saved operand leaves as two planes (X0 whole: 288 columns), the output gradients as two, and the
                 # weight-gradient GEMMs stream each (dY plane, X plane) pair of their three products
@@ -602,21 +706,29 @@ def main():
             copy_gbs = measured_copy_gbs(dev)
             mfma_meas = {"random_operands": ops.mfma_rate_tflops(2), "constant_operands": ops.mfma_rate_tflops(1)}
 
-            def mfma_entry(k):      # SURVEY 8d's algorithmic flops against the dense f16 MFMA peak; the executed f16 products (x 3) beside it
+            ct_bits, ct_mask = ops.cross_terms_state()
+            products = {"agg_forward": MIX_PRODUCTS_FWD if ct_mask & 2 else float(F16_PRODUCTS), "agg_backward": MIX_PRODUCTS_BWD if ct_mask & 4 else float(F16_PRODUCTS)}
+            if args.wgrad_planes == 2:
+                products = {"agg_forward": float(F16_PRODUCTS), "agg_backward": float(F16_PRODUCTS)}
+
+            def mfma_entry(k):      # SURVEY 8d's algorithmic flops against the dense f16 MFMA peak; the executed f16-product equivalents beside it
                 t = per[k]["ms_per_step"] * 1e-3
+                npr = products.get(k, float(F16_PRODUCTS))
                 return {"bound": "mfma", "kernel": k, "achieved": alg_flop[k] / t / 1e12, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": alg_flop[k] / t / 1e12 / PEAK_F16_MFMA_TFLOPS,
-                        "achieved_executed": F16_PRODUCTS * alg_flop[k] / t / 1e12,
-                        "frac_executed": F16_PRODUCTS * alg_flop[k] / t / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                        "achieved_executed": npr * alg_flop[k] / t / 1e12,
+                        "frac_executed": npr * alg_flop[k] / t / 1e12 / PEAK_F16_MFMA_TFLOPS,
                         "peak_measured": mfma_meas["random_operands"], "peak_measured_constant_operands": mfma_meas["constant_operands"],
-                        "frac_executed_of_measured": F16_PRODUCTS * alg_flop[k] / t / 1e12 / mfma_meas["random_operands"],
+                        "frac_executed_of_measured": npr * alg_flop[k] / t / 1e12 / mfma_meas["random_operands"],
                         "peak_measured_note": "register-resident v_mfma_f32_32x32x16_f16 on all CUs, timed in this run (pnerf_debug_mfma_rate): with pseudo-random f16 "
                                               "operands (they toggle like a GEMM's fragments) and with one constant -- the power management holds the clock down "
                                               "when the pipe's inputs switch, so the nominal peak is not reachable on real data",
-                        "frac_note": "frac = SURVEY 8d algorithmic flops / dense f16 MFMA peak; frac_executed = executed f16 products (3 per algorithmic "
-                                     "multiply-add: two-plane operands) / the same peak = matrix-pipe utilisation",
+                        "frac_note": "frac = SURVEY 8d algorithmic flops / dense f16 MFMA peak; frac_executed = executed f16-product equivalents per algorithmic "
+                                     "multiply-add (f16x3.h: three f16 products; mixq.h: one f16 product + two e4m3 products at half the pipe cycles = 2) / the same "
+                                     "peak = matrix-pipe utilisation in f16 terms",
                         "traffic": traffic.get(k), "traffic_source": traffic_source,
-                        "f16_products_per_multiply_add": F16_PRODUCTS,
+                        "f16_products_per_multiply_add": npr,
+                        "cross_terms": "e4m3 (csrc/mixq.h)" if npr < 3 else "f16 (csrc/f16x3.h)",
                         "algorithmic_flop_per_step": alg_flop[k], "ms_per_step": per[k]["ms_per_step"]}
 
             def hbm_entry(k):
@@ -626,6 +738,8 @@ def main():
                         "peak_measured": copy_gbs, "frac_of_measured": alg_byte[k] / t / 1e9 / copy_gbs,
                         "peak_measured_note": "device-to-device copy of 1 GiB (read + write counted), timed in this run",
                         "traffic": traffic.get(k), "traffic_source": traffic_source, "algorithmic_bytes_per_step": alg_byte[k],
+                        "survey_algorithmic_bytes_per_step": survey_byte.get(k),
+                        "traffic_over_survey_algorithmic": (traffic[k] / survey_byte[k]) if isinstance(traffic.get(k), (int, float)) and survey_byte.get(k) else None,
                         "ms_per_step": per[k]["ms_per_step"]}
             heavy = [k for k in ("agg_forward", "agg_backward", "wgrad") if k in per]
             if heavy:
@@ -645,13 +759,14 @@ def main():
         if not dist_on and args.cpu_rays > 0 and not args.render_only and args.config in ("lego", "chair"):
             try:
                 out["cpu_baseline"] = best_cpu_baseline(opt, n_points, args.cpu_rays, min(os.cpu_count() or 1, 32), points_fn, rays_fn)
+                if out["cpu_baseline"].get("kind") == "port":
+                    out["cpu_baseline"]["note"] = ("kind 'port': /root/reference does not exist on a GPU box (the checkout cannot travel), so the oracle's restatement is "
+                                                   "timed here; the reference's own modules on host cores (kind 'reference': its query kernels compiled for the host + "
+                                                   "PointAggregator.forward + ray_march + backward) are timed in the authoring container by `bench.py --cpu-baseline-only` "
+                                                   "-> profiles/r06_cpu_baseline_reference.json")
             except Exception as e:       # the checker failing must not hide the GPU number
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out))
-    if run_guard is not None:
-        run_guard.__exit__(None, None, None)
-    if dist_on:
-        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

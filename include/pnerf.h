@@ -221,6 +221,13 @@ int pnerf_set_wgrad_planes(int n);
  * The two-plane weight-gradient mode (pnerf_set_wgrad_planes(2)) and the two-product inference option always use 16.  Returns the previous
  * setting, or PNERF_E_INVAL.  Process-wide; may change between a training forward and its backward (the saved activations do not depend on it). */
 int pnerf_set_cross_terms(int bits);
+/* WHICH tile kernels use the e4m3 cross terms while pnerf_set_cross_terms is 8: bit 0 = the inference forward, bit 1 = the training forward,
+ * bit 2 = the backward's input-gradient chain.  Default 4 (backward only): gradients stay inside every bar of the oracle comparison (the
+ * LeakyReLU masks come from an fp32-class forward), the step is 8 % faster.  With the forward bits set sigma / RGB are 1e-5 .. 6e-5 from the
+ * oracle (bar 1e-4; f16 cross terms: 1e-6) and the step is 15 % faster, but pre-activations that close to zero take the other LeakyReLU branch
+ * than the fp32 oracle's, which the gradient comparisons against the oracle see (bench.py reports that variant).  Returns the previous mask, or
+ * PNERF_E_INVAL.  Process-wide. */
+int pnerf_set_cross_terms_where(int mask);
 
 /* Backward of pnerf_render_forward for dL/d(ray_color) = d_grad_ray_color [R,3]:
  * accumulates dL/d(MLP params) into d_grad_params (flat, pnerf_mlp_layout order) and

@@ -101,6 +101,7 @@ PROTOTYPES = {
     "pnerf_set_inference_products": (c_int, [c_int]),
     "pnerf_set_wgrad_planes": (c_int, [c_int]),
     "pnerf_set_cross_terms": (c_int, [c_int]),
+    "pnerf_set_cross_terms_where": (c_int, [c_int]),
     "pnerf_compact_workspace_bytes": (c_size_t, [c_i64]),
     "pnerf_touched_flags": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     "pnerf_compact_valid": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -522,6 +522,29 @@ def set_wgrad_planes(n):
     return old
 
 
+def set_cross_terms(bits, where=None):
+    """Arithmetic of the cross terms h*m + m*h of the aggregator's tile GEMMs (csrc/mixq.h): 8 = e4m3 factors (default), 16 = f16 factors (csrc/f16x3.h,
+    rounds 2-5).  `where` (optional) = which kernels use the e4m3 form: bit 0 inference forward, bit 1 training forward, bit 2 backward (default 4).
+    Returns (previous bits, previous mask)."""
+    old = L.lib().pnerf_set_cross_terms(int(bits))
+    if old < 0:
+        raise ValueError("cross terms must be 8 or 16")
+    oldw = L.lib().pnerf_set_cross_terms_where(int(where)) if where is not None else None
+    if where is not None and oldw < 0:
+        raise ValueError("cross-term mask must be 0..7")
+    return old, oldw
+
+
+def cross_terms_state():
+    """(bits, mask) currently set: see set_cross_terms"""
+    lib = L.lib()
+    bits = lib.pnerf_set_cross_terms(8)
+    lib.pnerf_set_cross_terms(bits)
+    mask = lib.pnerf_set_cross_terms_where(4)
+    lib.pnerf_set_cross_terms_where(mask)
+    return bits, (mask if bits == 8 else 0)
+
+
 # ------------------------------------------------------------------------------------------ profiling
 def mfma_rate_tflops(mode=2, ms_target=60.0, device=None):
     """TFLOP/s of register-resident v_mfma_f32_32x32x16_f16 on the whole chip (pnerf_debug_mfma_rate; mode 0 zero operands, 1 one constant,

@@ -42,7 +42,7 @@ def _oracle_grads(opt, xyz, attrs, inp, mlp, probe=None):
     return {k: v.grad for k, v in mlp.items()}, {k: points[k].grad[0] for k in attrs}, probe[0]
 
 
-def _check(name, a, b):
+def _check(name, a, b, point_cap=5e-3):
     """MLP tensors: every element within 5e-4 of the tensor's max |grad| (measured on MI355X over all cases of this file: worst 1.95e-4, on
     block1.0 of a 12-ray case; typical 1e-5 -- fp32 accumulation order on our side and on the oracle's, plus the one-plane dY of the
     weight-gradient GEMM, tests/test_split_f16_cpu.py).
@@ -54,7 +54,7 @@ def _check(name, a, b):
     e = (a - b).abs()
     err = float(e.max())
     point = name.startswith("points_")
-    tol, cap = (2e-4, 5e-3) if point else (5e-4, 5e-4)
+    tol, cap = (2e-4, point_cap) if point else (5e-4, 5e-4)
     frac_bad = float((e > tol * scale).float().mean())
     print("%-28s max|grad| %.3e  err %.3e  rel %.2e  frac>tol %.1e" % (name, scale, err, err / scale, frac_bad))
     assert frac_bad <= (2e-3 if point else 0.0), (name, frac_bad)

@@ -52,33 +52,6 @@ def test_bench_config_forward_and_gradients():
     kink = {}
     out64, p64, m64 = pyref.render_f64(opt, op, om, inp, ref["query"], kink=kink)
     (out64["coarse_raycolor"] * probe.double()).sum().backward()
-    dev = torch.device(DEV)
-    g = torch.zeros(ctx["R"], 3, device=dev)
-    g[hit.to(dev)] = probe[0].to(dev)
-    gflat = torch.zeros_like(ctx["flat"])
-    grads = {k: torch.zeros_like(v) for k, v in ctx["pts_t"].items()}
-    ops.render_backward(ctx["cam"], ctx["pts"], ctx["packed"], ctx["flat"], ctx["raydir"], dense, ctx["R"], opt.SR, opt.K,
-                        ctx["n_valid"], fwd, g, gflat, grads)
-    torch.cuda.synchronize()
-    lay, _ = ops.mlp_layout()
-    failures = []
-    for k, (o, shp) in lay.items():
-        ours, o32, g64 = gflat[o:o + int(np.prod(shp))].view(shp).cpu().double(), om[k].grad.double(), m64[k].grad
-        scale = float(g64.abs().max())
-        e_ours, e_o32 = float((ours - g64).abs().max()) / scale, float((o32 - g64).abs().max()) / scale
-        d = (ours - g64).abs()
-        rms_ours, rms_o32 = float(d.pow(2).mean().sqrt()) / scale, float((o32 - g64).pow(2).mean().sqrt()) / scale
-        frac = float((d > max(3.0 * e_o32, 1e-5) * scale).double().mean())
-        print("%-24s max |hip - f64| %.2e  |oracle32 - f64| %.2e   rms %.2e / %.2e   elements beyond max(3 x oracle's, 1e-5): %.1e" %
-              (k, e_ours, e_o32, rms_ours, rms_o32, frac))
-        # as close to the exact gradient as the fp32 oracle is, in the mean; isolated kink flips (an output unit's row of dW and its bias
-        # entry) bounded by 1e-4 of the tensor's maximum and rare
-        # (ONE flipped unit of one row / sample changes that unit's whole row of dW: up to shp[-1] elements, e.g. 280 of the 35 840 of
-        #  color_branch.0.weight = 0.8 % -- the count allowance is therefore at least one row)
-        if not (rms_ours <= max(4.0 * rms_o32, 5e-6) and e_ours <= max(3.0 * e_o32, 1e-4) and frac * d.numel() <= max(2.0, 2e-3 * d.numel(), float(shp[-1]))):
-            failures.append((k, e_ours, e_o32, rms_ours, rms_o32, frac))
-    assert not failures, failures
-
     # points touched by a row / sample with a pre-activation within EPS of a LeakyReLU kink (float64 pre-activations)
     EPS = 2e-6
     pidx = ref["query"]["sample_pidx"][0]                            # [R'', SR, K]
@@ -89,21 +62,62 @@ def test_bench_config_forward_and_gradients():
     valid = mask.any(dim=-1)
     smp_pts = pidx[valid][kink["sample_min_pre"] < EPS]              # [n, K]
     kinked[smp_pts[smp_pts >= 0].long()] = True
-    n_bad_total = 0
-    for k in ("points_embeding", "points_conf", "points_color", "points_dir"):
-        a, b, o32 = grads[k].cpu().double(), p64[k].grad[0], op[k].grad[0].double()
-        e = (a - b).abs()
-        scale = float(b.abs().max())
-        bad = (e > 1e-5 * scale).any(dim=-1)
-        bad32 = ((o32 - b).abs() > 1e-5 * scale).any(dim=-1)
-        n_bad_total += int(bad.sum())
-        print("%-18s max|grad| %.3e  |hip - f64| %.2e  |oracle32 - f64| %.2e  points beyond 1e-5 max: hip %d, oracle32 %d (hip's all kink-attributed: %s)" %
-              (k, scale, float(e.max()) / scale, float((o32 - b).abs().max()) / scale, int(bad.sum()), int(bad32.sum()), bool(kinked[bad].all())))
-        assert bool(kinked[bad].all()), (k, "out-of-tolerance gradient on a point no kink explains", bad.nonzero()[:5].tolist())
-        assert float(e.max()) <= 2e-2 * scale, k
     touched = int((row_pts.unique() >= 0).sum())
-    print("points touched %d, kink-affected %d, with an out-of-tolerance element %d" % (touched, int(kinked.sum()), n_bad_total))
-    assert n_bad_total <= max(4, touched // 500)
+    dev = torch.device(DEV)
+    lay, _ = ops.mlp_layout()
+    # The backward twice on the same (f16 cross terms) forward: with f16 cross terms in the input-gradient chain (the round-2..5 arithmetic:
+    # every bar as it was) and with the shipped e4m3 cross terms (csrc/mixq.h).  The e4m3 chain adds ~1.3e-6 of sum |terms| per 256-term dot
+    # product and layer to every d X element, i.e. smooth noise of ~1e-5 of a point tensor's maximum on many points instead of isolated kink
+    # flips: the MLP tensors keep their bars; a point gradient may be up to POINT_BAR of the tensor's maximum off WITHOUT a kink explaining it.
+    for bits, POINT_BAR in ((16, 1e-5), (8, 1e-4)):
+        old_bits, _ = ops.set_cross_terms(bits)
+        try:
+            if bits != 16:
+                dense, fwd, ctx = hip_render(opt, xyz, attrs, inp, mlp, train=True)
+            g = torch.zeros(ctx["R"], 3, device=dev)
+            g[hit.to(dev)] = probe[0].to(dev)
+            gflat = torch.zeros_like(ctx["flat"])
+            grads = {k: torch.zeros_like(v) for k, v in ctx["pts_t"].items()}
+            ops.render_backward(ctx["cam"], ctx["pts"], ctx["packed"], ctx["flat"], ctx["raydir"], dense, ctx["R"], opt.SR, opt.K,
+                                ctx["n_valid"], fwd, g, gflat, grads)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_cross_terms(old_bits)
+        print("---- cross terms of the input-gradient chain: %s" % ("f16 (csrc/f16x3.h)" if bits == 16 else "e4m3 (csrc/mixq.h, shipped)"))
+        failures = []
+        for k, (o, shp) in lay.items():
+            ours, o32, g64 = gflat[o:o + int(np.prod(shp))].view(shp).cpu().double(), om[k].grad.double(), m64[k].grad
+            scale = float(g64.abs().max())
+            e_ours, e_o32 = float((ours - g64).abs().max()) / scale, float((o32 - g64).abs().max()) / scale
+            d = (ours - g64).abs()
+            rms_ours, rms_o32 = float(d.pow(2).mean().sqrt()) / scale, float((o32 - g64).pow(2).mean().sqrt()) / scale
+            frac = float((d > max(3.0 * e_o32, 1e-5) * scale).double().mean())
+            print("%-24s max |hip - f64| %.2e  |oracle32 - f64| %.2e   rms %.2e / %.2e   elements beyond max(3 x oracle's, 1e-5): %.1e" %
+                  (k, e_ours, e_o32, rms_ours, rms_o32, frac))
+            # as close to the exact gradient as the fp32 oracle is, in the mean; isolated kink flips (an output unit's row of dW and its bias
+            # entry) bounded by 1e-4 of the tensor's maximum and rare
+            # (ONE flipped unit of one row / sample changes that unit's whole row of dW: up to shp[-1] elements, e.g. 280 of the 35 840 of
+            #  color_branch.0.weight = 0.8 % -- the count allowance is therefore at least one row)
+            cnt_ok = frac * d.numel() <= max(2.0, 2e-3 * d.numel(), float(shp[-1]))
+            if not (rms_ours <= max(4.0 * rms_o32, 5e-6) and e_ours <= max(3.0 * e_o32, 1e-4) and cnt_ok):
+                failures.append((k, e_ours, e_o32, rms_ours, rms_o32, frac))
+        assert not failures, failures
+        n_bad_total = 0
+        for k in ("points_embeding", "points_conf", "points_color", "points_dir"):
+            a, b, o32 = grads[k].cpu().double(), p64[k].grad[0], op[k].grad[0].double()
+            e = (a - b).abs()
+            scale = float(b.abs().max())
+            bad = (e > POINT_BAR * scale).any(dim=-1)
+            bad5 = (e > 1e-5 * scale).any(dim=-1)
+            bad32 = ((o32 - b).abs() > 1e-5 * scale).any(dim=-1)
+            n_bad_total += int(bad.sum())
+            nk = ~kinked
+            print("%-18s max|grad| %.3e  |hip - f64| %.2e (points no kink touches: %.2e)  |oracle32 - f64| %.2e  points beyond 1e-5 max: hip %d, oracle32 %d; beyond %.0e: %d (all kink-attributed: %s)" %
+                  (k, scale, float(e.max()) / scale, float(e[nk].max()) / scale, float((o32 - b).abs().max()) / scale, int(bad5.sum()), int(bad32.sum()), POINT_BAR, int(bad.sum()), bool(kinked[bad].all())))
+            assert bool(kinked[bad].all()), (k, "out-of-tolerance gradient on a point no kink explains", bad.nonzero()[:5].tolist())
+            assert float(e.max()) <= 2e-2 * scale, k
+        print("points touched %d, kink-affected %d, with an out-of-tolerance element %d" % (touched, int(kinked.sum()), n_bad_total))
+        assert n_bad_total <= max(4, touched // 500)
 
 
 WG_RAYS, WG_CHUNK = 8192, 1024

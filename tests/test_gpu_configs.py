@@ -62,8 +62,11 @@ def _run(opt, xyz_np, ray_fn, n_sub, n_full, seed):
     lay, _ = ops.mlp_layout()
     for k, (o, shp) in lay.items():
         TB._check(k, gflat[o:o + int(np.prod(shp))].view(shp).cpu(), om[k].grad)
+    # (point tensors: the fraction criterion of tests/test_gpu_backward.py as it is -- 99.8 % of the elements within 2e-4 of the tensor's maximum; the
+    #  cap on a single element is tests/test_gpu_bench_config.py's 2e-2: among 6 M / 20 M points x 32 columns ONE LeakyReLU kink flip against the
+    #  oracle shows as 6.5e-3 of the maximum, with f16 and with e4m3 cross terms alike: profiles/r06_configs_gradients.txt)
     for k in attrs:
-        TB._check(k, grads[k].cpu(), op[k].grad[0])
+        TB._check(k, grads[k].cpu(), op[k].grad[0], point_cap=2e-2)
     del op, om, grads, gflat, fwd, dense, ctx
     d = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in inp.items()}
     with torch.no_grad():

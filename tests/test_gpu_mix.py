@@ -55,6 +55,57 @@ def test_mixed_tile_gemm_saturates_instead_of_poisoning():
     ex, sab = mix_case.exact(xc, w)
     e = np.abs(o - ex) / sab
     print("rows with out-of-range values: max err / sum|terms| %.2e (rows 3, 5), %.2e (row 7: clamped to 65504)" % (e[[3, 5]].max(), e[7].max()))
-    assert e[[3, 5]].max() <= 3e-4 and e[7].max() <= 3e-4          # the outlier's own cross term is lost (2^-12 of its product), nothing else
+    assert e[[3, 5]].max() <= 6e-4 and e[7].max() <= 6e-4          # the outlier's own cross terms are lost (2 x 2^-12 of its product, which dominates sum |terms|), nothing else
     keep = np.ones(64, bool); keep[[3, 5, 7]] = False
     assert e[keep].max() <= 1e-5
+
+
+# ---- the OPTIONAL forward modes (pnerf_set_cross_terms_where bits 0 / 1: e4m3 cross terms in the inference / training forward; the default keeps f16
+# cross terms there): sigma / RGB / ray colour inside north_star's 1e-4 at configs[0], configs[1] and at trained-magnitude embeddings, figures printed
+def _forward_errors(opt, xyz, attrs, inp, mlp, train):
+    from gpu_util import hip_render
+    from oracle import pyref
+    from pointnerf_amd import ops
+    with torch.no_grad():
+        ref = pyref.render(opt, dict(xyz=xyz, **attrs), mlp, inp, nthreads=8)
+    out = {}
+    for tag, where in (("f16", 4), ("e4m3", 7)):
+        old = ops.set_cross_terms(8, where=where)
+        try:
+            dense, fwd, _ = hip_render(opt, xyz, attrs, inp, mlp, train=train)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_cross_terms(8, where=old[1])
+        hit = (dense["ray_hit"] > 0).cpu()
+        assert torch.equal(dense["sample_pidx"].cpu()[hit][None], ref["query"]["sample_pidx"])
+        dec, rv, d_ref = fwd["decoded"].cpu()[hit], ref["ray_valid"][0], ref["decoded_features"][0]
+        out[tag] = (float((dec[..., 0] - d_ref[..., 0])[rv].abs().max()), float((dec[..., 1:] - d_ref[..., 1:])[rv].abs().max()),
+                    float((fwd["ray_color"].cpu()[hit] - ref["coarse_raycolor"][0]).abs().max()), float(d_ref[..., 0].abs().max()))
+    return out
+
+
+@pytest.mark.parametrize("train", [False, True])
+@pytest.mark.parametrize("name", ["small_k8", "small_k4", "chair", "lego", "trained_k8"])
+def test_forward_with_e4m3_cross_terms_stays_inside_the_bar(name, train):
+    from cases import build_case
+    from pointnerf_amd import config, scenes
+    from oracle import pyref
+    torch.set_num_threads(8)
+    if name == "chair":                 # BASELINE.json configs[0]
+        opt = config.chair_opt()
+        xyz = torch.from_numpy(scenes.chair_points())
+        attrs = {k: torch.from_numpy(v) for k, v in scenes.point_attributes(8192, 32, 0).items()}
+        inp = pyref.to_torch_inputs(scenes.block_rays())
+        mlp = pyref.init_mlp_params(opt, seed=0, bias_scale=0.05)
+    elif name == "lego":                # configs[1], the timed configuration, 768-ray subsample
+        import test_gpu_bench_config as TBC
+        opt, xyz, attrs, inp, mlp = TBC._bench_case()
+    elif name == "trained_k8":          # embeddings ~N(0, 3^2), |e| <= 10 (tests/test_gpu_trig.py)
+        import test_gpu_trig as TT
+        opt, xyz, attrs, inp, mlp = TT._big_embedding_case("small_k8")
+    else:
+        opt, xyz, attrs, inp, mlp = build_case(name)
+    e = _forward_errors(opt, xyz, attrs, inp, mlp, train)
+    print("%s train=%s (sigma err, rgb err, ray colour err, max sigma): f16 cross terms %s   e4m3 cross terms %s" % (name, train, e["f16"], e["e4m3"]))
+    s, r, c, smax = e["e4m3"]
+    assert r <= 1e-4 and c <= 1e-4 and s <= 1e-4 * max(1.0, smax)
