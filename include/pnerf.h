@@ -61,6 +61,11 @@ int pnerf_grid_build(const pnerf_grid_params *gp, const float *d_xyz, int n_poin
                      void *d_grid_ws, size_t ws_bytes, void *stream);
 /* synchronous: copies the PNERF_GI_* words to host_info[PNERF_GI_LEN] (stream is synchronised) */
 int pnerf_grid_info(const void *d_grid_ws, int32_t *host_info, void *stream);
+/* Elementwise minimum and maximum over the points: d_out6 = {min x, min y, min z, max x, max y, max z} (device, 6 floats), what
+ * lighting_fast_querier.get_hyperparameters (models/neural_points/point_query.py:51-52) takes with torch.min / torch.max before it clamps to
+ * opt.ranges and pads: one HBM pass, asynchronous on `stream`.  Comparisons are exact (no arithmetic on the values); NaN coordinates are not
+ * ordered (the reference's reductions would propagate them). */
+int pnerf_points_minmax(const float *d_xyz, int64_t n_points, float *d_out6, void *stream);
 
 /* ---- query (replaces mask_raypos / get_shadingloc / query_neigh_along_ray_layered and the ATen
  * glue between them: query_worldcoords.cu:165-302, host :367-431; entry point

@@ -65,6 +65,7 @@ PROTOTYPES = {
     "pnerf_grid_workspace_bytes": (c_size_t, [ctypes.POINTER(GridParams), c_int]),
     "pnerf_grid_build": (c_int, [ctypes.POINTER(GridParams), c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "pnerf_grid_info": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_int32), c_void_p]),
+    "pnerf_points_minmax": (c_int, [c_void_p, c_i64, c_void_p, c_void_p]),
     "pnerf_query_workspace_bytes": (c_size_t, [c_int, c_int]),
     "pnerf_query": (c_int, [ctypes.POINTER(GridParams), c_void_p, c_void_p, ctypes.POINTER(c_f32), c_void_p, c_void_p,
                             c_f32, c_f32, c_f32, ctypes.c_uint64, c_int, c_int, c_int, c_int,

@@ -85,7 +85,21 @@ __global__ __launch_bounds__(256) void k_pack_mix(PackMTable t, const float *__r
             unsigned scw = 0u;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
+                // the lane's 16 columns (two 8-column groups), and the largest slot over ALL 32 columns of the fragment (both lane halves): the
+                // instruction's scale blocks are registers 0..3 of BOTH halves (scaled by lanes 0..31's byte) and registers 4..7 of both (lanes 32..63's),
+                // not "a lane's 32 slots" -- measured, tools/gpu_mix_diag.py; one exponent per (row, fragment) is right under either reading
                 float wh[16], wm[16], mx = 0.f;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const float w = W(m, 64 * s + 32 * j + i);
+#ifdef PN_EMU
+                    const float wc = fmaxf(fminf(w, 65504.f), -65504.f);
+#else
+                    const float wc = w;
+#endif
+                    const float h = (float)(_Float16)wc;
+                    mx = fmaxf(mx, fmaxf(fabsf(h), fabsf(w - h) * 2048.f));
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float w = W(m, 8 * (8 * s + 4 * j + 2 * hf + (i >> 3)) + (i & 7));
@@ -95,7 +109,6 @@ __global__ __launch_bounds__(256) void k_pack_mix(PackMTable t, const float *__r
                     const float wc = w;
 #endif
                     wh[i] = (float)(_Float16)wc; wm[i] = w - wh[i];
-                    mx = fmaxf(mx, fmaxf(fabsf(wh[i]), fabsf(wm[i]) * 2048.f));
                 }
                 int ex = 0;
                 const float fr = frexpf(mx, &ex);

@@ -264,14 +264,35 @@ template <int NC, int MB, int NFB, int WPF = PN_WPF, int NP = 3>
 struct PnGemmW {
     static constexpr int PF = WPF < NC ? WPF : NC - 1, NS = PF + 1;
     uint4 wh[NS][NFB], wm[NS][NFB];
-    const uint4 *wp;
+    // Round 6: buffer addressing -- the image's descriptor in scalar registers + the lane's 32-bit offset (one vector register for every load of the
+    // GEMM) + a wave-uniform scalar offset per load.  With flat pointers the chunk offsets (2 KB per chunk and feature block: beyond the 4 KB
+    // immediate range after two chunks) became 64-bit vector address pairs formed by v_add_co / v_addc in the loop.  fb0 / c0 must be wave-uniform.
+#ifdef PN_EMU
+    const char *base;
+#else
+    __amdgpu_buffer_rsrc_t rs;
+#endif
+    int wo, lo;
+    __device__ __forceinline__ uint4 ld16(int soff) const {
+#ifdef PN_EMU
+        return *reinterpret_cast<const uint4 *>(base + soff + lo);
+#else
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, lo, soff, 0));
+#endif
+    }
     template <int C> __device__ __forceinline__ void load() {
         constexpr int s = C % NS;
 #pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) { wh[s][fb] = wp[(C * MB + fb) * 128]; if (NP == 3) wm[s][fb] = wp[(C * MB + fb) * 128 + 64]; }
+        for (int fb = 0; fb < NFB; ++fb) { wh[s][fb] = ld16(wo + (C * MB + fb) * 2048); if (NP == 3) wm[s][fb] = ld16(wo + (C * MB + fb) * 2048 + 1024); }
     }
     __device__ __forceinline__ void prefetch(const uint4 *__restrict__ img, int fb0, int lane, int c0 = 0) {
-        wp = img + ((size_t)c0 * MB + fb0) * 128 + lane;
+#ifdef PN_EMU
+        base = reinterpret_cast<const char *>(img);
+#else
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(img), 0, 0x7fffffff, 0x00020000);
+#endif
+        wo = (c0 * MB + fb0) * 2048;
+        lo = lane * 16;
         pn_static_for<PF>([&](auto cc) { load<decltype(cc)::value>(); });
     }
 };

@@ -246,5 +246,50 @@ extern "C" int pnerf_grid_info(const void *ws, int32_t *host_info, void *stream)
     return 0;
 }
 
+// ---- a1: elementwise min / max over all points (lighting_fast_querier.get_hyperparameters, models/neural_points/point_query.py:51-52: the grid's
+// extent before it is clamped to opt.ranges and padded): one pass over xyz -- 24 MB at 2 M points, ~10 us at the HBM roof -- instead of two
+// ATen reductions of 1.1 .. 1.5 ms each (profiles/r05_kernel_stats.csv: as long as the whole grid build).  Floats are ordered as unsigned keys
+// (sign bit flipped for x >= 0, all bits for x < 0), per-wave shuffle reduction, one atomicMin / atomicMax per wave and component.
+namespace {
+__device__ __forceinline__ unsigned pn_fkey(float f) { const unsigned b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float pn_fkey_inv(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+__global__ void k_minmax_init(unsigned *__restrict__ key) { if (threadIdx.x < 6) key[threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u; }
+__global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ xyz, long long n, unsigned *__restrict__ key) {
+    unsigned mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const unsigned k = pn_fkey(xyz[3 * i + c]);
+            mn[c] = min(mn[c], k); mx[c] = max(mx[c], k);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { mn[c] = min(mn[c], __shfl_xor(mn[c], off, 64)); mx[c] = max(mx[c], __shfl_xor(mx[c], off, 64)); }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { atomicMin(&key[c], mn[c]); atomicMax(&key[3 + c], mx[c]); }
+    }
+}
+__global__ void k_minmax_decode(unsigned *__restrict__ key) {
+    if (threadIdx.x < 6) { const float f = pn_fkey_inv(key[threadIdx.x]); key[threadIdx.x] = __float_as_uint(f); }
+}
+}  // namespace
+
+extern "C" int pnerf_points_minmax(const float *d_xyz, int64_t n, float *d_out6, void *stream) {
+    if (!d_xyz || !d_out6 || n <= 0) return PNERF_E_INVAL;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned *key = reinterpret_cast<unsigned *>(d_out6);
+    PnProfScope prof(PNK_GRID, s);
+    hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(64), 0, s, key);
+    const int blocks = (int)(n / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_minmax, dim3(blocks), dim3(256), 0, s, d_xyz, (long long)n, key);
+    hipLaunchKernelGGL(k_minmax_decode, dim3(1), dim3(64), 0, s, key);
+    PN_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pnerf_version(void) { return 1000; }
 extern "C" const char *pnerf_arch(void) { return "gfx950"; }

@@ -12,7 +12,9 @@
 // subnormals kept (step 2^-9), and overflow gives NaN unless MODE.FP16_OVFL is set, in which case it SATURATES at +-448 (and v_cvt_f16_f32 at
 // +-65504) -- the tile kernels set that bit (pn_mode_saturate), so an outlier degrades a cross term instead of poisoning the tile;
 // v_mfma_scale_f32_32x32x64_f8f6f4 multiplies byte j of a lane's A registers with byte j of the same lane's B registers (any assignment of the
-// 64 k to (lane half, byte) works if both operands use it) and applies 2^(s - 127) per LANE from a byte of a VGPR chosen by op_sel.
+// 64 k to (lane half, byte) works if both operands use it) and applies 2^(s - 127) from a byte of a VGPR chosen by op_sel -- per SCALE BLOCK, and
+// the blocks are registers 0..3 of both lane halves (scaled by the byte lanes 0..31 hold) and registers 4..7 of both halves (lanes 32..63's
+// byte), not "a lane's 32 slots": a row's two lanes must agree wherever one exponent has to cover slots of both (measured: tools/gpu_mix_diag.py).
 //
 // Layout of a tile row in LDS (the two planes of f16x3.h keep their places and strides):
 //   plane 0  [row][k] f16     h = f16_rne(x), all columns                                (row stride PN_XRS)
@@ -26,8 +28,9 @@
 //                                                               r = 4, 5: e4m3 fragment of MFMA 0;  r = 6, 7: of MFMA 1 -- per 8-column group
 //                                                               [q8(wm 2^11 / 2^e) x 8 | q8(wh / 2^e) x 8]: slot-wise the partner of the row's unit
 //   tail chunk t:            [NS MB 8 64 + ((t MB + mb) 2 + plane) 64 + lane]          (f16x3.h's two-plane chunk)
-//   block scales:            uint32 [(s MB + mb) 64 + lane] behind the units: byte j = e + 127 of the lane's 32 slots of MFMA j (e chosen so that the
-//                            largest slot lies in (224, 448]: the weights are packed once per step, their block scale costs nothing in the loop)
+//   block scales:            uint32 [(s MB + mb) 64 + lane] behind the units: byte j = e + 127 of the ROW's 64 slots of MFMA j (both lanes of a row hold
+//                            the same byte; e chosen so that the largest slot lies in (224, 448]: the weights are packed once per step, their
+//                            block scale costs nothing in the loop)
 // The activations use fixed scales (1 for h, 2^-11 for m): a lane's 32 slots are 16 columns x (h, m 2^11), magnitudes |x| and <= |x| / 2.
 #pragma once
 #include "f16x3.h"

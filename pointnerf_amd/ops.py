@@ -83,7 +83,11 @@ def grid_hyperparameters(opt, xyz):
     vscale = np.asarray(opt.vscale, dtype=np.int32)
     scaled_vsize = (np.asarray(opt.vsize) * vscale).astype(np.float32)
     radius = np.asarray(opt.radius_limit_scale * max(opt.vsize[0], opt.vsize[1])).astype(np.float32)
-    mm = torch.stack([xyz.min(dim=0)[0], xyz.max(dim=0)[0]]).cpu()
+    _need_cuda(xyz, "xyz")
+    xyz = xyz.contiguous()
+    mm6 = torch.empty(6, dtype=torch.float32, device=xyz.device)
+    L.check(L.lib().pnerf_points_minmax(_ptr(xyz), int(xyz.shape[0]), _ptr(mm6), _stream()), "pnerf_points_minmax")
+    mm = mm6.cpu().view(2, 3)
     rmin = torch.as_tensor(opt.ranges[:3], dtype=torch.float32)
     rmax = torch.as_tensor(opt.ranges[3:], dtype=torch.float32)
     mn, mx = torch.maximum(mm[0], rmin), torch.minimum(mm[1], rmax)

@@ -37,8 +37,8 @@ def restate(x, w):
     wh = f16(w); wm32 = (w - wh).astype(np.float32)
     out = xh[:, :256].astype(np.float64) @ wh[:, :256].astype(np.float64).T
     x8h = q_e4m3(xh[:, :256]); x8m = q_e4m3(xm[:, :256].astype(np.float64) * 2048.0)
-    for blk in range(16):                       # 16 columns = one lane's 32 slots
-        c = slice(16 * blk, 16 * blk + 16)
+    for blk in range(8):                        # 32 columns = one e4m3 fragment (both lane halves): one block exponent per (row, fragment)
+        c = slice(32 * blk, 32 * blk + 32)
         mx = np.maximum(np.abs(wh[:, c]).max(1), np.abs(wm32[:, c]).max(1) * 2048.0).astype(np.float32)
         fr, ex = np.frexp(mx)
         be = np.where(mx > 0, np.where(fr > 0.875, ex - 8, ex - 9), 0).clip(-100, 100).astype(np.float64)

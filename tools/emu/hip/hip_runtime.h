@@ -216,13 +216,17 @@ static inline emu_f32x16 emu_mfma_scale_32x32x64_e4m3(emu_i8v a, emu_i8v b, emu_
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
         double acc = c[r];
+        // scale blocks (measured on gfx950, tools/gpu_mix_diag.py): registers 0..3 (bytes 0..15) of BOTH lane halves form K block 0, scaled by the
+        // byte of lanes 0..31; registers 4..7 (bytes 16..31) of both halves form K block 1, scaled by the byte of lanes 32..63
+        int sA[2][2], sB[2][2];
+        for (int kb = 0; kb < 2; ++kb) { memcpy(sA[kb], t2 + 64 * (i + 32 * kb), 8); memcpy(sB[kb], t2 + 64 * (j + 32 * kb), 8); }
         for (int kh = 0; kh < 2; ++kh) {
             const unsigned char *A = (const unsigned char *)mine + 64 * (i + 32 * kh), *B = (const unsigned char *)mine + 64 * (j + 32 * kh) + 32;
-            int sA[2], sB[2];
-            memcpy(sA, t2 + 64 * (i + 32 * kh), 8); memcpy(sB, t2 + 64 * (j + 32 * kh), 8);
-            double s = 0.0;
-            for (int q = 0; q < 32; ++q) s += (double)emu_e4m3_dec(A[q]) * (double)emu_e4m3_dec(B[q]);
-            acc += std::ldexp(s, (sA[0] - 127) + (sB[1] - 127));
+            for (int kb = 0; kb < 2; ++kb) {
+                double s = 0.0;
+                for (int q = 16 * kb; q < 16 * kb + 16; ++q) s += (double)emu_e4m3_dec(A[q]) * (double)emu_e4m3_dec(B[q]);
+                acc += std::ldexp(s, (sA[kb][0] - 127) + (sB[kb][1] - 127));
+            }
         }
         c[r] = (float)acc;
     }
