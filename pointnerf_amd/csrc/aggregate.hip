@@ -542,7 +542,8 @@ __device__ __forceinline__ void f_gather(const FwdArgs &a, FGather &G, int si_, 
 // X0 row of the tile: [e(32) | PE3(e) (192) | PE5(dists) (60) | 1 | 0 0 0], the row's raw weight and layer-3 extras
 // (point_aggregators.py:773-784, :425-428, :506, :566; networks.py:175-190)
 // MIX: the tile in the mixed format of mixq.h (columns < 256: h plane + e4m3 units; from 256 on the two f16 planes, h to nearest)
-template <bool PERS, bool MIX = false>
+// HR: f16x3.h's two planes with h rounded to NEAREST (the training forward: its k-major copy-outs then read the h plane only)
+template <bool PERS, bool MIX = false, bool HR = false>
 __device__ __forceinline__ void f_build(const FwdArgs &a, const FGather &G, char *X, float *exb, float *wraw, int *sidx, int si, int p, int row, int q) {
     const float dwx = G.px - G.lx, dwy = G.py - G.ly, dwz = G.pz - G.lz;
     float ppx, ppy, pcz, spx, spy, scz;
@@ -576,16 +577,22 @@ __device__ __forceinline__ void f_build(const FwdArgs &a, const FGather &G, char
             pn_xq_store4(X, row, col + 8, s1[1], c1[1], s1[2], c1[2]);
         }
     } else {
-    pn_x_store4<false>(X, row, EPT * q, e[0], e[1], e[2], e[3]);
-    pn_x_store4<false>(X, row, EPT * q + 4, e[4], e[5], e[6], e[7]);
+    if (HR) { pn_xt_store4(X, row, EPT * q, e[0], e[1], e[2], e[3]); pn_xt_store4(X, row, EPT * q + 4, e[4], e[5], e[6], e[7]); }
+    else { pn_x_store4<false>(X, row, EPT * q, e[0], e[1], e[2], e[3]); pn_x_store4<false>(X, row, EPT * q + 4, e[4], e[5], e[6], e[7]); }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int dd = EPT * q + i;
         float s[3], c[3];
         pn_pe_octaves<3>(e[i], s, c);
-        pn_x_store2(X, row, PN_F + dd * 6, s[0], c[0]);
-        pn_x_store2(X, row, PN_F + dd * 6 + 2, s[1], c[1]);
-        pn_x_store2(X, row, PN_F + dd * 6 + 4, s[2], c[2]);
+        if (HR) {
+            pn_xt_store2(X, row, PN_F + dd * 6, s[0], c[0]);
+            pn_xt_store2(X, row, PN_F + dd * 6 + 2, s[1], c[1]);
+            pn_xt_store2(X, row, PN_F + dd * 6 + 4, s[2], c[2]);
+        } else {
+            pn_x_store2(X, row, PN_F + dd * 6, s[0], c[0]);
+            pn_x_store2(X, row, PN_F + dd * 6 + 2, s[1], c[1]);
+            pn_x_store2(X, row, PN_F + dd * 6 + 4, s[2], c[2]);
+        }
         if (PN_NW == 8 && (i & 1)) __builtin_amdgcn_sched_barrier(0);      // (register budget of the 8-wave organisation)
     }
     }
@@ -599,12 +606,13 @@ __device__ __forceinline__ void f_build(const FwdArgs &a, const FGather &G, char
 #pragma unroll
             for (int f = 0; f < 5; ++f) {
                 if (MIX) pn_xa_store2(X, row, PN_F * 7 + (comp * 5 + f) * 2, s[f], c[f]);
+                else if (HR) pn_xt_store2(X, row, PN_F * 7 + (comp * 5 + f) * 2, s[f], c[f]);
                 else pn_x_store2(X, row, PN_F * 7 + (comp * 5 + f) * 2, s[f], c[f]);
             }
         }
     }
     if (q == 3) {
-        if (MIX) pn_xt_store4(X, row, PN_ONES1, 1.f, 0.f, 0.f, 0.f);
+        if (MIX || HR) pn_xt_store4(X, row, PN_ONES1, 1.f, 0.f, 0.f, 0.f);
         else pn_x_store4<false>(X, row, PN_ONES1, 1.f, 0.f, 0.f, 0.f);
     }
     if (q == 0) {
@@ -639,7 +647,7 @@ __device__ __forceinline__ void f_acc_bias(const float *__restrict__ bias, int w
 // Sign word: one v_alignbit_b32 per element shifts the element's sign bit into a 32-bit accumulator (MSB first), element
 // e = (rb * 4 + g) * 4 + i of a lane's feature block -> bit 31 - e of the block's word; bit set = negative = slope 0.01 in the backward.
 // mw[fb] = the word of the wave's feature block fb (global block PN_NFB * wave + fb): stored as lmask[tile][layer][block][lane].
-template <bool BITS, bool MIX = false>
+template <bool BITS, bool MIX = false, bool HR = false>
 __device__ __forceinline__ void f_epilogue(const f32x16 (&acc)[PN_NFB][2], char *X, int wave, int lane, unsigned (&mw)[PN_NFB]) {
 #pragma unroll
     for (int fb = 0; fb < PN_NFB; ++fb) mw[fb] = 0u;
@@ -658,6 +666,7 @@ __device__ __forceinline__ void f_epilogue(const f32x16 (&acc)[PN_NFB][2], char 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.01f * v[i]);
                 if (MIX) pn_xq_store4(X, 32 * rb + (lane & 31), f0, v[0], v[1], v[2], v[3]);
+                else if (HR) pn_xt_store4(X, 32 * rb + (lane & 31), f0, v[0], v[1], v[2], v[3]);
                 else pn_x_store4<false>(X, 32 * rb + (lane & 31), f0, v[0], v[1], v[2], v[3]);
             }
 }
@@ -777,6 +786,7 @@ PN_TR_DECL(pn_trace_fwd);
 template <bool TRAIN, bool PERS, int NP, bool WG2 = false>
 __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
     constexpr bool MIX = NP == 4;
+    constexpr bool HR = TRAIN && !WG2 && !MIX;      // f16x3 tiles with h rounded to nearest: h-only copy-outs
     constexpr int NPC = MIX ? 3 : NP;          // (what the classic templates are instantiated with where MIX compiles them away)
     static_assert(!(MIX && WG2), "the two-plane weight-gradient mode keeps f16x3.h's arithmetic everywhere");
     pn_mode_saturate();
@@ -840,7 +850,7 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
         const long long gtile = tb + tile;               // tile index inside the saved area
         PN_LDS_BARRIER();                                 // the previous tile's readers are done with X and the row arrays
         PN_TR(pn_trace_fwd, 0); PN_TR_HWID(pn_trace_fwd);
-        if (bw) f_build<PERS, MIX>(a, G, X, exb, wraw, sidx, si0, p0, row, q);
+        if (bw) f_build<PERS, MIX, HR>(a, G, X, exb, wraw, sidx, si0, p0, row, q);
         // Round 4: what the next GEMM needs from GLOBAL memory -- its bias (the accumulators' initial value) and its first weight-fragment
         // chunks -- is requested in front of the barrier that precedes it, not behind: neither depends on LDS, and the L2 round trip
         // (0.6 .. 1.1 us per layer in profiles/r03_phase_trace.json: the "acc = bias" phases) passes under the barrier wait.
@@ -873,7 +883,7 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
         if constexpr (MIX) pn_gemm_mix_run<PN_MIX_NS, 2, 8, PN_NFB>(X, M1, lane, acc);
         else pn_gemm_f16x3_run<18, 8, PN_NFB, PN_WPF, NPC>(X, W1, lane, acc);
         if (TRAIN) {           // (behind the GEMM: see above)
-            if (MIX) {         // the mixed tile's h plane IS the nearest f16: the k-major plane is its transpose
+            if (MIX || HR) {         // the tile's h plane IS the nearest f16: the k-major plane is its transpose
                 if (a.save_x0) pn_copy_out_kmajor_h<PN_NF1, PN_XRS, PN_NW>(X, a.sv.x0k, gtile * 8, tid);
                 else pn_copy_out_kmajor_cols64_h<224, PN_NW>(X, a.sv.x0k, gtile * 8, tid);
             } else if (WG2) pn_copy_out_kmajor<PN_NF1, true, PN_NW>(X, a.sv.x0k, gtile * 8, tid, a.sv.x0m);
@@ -882,7 +892,7 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
         }
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 3);
-        f_epilogue<TRAIN, MIX>(acc, X, wave, lane, mask);
+        f_epilogue<TRAIN, MIX, HR>(acc, X, wave, lane, mask);
         if (TRAIN) f_store_masks(a.sv.lmask, gtile, 0, wave, lane, mask);
         f_acc_bias(P + PO_B2, wave, lane, acc);
         PnGemmW<16, 8, PN_NFB, PN_WPF, NPC> W2;
@@ -896,16 +906,16 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
         if constexpr (MIX) pn_gemm_mix_run<PN_MIX_NS, 0, 8, PN_NFB>(X, M2, lane, acc);
         else pn_gemm_f16x3_run<16, 8, PN_NFB, PN_WPF, NPC>(X, W2, lane, acc);
         if (TRAIN) {      // (behind the GEMM: see below)
-            if (MIX) pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X, a.sv.h1k, gtile * 8, tid);
+            if (MIX || HR) pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X, a.sv.h1k, gtile * 8, tid);
             else pn_copy_out_kmajor<PN_H, WG2, PN_NW>(X, a.sv.h1k, gtile * 8, tid, a.sv.h1m);
         }
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 6);
-        f_epilogue<TRAIN, MIX>(acc, X, wave, lane, mask);
+        f_epilogue<TRAIN, MIX, HR>(acc, X, wave, lane, mask);
         if (TRAIN) f_store_masks(a.sv.lmask, gtile, 1, wave, lane, mask);
         if (tid < PN_TILE) {     // the row's extras next to h2: columns 256..262, the ones column, zeros up to 271
             const float4 u = *reinterpret_cast<const float4 *>(exb + tid * 8), v = *reinterpret_cast<const float4 *>(exb + tid * 8 + 4);
-            if (MIX) {
+            if (MIX || HR) {
                 pn_xt_store4(X, tid, PN_H, u.x, u.y, u.z, u.w);
                 pn_xt_store4(X, tid, PN_H + 4, v.x, v.y, v.z, v.w);
                 pn_xt_store4(X, tid, PN_H + 8, 0.f, 0.f, 0.f, 0.f);
@@ -929,12 +939,12 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
         if constexpr (MIX) pn_gemm_mix_run<PN_MIX_NS, 1, 8, PN_NFB>(X, M3, lane, acc);
         else pn_gemm_f16x3_run<17, 8, PN_NFB, PN_WPF, NPC>(X, W3, lane, acc);
         if (TRAIN) {      // (behind the GEMM: see below)
-            if (MIX) pn_copy_out_kmajor_h<PN_NF1, PN_XRS, PN_NW>(X, a.sv.h2k, gtile * 8, tid);
+            if (MIX || HR) pn_copy_out_kmajor_h<PN_NF1, PN_XRS, PN_NW>(X, a.sv.h2k, gtile * 8, tid);
             else pn_copy_out_kmajor<PN_NF1, WG2, PN_NW>(X, a.sv.h2k, gtile * 8, tid, a.sv.h2m);
         }
         PN_LDS_BARRIER();
         PN_TR(pn_trace_fwd, 9);
-        f_epilogue<TRAIN, MIX>(acc, X, wave, lane, mask);
+        f_epilogue<TRAIN, MIX, HR>(acc, X, wave, lane, mask);
         if (TRAIN) f_store_masks(a.sv.lmask, gtile, 2, wave, lane, mask);
         f_acc_bias(P + PO_B4, wave, lane, acc);
         PnGemmW<16, 8, PN_NFB, PN_WPF, NPC> W4;
@@ -948,7 +958,7 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
         if constexpr (MIX) pn_gemm_mix_run<PN_MIX_NS, 0, 8, PN_NFB>(X, M4, lane, acc);
         else pn_gemm_f16x3_run<16, 8, PN_NFB, PN_WPF, NPC>(X, W4, lane, acc);
         if (TRAIN) {
-            if (MIX) pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X, a.sv.h3k, gtile * 8, tid);
+            if (MIX || HR) pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X, a.sv.h3k, gtile * 8, tid);
             else pn_copy_out_kmajor<PN_H, WG2, PN_NW>(X, a.sv.h3k, gtile * 8, tid, a.sv.h3m);
         }
         PN_TR(pn_trace_fwd, 12);

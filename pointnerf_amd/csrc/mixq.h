@@ -119,7 +119,16 @@ __device__ __forceinline__ void pn_xa_store2(char *X, int row, int col, float v0
     *reinterpret_cast<unsigned *>(X + row * PN_XRS + col * 2) = h;
     *reinterpret_cast<unsigned *>(X + PN_XPLANE + row * PN_XRS + col * 2) = m;
 }
-// four values at columns >= 256 (col % 4 == 0): f16x3.h's two planes with h rounded to nearest
+// two values, f16x3.h's two planes with h rounded to nearest (any column)
+__device__ __forceinline__ void pn_xt_store2(char *X, int row, int col, float v0, float v1) {
+    unsigned h, m;
+    pn_split2_rne(v0, v1, h, m);
+    *reinterpret_cast<unsigned *>(X + row * PN_XRS + col * 2) = h;
+    *reinterpret_cast<unsigned *>(X + PN_XPLANE + row * PN_XRS + col * 2) = m;
+}
+// four values (col % 4 == 0): f16x3.h's two planes with h rounded to nearest -- the mixed tile's columns >= 256, and every column of the training
+// forward's f16x3 tiles (round 6: h IS then the nearest f16 of the value, so the k-major plane the weight-gradient GEMM streams is the transpose
+// of the h plane alone: the copy-out reads one plane instead of two and adds nothing)
 __device__ __forceinline__ void pn_xt_store4(char *X, int row, int col, float v0, float v1, float v2, float v3) {
     unsigned h0, m0, h1, m1;
     pn_split2_rne(v0, v1, h0, m0); pn_split2_rne(v2, v3, h1, m1);

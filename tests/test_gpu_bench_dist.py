@@ -35,6 +35,14 @@ def test_bench_json_contract_single_gpu():
     # the headline line carries the fp32-class weight-gradient variant of the same step (--wgrad-planes 2) next to the shipped arithmetic
     v = d["config"]["fp32_class_variant"]
     assert d["config"]["wgrad_planes"] == 1 and v["ms_per_step"] > 0 and v["value"] > 0 and abs(v["final_loss"]) < 1e3
+    assert d["scaling"] == "weak" and d["config"]["global_batch_rays"] == 8192        # (N = 1: the two readings coincide)
+    # ... and the other priced variants of the same step: f16 cross terms everywhere (the round-5 arithmetic), e4m3 cross terms in the training forward
+    # too, and the route the reference's unmodified shell takes (compacted outputs, ATen losses, two torch.optim.Adam)
+    for name in ("f16_cross_terms_variant", "e4m3_forward_variant", "reference_shell_variant"):
+        vv = d["config"][name]
+        assert vv["ms_per_step"] > 0 and vv["value"] > 0 and abs(vv["final_loss"]) < 1e3, name
+    hb = d["roofline_hbm"]["agg_backward"]
+    assert hb["survey_algorithmic_bytes_per_step"] > 0 and d["cpu_baseline"].get("note") or d["cpu_baseline"]["kind"] == "reference"
     # and the mode can be timed on its own
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--rays", "8192",
                                    "--points", "300000", "--cpu-rays", "0", "--wgrad-planes", "2"], cwd=ROOT, timeout=900)
@@ -89,8 +97,12 @@ def _two_ranks(extra, port_off):
 
 def test_bench_two_ranks_on_one_gpu():
     d = _two_ranks([], 0)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    # N > 1 defaults to BASELINE.json configs[2] as SURVEY 8d defines it: ONE global batch of --rays rays split contiguously over the ranks
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["global_batch_rays"] == 4096 and d["config"]["rays_per_gpu_per_step"] == 2048 and "configs[2]" in d["config"]["workload"]
     assert "cpu_baseline" not in d                      # rank 0 at N=1 only
+    w = _two_ranks(["--weak"], 1)                       # the optional weak-scaling variant: --rays rays per GPU
+    assert w["scaling"] == "weak" and w["config"]["global_batch_rays"] == 8192 and w["config"]["rays_per_gpu_per_step"] == 4096
     # the point-gradient all-reduce issued on a side stream behind the library's "point gradients ready" event (overlapping the
     # weight-gradient GEMMs; the default) gives the same training trajectory as the all-reduce after the whole backward
     n = _two_ranks(["--no-overlap-comm"], 3)
