@@ -786,7 +786,8 @@ PN_TR_DECL(pn_trace_fwd);
 template <bool TRAIN, bool PERS, int NP, bool WG2 = false>
 __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
     constexpr bool MIX = NP == 4;
-    constexpr bool HR = TRAIN && !WG2 && !MIX;      // f16x3 tiles with h rounded to nearest: h-only copy-outs
+    constexpr bool HR = !MIX;                       // f16x3 tiles with h rounded to nearest (inference and training alike: the same bits); training: h-only copy-outs
+    constexpr bool HC = TRAIN && !WG2;              // the k-major copy-outs read the h plane alone
     constexpr int NPC = MIX ? 3 : NP;          // (what the classic templates are instantiated with where MIX compiles them away)
     static_assert(!(MIX && WG2), "the two-plane weight-gradient mode keeps f16x3.h's arithmetic everywhere");
     pn_mode_saturate();
@@ -883,7 +884,7 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
         if constexpr (MIX) pn_gemm_mix_run<PN_MIX_NS, 2, 8, PN_NFB>(X, M1, lane, acc);
         else pn_gemm_f16x3_run<18, 8, PN_NFB, PN_WPF, NPC>(X, W1, lane, acc);
         if (TRAIN) {           // (behind the GEMM: see above)
-            if (MIX || HR) {         // the tile's h plane IS the nearest f16: the k-major plane is its transpose
+            if (HC) {         // the tile's h plane IS the nearest f16: the k-major plane is its transpose
                 if (a.save_x0) pn_copy_out_kmajor_h<PN_NF1, PN_XRS, PN_NW>(X, a.sv.x0k, gtile * 8, tid);
                 else pn_copy_out_kmajor_cols64_h<224, PN_NW>(X, a.sv.x0k, gtile * 8, tid);
             } else if (WG2) pn_copy_out_kmajor<PN_NF1, true, PN_NW>(X, a.sv.x0k, gtile * 8, tid, a.sv.x0m);
@@ -906,7 +907,7 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
         if constexpr (MIX) pn_gemm_mix_run<PN_MIX_NS, 0, 8, PN_NFB>(X, M2, lane, acc);
         else pn_gemm_f16x3_run<16, 8, PN_NFB, PN_WPF, NPC>(X, W2, lane, acc);
         if (TRAIN) {      // (behind the GEMM: see below)
-            if (MIX || HR) pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X, a.sv.h1k, gtile * 8, tid);
+            if (HC) pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X, a.sv.h1k, gtile * 8, tid);
             else pn_copy_out_kmajor<PN_H, WG2, PN_NW>(X, a.sv.h1k, gtile * 8, tid, a.sv.h1m);
         }
         PN_LDS_BARRIER();
@@ -939,7 +940,7 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
         if constexpr (MIX) pn_gemm_mix_run<PN_MIX_NS, 1, 8, PN_NFB>(X, M3, lane, acc);
         else pn_gemm_f16x3_run<17, 8, PN_NFB, PN_WPF, NPC>(X, W3, lane, acc);
         if (TRAIN) {      // (behind the GEMM: see below)
-            if (MIX || HR) pn_copy_out_kmajor_h<PN_NF1, PN_XRS, PN_NW>(X, a.sv.h2k, gtile * 8, tid);
+            if (HC) pn_copy_out_kmajor_h<PN_NF1, PN_XRS, PN_NW>(X, a.sv.h2k, gtile * 8, tid);
             else pn_copy_out_kmajor<PN_NF1, WG2, PN_NW>(X, a.sv.h2k, gtile * 8, tid, a.sv.h2m);
         }
         PN_LDS_BARRIER();
@@ -958,7 +959,7 @@ __global__ __launch_bounds__(PN_NTHR, PN_NW / 2) void k_agg_forward(FwdArgs a) {
         if constexpr (MIX) pn_gemm_mix_run<PN_MIX_NS, 0, 8, PN_NFB>(X, M4, lane, acc);
         else pn_gemm_f16x3_run<16, 8, PN_NFB, PN_WPF, NPC>(X, W4, lane, acc);
         if (TRAIN) {
-            if (MIX || HR) pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X, a.sv.h3k, gtile * 8, tid);
+            if (HC) pn_copy_out_kmajor_h<PN_H, PN_XRS, PN_NW>(X, a.sv.h3k, gtile * 8, tid);
             else pn_copy_out_kmajor<PN_H, WG2, PN_NW>(X, a.sv.h3k, gtile * 8, tid, a.sv.h3m);
         }
         PN_TR(pn_trace_fwd, 12);

@@ -211,8 +211,14 @@ extern "C" int pnerf_extract_2d(const float *d_cam_xyz, int64_t n_points, const 
     if (d_mask && hipMemsetAsync(d_mask, 0, (size_t)n_views * n_points, s) != hipSuccess) return PNERF_E_LAUNCH;
     hipLaunchKernelGGL(k_ex2d_project, dim3(pn_cdiv((long long)n_points * n_views, 256)), dim3(256), 0, s, a, proj, zbuf);
     PN_CHECK_LAUNCH();
+    // descriptors whose output columns overlap: the first-form kernel lets the FIRST matching map win per column; the tiled one would let
+    // whichever wave writes the LDS cell last win (a race) -- such calls take the first form
+    bool overlap = false;
+    for (int m = 0; m < n_maps && !overlap; ++m)
+        for (int k = 0; k < m; ++k)
+            if (maps[m].is_color == maps[k].is_color && maps[m].out_col < maps[k].out_col + maps[k].C && maps[k].out_col < maps[m].out_col + maps[m].C) { overlap = true; break; }
     const size_t tile_bytes = (size_t)EX_PTS * (feat_cols + color_cols + 1) * sizeof(float);
-    if (tile_bytes <= 64 * 1024) {
+    if (tile_bytes <= 64 * 1024 && !overlap) {
         if (hipFuncSetAttribute((const void *)k_ex2d_sample_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes) != hipSuccess) return PNERF_E_LAUNCH;
         hipLaunchKernelGGL(k_ex2d_sample_tiled, dim3(pn_cdiv((long long)n_points, EX_PTS)), dim3(256), tile_bytes, s, a, proj, zbuf, d_feats, d_colors, d_mask);
     } else {

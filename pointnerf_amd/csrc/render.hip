@@ -205,6 +205,20 @@ __global__ __launch_bounds__(TPB) void k_gather_rows(const float *__restrict__ s
         dst[e] = src[(long long)p * width + c];
     }
 }
+// width a multiple of 4 with width / 4 a power of two <= 64 (the embedding: 32 floats = 8 lanes x 16 bytes per row): a group of W4 lanes copies one
+// row with 16-byte accesses, no per-element division.  (Round 3's 4.2 TB/s for this kernel came from the loop vectoriser, which the library has
+// had switched off since round 4 -- the packed-fp32 fault, csrc/Makefile --: the scalar form above fell to 3.1 TB/s; profiles/r0[345]_microbench.json.)
+template <int W4>
+__global__ __launch_bounds__(TPB) void k_gather_rows_v4(const float4 *__restrict__ src, int n_src, const int *__restrict__ idx, long long n_idx, float4 *__restrict__ dst) {
+    const int c = threadIdx.x & (W4 - 1);
+    for (long long i = ((long long)blockIdx.x * TPB + threadIdx.x) / W4; i < n_idx; i += (long long)gridDim.x * (TPB / W4)) {
+        int p = idx[i];
+        p = p < 0 ? 0 : (p >= n_src ? n_src - 1 : p);
+        const float4 v = src[(long long)p * W4 + c];
+        pn_f4 t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<pn_f4 *>(dst + i * W4 + c));
+    }
+}
 // -1 slots were gathered from point 0 (A.9 of SURVEY.md: the reference lets point 0 collect gradient from every
 // empty slot).  Those are the vast majority of the slots, all hitting ONE row: they are summed per block in LDS
 // first and leave as one atomic per column per block; real indices go straight to global atomics.
@@ -430,7 +444,12 @@ extern "C" int pnerf_gather_rows(const float *d_src, int n_src, int width, const
     long long total = n_idx * width;
     int grid = (int)((total + TPB - 1) / TPB < 16384 ? (total + TPB - 1) / TPB : 16384);
     PnProfScope prof(PNK_GATHER, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, d_src, n_src, width, d_idx, (long long)n_idx, d_dst);
+    const bool al = ((uintptr_t)d_src % 16 == 0) && ((uintptr_t)d_dst % 16 == 0);
+    const long long rows_per_block = TPB / (width / 4 > 0 ? width / 4 : 1);
+    const int gridv = (int)((n_idx + rows_per_block - 1) / rows_per_block < 16384 ? (n_idx + rows_per_block - 1) / rows_per_block : 16384);
+    if (al && width == 32) hipLaunchKernelGGL(k_gather_rows_v4<8>, dim3(gridv), dim3(TPB), 0, (hipStream_t)stream, (const float4 *)d_src, n_src, d_idx, (long long)n_idx, (float4 *)d_dst);
+    else if (al && width == 4) hipLaunchKernelGGL(k_gather_rows_v4<1>, dim3(gridv), dim3(TPB), 0, (hipStream_t)stream, (const float4 *)d_src, n_src, d_idx, (long long)n_idx, (float4 *)d_dst);
+    else hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(TPB), 0, (hipStream_t)stream, d_src, n_src, width, d_idx, (long long)n_idx, d_dst);
     PN_CHECK_LAUNCH();
     return 0;
 }

@@ -146,8 +146,13 @@ class MvsPointsVolumetricModel:
             # every colour-loss item that carries a gradient is a ray_masked one -- the lego script's items are (ray_masked 1.0, ray_miss 0.0,
             # full image 0.0); ray_miss predicts the constant background and has no gradient, a full-image item with a non-zero weight would
             # need the gradient of the filled image and keeps the compacted form
+            # On that path the rendered outputs in self.output (coarse_raycolor, coarse_point_opacity, coarse_is_background) are DETACHED -- the
+            # gradient flows through ops.color_loss_sum_rays only -- so it is not taken when anything else could want a gradient through a rendered
+            # tensor: an l2-size item, the sparse loss (it reads the opacities), or opt.fused_color_loss = 0 (the opt-out for subclasses / hooks that
+            # build their own loss from model.output; the reference's outputs are differentiable).
             items = list(zip(getattr(opt, "color_loss_items", []), getattr(opt, "color_loss_weights", [])))
-            self.net_ray_marching.fused_color_loss = bool(items) and all(
+            others = bool(getattr(opt, "l2_size_loss_items", None)) or float(getattr(opt, "sparse_loss_weight", 0) or 0) > 0
+            self.net_ray_marching.fused_color_loss = bool(items) and not others and int(getattr(opt, "fused_color_loss", 1)) != 0 and all(
                 n == "ray_masked_coarse_raycolor" or n.startswith("ray_miss") or float(w) == 0.0 for n, w in items)
         self.model_names = ["ray_marching"]
 

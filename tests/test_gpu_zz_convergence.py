@@ -24,7 +24,8 @@ DEV = torch.device("cuda:0")
 
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trajectory_envelope.npz")
-EARLY, LOOKAHEAD = 75, 25
+EARLY, LOOKAHEAD = 100, 25          # (the fixture's envelope stays below 1e-4 / 3 up to step 107)
+LATE_CAP = 0.15                     # no assertion ever tolerates more than this relative loss difference (3 x the final envelope is 0.144)
 
 
 def envelope_bar(env):
@@ -33,7 +34,7 @@ def envelope_bar(env):
     earliest of the 16 ensemble members is still inside.)"""
     run_max = np.maximum.accumulate(env)
     ahead = np.concatenate([run_max[LOOKAHEAD:], np.full(LOOKAHEAD, run_max[-1])])
-    return np.maximum(3.0 * ahead, 1e-4)
+    return np.minimum(np.maximum(3.0 * ahead, 1e-4), LATE_CAP)
 
 
 def test_200_steps_inside_the_oracle_ensemble():
@@ -42,7 +43,7 @@ def test_200_steps_inside_the_oracle_ensemble():
     element to ~lr, so a last-bit difference grows step by step, and the step at which a run leaves the common trajectory is chance (a pre-activation crossing
     a LeakyReLU kink).  No assertion here depends on when that happens:
 
-    (i)  steps 1 .. 75 are deterministic to rounding: the device loss is within 1e-4 relative of the oracle's (measured <= 3e-6 on every box seen: 30 x
+    (i)  steps 1 .. 100 are deterministic to rounding: the device loss is within 1e-4 relative of the oracle's (measured <= 3e-6 on every box seen: 30 x
          margin), against the oracle run live on this box AND against the committed trajectory (which pins the fixture to this box's oracle);
     (ii) over all 200 steps the device stays inside 3 x the ENVELOPE of an ensemble of 16 perturbed oracle runs (every MLP weight x (1 +- 2^-23), a
          different sign mask per run; tests/golden/make_trajectory_envelope.py), with a 25-step look-ahead -- for the shipped one-plane weight gradients and
