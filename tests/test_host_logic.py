@@ -1,6 +1,10 @@
 """CPU tests of the host-side mirror of the reference interface (no kernels involved)."""
+import os
+
 import numpy as np
 import torch
+
+from emu_util import emu_backend
 
 from pointnerf_amd import config, ops, scenes, dist as pdist
 from pointnerf_amd.point_aggregators import PointAggregator
@@ -12,7 +16,8 @@ def test_grid_hyperparameters_match_oracle():
                      (config.lego_opt(vscale=[3, 3, 3], kernel_size=[5, 5, 5], ranges=[-0.05] * 3 + [0.05] * 3), scenes.chair_points(500))]:
         x = torch.from_numpy(xyz)
         hp = pyref.grid_hyperparameters(opt, x)
-        ranges, svs, svd, radius = ops.grid_hyperparameters(opt, x)
+        with emu_backend():            # (the min / max pass is a HIP kernel since round 6: here on the host emulator, tools/emu)
+            ranges, svs, svd, radius = ops.grid_hyperparameters(opt, x)
         assert np.array_equal(ranges, hp["ranges"]) and np.array_equal(svs, hp["scaled_vsize"])
         assert np.array_equal(svd, hp["scaled_vdim"]) and radius == hp["radius"]
 
@@ -110,3 +115,24 @@ def test_fill_invalid_on_dense_results_equals_the_scatter_form():
         for k in ("coarse_raycolor", "coarse_point_opacity", "coarse_is_background", "coarse_mask", "queried_shading"):
             assert a[k].shape == b[k].shape and torch.allclose(a[k], b[k], rtol=0, atol=1e-7), (k, bg_ray is not None)
         assert not b["coarse_raycolor"].requires_grad
+
+
+def test_microbench_figures_do_not_regress_between_rounds():
+    """profiles/rNN_microbench.json (tools/gpu_microbench.py on an MI355X, committed once per round): no kernel of the latest round is more than 10 %
+    slower than in the round before.  (Round 4 lost 36 % of the stand-alone embedding gather -- the loop vectoriser it had relied on was switched off
+    library-wide -- and nobody noticed for two rounds; round 6 restored it with explicit 16-byte accesses.)"""
+    import glob
+    import json
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_microbench.json")), key=lambda p: int(re.search(r"r(\d+)_", os.path.basename(p)).group(1)))
+    assert len(files) >= 2
+    new, old = json.load(open(files[-1])), json.load(open(files[-2]))
+    checked = 0
+    for k, v in new.items():
+        if isinstance(v, dict) and "ms" in v and isinstance(old.get(k), dict) and "ms" in old[k]:
+            assert v["ms"] <= 1.10 * old[k]["ms"], (k, v["ms"], old[k]["ms"], os.path.basename(files[-1]), os.path.basename(files[-2]))
+            checked += 1
+    assert checked >= 4
+    g = new["gather_rows_emb32"]
+    assert g["GBps"] >= 4000.0, g          # the figure DESIGN.md quotes for the stand-alone gather
