@@ -106,6 +106,8 @@ def parse():
     ap.add_argument("--config", default="lego", choices=sorted(CONFIGS), help="BASELINE.json configuration (default: configs[1], the headline)")
     ap.add_argument("--rays", type=int, default=65536, help="rays of the global batch per step (N > 1: split contiguously over the ranks; with --weak: rays per GPU)")
     ap.add_argument("--weak", action="store_true", help="N > 1: weak scaling (--rays rays per GPU, global batch N x --rays) instead of the default strong scaling (configs[2])")
+    ap.add_argument("--cross-terms", type=int, default=8, choices=(8, 16), help="cross terms of the aggregator's tile GEMMs: 8 = e4m3 (csrc/mixq.h, default), 16 = f16 (csrc/f16x3.h)")
+    ap.add_argument("--cross-terms-where", type=int, default=None, help="bit mask of the kernels that use the e4m3 cross terms: 1 inference forward, 2 training forward, 4 backward (library default: 4)")
     ap.add_argument("--no-variants", action="store_true", help="skip the supplementary variants of the default run (f16 cross terms, e4m3 forward, reference shell, fp32-class weight gradients)")
     ap.add_argument("--points", type=int, default=0, help="neural points (0 = the configuration's own count)")
     ap.add_argument("--cpu-rays", type=int, default=12288, help="rays of the bounded CPU-baseline sample (0 = skip)")
@@ -383,6 +385,7 @@ def main():
         if not selftest:
             raise SystemExit("bench.py: the collective self-test did not run: refusing to time a multi-GPU step")
     ops.set_wgrad_planes(args.wgrad_planes)
+    ops.set_cross_terms(args.cross_terms, where=args.cross_terms_where)
     # N > 1: a rank that stops inside a later collective (a mismatch between the ranks' call sequences) also leaves a record
     # (re-armed per phase: a slow but healthy run -- a cold first build, the Barn cloud on 8 ranks -- is not killed by one global budget)
     guard_s = int(os.environ.get("PNERF_RUN_TIMEOUT", "1500"))
@@ -563,7 +566,7 @@ def _run(args, world, rank, dev, dist_on, selftest, rearm):
                 restore()
             return {"ms_per_step": msv, "value": rays_rank / (msv * 1e-3), "unit": "rays/s", "steps": nv, "final_loss": float(lv.item()), "what": what}
 
-        if not dist_on and not args.no_variants:
+        if not dist_on and not args.no_variants and args.cross_terms == 8 and args.cross_terms_where is None:
             # (a) f16 cross terms everywhere: the arithmetic of rounds 2-5 (csrc/f16x3.h: three f16 products per multiply-add in forward and backward)
             extra["f16_cross_terms_variant"] = variant(
                 "pnerf_set_cross_terms(16): f16 cross terms in every tile GEMM (three f16 products per multiply-add, the round-5 arithmetic); the headline runs "
@@ -659,7 +662,7 @@ def _run(args, world, rank, dev, dist_on, selftest, rearm):
                                          ("configs[2]: one global batch of %d rays/step split contiguously over %d GPUs (%d rays/GPU/step)" % (args.rays, world, rays_rank)) if strong
                                          else ("%d rays/GPU/step" % rays_rank) + (" (weak-scaling variant: global batch %d)" % (rays_rank * world) if world > 1 else "")),
                           "rays_per_gpu_per_step": rays_rank, "global_batch_rays": rays_rank * world,
-                          "wgrad_planes": args.wgrad_planes, "collective_selftest": selftest,
+                          "wgrad_planes": args.wgrad_planes, "cross_terms": dict(zip(("bits", "where_mask"), ops.cross_terms_state())), "collective_selftest": selftest,
                           "parity_note": ("the synthetic Barn shell puts up to ~70 points in a 0.009 cell, beyond P = 11: the reference switches to a wall-clock-seeded "
                                           "reservoir there (parity undefined); the HIP path and the oracle both keep the first P by index, so parity on this "
                                           "configuration is HIP-vs-oracle truncation only (pointnerf_amd/config.py barn_opt)") if args.config == "barn" else None,

@@ -36,7 +36,7 @@ except Exception:
     commit, dirty = None, None
 # (the command of tools/gpu_profile.sh's --pmc passes; the library is the one built from `commit`)
 traffic["_source"] = {"commit": commit, "uncommitted_changes_in_the_library_or_bench": dirty, "tag": tag,
-                      "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- python bench.py --steps 3 --warmup 1 --cpu-rays 0 --no-prof --no-fp32-class-variant",
+                      "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- python bench.py --steps 3 --warmup 1 --cpu-rays 0 --no-prof --no-variants",
                       "correction": "(2 x FETCH_SIZE + WRITE_SIZE) KiB per step (MI355X_MICROARCH.md, HBM section)"}
 json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
