@@ -1211,7 +1211,7 @@ extern "C" int pnerf_set_cross_terms(int bits) {
 // which tile kernels run the mixed format when the cross terms are e4m3 (include/pnerf.h: pnerf_set_cross_terms_where): bit 0 = inference
 // forward, bit 1 = training forward, bit 2 = backward (the input-gradient chain).  Default 4: the forward keeps f16 cross terms -- with e4m3 ones
 // its sigma / RGB are 1e-5 .. 6e-5 from the fp32 oracle instead of 1e-6 (inside the 1e-4 bar), but pre-activations within that distance of zero
-// take the other LeakyReLU branch than the oracle's, and the gradient tests against the oracle see those flips (profiles/r06_cross_terms_ab.md)
+// take the other LeakyReLU branch than the oracle's, and the gradient tests against the oracle see those flips (profiles/r06_cross_terms_ab.json)
 #ifndef PN_MIX_DEFAULT_MASK
 #define PN_MIX_DEFAULT_MASK 4
 #endif
