@@ -144,7 +144,9 @@ int pnerf_color_loss_backward_rays(const float *d_ray_color, const float *d_gt, 
 #define PNERF_MLP_NTENSORS 18
 int pnerf_mlp_layout(int feat_dim, int64_t *offsets /*[PNERF_MLP_NTENSORS+1]*/);
 size_t pnerf_mlp_packed_bytes(void);
-/* repack the flat parameter vector into MFMA fragment order (forward and dgrad images) */
+/* repack the flat parameter vector into MFMA fragment order: 14 two-plane f16 images (forward W and dgrad W^T of the four aggregator and three colour
+ * layers, csrc/f16x3.h) and the 8 mixed-format images of the aggregator layers (f16 h fragments + e4m3 cross-term fragments with block exponents,
+ * csrc/mixq.h).  Called once per optimisation step (the weights change); ~20 us. */
 int pnerf_mlp_pack(const float *d_params, void *d_packed, void *stream);
 
 typedef struct pnerf_camera {

@@ -70,6 +70,18 @@ def test_emulated_mixed_tile_gemm_matches_the_numpy_restatement(K):
         assert np.abs(e).max() <= 1e-5 and np.sqrt((e ** 2).mean()) <= 2e-6
 
 
+def test_emulated_forward_with_e4m3_cross_terms_stays_inside_the_bar():
+    """the optional forward modes of csrc/mixq.h (pnerf_set_cross_terms_where bits 0 / 1) on the emulator: sigma / RGB / ray colour within 1e-4 of the
+    oracle (the default, f16 cross terms in the forward, is what every other test of this file runs)"""
+    from pointnerf_amd import ops
+    old = ops.set_cross_terms(8, where=7)
+    try:
+        errs = TR._compare(*build_case("small_k4"))
+    finally:
+        ops.set_cross_terms(8, where=old[1])
+    assert 2e-6 < errs["decoded"] <= 1e-4          # (the mode is really on: f16 cross terms give < 1e-6)
+
+
 def test_emulated_f16_mfma_layout_and_subnormals():
     import ctypes
     import mfma_case

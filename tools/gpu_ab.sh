@@ -5,7 +5,7 @@ O=gpurun_out/ab; mkdir -p $O
 cp pointnerf_amd/libpnerf_hip.so /tmp/shipped.so
 for V in shipped "$@"; do
   [ $V != shipped ] && cp tools/_build/$V.so pointnerf_amd/libpnerf_hip.so
-  PNERF_BENCH_ALLOW_NAN=1 timeout 300 python bench.py --cpu-rays 0 --steps 10 > $O/bench_$V.json 2>$O/bench_$V.err
+  PNERF_BENCH_ALLOW_NAN=1 timeout 300 python bench.py --cpu-rays 0 --steps 10 --no-variants > $O/bench_$V.json 2>$O/bench_$V.err
   python - <<PY
 import json
 try:
