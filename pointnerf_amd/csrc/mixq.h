@@ -6,7 +6,8 @@
 // -- 4 x 32 + 2 x 64 = 256 pipe cycles per 64 columns and 32 x 32 block instead of 12 x 32 = 384 (measured with toggling register operands, two
 // waves per SIMD: 1170 against 1820 ns per 64-column step, tools/mx_probe.hip / profiles/r06_mx_probe.jsonl).  Each e4m3 factor carries a relative
 // rounding of <= 2^-4, so a cross term is good to ~2^-4 of 2^-11 of the product: error 1.1e-6 rms of sum |terms| over a 256-term dot product
-// measured on the device (profiles/r05_fp8_gemm_probe.jsonl; three f16 products: 3e-8; the parity bar downstream is 1e-4).
+// measured on the device by a probe (profiles/r05_fp8_gemm_probe.jsonl) and 1.3e-6 rms / 5.6e-6 max through this format (tests/test_gpu_mix.py); three
+// f16 products: 3e-8; the parity bar downstream is 1e-4.
 //
 // Instruction semantics pinned on the hardware (tools/mx_probe.hip): v_cvt_scalef32_pk_fp8_f16 converts value / scale, round to nearest even,
 // subnormals kept (step 2^-9), and overflow gives NaN unless MODE.FP16_OVFL is set, in which case it SATURATES at +-448 (and v_cvt_f16_f32 at

@@ -219,3 +219,21 @@ def test_two_plane_split_is_bit_exact():
         eh, em = mfma_case.split_expected(xs, sat)
         assert np.array_equal(h.cpu().numpy().view(np.uint16), eh.view(np.uint16))
         assert np.array_equal(m.cpu().numpy().view(np.uint16), em.view(np.uint16))
+
+
+def test_points_minmax_equals_torch_reductions():
+    """pnerf_points_minmax (a1: the min / max pass of get_hyperparameters, point_query.py:51-52) against torch.min / torch.max, bit for bit: mixed
+    signs, denormals, +-0, one point, 2 M points"""
+    import ctypes
+    from pointnerf_amd import _lib as L
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(9)
+    for n in (1, 7, 70001, 2_000_000):
+        x = (torch.randn(n, 3, generator=g) * torch.tensor([1e-3, 1.0, 1e4])).to(dev)
+        if n > 5:
+            x[3, 0] = 0.0; x[4, 0] = -0.0; x[5, 1] = 1e-41; x[2, 2] = -1e-41
+        out = torch.full((6,), float("nan"), device=dev)
+        L.check(L.lib().pnerf_points_minmax(ctypes.c_void_p(x.data_ptr()), n, ctypes.c_void_p(out.data_ptr()),
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "pnerf_points_minmax")
+        want = torch.cat([x.min(dim=0)[0], x.max(dim=0)[0]])
+        assert bool((out.cpu() == want.cpu()).all()), (n, out, want)          # (value equality: -0.0 == 0.0)
