@@ -268,9 +268,18 @@ __global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ xyz, l
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { mn[c] = min(mn[c], __shfl_xor(mn[c], off, 64)); mx[c] = max(mx[c], __shfl_xor(mx[c], off, 64)); }
     }
+    // one atomic per BLOCK and component (six addresses take every atomic of the launch: 2048 blocks x 4 waves of them serialised in L2 for 0.5 ms
+    // in the first form of this kernel)
+    __shared__ unsigned red[4][6];
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { atomicMin(&key[c], mn[c]); atomicMax(&key[3 + c], mx[c]); }
+        for (int c = 0; c < 3; ++c) { red[threadIdx.x >> 6][c] = mn[c]; red[threadIdx.x >> 6][3 + c] = mx[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        unsigned v = red[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
+        if (threadIdx.x < 3) atomicMin(&key[threadIdx.x], v); else atomicMax(&key[threadIdx.x], v);
     }
 }
 __global__ void k_minmax_decode(unsigned *__restrict__ key) {
@@ -284,7 +293,7 @@ extern "C" int pnerf_points_minmax(const float *d_xyz, int64_t n, float *d_out6,
     unsigned *key = reinterpret_cast<unsigned *>(d_out6);
     PnProfScope prof(PNK_GRID, s);
     hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(64), 0, s, key);
-    const int blocks = (int)(n / 256 < 2048 ? (n + 255) / 256 : 2048);
+    const int blocks = (int)(n / 256 < 512 ? (n + 255) / 256 : 512);
     hipLaunchKernelGGL(k_minmax, dim3(blocks), dim3(256), 0, s, d_xyz, (long long)n, key);
     hipLaunchKernelGGL(k_minmax_decode, dim3(1), dim3(64), 0, s, key);
     PN_CHECK_LAUNCH();

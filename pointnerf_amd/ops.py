@@ -87,15 +87,15 @@ def grid_hyperparameters(opt, xyz):
     xyz = xyz.contiguous()
     mm6 = torch.empty(6, dtype=torch.float32, device=xyz.device)
     L.check(L.lib().pnerf_points_minmax(_ptr(xyz), int(xyz.shape[0]), _ptr(mm6), _stream()), "pnerf_points_minmax")
-    mm = mm6.cpu().view(2, 3)
-    rmin = torch.as_tensor(opt.ranges[:3], dtype=torch.float32)
-    rmax = torch.as_tensor(opt.ranges[3:], dtype=torch.float32)
-    mn, mx = torch.maximum(mm[0], rmin), torch.minimum(mm[1], rmax)
-    pad = torch.as_tensor(scaled_vsize * np.asarray(opt.kernel_size) / 2, dtype=torch.float32)
-    mn, mx = mn - pad, mx + pad
-    vdim = (mx - mn).numpy() / vsize64
+    mm = mm6.cpu().numpy().reshape(2, 3)                  # (the one device -> host read of a grid rebuild; fp32 arithmetic below, like the reference's torch ops)
+    rmin = np.asarray(opt.ranges[:3], dtype=np.float32)
+    rmax = np.asarray(opt.ranges[3:], dtype=np.float32)
+    mn, mx = np.maximum(mm[0], rmin), np.minimum(mm[1], rmax)
+    pad = (scaled_vsize * np.asarray(opt.kernel_size) / 2).astype(np.float32)
+    mn, mx = (mn - pad).astype(np.float32), (mx + pad).astype(np.float32)
+    vdim = (mx - mn).astype(np.float32) / vsize64
     scaled_vdim = np.ceil(vdim / vscale).astype(np.int32)
-    ranges = torch.cat([mn, mx]).numpy().astype(np.float32)
+    ranges = np.concatenate([mn, mx]).astype(np.float32)
     return ranges, scaled_vsize, scaled_vdim, float(radius)
 
 
